@@ -1,0 +1,293 @@
+"""A minimal torch-CPU backed stand-in for the ``paddle`` API surface that the
+reference's MoCo-v2 path touches.  TEST INFRASTRUCTURE ONLY.
+
+Purpose: ``import paddle`` is impossible in the build container (no wheel, no
+network), so the reference's own Python (moco.py, contrastive_head.py,
+base_neck.py, resnet.py over the vendored resnetimagenet.py, freeze.py,
+registry.py) cannot run as shipped.  With this shim installed as
+``sys.modules['paddle']`` those *unmodified* source files execute on torch-CPU,
+which pins the oracle at the PASSL-Python level (control flow, parameter
+iteration order, what is EMA'd, queue indexing, loss/accuracy formulae).
+
+What the shim itself asserts about Paddle (= the [Paddle-semantics] list in
+oracle/README.md): BatchNorm2D momentum 0.9 / eps 1e-5 / biased running var,
+``_mean/_variance`` are non-trainable members of ``parameters()`` ordered
+``weight, bias, _mean, _variance``; Linear weight is [in, out];
+``F.normalize`` divides by max(norm, 1e-12); CrossEntropyLoss = mean of
+-log_softmax at the label.
+
+It monkey-patches a few ``torch.Tensor`` methods (``transpose(list)``,
+``set_value``, ``stop_gradient``, ``cuda`` no-op) — run it in a process that
+does nothing else (tests use a subprocess).
+"""
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as TF
+
+_T = torch.Tensor
+
+
+# ------------------------------------------------------------------ Tensor
+def _install_tensor_patches():
+    if getattr(_T, '_paddle_shim', False):
+        return
+    _orig_transpose = _T.transpose
+
+    def transpose(self, *args):
+        if len(args) == 1 and isinstance(args[0], (list, tuple)):
+            return self.permute(*args[0])
+        return _orig_transpose(self, *args)
+
+    def set_value(self, value):
+        with torch.no_grad():
+            self.copy_(torch.as_tensor(value, dtype=self.dtype))
+
+    _T.transpose = transpose
+    _T.set_value = set_value
+    _T.stop_gradient = property(lambda s: not s.requires_grad,
+                                lambda s, v: s.requires_grad_(not v) if s.is_leaf else None)
+    _T.cuda = lambda self, *a, **k: self
+    _T.astype = lambda self, dt: self.to(_dtype(dt))
+    _T._paddle_shim = True
+
+
+def _dtype(dt):
+    if isinstance(dt, torch.dtype):
+        return dt
+    return {'float32': torch.float32, 'float64': torch.float64, 'int64': torch.int64,
+            'int32': torch.int32, 'bool': torch.bool, None: torch.float32}[dt]
+
+
+# ------------------------------------------------------------------ nn
+class Layer(torch.nn.Module):
+    def sublayers(self, include_self=False):
+        mods = list(self.modules())
+        return mods if include_self else mods[1:]
+
+    def create_parameter(self, shape, attr=None, dtype='float32', is_bias=False,
+                         default_initializer=None):
+        return torch.nn.Parameter(torch.zeros(*shape, dtype=_dtype(dtype)))
+
+    def set_state_dict(self, sd):
+        return self.load_state_dict(sd)
+
+
+class Sequential(torch.nn.Sequential, Layer):
+    pass
+
+
+class ReLU(torch.nn.ReLU, Layer):
+    pass
+
+
+class Conv2D(Layer):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0,
+                 dilation=1, groups=1, padding_mode='zeros', weight_attr=None,
+                 bias_attr=None, data_format='NCHW'):
+        super().__init__()
+        assert groups == 1 and dilation == 1 and data_format == 'NCHW'
+        k = kernel_size if isinstance(kernel_size, (tuple, list)) else (kernel_size,) * 2
+        self._stride, self._padding = stride, padding
+        self.weight = torch.nn.Parameter(torch.randn(out_channels, in_channels, *k) * 0.01)
+        self.bias = None if bias_attr is False else torch.nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x):
+        return TF.conv2d(x, self.weight, self.bias, self._stride, self._padding)
+
+
+class _BatchNormBase(Layer):
+    """paddle.nn.layer.norm._BatchNormBase: stats are non-trainable Parameters
+    (so they appear in parameters()), order weight, bias, _mean, _variance."""
+
+    def __init__(self, num_features, momentum=0.9, epsilon=1e-05, weight_attr=None,
+                 bias_attr=None, data_format='NCHW', use_global_stats=None, name=None):
+        super().__init__()
+        self._momentum, self._epsilon = momentum, epsilon
+        self._use_global_stats = use_global_stats
+        self.weight = torch.nn.Parameter(torch.ones(num_features))
+        self.bias = torch.nn.Parameter(torch.zeros(num_features))
+        self._mean = torch.nn.Parameter(torch.zeros(num_features), requires_grad=False)
+        self._variance = torch.nn.Parameter(torch.ones(num_features), requires_grad=False)
+
+    def forward(self, x):
+        dims = [d for d in range(x.dim()) if d != 1]
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        use_global = self._use_global_stats if self._use_global_stats is not None \
+            else (not self.training)
+        if use_global:
+            mean, var = self._mean, self._variance
+        else:
+            mean = x.mean(dim=dims)
+            var = x.var(dim=dims, unbiased=False)
+            with torch.no_grad():
+                m = self._momentum
+                self._mean.copy_(m * self._mean + (1 - m) * mean)
+                self._variance.copy_(m * self._variance + (1 - m) * var)
+        inv = torch.rsqrt(var + self._epsilon)
+        return (x - mean.reshape(shape)) * (inv * self.weight).reshape(shape) \
+            + self.bias.reshape(shape)
+
+
+class BatchNorm2D(_BatchNormBase):
+    pass
+
+
+class BatchNorm1D(_BatchNormBase):
+    pass
+
+
+class BatchNorm(_BatchNormBase):
+    pass
+
+
+class SyncBatchNorm(_BatchNormBase):
+    pass
+
+
+class GroupNorm(Layer):
+    pass
+
+
+class MaxPool2D(Layer):
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super().__init__()
+        self.k, self.s, self.p = kernel_size, stride, padding
+
+    def forward(self, x):
+        return TF.max_pool2d(x, self.k, self.s, self.p)
+
+
+class AdaptiveAvgPool2D(Layer):
+    def __init__(self, output_size):
+        super().__init__()
+        self.o = output_size
+
+    def forward(self, x):
+        return TF.adaptive_avg_pool2d(x, self.o)
+
+
+class Linear(Layer):
+    def __init__(self, in_features, out_features, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(in_features, out_features) * 0.01)
+        self.bias = None if bias_attr is False else torch.nn.Parameter(torch.zeros(out_features))
+
+    def forward(self, x):
+        y = x @ self.weight
+        return y if self.bias is None else y + self.bias
+
+
+class CrossEntropyLoss(Layer):
+    def forward(self, logits, labels):
+        return TF.cross_entropy(logits, labels)
+
+
+def _normalize(x, p=2, axis=1, epsilon=1e-12, name=None):
+    n = x.pow(2).sum(dim=axis, keepdim=True).sqrt().clamp_min(epsilon)
+    return x / n
+
+
+# ------------------------------------------------------------------ module tree
+def install():
+    """Create and register the fake ``paddle`` package.  Idempotent."""
+    if 'paddle' in sys.modules and getattr(sys.modules['paddle'], '_is_shim', False):
+        return sys.modules['paddle']
+    _install_tensor_patches()
+
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+
+    paddle = mod('paddle')
+    paddle._is_shim = True
+    paddle.__version__ = '0.0-torch-shim'
+    paddle.Tensor = torch.Tensor
+    paddle.no_grad = torch.no_grad
+    paddle.randn = lambda shape, dtype=None: torch.randn(*shape)
+    paddle.zeros = lambda shape, dtype='float32': torch.zeros(*shape, dtype=_dtype(dtype))
+    paddle.ones = lambda shape, dtype='float32': torch.ones(*shape, dtype=_dtype(dtype))
+    paddle.full = lambda shape, v, dtype=None: torch.full(tuple(shape), float(v))
+    paddle.normal = lambda mean=0.0, std=1.0, shape=None: torch.randn(*shape) * std + mean
+    paddle.uniform = lambda shape, dtype=None, min=-1.0, max=1.0: \
+        torch.rand(*shape) * (max - min) + min
+    paddle.numel = lambda t: torch.tensor(t.numel())
+    paddle.to_tensor = lambda x, dtype=None, **k: torch.as_tensor(
+        x, dtype=None if dtype is None else _dtype(dtype))
+    paddle.concat = lambda xs, axis=0: torch.cat(list(xs), dim=axis)
+    paddle.matmul = torch.matmul
+    paddle.sum = lambda x, axis=None, keepdim=False: x.sum() if axis is None \
+        else x.sum(dim=axis, keepdim=keepdim)
+    paddle.cast = lambda x, dt: x.to(_dtype(dt))
+    paddle.flatten = lambda x, start_axis=0, stop_axis=-1: torch.flatten(x, start_axis, stop_axis)
+    paddle.randperm = lambda n: torch.randperm(n)
+    paddle.argsort = lambda x, axis=-1: torch.argsort(x, dim=axis)
+    paddle.index_select = lambda x, index, axis=0: torch.index_select(x, axis, index)
+
+    def assign(x, output=None):
+        if output is None:
+            return x.clone()
+        with torch.no_grad():
+            output.copy_(x)
+        return output
+    paddle.assign = assign
+
+    nn = mod('paddle.nn')
+    paddle.nn = nn
+    for cls in (Layer, Sequential, ReLU, Conv2D, BatchNorm2D, BatchNorm1D, BatchNorm,
+                SyncBatchNorm, GroupNorm, MaxPool2D, AdaptiveAvgPool2D, Linear,
+                CrossEntropyLoss):
+        setattr(nn, cls.__name__, cls)
+    F = mod('paddle.nn.functional')
+    nn.functional = F
+    F.normalize = _normalize
+    F.relu = TF.relu
+    layer = mod('paddle.nn.layer')
+    nn.layer = layer
+    norm = mod('paddle.nn.layer.norm')
+    layer.norm = norm
+    norm._BatchNormBase = _BatchNormBase
+
+    dist = mod('paddle.distributed')
+    paddle.distributed = dist
+    dist.get_world_size = lambda: 1
+    dist.get_rank = lambda: 0
+
+    class ParallelEnv:
+        local_rank = 0
+        nranks = 1
+    dist.ParallelEnv = ParallelEnv
+
+    fluid = mod('paddle.fluid')
+    paddle.fluid = fluid
+    fl = mod('paddle.fluid.layers')
+    fluid.layers = fl
+    fl.l2_normalize = lambda x, axis: _normalize(x, axis=axis)
+    fl.squeeze = lambda x, axes: x
+
+    utils = mod('paddle.utils')
+    paddle.utils = utils
+    dl = mod('paddle.utils.download')
+    utils.download = dl
+    dl.get_weights_path_from_url = lambda *a, **k: None
+
+    vision = mod('paddle.vision')
+    paddle.vision = vision
+    models = mod('paddle.vision.models')
+    vision.models = models
+    resnet = mod('paddle.vision.models.resnet')
+    models.resnet = resnet
+    return paddle
+
+
+def bind_vision_resnet(resnetimagenet_module):
+    """paddle.vision.models.ResNet := the reference's vendored copy
+    (passl_v110/modeling/backbones/resnetimagenet.py)."""
+    models = sys.modules['paddle.vision.models']
+    resnet = sys.modules['paddle.vision.models.resnet']
+    for n in ('ResNet', 'BasicBlock', 'BottleneckBlock'):
+        setattr(resnet, n, getattr(resnetimagenet_module, n))
+    models.ResNet = resnetimagenet_module.ResNet

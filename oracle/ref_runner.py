@@ -1,0 +1,127 @@
+"""Run the reference's *own* MoCo-v2 sources on torch-CPU through the paddle
+shim.  TEST INFRASTRUCTURE ONLY; needs /root/reference (build container only —
+nothing on the GPU box imports this module).
+
+The reference files are imported where they lie (never copied).  Package
+``__init__`` files are bypassed (they import every backbone / dataset in the
+tree, most of which need far more of Paddle than the shim offers): empty
+package objects with the right ``__path__`` are pre-seeded in ``sys.modules`` and
+only the files on the hot path are executed:
+
+    utils/registry.py  modules/init.py  modules/freeze.py
+    modeling/backbones/{builder,resnetimagenet,resnet}.py
+    modeling/necks/{builder,base_neck}.py
+    modeling/heads/{builder,contrastive_head}.py
+    modeling/architectures/{builder,moco}.py
+"""
+import importlib
+import os
+import sys
+import types
+
+REF_ROOT = os.environ.get('PASSL_REFERENCE', '/root/reference')
+PKG = 'refpassl'
+
+
+def available():
+    return os.path.isdir(os.path.join(REF_ROOT, 'passl_v110'))
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    m.__package__ = name
+    sys.modules[name] = m
+    return m
+
+
+def load():
+    """Returns a namespace with the reference's MoCo, ContrastiveHead, ... classes."""
+    if PKG + '.modeling.architectures.moco' in sys.modules:
+        return _namespace()
+    from . import paddle_shim
+    paddle_shim.install()
+    base = os.path.join(REF_ROOT, 'passl_v110')
+    _pkg(PKG, base)
+    for sub in ('utils', 'modules', 'modeling', 'modeling/backbones', 'modeling/necks',
+                'modeling/heads', 'modeling/architectures'):
+        _pkg(PKG + '.' + sub.replace('/', '.'), os.path.join(base, sub))
+    imp = importlib.import_module
+    # utils.logger needs paddle.distributed.ParallelEnv (shimmed)
+    imp(PKG + '.utils.registry')
+    imp(PKG + '.utils.logger')
+    # modules: `from ...modules import freeze_batchnorm_statictis`, `init`, `freeze`
+    modules = sys.modules[PKG + '.modules']
+    modules.init = imp(PKG + '.modules.init')
+    modules.freeze = imp(PKG + '.modules.freeze')
+    modules.freeze_batchnorm_statictis = modules.freeze.freeze_batchnorm_statictis
+    # backbones: vendored paddle.vision ResNet first, then bind it as paddle.vision.models.ResNet
+    rin = imp(PKG + '.modeling.backbones.resnetimagenet')
+    paddle_shim.bind_vision_resnet(rin)
+    bb = sys.modules[PKG + '.modeling.backbones']
+    bb.build_backbone = imp(PKG + '.modeling.backbones.builder').build_backbone
+    imp(PKG + '.modeling.backbones.resnet')
+    # architectures/builder.py:18 imports discrete_vae names it never uses on this path
+    dv = types.ModuleType(PKG + '.modeling.backbones.discrete_vae')
+    for n in ('Dalle_VAE', 'DiscreteVAE', 'load_model', 'Encoder', 'Decoder'):
+        setattr(dv, n, None)
+    sys.modules[dv.__name__] = dv
+    nk = sys.modules[PKG + '.modeling.necks']
+    nk.build_neck = imp(PKG + '.modeling.necks.builder').build_neck
+    imp(PKG + '.modeling.necks.base_neck')
+    hd = sys.modules[PKG + '.modeling.heads']
+    hd.build_head = imp(PKG + '.modeling.heads.builder').build_head
+    imp(PKG + '.modeling.heads.contrastive_head')
+    imp(PKG + '.modeling.architectures.builder')
+    imp(PKG + '.modeling.architectures.moco')
+    return _namespace()
+
+
+def _namespace():
+    ns = types.SimpleNamespace()
+    ns.moco = sys.modules[PKG + '.modeling.architectures.moco']
+    ns.MoCo = ns.moco.MoCo
+    ns.ContrastiveHead = sys.modules[PKG + '.modeling.heads.contrastive_head'].ContrastiveHead
+    ns.accuracy = sys.modules[PKG + '.modeling.heads.contrastive_head'].accuracy
+    ns.build_model = sys.modules[PKG + '.modeling.architectures.builder'].build_model
+    ns.registry = sys.modules[PKG + '.utils.registry']
+    ns.MODELS = sys.modules[PKG + '.modeling.architectures.builder'].MODELS
+    ns.BACKBONES = sys.modules[PKG + '.modeling.backbones.builder'].BACKBONES
+    ns.NECKS = sys.modules[PKG + '.modeling.necks.builder'].NECKS
+    ns.HEADS = sys.modules[PKG + '.modeling.heads.builder'].HEADS
+    return ns
+
+
+MOCO_V2_CFG = dict(
+    name='MoCo',
+    backbone=dict(name='ResNet', depth=50),
+    neck=dict(name='NonLinearNeckV1', in_channels=2048, hid_channels=2048,
+              out_channels=128, with_avg_pool=True),
+    head=dict(name='ContrastiveHead', temperature=0.2),
+)
+
+
+def build_reference_moco(K=65536, dim=128, m=0.999, T=0.2):
+    """MoCo built by the reference's registries from the configs/moco/moco_v2_r50.yaml
+    `model:` block (restated in MOCO_V2_CFG; T=0.2 there is the head temperature,
+    the architecture's own T default is unused by train_iter)."""
+    import copy
+    ns = load()
+    cfg = copy.deepcopy(MOCO_V2_CFG)
+    cfg.update(K=K, dim=dim, m=m)
+    cfg['head']['temperature'] = T
+    return ns.build_model(cfg)
+
+
+def load_oracle_state(model, oracle):
+    """Copy a MoCoOracle's q/k/queue state into a reference MoCo instance."""
+    import torch
+    with torch.no_grad():
+        for enc, st in (('encoder_q', oracle.q), ('encoder_k', oracle.k)):
+            sd = getattr(model, enc).state_dict()
+            assert list(sd.keys()) == list(st.keys()), 'state_dict key order differs'
+            for n, t in st.items():
+                assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)
+                sd[n].copy_(t.detach())
+        model.queue.copy_(oracle.queue)
+        model.queue_ptr[0] = oracle.queue_ptr

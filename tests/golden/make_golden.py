@@ -1,0 +1,107 @@
+"""Generate the golden vectors in tests/golden/*.npz by EXECUTING THE REFERENCE.
+
+Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+For each case the reference's own MoCo (passl_v110/modeling/architectures/moco.py
+built through its registries, see oracle/ref_runner.py) runs ``steps`` training
+iterations on torch-CPU through the paddle shim; the backward pass is torch
+autograd over the reference's forward graph and the Momentum update is
+oracle.moco.MoCoOracle.apply_momentum (Paddle's optimizer kernel is not in the
+reference tree).  Inputs and initial weights are seed-defined so that the GPU
+box can regenerate them without /root/reference:
+
+    weights/queue : oracle.moco.MoCoOracle(seed=0, K=K)
+    views         : torch.Generator().manual_seed(1234); per step x_q then x_k ~ N(0,1)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import ref_runner                      # noqa: E402
+from oracle.moco import MoCoOracle                 # noqa: E402
+
+CASES = {
+    # BASELINE.json configs[0]: MoCo-v2 R50, 2x224^2 views, bs=32, K=65536, 1 rank
+    'moco_v2_r50_cfg1': dict(N=32, hw=224, K=65536, steps=2),
+    # fast case for every-commit runs
+    'moco_v2_r50_small': dict(N=8, hw=64, K=1024, steps=3),
+}
+WATCH = ['0.conv1.weight', '0.layer1.0.conv2.weight', '0.layer2.0.downsample.0.weight',
+         '0.layer4.2.conv3.weight', '0.layer3.5.bn2.weight', '0.bn1.bias',
+         '1.mlp.0.weight', '1.mlp.2.weight', '1.mlp.2.bias']
+WATCH_STATS = ['0.bn1._mean', '0.bn1._variance', '0.layer4.2.bn3._mean',
+               '0.layer4.2.bn3._variance']
+
+
+def views(gen, N, hw):
+    xq = torch.randn(N, 3, hw, hw, generator=gen)
+    xk = torch.randn(N, 3, hw, hw, generator=gen)
+    return xq, xk
+
+
+def run_case(name, N, hw, K, steps):
+    torch.manual_seed(0)
+    oracle = MoCoOracle(K=K, seed=0, t_max=200 * 5004)
+    model = ref_runner.build_reference_moco(K=K)
+    ref_runner.load_oracle_state(model, oracle)
+    model.train()
+    captured = {}
+    model.head.register_forward_pre_hook(
+        lambda mod, args: captured.update(pos=args[0].detach().clone(),
+                                          neg=args[1].detach().clone()))
+    gen = torch.Generator().manual_seed(1234)
+    out = {}
+    for s in range(steps):
+        xq, xk = views(gen, N, hw)
+        ptr0 = int(model.queue_ptr[0])
+        for p in model.parameters():
+            p.grad = None
+        res = model(xq, xk, mode='train', total_iters=steps, current_iter=s + 1, mixup_fn=None)
+        res['loss'].backward()
+        qsd = dict(model.encoder_q.named_parameters())
+        grads = {n: qsd[n].grad.detach().clone() for n in qsd if qsd[n].requires_grad}
+        # Momentum step (restated) applied to the reference model's own parameters
+        oracle.q = {n: p.detach().clone() for n, p in model.encoder_q.state_dict().items()}
+        oracle.apply_momentum(grads)
+        with torch.no_grad():
+            for n, p in model.encoder_q.state_dict().items():
+                p.copy_(oracle.q[n])
+        ksd = model.encoder_k.state_dict()
+        pre = 's%d_' % s
+        out[pre + 'loss'] = np.float64(res['loss'].item())
+        out[pre + 'acc1'] = np.float64(float(res['acc1']))
+        out[pre + 'acc5'] = np.float64(float(res['acc5']))
+        logits = torch.cat((captured['pos'], captured['neg']), dim=1) / model.head.temperature
+        out[pre + 'logits_head'] = logits[:, :8].numpy().copy()
+        out[pre + 'logits_rowsum64'] = logits.double().sum(dim=1).numpy()
+        out[pre + 'logits_rowlse64'] = torch.logsumexp(logits.double(), dim=1).numpy()
+        out[pre + 'queue_ptr'] = np.int64(int(model.queue_ptr[0]))
+        out[pre + 'queue_new'] = model.queue[:, ptr0:ptr0 + N].detach().numpy().copy()
+        out[pre + 'queue_sum64'] = np.float64(model.queue.double().sum().item())
+        for n in WATCH:
+            out[pre + 'gradnorm/' + n] = np.float64(grads[n].double().norm().item())
+            out[pre + 'qnorm/' + n] = np.float64(oracle.q[n].double().norm().item())
+            out[pre + 'knorm/' + n] = np.float64(ksd[n].double().norm().item())
+            out[pre + 'kdot/' + n] = np.float64(
+                (ksd[n].double() * oracle.q[n].double()).sum().item())
+        for n in WATCH_STATS:
+            out[pre + 'qstat/' + n] = oracle.q[n][:8].numpy().astype(np.float64)
+            out[pre + 'kstat/' + n] = ksd[n][:8].numpy().astype(np.float64)
+        print(name, 'step', s, 'loss %.6f acc1 %.2f acc5 %.2f ptr %d' % (
+            out[pre + 'loss'], out[pre + 'acc1'], out[pre + 'acc5'], out[pre + 'queue_ptr']))
+    out['meta'] = np.array([N, hw, K, steps], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+
+
+if __name__ == '__main__':
+    assert ref_runner.available(), 'needs /root/reference'
+    which = sys.argv[1:] or list(CASES)
+    for name in which:
+        run_case(name, **CASES[name])
