@@ -1,0 +1,238 @@
+/*
+ * passl_hip.h — C ABI of libpassl_hip.so: the MI355X (gfx950) kernels behind the
+ * MoCo-v2 ResNet-50 data-parallel training step.
+ *
+ * PASSL (the reference) is 100 % Python and has NO FFI / operator boundary of its own:
+ * every op on the hot path is a PaddlePaddle call made from Python
+ * (SURVEY.md §8b).  This header therefore defines the boundary a maintainer would bind
+ * (ctypes — see INTEGRATION.md); each entry point cites the reference call site whose
+ * Paddle op(s) it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *   - every function enqueues work on `stream` (hipStream_t passed as void*) and returns
+ *     immediately: no allocation, no host synchronisation, graph-capture safe
+ *   - returns 0 on success, negative passl_status otherwise (argument errors are detected
+ *     before anything is launched)
+ *   - activations are NHWC ("channels-last"), channel count a multiple of 8;
+ *     `dtype` selects the arithmetic/storage type of activations and packed weights:
+ *     PASSL_F32 (exact-fp32 MFMA, parity runs) or PASSL_BF16 (bf16 storage, fp32 accumulate)
+ *   - master parameters, gradients, optimizer state, BN statistics, q/k/queue are fp32
+ */
+#ifndef PASSL_HIP_H_
+#define PASSL_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* passl_stream_t;
+
+enum passl_status {
+  PASSL_OK = 0,
+  PASSL_EINVAL = -1,       /* bad argument (null pointer, misaligned, unsupported shape) */
+  PASSL_ELAUNCH = -2,      /* hipLaunch failed */
+  PASSL_EUNSUPPORTED = -3  /* dtype/shape combination not built */
+};
+
+enum passl_dtype { PASSL_F32 = 0, PASSL_BF16 = 1 };
+
+int passl_hip_abi_version(void);
+/* Human readable text for a passl_status. */
+const char* passl_hip_strerror(int status);
+
+/* ---------------------------------------------------------------- flat-buffer ops */
+
+/* k[i] = k[i]*m + q[i]*(1-m) over a flat fp32 buffer; if k_lp != NULL also writes the bf16
+ * copy of the new k (the key encoder's compute weights).
+ * Replaces the 269 per-tensor paddle.assign launches of
+ * MoCo._momentum_update_key_encoder, passl_v110/modeling/architectures/moco.py:82-90. */
+int passl_hip_ema_update(float* k, const float* q, void* k_lp, int64_t n, float m,
+                         passl_stream_t stream);
+
+/* Momentum-SGD with L2 decay folded into the gradient, over flat fp32 buffers:
+ *   g' = g*grad_scale + wd*p;  v = mu*v + g';  p = p - lr*v
+ * Replaces paddle.optimizer.Momentum.step() called from
+ * passl_v110/hooks/optimizer_hook.py:43-47 (rule restated in-tree at
+ * passl/optimizer/momentum.py:150-158). */
+int passl_hip_momentum_sgd(float* p, const float* g, float* v, int64_t n, float lr, float mu,
+                           float wd, float grad_scale, passl_stream_t stream);
+
+/* dst_bf16[i] = bf16(src[i]) (round-to-nearest-even). */
+int passl_hip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, passl_stream_t stream);
+
+/* Weight (re)packing for the implicit-GEMM kernels.  One launch executes `n_jobs` jobs read
+ * from device memory; each job writes   dst[c][tr][ts][k] (or [k][tr][ts][c] when
+ * !transpose) = src[k][r_base + tr*r_step][s_base + ts*s_step][c]   from the fp32 master
+ * weights (physically [K][R][S][C]) into the compute-dtype buffer.  `jobs` is an array of
+ * passl_pack_job, `block_job`/`block_start` map each 256-thread block to (job, first element). */
+typedef struct passl_pack_job {
+  int64_t src_off;   /* element offset into src (fp32) */
+  int64_t dst_off;   /* element offset into dst (compute dtype) */
+  int32_t K, R, S, C;          /* source dims */
+  int32_t TR, TS;              /* taps kept */
+  int32_t r_base, r_step, s_base, s_step;
+  int32_t transpose;           /* 1: dst is [C][TR][TS][K]; 0: dst is [K][TR][TS][C] */
+  int32_t c_pad;               /* dst innermost-dim padding: dst C (or K) dim is c_pad wide (>= C), zero filled; 0 = no pad */
+} passl_pack_job;
+int passl_hip_pack_weights(const float* src, void* dst, int dtype, const passl_pack_job* jobs,
+                           const int32_t* block_job, const int32_t* block_start, int n_blocks,
+                           passl_stream_t stream);
+
+/* x fp32 NCHW [N,C,H,W] -> y NHWC [N, H+2*pad, Wp, Cp] in `dtype`, zero border / zero extra
+ * channels (Wp >= W+2*pad, Cp >= C).  The stem conv reads this padded image.
+ * Replaces the NCHW input handling of paddle.nn.Conv2D at
+ * passl_v110/modeling/backbones/resnetimagenet.py:190-195. */
+int passl_hip_nchw_to_nhwc_pad(const float* x, void* y, int N, int C, int H, int W, int pad,
+                               int Wp, int Cp, int dtype, passl_stream_t stream);
+
+/* ---------------------------------------------------------------- implicit-GEMM convolution */
+
+/* One descriptor drives forward convs, data-gradient convs (as convs over dy with repacked
+ * weights, optionally writing a strided sub-lattice of dx) and Linear layers (1x1, OP=OQ=1).
+ *
+ *   y[n,op,oq,col] = epi( sum_{r,s,c} A[n, op*sh + r - ph, oq*sw + s - pw, c] * B[col][r][s][c] )
+ *   epi(v) = relu?( v*scale[col] + shift[col] + residual[n,op,oq,col] )
+ *
+ * A is addressed with explicit element strides (a_sn,a_sh,a_sw; channel stride 1); taps
+ * outside [0,IH)x[0,IW) contribute zero.  B is [NCOLS][R*S*C] row-major in `dtype`.
+ * If C is not a multiple of the K-tile (64 bf16 / 32 fp32) the kernel decomposes k per
+ * 16-byte chunk (stem).  Output rows are addressed with (y_sn,y_sh,y_sw), channel stride 1.
+ * Replaces paddle.nn.Conv2D / nn.Linear forward+backward-data as used by
+ * resnetimagenet.py:114-131,190-198,216-224 and necks/base_neck.py:80-97. */
+typedef struct passl_conv_desc {
+  const void* a;
+  const void* b;
+  void* y;
+  const float* scale;      /* [NCOLS] or NULL (=1) */
+  const float* shift;      /* [NCOLS] or NULL (=0) */
+  const void* residual;    /* addressed like y, dtype = out dtype; or NULL */
+  float* stats;            /* reserved (fused BN partial sums), must be NULL */
+  int32_t N, OP, OQ;       /* M = N*OP*OQ */
+  int32_t NCOLS;
+  int32_t R, S, C;
+  int32_t IH, IW;
+  int32_t sh, sw, ph, pw;
+  int64_t a_sn, a_sh, a_sw;
+  int64_t y_sn, y_sh, y_sw;
+  int32_t relu;
+  int32_t dtype;           /* passl_dtype of A, B */
+  int32_t out_f32;         /* 1: y (and residual) are fp32 regardless of dtype */
+} passl_conv_desc;
+int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream);
+
+/* Weight gradient:  dw[col][r][s][c] += sum_{n,op,oq} dy[n,op,oq,col] * A[n, op*sh+r-ph, oq*sw+s-pw, c]
+ * dw is fp32 [NCOLS][R*S*C] and is ACCUMULATED into (atomics; caller zeroes it).
+ * dy is [M][NCOLS] dense (row stride dy_ld elements).  `splits` = number of M-slices (>=1).
+ * Replaces Conv2D/Linear backward-filter (autograd of the call sites above). */
+typedef struct passl_wgrad_desc {
+  const void* a;
+  const void* dy;
+  float* dw;
+  int32_t N, OP, OQ;
+  int32_t NCOLS;
+  int32_t R, S, C;
+  int32_t IH, IW;
+  int32_t sh, sw, ph, pw;
+  int64_t a_sn, a_sh, a_sw;
+  int64_t dy_ld;
+  int32_t dtype;
+  int32_t splits;
+} passl_wgrad_desc;
+int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t stream);
+
+/* ---------------------------------------------------------------- BatchNorm (+ReLU, +residual) */
+
+/* Training-mode BN over NHWC rows x[M][C].  Three launches:
+ *  stats:     partial[b][c][0..1] = sum, sum of squares over the b-th row slab   (nblocks slabs)
+ *  finalize:  mean/invstd (biased var, eps), scale=gamma*invstd, shift=beta-mean*scale,
+ *             running = momentum*running + (1-momentum)*batch   [Paddle: momentum 0.9, biased var]
+ *  apply:     z = relu?( x*scale + shift + residual )
+ * Replaces paddle.nn.BatchNorm2D + ReLU (+ `out += identity`) at
+ * resnetimagenet.py:133-153,196-197,236-238. */
+int passl_hip_bn_stats(const void* x, float* partial, int64_t M, int C, int nblocks, int dtype,
+                       passl_stream_t stream);
+int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t M, int C, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale,
+                          float* shift, passl_stream_t stream);
+int passl_hip_bn_apply(const void* x, const float* scale, const float* shift, const void* residual,
+                       void* z, int64_t M, int C, int relu, int dtype, passl_stream_t stream);
+/* Backward.  g = dz * (z > 0 if relu);   reduce: partial[b][c] = (sum g, sum g*xhat);
+ * finalize: dgamma += .., dbeta += .. (accumulated) and the per-channel coefficients (A,B,Cc)
+ *           of dx = A*g + B*x + Cc;
+ * apply: writes dx and, if dres != NULL, dres = g (gradient of the residual branch). */
+int passl_hip_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean,
+                            const float* invstd, float* partial, int64_t M, int C, int nblocks,
+                            int relu, int dtype, passl_stream_t stream);
+int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int64_t M, int C,
+                              const float* gamma, const float* mean, const float* invstd,
+                              float* dgamma, float* dbeta, float* coef /* [3][C] */,
+                              passl_stream_t stream);
+int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* coef,
+                           void* dx, void* dres, int64_t M, int C, int relu, int dtype,
+                           passl_stream_t stream);
+
+/* ---------------------------------------------------------------- pooling */
+
+/* 3x3 stride-2 pad-1 max pool, NHWC; idx[n,p,q,c] (uint8) = winning tap r*3+s (first max in
+ * row-major window order).  Replaces nn.MaxPool2D at resnetimagenet.py:198,239. */
+int passl_hip_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C,
+                               int dtype, passl_stream_t stream);
+int passl_hip_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W,
+                               int C, int dtype, passl_stream_t stream);
+/* Global average pool [N,HW,C] -> [N,C] and its backward.  Replaces AdaptiveAvgPool2D((1,1)) at
+ * necks/base_neck.py:79,94. */
+int passl_hip_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype,
+                          passl_stream_t stream);
+int passl_hip_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype,
+                          passl_stream_t stream);
+/* out[c] = sum_m x[m][c] (fp32 out) — Linear bias gradient. */
+int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype, passl_stream_t stream);
+
+/* ---------------------------------------------------------------- contrastive head */
+
+/* y = x / max(||x||_2, eps) per row (fp32), saves the clamped norm.
+ * Replaces F.normalize(axis=1) at moco.py:159,170. */
+int passl_hip_l2norm_fwd(const float* x, float* y, float* norm, int N, int D, float eps,
+                         passl_stream_t stream);
+/* dx = (dy - y*(y.dy)) / norm ; written as fp32 (dtype F32) or bf16. */
+int passl_hip_l2norm_bwd(const float* dy, const float* y, const float* norm, void* dx, int N,
+                         int D, int dtype, passl_stream_t stream);
+
+/* Fused InfoNCE forward (moco.py:178-180 + heads/contrastive_head.py:47-78):
+ *   l_pos[i] = q[i].k[i];  l_neg[i][j] = q[i].queue[:,j];  logits = [l_pos | l_neg]/T
+ *   loss = mean_i( logsumexp(logits[i]) - logits[i][0] ),  acc1/acc5 = % rows whose column 0
+ *   has rank < 1 / < 5 among strictly greater logits.
+ * q,k: [N][D] fp32, queue: [D][K] fp32 (dim-major, as the reference stores it).
+ * Outputs: out[0..2] = loss, acc1, acc5; row_lse[N]; optional logits [N][K+1] (may be NULL).
+ * workspace: >= passl_hip_infonce_workspace_bytes(N,K) bytes. D must be 128, K % 128 == 0. */
+int64_t passl_hip_infonce_workspace_bytes(int N, int K);
+int passl_hip_infonce_fwd(const float* q, const float* k, const float* queue, int N, int D, int K,
+                          float T, float* out, float* row_lse, float* logits, void* workspace,
+                          passl_stream_t stream);
+/* dq[i] = gscale/(N*T) * ( (p_i0 - 1)*k[i] + sum_j p_ij * queue[:,j] ),  p = softmax(logits).
+ * dq must be zeroed by the caller (accumulated with atomics). `gscale` device pointer to the
+ * upstream scalar gradient (or NULL = 1). */
+int passl_hip_infonce_bwd(const float* q, const float* k, const float* queue,
+                          const float* row_lse, const float* gscale, int N, int D, int K, float T,
+                          float* dq, passl_stream_t stream);
+/* queue[:, ptr:ptr+B] = keys^T  (keys [B][D]).  Replaces the slice-assign of
+ * MoCo._dequeue_and_enqueue, moco.py:101-102 (the pointer arithmetic stays on the host). */
+int passl_hip_enqueue(float* queue, const float* keys, int D, int K, int ptr, int B,
+                      passl_stream_t stream);
+
+/* ---------------------------------------------------------------- measurement hooks */
+
+/* When enabled, every passl_hip_conv_igemm / passl_hip_conv_wgrad launch is bracketed by HIP
+ * events on its own stream; passl_hip_prof_collect synchronises those events and returns the
+ * accumulated kernel time (ms) and launch count per kernel class (0 = igemm, 1 = wgrad). */
+int passl_hip_prof_enable(int on);
+int passl_hip_prof_collect(int kernel_class, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASSL_HIP_H_ */

@@ -1,0 +1,325 @@
+// Training-mode BatchNorm (+ReLU, +residual add) over NHWC rows x[M][C], forward and backward.
+// HBM-bound streaming kernels.  Per-channel reductions are two-level: each block reduces a row
+// slab in registers + LDS and writes a partial (no atomics, deterministic); a small finalize
+// kernel combines the partials in fp64.
+//
+// Algorithmic bytes per activation (bf16): stats 2, apply 4 (+2 with residual),
+// bwd_reduce 6, bwd_apply 8 (+2 with residual).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// Thread layout for the reductions: the C/8 "chunk columns" (8 channels = one 16 B bf16 vector)
+// are spread over threadIdx % cols; the remaining threads stride over rows.
+// C/8 may exceed 256 (not on this path: C <= 2048) -> column loop.
+
+template <typename T, int MODE>
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat) with g = dz * (z>0 | 1)
+__global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dz, const T* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
+    int64_t M, int C, int rows_per_block, int relu) {
+  extern __shared__ float red[];  // [kThreads][16]
+  const int cols = C >> 3;
+  const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+  int64_t row1 = row0 + rows_per_block;
+  if (row1 > M) row1 = M;
+  for (int cbase = 0; cbase < cols; cbase += kThreads) {
+    const int ncol = (cols - cbase) < kThreads ? (cols - cbase) : kThreads;  // columns this pass
+    const int lanes = kThreads / ncol;                                        // row lanes (>=1)
+    const int col = cbase + (threadIdx.x % ncol);
+    const int rl = threadIdx.x / ncol;
+    float a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+    float mu[8], is[8];
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mu[e] = mean[col * 8 + e]; is[e] = invstd[col * 8 + e]; }
+    }
+    if (rl < lanes) {
+      for (int64_t r = row0 + rl; r < row1; r += lanes) {
+        float v[8];
+        ElemTraits<T>::load8(x + r * C + col * 8, v);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a0[e] += v[e]; a1[e] += v[e] * v[e]; }
+        } else {
+          float g[8];
+          ElemTraits<T>::load8(dz + r * C + col * 8, g);
+          if (relu) {
+            float zz[8];
+            ElemTraits<T>::load8(z + r * C + col * 8, zz);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { a0[e] += g[e]; a1[e] += g[e] * (v[e] - mu[e]) * is[e]; }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[threadIdx.x * 16 + e] = a0[e];
+      red[threadIdx.x * 16 + 8 + e] = a1[e];
+    }
+    __syncthreads();
+    // thread t < ncol sums its column over the row lanes
+    if (threadIdx.x < ncol) {
+      float s0[8], s1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+      for (int l = 0; l < lanes; ++l) {
+        const int t = l * ncol + threadIdx.x;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] += red[t * 16 + e]; s1[e] += red[t * 16 + 8 + e]; }
+      }
+      float* o = partial + ((int64_t)blockIdx.x * C + col * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { o[e * 2] = s0[e]; o[e * 2 + 1] = s1[e]; }
+    }
+  }
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per channel (4 channels per 256-thread block); fp64 combine of the partials
+__global__ void __launch_bounds__(kThreads) bn_finalize_kernel(
+    const float* __restrict__ partial, int nblocks, int64_t M, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
+    float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = lane; b < nblocks; b += 64) {
+    const float2 p = *reinterpret_cast<const float2*>(partial + ((int64_t)b * C + c) * 2);
+    s += (double)p.x;
+    ss += (double)p.y;
+  }
+  s = wave_sum_f64(s);
+  ss = wave_sum_f64(ss);
+  if (lane != 0) return;
+  const double mu = s / (double)M;
+  double var = ss / (double)M - mu * mu;   // biased
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mu * sc;
+  if (rmean) {
+    rmean[c] = momentum * rmean[c] + (1.0f - momentum) * (float)mu;
+    rvar[c] = momentum * rvar[c] + (1.0f - momentum) * (float)var;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int nblocks, int64_t M, int C,
+    const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ coef) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int b = lane; b < nblocks; b += 64) {
+    const float2 p = *reinterpret_cast<const float2*>(partial + ((int64_t)b * C + c) * 2);
+    sg += (double)p.x;
+    sgx += (double)p.y;
+  }
+  sg = wave_sum_f64(sg);
+  sgx = wave_sum_f64(sgx);
+  if (lane != 0) return;
+  dbeta[c] += (float)sg;      // accumulate: the flat gradient buffer is zeroed by clear_grad()
+  dgamma[c] += (float)sgx;
+  // dx = gamma*invstd*( g - sg/M - xhat*sgx/M ),  xhat = (x-mean)*invstd
+  const double gi = (double)gamma[c] * (double)invstd[c];
+  const double A = gi;
+  const double B = -gi * (double)invstd[c] * sgx / (double)M;
+  const double Cc = -gi * sg / (double)M - B * (double)mean[c];
+  coef[c] = (float)A;
+  coef[C + c] = (float)B;
+  coef[2 * C + c] = (float)Cc;
+}
+
+// z = relu?(x*scale + shift + res)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict__ x,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const T* __restrict__ res,
+                                                            T* __restrict__ z, int64_t nchunks,
+                                                            int cols, int relu) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
+    const int col = (int)(i % cols);
+    float v[8];
+    ElemTraits<T>::load8(x + i * 8, v);
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + col * 8);
+    const float4 s1 = *reinterpret_cast<const float4*>(scale + col * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(shift + col * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(shift + col * 8 + 4);
+    v[0] = v[0] * s0.x + b0.x; v[1] = v[1] * s0.y + b0.y;
+    v[2] = v[2] * s0.z + b0.z; v[3] = v[3] * s0.w + b0.w;
+    v[4] = v[4] * s1.x + b1.x; v[5] = v[5] * s1.y + b1.y;
+    v[6] = v[6] * s1.z + b1.z; v[7] = v[7] * s1.w + b1.w;
+    if (res) {
+      float r[8];
+      ElemTraits<T>::load8(res + i * 8, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    ElemTraits<T>::store8(z + i * 8, v);
+  }
+}
+
+// dx = A*g + B*x + Cc ; dres = g
+template <typename T>
+__global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(
+    const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ x,
+    const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres, int64_t nchunks,
+    int cols, int C, int relu) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
+    const int col = (int)(i % cols);
+    float g[8], v[8];
+    ElemTraits<T>::load8(dz + i * 8, g);
+    ElemTraits<T>::load8(x + i * 8, v);
+    if (relu) {
+      float zz[8];
+      ElemTraits<T>::load8(z + i * 8, zz);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+    }
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = col * 8 + e;
+      o[e] = coef[c] * g[e] + coef[C + c] * v[e] + coef[2 * C + c];
+    }
+    ElemTraits<T>::store8(dx + i * 8, o);
+    if (dres) ElemTraits<T>::store8(dres + i * 8, g);
+  }
+}
+
+static inline int grid_for(int64_t n) {
+  int64_t b = (n + kThreads - 1) / kThreads;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, ...)                          \
+  if ((dtype) == PASSL_BF16) { using T = bf16_t; __VA_ARGS__ } \
+  else if ((dtype) == PASSL_F32) { using T = float; __VA_ARGS__ } \
+  else return PASSL_EUNSUPPORTED;
+
+extern "C" int passl_hip_bn_stats(const void* x, float* partial, int64_t M, int C, int nblocks,
+                                  int dtype, passl_stream_t stream) {
+  if (!x || !partial || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || !aligned16(x))
+    return PASSL_EINVAL;
+  const int rows = (int)((M + nblocks - 1) / nblocks);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(nblocks), dim3(kThreads),
+                                           kThreads * 16 * sizeof(float), as_stream(stream),
+                                           reinterpret_cast<const T*>(x), nullptr, nullptr, nullptr,
+                                           nullptr, partial, M, C, rows, 0);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t M, int C,
+                                     const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float momentum, float eps, float* mean,
+                                     float* invstd, float* scale, float* shift,
+                                     passl_stream_t stream) {
+  if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || M <= 0 || C <= 0 ||
+      nblocks <= 0 || (running_mean && !running_var))
+    return PASSL_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(kThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, gamma, beta, running_mean, running_var, momentum, eps,
+                     mean, invstd, scale, shift);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_apply(const void* x, const float* scale, const float* shift,
+                                  const void* residual, void* z, int64_t M, int C, int relu,
+                                  int dtype, passl_stream_t stream) {
+  if (!x || !scale || !shift || !z || M <= 0 || C <= 0 || (C & 7) || !aligned16(x) ||
+      !aligned16(z) || (residual && !aligned16(residual)) || !aligned16(scale) || !aligned16(shift))
+    return PASSL_EINVAL;
+  const int64_t nchunks = M * (C >> 3);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(nchunks)),
+                                           dim3(kThreads), 0, as_stream(stream),
+                                           reinterpret_cast<const T*>(x), scale, shift,
+                                           reinterpret_cast<const T*>(residual),
+                                           reinterpret_cast<T*>(z), nchunks, C >> 3, relu);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_bwd_reduce(const void* dz, const void* z, const void* x,
+                                       const float* mean, const float* invstd, float* partial,
+                                       int64_t M, int C, int nblocks, int relu, int dtype,
+                                       passl_stream_t stream) {
+  if (!dz || !x || !mean || !invstd || !partial || (relu && !z) || M <= 0 || C <= 0 || (C & 7) ||
+      nblocks <= 0 || !aligned16(dz) || !aligned16(x) || (z && !aligned16(z)))
+    return PASSL_EINVAL;
+  const int rows = (int)((M + nblocks - 1) / nblocks);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(nblocks), dim3(kThreads),
+                                           kThreads * 16 * sizeof(float), as_stream(stream),
+                                           reinterpret_cast<const T*>(x),
+                                           reinterpret_cast<const T*>(dz),
+                                           reinterpret_cast<const T*>(z), mean, invstd, partial, M,
+                                           C, rows, relu);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int64_t M, int C,
+                                         const float* gamma, const float* mean,
+                                         const float* invstd, float* dgamma, float* dbeta,
+                                         float* coef, passl_stream_t stream) {
+  if (!partial || !gamma || !mean || !invstd || !dgamma || !dbeta || !coef || M <= 0 || C <= 0 ||
+      nblocks <= 0)
+    return PASSL_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(kThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, gamma, mean, invstd, dgamma, dbeta, coef);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void* x,
+                                      const float* coef, void* dx, void* dres, int64_t M, int C,
+                                      int relu, int dtype, passl_stream_t stream) {
+  if (!dz || !x || !coef || !dx || (relu && !z) || M <= 0 || C <= 0 || (C & 7) ||
+      !aligned16(dz) || !aligned16(x) || !aligned16(dx) || (z && !aligned16(z)) ||
+      (dres && !aligned16(dres)))
+    return PASSL_EINVAL;
+  const int64_t nchunks = M * (C >> 3);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(nchunks)),
+                                           dim3(kThreads), 0, as_stream(stream),
+                                           reinterpret_cast<const T*>(dz),
+                                           reinterpret_cast<const T*>(z),
+                                           reinterpret_cast<const T*>(x), coef,
+                                           reinterpret_cast<T*>(dx), reinterpret_cast<T*>(dres),
+                                           nchunks, C >> 3, C, relu);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}

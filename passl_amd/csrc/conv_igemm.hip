@@ -1,0 +1,377 @@
+// Implicit-GEMM convolution for gfx950 (MFMA), NHWC activations x [K][R][S][C] weights.
+//
+//   Y[m][col] = epi( sum_k A[m][k] * B[col][k] ),  m = (n,op,oq), k = (r,s,c) with c fastest
+//
+// One kernel serves forward convs, data-gradient convs (conv over dy with repacked weights,
+// optionally writing a strided sub-lattice of dx) and Linear layers.
+//
+// Tiling (per 256-thread workgroup = 4 waves, 2x2):
+//   block tile  BM x BN  (128x128 or 128x64), K-tile = 128 BYTES of k per row
+//               (64 bf16 / 32 fp32 elements) so the staging code is dtype independent
+//   wave tile   64 x BN/2  =  4 x (BN/32) MFMA 16x16 accumulator fragments
+//   bf16: v_mfma_f32_16x16x32_bf16 (2 k-steps / tile);  fp32: v_mfma_f32_16x16x4_f32 (8 k-steps)
+// LDS: double-buffered A and B tiles, rows of 8 x 16-byte slots, slot index XOR-swizzled with
+//   (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct slots of the 256-byte
+//   bank row (conflict-free), global->register->LDS staging with the next tile's loads issued
+//   before the current tile's MFMAs (one barrier per K-tile).
+// Epilogue: accumulators -> LDS (fp32) -> coalesced 16/32-byte row stores with the fused
+//   per-channel affine (BatchNorm in inference form), residual add and ReLU.
+// Grid: one workgroup per output tile, N-tiles fastest, remapped so that every XCD (private L2)
+//   walks a contiguous range of tiles: the N-tiles that share an A row-panel hit the same L2.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 128;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+struct Params {
+  const char* a;
+  const char* b;
+  char* y;
+  const float* scale;
+  const float* shift;
+  const char* res;
+  int M, NCOLS, KDIM;
+  int OP, OQ, R, S, C, IH, IW, sh, sw, ph, pw;
+  int64_t a_sn, a_sh, a_sw;
+  int64_t y_sn, y_sh, y_sw;
+  int relu, out_f32;
+  int tiles_n, ntiles;
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
+
+template <typename T, int BM, int BN, bool GENERIC>
+__global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
+  constexpr int ES = sizeof(T);
+  constexpr int VEC = 16 / ES;          // elements per 16-byte slot
+  constexpr int BK = kRowBytes / ES;    // elements per K-tile
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int ACH = BM * 8 / kThreads;  // A chunks per thread
+  constexpr int BCH = BN * 8 / kThreads;  // B chunks per thread
+  constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
+  constexpr int LDO = BN + 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [A0][A1][B0][B1] ; epilogue reuses the front as float out[BM][LDO]; row offsets at the end
+  char* As = smem;
+  char* Bs = smem + 2 * A_BYTES;
+  constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
+  constexpr int EPI_BYTES = BM * LDO * 4;
+  constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+  int64_t* rowoff = reinterpret_cast<int64_t*>(smem + MAIN_BYTES);
+
+  // ---- XCD-aware tile mapping (bijective for any ntiles)
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = p.ntiles >> 3, r = p.ntiles & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    tile = start + local;
+  }
+  const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int slot = tid & 7;
+  const int opq = p.OP * p.OQ;
+
+  // ---- per-thread A rows
+  int64_t a_base[ACH];
+  int ih0[ACH], iw0[ACH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    const int m = m0 + row;
+    if (m < p.M) {
+      const int n = m / opq;
+      const int rem = m - n * opq;
+      const int op = rem / p.OQ;
+      const int oq = rem - op * p.OQ;
+      a_base[i] = (int64_t)n * p.a_sn;
+      ih0[i] = op * p.sh - p.ph;
+      iw0[i] = oq * p.sw - p.pw;
+    } else {
+      a_base[i] = 0;
+      ih0[i] = -(1 << 28);
+      iw0[i] = 0;
+    }
+  }
+  // output row offsets (elements) for the epilogue; -1 = row out of range
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int64_t off = -1;
+    if (m < p.M) {
+      const int n = m / opq;
+      const int rem = m - n * opq;
+      const int op = rem / p.OQ;
+      const int oq = rem - op * p.OQ;
+      off = (int64_t)n * p.y_sn + (int64_t)op * p.y_sh + (int64_t)oq * p.y_sw;
+    }
+    rowoff[tid] = off;
+  }
+
+  uint4 ra[ACH], rb[BCH];
+  const int nk = (p.KDIM + BK - 1) / BK;
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    int r, s, c;
+    bool kvalid = true;
+    if (GENERIC) {
+      const int kc = k0 + slot * VEC;
+      kvalid = kc < p.KDIM;
+      const int rs = kc / p.C;
+      c = kc - rs * p.C;
+      r = rs / p.S;
+      s = rs - r * p.S;
+    } else {
+      const int rs = k0 / p.C;           // wave-uniform
+      c = k0 - rs * p.C + slot * VEC;
+      r = rs / p.S;
+      s = rs - r * p.S;
+    }
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int ih = ih0[i] + r, iw = iw0[i] + s;
+      const bool ok = kvalid && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        const int64_t off = a_base[i] + (int64_t)ih * p.a_sh + (int64_t)iw * p.a_sw + c;
+        v = *reinterpret_cast<const uint4*>(p.a + off * ES);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      const int col = n0 + (tid >> 3) + 32 * j;
+      const int kc = k0 + slot * VEC;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (col < p.NCOLS && kc < p.KDIM)
+        v = *reinterpret_cast<const uint4*>(p.b + ((int64_t)col * p.KDIM + kc) * ES);
+      rb[j] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      *reinterpret_cast<uint4*>(As + buf * A_BYTES + row * kRowBytes + (swz(row, slot) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      const int row = (tid >> 3) + 32 * j;
+      *reinterpret_cast<uint4*>(Bs + buf * B_BYTES + row * kRowBytes + (swz(row, slot) << 4)) = rb[j];
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int l15 = lane & 15, l4 = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* Ab = As + buf * A_BYTES;
+    const char* Bb = Bs + buf * B_BYTES;
+    if constexpr (ES == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = wm * WM + i * 16 + l15;
+          const uint4 v = *reinterpret_cast<const uint4*>(Ab + row * kRowBytes + (swz(row, ks * 4 + l4) << 4));
+          af[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int row = wn * WN + j * 16 + l15;
+          const uint4 v = *reinterpret_cast<const uint4*>(Bb + row * kRowBytes + (swz(row, ks * 4 + l4) << 4));
+          bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        float af[FM], bfr[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = wm * WM + i * 16 + l15;
+          af[i] = *reinterpret_cast<const float*>(Ab + row * kRowBytes + (swz(row, ks) << 4) + (l4 << 2));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int row = wn * WN + j * 16 + l15;
+          bfr[j] = *reinterpret_cast<const float*>(Bb + row * kRowBytes + (swz(row, ks) << 4) + (l4 << 2));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue phase 1: accumulators -> LDS fp32 tile
+  float* out = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * WM + i * 16 + l4 * 4 + r;
+        const int col = wn * WN + j * 16 + l15;
+        out[row * LDO + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  // ---- phase 2: coalesced row stores, 8 columns per thread-chunk
+  constexpr int CPR = BN / 8;  // chunks per row
+#pragma unroll
+  for (int t = 0; t < BM * CPR / kThreads; ++t) {
+    const int chunk = tid + t * kThreads;
+    const int row = chunk / CPR, cc = chunk - row * CPR;
+    const int gcol = n0 + cc * 8;
+    const int64_t roff = rowoff[row];
+    if (roff < 0 || gcol >= p.NCOLS) continue;
+    float v[8];
+    const float4 v0 = *reinterpret_cast<const float4*>(out + row * LDO + cc * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(out + row * LDO + cc * 8 + 4);
+    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+    v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    if (p.scale) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.scale[gcol + e];
+    }
+    if (p.shift) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += p.shift[gcol + e];
+    }
+    const int64_t o = roff + gcol;
+    if (p.out_f32) {
+      if (p.res) {
+        float rr[8];
+        ElemTraits<float>::load8(reinterpret_cast<const float*>(p.res) + o, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      ElemTraits<float>::store8(reinterpret_cast<float*>(p.y) + o, v);
+    } else {
+      if (p.res) {
+        float rr[8];
+        ElemTraits<T>::load8(reinterpret_cast<const T*>(p.res) + o, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      ElemTraits<T>::store8(reinterpret_cast<T*>(p.y) + o, v);
+    }
+  }
+}
+
+template <typename T, int BM, int BN>
+int launch(const Params& p, bool generic, hipStream_t st) {
+  constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
+  constexpr int STAGE = 2 * (A_BYTES + B_BYTES);
+  constexpr int EPI = BM * (BN + 4) * 4;
+  constexpr int LDS = (STAGE > EPI ? STAGE : EPI) + BM * 8;
+  static bool attr_set[2] = {false, false};
+  if (generic) {
+    if (!attr_set[1]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr_set[1] = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, true>), dim3(p.ntiles), dim3(kThreads), LDS, st, p);
+  } else {
+    if (!attr_set[0]) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr_set[0] = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, false>), dim3(p.ntiles), dim3(kThreads), LDS, st, p);
+  }
+  return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream) {
+  if (!d || !d->a || !d->b || !d->y || d->stats) return PASSL_EINVAL;
+  if (d->N <= 0 || d->OP <= 0 || d->OQ <= 0 || d->NCOLS <= 0 || d->R <= 0 || d->S <= 0 ||
+      d->C <= 0 || d->IH <= 0 || d->IW <= 0)
+    return PASSL_EINVAL;
+  if (d->dtype != PASSL_F32 && d->dtype != PASSL_BF16) return PASSL_EUNSUPPORTED;
+  const int es = d->dtype == PASSL_BF16 ? 2 : 4;
+  const int vec = 16 / es, bk = 128 / es;
+  if ((d->C % vec) || (d->NCOLS & 7)) return PASSL_EINVAL;
+  if ((d->a_sn % vec) || (d->a_sh % vec) || (d->a_sw % vec)) return PASSL_EINVAL;
+  if ((d->y_sn & 7) || (d->y_sh & 7) || (d->y_sw & 7)) return PASSL_EINVAL;
+  if (!aligned16(d->a) || !aligned16(d->b) || !aligned16(d->y) ||
+      (d->residual && !aligned16(d->residual)) || (d->scale && !aligned16(d->scale)) ||
+      (d->shift && !aligned16(d->shift)))
+    return PASSL_EINVAL;
+  const int64_t M64 = (int64_t)d->N * d->OP * d->OQ;
+  const int64_t K64 = (int64_t)d->R * d->S * d->C;
+  if (M64 > 0x7fffffff || K64 > 0x7fffffff) return PASSL_EINVAL;
+
+  Params p;
+  p.a = reinterpret_cast<const char*>(d->a);
+  p.b = reinterpret_cast<const char*>(d->b);
+  p.y = reinterpret_cast<char*>(d->y);
+  p.scale = d->scale; p.shift = d->shift;
+  p.res = reinterpret_cast<const char*>(d->residual);
+  p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
+  p.OP = d->OP; p.OQ = d->OQ; p.R = d->R; p.S = d->S; p.C = d->C;
+  p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
+  p.a_sn = d->a_sn; p.a_sh = d->a_sh; p.a_sw = d->a_sw;
+  p.y_sn = d->y_sn; p.y_sh = d->y_sh; p.y_sw = d->y_sw;
+  p.relu = d->relu; p.out_f32 = d->out_f32;
+  const bool generic = (d->C % bk) != 0;
+  const bool narrow = d->NCOLS <= 64;
+  const int bn = narrow ? 64 : 128;
+  p.tiles_n = (d->NCOLS + bn - 1) / bn;
+  const int tiles_m = (p.M + 127) / 128;
+  p.ntiles = tiles_m * p.tiles_n;
+  hipStream_t st = as_stream(stream);
+  passl_prof_begin(0, st);
+  int rc;
+  if (d->dtype == PASSL_BF16)
+    rc = narrow ? launch<bf16_t, 128, 64>(p, generic, st) : launch<bf16_t, 128, 128>(p, generic, st);
+  else
+    rc = narrow ? launch<float, 128, 64>(p, generic, st) : launch<float, 128, 128>(p, generic, st);
+  passl_prof_end(0, st);
+  return rc;
+}

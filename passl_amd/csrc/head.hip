@@ -1,0 +1,369 @@
+// MoCo contrastive head on gfx950: row L2-normalise, fused InfoNCE (positive + 65 536 negatives,
+// online log-sum-exp, rank-of-positive accuracy) forward/backward, queue enqueue.
+// Everything here is fp32 (exact-fp32 MFMA v_mfma_f32_16x16x4_f32): the 1e-3 parity bound on
+// 65 537-way logits at T=0.2 does not survive bf16 operands.
+//
+// InfoNCE data flow.  queue is [D=128][K] (dim-major, as the reference stores it).  One workgroup
+// owns a 128-column slice of the queue, staged ONCE in LDS (64 KB), and sweeps all N query rows in
+// chunks of 64 (4 waves x 16 rows).  The MFMA is issued "swapped" — A = queue slice (m = column),
+// B = q (n = row) — so that each lane ends up with 32 logits of ONE row: the row max / sum-exp /
+// rank reductions are in-lane plus two wave shuffles (lanes l, l^16, l^32 share a row).
+// Per (slice,row) partials (max, sumexp, #greater) go to a workspace; a finalize kernel folds in
+// the positive logit and produces loss / acc1 / acc5 / row lse.  HBM traffic = the queue once
+// (33.5 MB) + optional logits (N x (K+1) x 4 B).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int D = 128;          // feature dim (fixed by the tiling)
+constexpr int BC = 128;         // queue columns per workgroup
+constexpr int PITCH = BC + 4;   // LDS row pitch in floats (16-byte aligned rows)
+constexpr int kLds = D * PITCH * 4;
+
+__device__ __forceinline__ float row_max4(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+__device__ __forceinline__ float row_sum4(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// stage queue[:, c0:c0+BC] into LDS as [D][PITCH]
+__device__ __forceinline__ void stage_queue(const float* __restrict__ queue, int K, int c0,
+                                            float* qs) {
+  // D*BC/4 = 4096 float4 chunks, 16 per thread; a row of BC floats = 32 chunks
+  for (int ch = threadIdx.x; ch < D * BC / 4; ch += kThreads) {
+    const int d = ch >> 5, cc = ch & 31;
+    const float4 v = *reinterpret_cast<const float4*>(queue + (int64_t)d * K + c0 + cc * 4);
+    *reinterpret_cast<float4*>(qs + d * PITCH + cc * 4) = v;
+  }
+}
+
+// S^T fragments for 16 rows: acc[j][r] = sum_d q[row=l15][d] * queue[d][col = j*16 + l4*4 + r]
+// lane (l15,l4) owns d in [l4*32, l4*32+32) for the k loop (same assignment for A and B).
+__device__ __forceinline__ void qk_scores(const float* qs, const float (&qreg)[32], int l15, int l4,
+                                          f32x4 (&acc)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    const float* rowp = qs + (l4 * 32 + ks) * PITCH + l15;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(rowp[j * 16], qreg[ks], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fully unrolled k loop from hoisting 256 LDS loads
+  }
+}
+
+__device__ __forceinline__ void load_q_rows(const float* __restrict__ q, int N, int row, int l4,
+                                            float (&qreg)[32]) {
+  if (row < N) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const float4 t = *reinterpret_cast<const float4*>(q + (int64_t)row * D + l4 * 32 + v * 4);
+      qreg[v * 4] = t.x; qreg[v * 4 + 1] = t.y; qreg[v * 4 + 2] = t.z; qreg[v * 4 + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < 32; ++v) qreg[v] = 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads, 2) infonce_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ queue,
+    int N, int K, float invT, float* __restrict__ part /* [nblk][N][4] */,
+    float* __restrict__ logits /* [N][K+1] or null */) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];
+  const int c0 = blockIdx.x * BC;
+  stage_queue(queue, K, c0, qs);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  for (int r0 = 0; r0 < N; r0 += 64) {
+    const int row = r0 + wave * 16 + l15;
+    float qreg[32];
+    load_q_rows(q, N, row, l4, qreg);
+    // positive similarity of this row (needed for the rank count)
+    float pos = 0.f;
+    if (row < N) {
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float4 t = *reinterpret_cast<const float4*>(k + (int64_t)row * D + l4 * 32 + v * 4);
+        pos += qreg[v * 4] * t.x + qreg[v * 4 + 1] * t.y + qreg[v * 4 + 2] * t.z + qreg[v * 4 + 3] * t.w;
+      }
+    }
+    pos = row_sum4(pos);
+    f32x4 acc[8];
+    qk_scores(qs, qreg, l15, l4, acc);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[j][r]);
+    mx = row_max4(mx);
+    float se = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        se += __expf((acc[j][r] - mx) * invT);
+        cnt += acc[j][r] > pos ? 1.f : 0.f;
+      }
+    se = row_sum4(se);
+    cnt = row_sum4(cnt);
+    if (row < N) {
+      if (l4 == 0) {
+        float* o = part + ((int64_t)blockIdx.x * N + row) * 4;
+        *reinterpret_cast<float4*>(o) = make_float4(mx * invT, se, cnt, 0.f);
+      }
+      if (logits) {
+        float* lr = logits + (int64_t)row * (K + 1) + 1 + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lr[j * 16 + l4 * 4 + r] = acc[j][r] * invT;
+      }
+    }
+  }
+}
+
+// one wave per row: combine partials + positive; block-level mean via atomics into out[0..2]
+__global__ void __launch_bounds__(kThreads) infonce_finalize_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ part,
+    int nblk, int N, int K, float invT, float* __restrict__ out, float* __restrict__ row_lse,
+    float* __restrict__ logits) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float pos = q[(int64_t)row * D + lane] * k[(int64_t)row * D + lane] +
+              q[(int64_t)row * D + 64 + lane] * k[(int64_t)row * D + 64 + lane];
+  pos = wave_sum(pos);
+  const float lp = pos * invT;
+  float mx = lp;
+  for (int b = lane; b < nblk; b += 64) mx = fmaxf(mx, part[((int64_t)b * N + row) * 4]);
+  mx = wave_max(mx);
+  float se = 0.f, cnt = 0.f;
+  for (int b = lane; b < nblk; b += 64) {
+    const float4 p = *reinterpret_cast<const float4*>(part + ((int64_t)b * N + row) * 4);
+    se += p.y * __expf(p.x - mx);
+    cnt += p.z;
+  }
+  se = wave_sum(se);
+  cnt = wave_sum(cnt);
+  se += __expf(lp - mx);
+  const float lse = mx + __logf(se);
+  if (lane == 0) {
+    row_lse[row] = lse;
+    if (logits) logits[(int64_t)row * (K + 1)] = lp;
+    const float invN = 1.0f / (float)N;
+    atomicAdd(out + 0, (lse - lp) * invN);
+    atomicAdd(out + 1, (cnt < 0.5f ? 100.f : 0.f) * invN);
+    atomicAdd(out + 2, (cnt < 4.5f ? 100.f : 0.f) * invN);
+  }
+}
+
+// dq += coef * ( sum_j p_ij queue[:,j]  [+ (p_i0 - 1) k_i  from block 0] )
+__global__ void __launch_bounds__(kThreads, 2) infonce_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ queue,
+    const float* __restrict__ row_lse, const float* __restrict__ gscale, int N, int K, float invT,
+    float* __restrict__ dq) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];
+  const int c0 = blockIdx.x * BC;
+  stage_queue(queue, K, c0, qs);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const float coef = (gscale ? *gscale : 1.0f) * invT / (float)N;
+  for (int r0 = 0; r0 < N; r0 += 64) {
+    const int row = r0 + wave * 16 + l15;
+    float qreg[32];
+    load_q_rows(q, N, row, l4, qreg);
+    const float lse = row < N ? row_lse[row] : 0.f;
+    f32x4 acc[8];
+    qk_scores(qs, qreg, l15, l4, acc);
+    // P[row=l15][col = j*16 + l4*4 + r], already in the A-operand layout of the second MFMA
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[j][r] = row < N ? __expf(acc[j][r] * invT - lse) * coef : 0.f;
+    // G[row][d] = sum_col P[row][col] * queue[d][col];  D layout: G[row = l4*4+r][d = jd*16 + l15]
+    f32x4 g[8];
+#pragma unroll
+    for (int jd = 0; jd < 8; ++jd) g[jd] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = j * 16 + l4 * 4 + r;
+#pragma unroll
+        for (int jd = 0; jd < 8; ++jd)
+          g[jd] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[j][r], qs[(jd * 16 + l15) * PITCH + col],
+                                                       g[jd], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+    for (int jd = 0; jd < 8; ++jd)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = r0 + wave * 16 + l4 * 4 + r;
+        if (orow < N) atomicAdd(dq + (int64_t)orow * D + jd * 16 + l15, g[jd][r]);
+      }
+    if (blockIdx.x == 0 && row < N) {
+      // positive term: (p_i0 - 1) * k_i ; lane (l15,l4) covers d in [l4*32, l4*32+32)
+      float pos = 0.f;
+      float kreg[32];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float4 t = *reinterpret_cast<const float4*>(k + (int64_t)row * D + l4 * 32 + v * 4);
+        kreg[v * 4] = t.x; kreg[v * 4 + 1] = t.y; kreg[v * 4 + 2] = t.z; kreg[v * 4 + 3] = t.w;
+      }
+#pragma unroll
+      for (int v = 0; v < 32; ++v) pos += qreg[v] * kreg[v];
+      pos = row_sum4(pos);
+      const float w = (__expf(pos * invT - lse) - 1.0f) * coef;
+#pragma unroll
+      for (int v = 0; v < 32; ++v) atomicAdd(dq + (int64_t)row * D + l4 * 32 + v, w * kreg[v]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) enqueue_kernel(float* __restrict__ queue,
+                                                           const float* __restrict__ keys, int Dd,
+                                                           int K, int ptr, int B) {
+  const int64_t total = (int64_t)Dd * B;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int b = (int)(i % B), d = (int)(i / B);
+    queue[(int64_t)d * K + ptr + b] = keys[(int64_t)b * Dd + d];
+  }
+}
+
+// one wave per row
+__global__ void __launch_bounds__(kThreads) l2norm_fwd_kernel(const float* __restrict__ x,
+                                                              float* __restrict__ y,
+                                                              float* __restrict__ norm, int N,
+                                                              int Dd, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float ss = 0.f;
+  for (int d = lane; d < Dd; d += 64) { const float v = x[(int64_t)row * Dd + d]; ss += v * v; }
+  ss = wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), eps);
+  const float inv = 1.0f / nrm;
+  for (int d = lane; d < Dd; d += 64) y[(int64_t)row * Dd + d] = x[(int64_t)row * Dd + d] * inv;
+  if (lane == 0) norm[row] = nrm;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) l2norm_bwd_kernel(const float* __restrict__ dy,
+                                                              const float* __restrict__ y,
+                                                              const float* __restrict__ norm,
+                                                              T* __restrict__ dx, int N, int Dd) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float dot = 0.f;
+  for (int d = lane; d < Dd; d += 64) dot += dy[(int64_t)row * Dd + d] * y[(int64_t)row * Dd + d];
+  dot = wave_sum(dot);
+  const float inv = 1.0f / norm[row];
+  for (int d = lane; d < Dd; d += 64) {
+    const int64_t o = (int64_t)row * Dd + d;
+    ElemTraits<T>::st(dx + o, (dy[o] - y[o] * dot) * inv);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t passl_hip_infonce_workspace_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (int64_t)(K / BC) * N * 4 * (int64_t)sizeof(float);
+}
+
+extern "C" int passl_hip_infonce_fwd(const float* q, const float* k, const float* queue, int N,
+                                     int Dd, int K, float T, float* out, float* row_lse,
+                                     float* logits, void* workspace, passl_stream_t stream) {
+  if (!q || !k || !queue || !out || !row_lse || !workspace || N <= 0 || Dd != D || K <= 0 ||
+      (K % BC) || !(T > 0.f) || !aligned16(q) || !aligned16(k) || !aligned16(queue) ||
+      !aligned16(workspace))
+    return PASSL_EINVAL;
+  hipStream_t st = as_stream(stream);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&infonce_fwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&infonce_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    attr = true;
+  }
+  if (hipMemsetAsync(out, 0, 3 * sizeof(float), st) != hipSuccess) return PASSL_ELAUNCH;
+  const int nblk = K / BC;
+  hipLaunchKernelGGL(infonce_fwd_kernel, dim3(nblk), dim3(kThreads), kLds, st, q, k, queue, N, K,
+                     1.0f / T, reinterpret_cast<float*>(workspace), logits);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(infonce_finalize_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, st, q, k,
+                     reinterpret_cast<const float*>(workspace), nblk, N, K, 1.0f / T, out, row_lse,
+                     logits);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_infonce_bwd(const float* q, const float* k, const float* queue,
+                                     const float* row_lse, const float* gscale, int N, int Dd,
+                                     int K, float T, float* dq, passl_stream_t stream) {
+  if (!q || !k || !queue || !row_lse || !dq || N <= 0 || Dd != D || K <= 0 || (K % BC) ||
+      !(T > 0.f) || !aligned16(q) || !aligned16(k) || !aligned16(queue))
+    return PASSL_EINVAL;
+  hipStream_t st = as_stream(stream);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&infonce_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(infonce_bwd_kernel, dim3(K / BC), dim3(kThreads), kLds, st, q, k, queue,
+                     row_lse, gscale, N, K, 1.0f / T, dq);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_enqueue(float* queue, const float* keys, int Dd, int K, int ptr, int B,
+                                 passl_stream_t stream) {
+  if (!queue || !keys || Dd <= 0 || K <= 0 || B <= 0 || ptr < 0 || ptr + B > K) return PASSL_EINVAL;
+  const int64_t total = (int64_t)Dd * B;
+  int grid = (int)((total + kThreads - 1) / kThreads);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(enqueue_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), queue, keys,
+                     Dd, K, ptr, B);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_l2norm_fwd(const float* x, float* y, float* norm, int N, int Dd, float eps,
+                                    passl_stream_t stream) {
+  if (!x || !y || !norm || N <= 0 || Dd <= 0) return PASSL_EINVAL;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, as_stream(stream), x,
+                     y, norm, N, Dd, eps);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_l2norm_bwd(const float* dy, const float* y, const float* norm, void* dx,
+                                    int N, int Dd, int dtype, passl_stream_t stream) {
+  if (!dy || !y || !norm || !dx || N <= 0 || Dd <= 0) return PASSL_EINVAL;
+  if (dtype == PASSL_F32)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<float>, dim3((N + 3) / 4), dim3(kThreads), 0,
+                       as_stream(stream), dy, y, norm, reinterpret_cast<float*>(dx), N, Dd);
+  else if (dtype == PASSL_BF16)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<bf16_t>, dim3((N + 3) / 4), dim3(kThreads), 0,
+                       as_stream(stream), dy, y, norm, reinterpret_cast<bf16_t*>(dx), N, Dd);
+  else
+    return PASSL_EUNSUPPORTED;
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}

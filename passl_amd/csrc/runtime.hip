@@ -1,0 +1,72 @@
+// ABI version, error strings and the event-based kernel timing hooks.
+#include <mutex>
+#include <vector>
+#include "common.h"
+#include "prof.h"
+
+namespace {
+struct Pair { hipEvent_t a, b; int cls; };
+bool g_on = false;
+std::mutex g_mu;
+std::vector<Pair> g_used;
+std::vector<Pair> g_free;
+Pair g_cur[2];
+bool g_open[2] = {false, false};
+double g_ms[2] = {0, 0};
+int64_t g_n[2] = {0, 0};
+}  // namespace
+
+void passl_prof_begin(int cls, hipStream_t st) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Pair p;
+  if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
+  else { (void)hipEventCreate(&p.a); (void)hipEventCreate(&p.b); }
+  p.cls = cls;
+  (void)hipEventRecord(p.a, st);
+  g_cur[cls] = p;
+  g_open[cls] = true;
+}
+
+void passl_prof_end(int cls, hipStream_t st) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_open[cls]) return;
+  (void)hipEventRecord(g_cur[cls].b, st);
+  g_used.push_back(g_cur[cls]);
+  g_open[cls] = false;
+}
+
+extern "C" int passl_hip_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_on = on != 0;
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_prof_collect(int cls, double* total_ms, int64_t* launches) {
+  if (cls < 0 || cls > 1 || !total_ms || !launches) return PASSL_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& p : g_used) {
+    (void)hipEventSynchronize(p.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_ms[p.cls] += ms; g_n[p.cls] += 1; }
+    g_free.push_back(p);
+  }
+  g_used.clear();
+  *total_ms = g_ms[cls];
+  *launches = g_n[cls];
+  g_ms[cls] = 0; g_n[cls] = 0;
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_abi_version(void) { return 1; }
+
+extern "C" const char* passl_hip_strerror(int status) {
+  switch (status) {
+    case PASSL_OK: return "ok";
+    case PASSL_EINVAL: return "invalid argument (null/misaligned pointer or unsupported shape)";
+    case PASSL_ELAUNCH: return "kernel launch failed";
+    case PASSL_EUNSUPPORTED: return "dtype/shape combination not built";
+    default: return "unknown status";
+  }
+}

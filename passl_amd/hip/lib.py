@@ -1,0 +1,140 @@
+"""ctypes binding of libpassl_hip.so (C ABI: include/passl_hip.h).
+
+The library is the product's compute path.  There is NO fallback: if it cannot be loaded or a
+tensor is not on a HIP device, calls raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libpassl_hip.so')
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_l = C.c_int64
+c_f = C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('a', c_p), ('b', c_p), ('y', c_p), ('scale', c_p), ('shift', c_p),
+                ('residual', c_p), ('stats', c_p),
+                ('N', C.c_int32), ('OP', C.c_int32), ('OQ', C.c_int32), ('NCOLS', C.c_int32),
+                ('R', C.c_int32), ('S', C.c_int32), ('C', C.c_int32),
+                ('IH', C.c_int32), ('IW', C.c_int32),
+                ('sh', C.c_int32), ('sw', C.c_int32), ('ph', C.c_int32), ('pw', C.c_int32),
+                ('a_sn', c_l), ('a_sh', c_l), ('a_sw', c_l),
+                ('y_sn', c_l), ('y_sh', c_l), ('y_sw', c_l),
+                ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('a', c_p), ('dy', c_p), ('dw', c_p),
+                ('N', C.c_int32), ('OP', C.c_int32), ('OQ', C.c_int32), ('NCOLS', C.c_int32),
+                ('R', C.c_int32), ('S', C.c_int32), ('C', C.c_int32),
+                ('IH', C.c_int32), ('IW', C.c_int32),
+                ('sh', C.c_int32), ('sw', C.c_int32), ('ph', C.c_int32), ('pw', C.c_int32),
+                ('a_sn', c_l), ('a_sh', c_l), ('a_sw', c_l), ('dy_ld', c_l),
+                ('dtype', C.c_int32), ('splits', C.c_int32)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [('src_off', c_l), ('dst_off', c_l),
+                ('K', C.c_int32), ('R', C.c_int32), ('S', C.c_int32), ('C', C.c_int32),
+                ('TR', C.c_int32), ('TS', C.c_int32),
+                ('r_base', C.c_int32), ('r_step', C.c_int32),
+                ('s_base', C.c_int32), ('s_step', C.c_int32),
+                ('transpose', C.c_int32), ('c_pad', C.c_int32)]
+
+
+# name -> (restype, argtypes); must list EVERY symbol declared in include/passl_hip.h
+SIGNATURES = {
+    'passl_hip_abi_version': (c_i, []),
+    'passl_hip_strerror': (C.c_char_p, [c_i]),
+    'passl_hip_ema_update': (c_i, [c_p, c_p, c_p, c_l, c_f, c_p]),
+    'passl_hip_momentum_sgd': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p]),
+    'passl_hip_cast_f32_to_bf16': (c_i, [c_p, c_p, c_l, c_p]),
+    'passl_hip_pack_weights': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p]),
+    'passl_hip_nchw_to_nhwc_pad': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_conv_igemm': (c_i, [C.POINTER(ConvDesc), c_p]),
+    'passl_hip_conv_wgrad': (c_i, [C.POINTER(WgradDesc), c_p]),
+    'passl_hip_bn_stats': (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_finalize': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p,
+                                    c_p, c_p, c_p]),
+    'passl_hip_bn_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_bwd_reduce': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_bwd_finalize': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'passl_hip_bn_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    'passl_hip_maxpool3x3s2_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_maxpool3x3s2_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_colsum': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
+    'passl_hip_l2norm_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
+    'passl_hip_l2norm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    'passl_hip_infonce_workspace_bytes': (c_l, [c_i, c_i]),
+    'passl_hip_infonce_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
+    'passl_hip_infonce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    'passl_hip_enqueue': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_prof_enable': (c_i, [c_i]),
+    'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),
+}
+
+_lib = None
+
+
+class PasslHipError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen the library and bind every symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise PasslHipError(
+            'libpassl_hip.so not found at %s — build it with `python -m passl_amd.csrc.build` '
+            '(the HIP path has no CPU fallback)' % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().passl_hip_strerror(rc).decode()
+        raise PasslHipError('%s failed: %s (status %d)' % (what or 'passl_hip call', msg, rc))
+
+
+def dt(t):
+    """passl_dtype code of a tensor / torch dtype."""
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise PasslHipError('unsupported dtype %s' % d)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: no CPU fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PasslHipError('passl_amd HIP op called with a %s tensor: the product path runs '
+                            'on MI355X only (no CPU fallback)' % t.device)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
