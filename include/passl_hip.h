@@ -189,6 +189,10 @@ int passl_hip_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtyp
                           passl_stream_t stream);
 int passl_hip_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dtype,
                           passl_stream_t stream);
+/* dx = dy * (y > 0), n elements (multiple of 8) — backward of the projector's ReLU
+ * (necks/base_neck.py:83). */
+int passl_hip_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype,
+                       passl_stream_t stream);
 /* out[c] = sum_m x[m][c] (fp32 out) — Linear bias gradient. */
 int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype, passl_stream_t stream);
 

@@ -182,6 +182,22 @@ __global__ void __launch_bounds__(kThreads) colsum_kernel(const T* __restrict__ 
   if (threadIdx.x < 8) out[c8 * 8 + threadIdx.x] = red[0][threadIdx.x];
 }
 
+// dx = dy * (y > 0)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) relu_bwd_kernel(const T* __restrict__ dy,
+                                                            const T* __restrict__ y,
+                                                            T* __restrict__ dx, int64_t nchunks) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
+    float g[8], v[8];
+    ElemTraits<T>::load8(dy + i * 8, g);
+    ElemTraits<T>::load8(y + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = v[e] > 0.f ? g[e] : 0.f;
+    ElemTraits<T>::store8(dx + i * 8, g);
+  }
+}
+
 static inline int grid_for(int64_t n) {
   int64_t b = (n + kThreads - 1) / kThreads;
   if (b > 4096) b = 4096;
@@ -273,6 +289,20 @@ extern "C" int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(C >> 3), dim3(kThreads), 0,
                                            as_stream(stream), reinterpret_cast<const T*>(x), out,
                                            M, C);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype,
+                                  passl_stream_t stream) {
+  if (!dy || !y || !dx || n <= 0 || (n & 7) || !aligned16(dy) || !aligned16(y) || !aligned16(dx))
+    return PASSL_EINVAL;
+  const int64_t nchunks = n >> 3;
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(grid_for(nchunks)),
+                                           dim3(kThreads), 0, as_stream(stream),
+                                           reinterpret_cast<const T*>(dy),
+                                           reinterpret_cast<const T*>(y),
+                                           reinterpret_cast<T*>(dx), nchunks);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

@@ -73,6 +73,7 @@ SIGNATURES = {
     'passl_hip_maxpool3x3s2_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_relu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_colsum': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
     'passl_hip_l2norm_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
     'passl_hip_l2norm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

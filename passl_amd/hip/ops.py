@@ -1,0 +1,260 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see functional.py).
+
+torch is used for device memory and the current stream only.  Every function launches HIP
+kernels from libpassl_hip.so; host tensors are refused (lib.ptr raises).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from . import plan as P
+
+
+def _lib():
+    return L.load()
+
+
+# ------------------------------------------------------------------ convolution
+_desc_cache = {}
+
+
+def _conv_struct(d: P.Desc):
+    key = id(d)
+    hit = _desc_cache.get(key)
+    if hit is not None and hit[0] is d:
+        return hit[1]
+    s = L.ConvDesc()
+    for f in ('N', 'OP', 'OQ', 'NCOLS', 'R', 'S', 'C', 'IH', 'IW', 'sh', 'sw', 'ph', 'pw',
+              'a_sn', 'a_sh', 'a_sw', 'y_sn', 'y_sh', 'y_sw'):
+        setattr(s, f, getattr(d, f))
+    s.stats = None
+    _desc_cache[key] = (d, s)
+    return s
+
+
+def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=False,
+               out_f32=False):
+    """Launch one implicit-GEMM conv described by `d` (plan.Desc).  `a` activation tensor,
+    `b` packed weights [NCOLS, R*S*C] (same dtype as a), `y` output tensor (written in place at
+    d.y_off with d's strides)."""
+    s = _conv_struct(d)
+    esz = 4 if out_f32 else y.element_size()
+    s.a = L.ptr(a)
+    s.b = L.ptr(b)
+    s.y = L.ptr(y) + d.y_off * esz
+    s.scale = L.ptr(scale)
+    s.shift = L.ptr(shift)
+    s.residual = (L.ptr(residual) + d.y_off * esz) if residual is not None else None
+    s.relu = 1 if relu else 0
+    s.dtype = L.dt(a)
+    s.out_f32 = 1 if out_f32 else 0
+    L.check(_lib().passl_hip_conv_igemm(C.byref(s), L.stream()), 'conv_igemm')
+    return y
+
+
+_wdesc_cache = {}
+
+
+def conv_wgrad(d: P.Desc, a, dy, dw, splits=None):
+    """dw[NCOLS, R*S*C] (fp32) += dy^T . gather(a)."""
+    key = id(d)
+    hit = _wdesc_cache.get(key)
+    if hit is not None and hit[0] is d:
+        s = hit[1]
+    else:
+        s = L.WgradDesc()
+        for f in ('N', 'OP', 'OQ', 'NCOLS', 'R', 'S', 'C', 'IH', 'IW', 'sh', 'sw', 'ph', 'pw',
+                  'a_sn', 'a_sh', 'a_sw'):
+            setattr(s, f, getattr(d, f))
+        _wdesc_cache[key] = (d, s)
+    s.a = L.ptr(a)
+    s.dy = L.ptr(dy)
+    s.dw = L.ptr(dw)
+    s.dy_ld = d.NCOLS
+    s.dtype = L.dt(a)
+    M = d.N * d.OP * d.OQ
+    bkm = 64 if a.dtype == torch.bfloat16 else 32
+    s.splits = splits or P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm)
+    L.check(_lib().passl_hip_conv_wgrad(C.byref(s), L.stream()), 'conv_wgrad')
+    return dw
+
+
+# ------------------------------------------------------------------ batch norm
+def _bn_blocks(M, Cch):
+    lanes = max(1, 256 // max(Cch // 8, 1))
+    return int(max(1, min(1024, -(-M // (16 * lanes)))))
+
+
+def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum=0.9, eps=1e-5):
+    """x: [..., C] NHWC rows.  Returns z, mean, invstd; updates rmean/rvar in place."""
+    Cch = x.shape[-1]
+    M = x.numel() // Cch
+    nb = _bn_blocks(M, Cch)
+    dev = x.device
+    partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
+    stats = torch.empty(4, Cch, dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+    lib, st, dtc = _lib(), L.stream(), L.dt(x)
+    L.check(lib.passl_hip_bn_stats(L.ptr(x), L.ptr(partial), M, Cch, nb, dtc, st), 'bn_stats')
+    L.check(lib.passl_hip_bn_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(beta),
+                                      L.ptr(rmean), L.ptr(rvar), momentum, eps,
+                                      L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
+                                      L.ptr(stats[3]), st), 'bn_finalize')
+    z = torch.empty_like(x)
+    L.check(lib.passl_hip_bn_apply(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(residual),
+                                   L.ptr(z), M, Cch, 1 if relu else 0, dtc, st), 'bn_apply')
+    return z, stats[0], stats[1]
+
+
+def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=False):
+    """Returns dx (and dres).  dgamma/dbeta (fp32 [C]) are accumulated into."""
+    Cch = x.shape[-1]
+    M = x.numel() // Cch
+    nb = _bn_blocks(M, Cch)
+    dev = x.device
+    partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
+    coef = torch.empty(3 * Cch, dtype=torch.float32, device=dev)
+    lib, st, dtc = _lib(), L.stream(), L.dt(x)
+    r = 1 if relu else 0
+    L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), L.ptr(z) if relu else None, L.ptr(x),
+                                        L.ptr(mean), L.ptr(invstd), L.ptr(partial), M, Cch, nb, r,
+                                        dtc, st), 'bn_bwd_reduce')
+    L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(mean),
+                                          L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
+                                          st), 'bn_bwd_finalize')
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    L.check(lib.passl_hip_bn_bwd_apply(L.ptr(dz), L.ptr(z) if relu else None, L.ptr(x),
+                                       L.ptr(coef), L.ptr(dx), L.ptr(dres), M, Cch, r, dtc, st),
+            'bn_bwd_apply')
+    return dx, dres
+
+
+# ------------------------------------------------------------------ pooling / layout
+def nchw_to_nhwc_pad(x, pad, Wp, Cp, dtype):
+    N, Cc, H, W = x.shape
+    y = torch.empty(N, H + 2 * pad, Wp, Cp, dtype=dtype, device=x.device)
+    L.check(_lib().passl_hip_nchw_to_nhwc_pad(L.ptr(x), L.ptr(y), N, Cc, H, W, pad, Wp, Cp,
+                                              L.dt(dtype), L.stream()), 'nchw_to_nhwc_pad')
+    return y
+
+
+def maxpool_fwd(x):
+    N, H, W, Cc = x.shape
+    P_, Q_ = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(N, P_, Q_, Cc, dtype=x.dtype, device=x.device)
+    idx = torch.empty(N, P_, Q_, Cc, dtype=torch.uint8, device=x.device)
+    L.check(_lib().passl_hip_maxpool3x3s2_fwd(L.ptr(x), L.ptr(y), L.ptr(idx), N, H, W, Cc,
+                                              L.dt(x), L.stream()), 'maxpool_fwd')
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, H, W):
+    N, _, _, Cc = dy.shape
+    dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    L.check(_lib().passl_hip_maxpool3x3s2_bwd(L.ptr(dy), L.ptr(idx), L.ptr(dx), N, H, W, Cc,
+                                              L.dt(dy), L.stream()), 'maxpool_bwd')
+    return dx
+
+
+def avgpool_fwd(x):
+    N, H, W, Cc = x.shape
+    y = torch.empty(N, Cc, dtype=x.dtype, device=x.device)
+    L.check(_lib().passl_hip_avgpool_fwd(L.ptr(x), L.ptr(y), N, H * W, Cc, L.dt(x), L.stream()),
+            'avgpool_fwd')
+    return y
+
+
+def avgpool_bwd(dy, H, W):
+    N, Cc = dy.shape
+    dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
+    L.check(_lib().passl_hip_avgpool_bwd(L.ptr(dy), L.ptr(dx), N, H * W, Cc, L.dt(dy), L.stream()),
+            'avgpool_bwd')
+    return dx
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    L.check(_lib().passl_hip_relu_bwd(L.ptr(dy), L.ptr(y), L.ptr(dx), dy.numel(), L.dt(dy),
+                                      L.stream()), 'relu_bwd')
+    return dx
+
+
+def colsum_into(x, out):
+    """out[C] (fp32) = column sums of x [M, C]."""
+    M, Cc = x.shape
+    L.check(_lib().passl_hip_colsum(L.ptr(x), L.ptr(out), M, Cc, L.dt(x), L.stream()), 'colsum')
+    return out
+
+
+# ------------------------------------------------------------------ contrastive head
+def l2norm_fwd(x, eps=1e-12):
+    N, Dd = x.shape
+    y = torch.empty_like(x)
+    norm = torch.empty(N, dtype=torch.float32, device=x.device)
+    L.check(_lib().passl_hip_l2norm_fwd(L.ptr(x), L.ptr(y), L.ptr(norm), N, Dd, eps, L.stream()),
+            'l2norm_fwd')
+    return y, norm
+
+
+def l2norm_bwd(dy, y, norm, out_dtype):
+    N, Dd = y.shape
+    dx = torch.empty(N, Dd, dtype=out_dtype, device=y.device)
+    L.check(_lib().passl_hip_l2norm_bwd(L.ptr(dy), L.ptr(y), L.ptr(norm), L.ptr(dx), N, Dd,
+                                        L.dt(out_dtype), L.stream()), 'l2norm_bwd')
+    return dx
+
+
+def infonce_fwd(q, k, queue, T, want_logits=False):
+    """Returns out[3] (loss, acc1, acc5), row_lse[N], logits[N,K+1] or None."""
+    N, Dd = q.shape
+    K = queue.shape[1]
+    lib = _lib()
+    ws = torch.empty(max(lib.passl_hip_infonce_workspace_bytes(N, K) // 4, 4),
+                     dtype=torch.float32, device=q.device)
+    out = torch.empty(3, dtype=torch.float32, device=q.device)
+    lse = torch.empty(N, dtype=torch.float32, device=q.device)
+    logits = torch.empty(N, K + 1, dtype=torch.float32, device=q.device) if want_logits else None
+    L.check(lib.passl_hip_infonce_fwd(L.ptr(q), L.ptr(k), L.ptr(queue), N, Dd, K, T, L.ptr(out),
+                                      L.ptr(lse), L.ptr(logits), L.ptr(ws), L.stream()),
+            'infonce_fwd')
+    return out, lse, logits
+
+
+def infonce_bwd(q, k, queue, lse, gscale, T):
+    N, Dd = q.shape
+    K = queue.shape[1]
+    dq = torch.zeros_like(q)
+    L.check(_lib().passl_hip_infonce_bwd(L.ptr(q), L.ptr(k), L.ptr(queue), L.ptr(lse),
+                                         L.ptr(gscale), N, Dd, K, T, L.ptr(dq), L.stream()),
+            'infonce_bwd')
+    return dq
+
+
+def enqueue(queue, keys, ptr):
+    Dd, K = queue.shape
+    B = keys.shape[0]
+    L.check(_lib().passl_hip_enqueue(L.ptr(queue), L.ptr(keys), Dd, K, int(ptr), B, L.stream()),
+            'enqueue')
+
+
+# ------------------------------------------------------------------ flat buffers
+def ema_update(k_flat, q_flat, m, k_lp=None):
+    L.check(_lib().passl_hip_ema_update(L.ptr(k_flat), L.ptr(q_flat), L.ptr(k_lp),
+                                        k_flat.numel(), m, L.stream()), 'ema_update')
+
+
+def momentum_sgd(p, g, v, lr, mu, wd, grad_scale=1.0):
+    L.check(_lib().passl_hip_momentum_sgd(L.ptr(p), L.ptr(g), L.ptr(v), p.numel(), lr, mu, wd,
+                                          grad_scale, L.stream()), 'momentum_sgd')
+
+
+def cast_bf16(src, dst):
+    L.check(_lib().passl_hip_cast_f32_to_bf16(L.ptr(src), L.ptr(dst), src.numel(), L.stream()),
+            'cast_f32_to_bf16')
+
+
+def pack_weights(src, dst, jobs_dev, block_job, block_start, n_blocks):
+    L.check(_lib().passl_hip_pack_weights(L.ptr(src), L.ptr(dst), L.dt(dst), L.ptr(jobs_dev),
+                                          L.ptr(block_job), L.ptr(block_start), n_blocks,
+                                          L.stream()), 'pack_weights')

@@ -95,12 +95,13 @@ def _taps(a, pad, k, st):
     return J, r_min + st * (J - 1), -st, off
 
 
-def dgrad_plan(g: ConvGeom, N, H, W):
+def dgrad_plan(g: ConvGeom, N, H, W, packs=None):
     """dx[n,h,w,c] = sum_{k,r,s} dy[n,(h+pad-r)/st,(w+pad-s)/st,k] w[k,r,s,c] as one
     forward-style conv over dy per residue class (a,b) = (h % st, w % st), each writing the
     sub-lattice dx[:, a::st, b::st, :].  stride 1 -> a single class = the classic flipped-filter
     conv.  Returns (descs, needs_zero_fill): classes with no contributing tap are skipped and
-    dx must then be zero-filled first."""
+    dx must then be zero-filled first.  `packs` (dict (a,b) -> Pack) lets a caller reuse Pack
+    objects already registered with a WeightPacker (pack geometry is size independent)."""
     P, Q = g.out_hw(H, W)
     st = g.stride
     dy = dense_strides(P, Q, g.cout)
@@ -124,9 +125,23 @@ def dgrad_plan(g: ConvGeom, N, H, W):
                 a_sn=dy[0], a_sh=dy[1], a_sw=dy[2],
                 y_sn=dx[0], y_sh=dx[1] * st, y_sw=dx[2] * st,
                 y_off=a * dx[1] + b * dx[2],
-                pack=Pack(TR=Ja, TS=Jb, r_base=rb, r_step=rstep, s_base=sb, s_step=sstep,
-                          transpose=1, size=g.cin * Ja * Jb * g.cout)))
+                pack=(packs[(a, b)] if packs is not None else
+                      Pack(TR=Ja, TS=Jb, r_base=rb, r_step=rstep, s_base=sb, s_step=sstep,
+                           transpose=1, size=g.cin * Ja * Jb * g.cout))))
     return descs, skipped
+
+
+def dgrad_packs(g: ConvGeom):
+    """Size-independent Pack per residue class (a,b) that has contributing taps."""
+    out = {}
+    for a in range(g.stride):
+        Ja, rb, rstep, _ = _taps(a, g.pad, g.k, g.stride)
+        for b in range(g.stride):
+            Jb, sb, sstep, _ = _taps(b, g.pad, g.k, g.stride)
+            if Ja and Jb:
+                out[(a, b)] = Pack(TR=Ja, TS=Jb, r_base=rb, r_step=rstep, s_base=sb,
+                                   s_step=sstep, transpose=1, size=g.cin * Ja * Jb * g.cout)
+    return out
 
 
 def wgrad_desc(g: ConvGeom, N, H, W) -> Desc:

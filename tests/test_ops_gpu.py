@@ -1,0 +1,350 @@
+"""Per-kernel parity tests on a real MI355X: every HIP entry point of libpassl_hip.so, called
+through the C ABI (ctypes), against a plain PyTorch fp32 reference of the same op.
+
+Tolerances: fp32 kernels 1e-4 relative-to-max (exact-fp32 MFMA, different summation order);
+bf16 kernels compare against the fp32 reference evaluated on bf16-rounded inputs, 2e-2
+relative-to-max on outputs that are themselves rounded to bf16.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import emu                                    # noqa: E402
+from passl_amd.hip import ops, plan as P      # noqa: E402
+from passl_amd.hip.packer import WeightPacker  # noqa: E402
+
+DEV = 'cuda'
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def relmax(a, b):
+    a = a.double().cpu()
+    b = b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 2e-2
+
+
+def rnd(t, dtype):
+    """round-trip through the compute dtype so the fp32 reference sees the same inputs"""
+    return t.to(dtype).float()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+# ---------------------------------------------------------------- flat kernels
+@pytest.mark.parametrize('n', [1024, 4099, 3_000_003])
+def test_ema_sgd_cast(n):
+    g = torch.Generator().manual_seed(n)
+    k = torch.randn(n, generator=g)
+    q = torch.randn(n, generator=g)
+    kd, qd = k.to(DEV), q.to(DEV)
+    klp = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ops.ema_update(kd, qd, 0.999, klp)
+    ref = k * 0.999 + q * (1 - 0.999)
+    assert (kd.cpu() - ref).abs().max() < 1e-6
+    # the bf16 copy is the RNE rounding of the kernel's own fp32 result (GPU fma vs CPU mul+add
+    # can differ by 1 fp32 ulp, which may flip a bf16 tie)
+    assert (klp.float() - kd.to(torch.bfloat16).float()).abs().max().item() == 0
+    # momentum sgd, two steps
+    p = torch.randn(n, generator=g); gr = torch.randn(n, generator=g); v = torch.zeros(n)
+    pd, gd, vd = p.to(DEV), gr.to(DEV), v.to(DEV)
+    for lr in (0.015, 0.01):
+        ops.momentum_sgd(pd, gd, vd, lr, 0.9, 1e-4, 1.0)
+        gg = gr + 1e-4 * p
+        v = 0.9 * v + gg
+        p = p - lr * v
+    assert (pd.cpu() - p).abs().max() < 1e-5
+    assert (vd.cpu() - v).abs().max() < 1e-5
+    dst = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(qd, dst)
+    assert (dst.float().cpu() - q.to(torch.bfloat16).float()).abs().max() == 0
+
+
+def test_nchw_to_nhwc_pad():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 3, 20, 18, generator=g)
+    for dtype in DTYPES:
+        Hp, Wp = P.stem_padded_hw(20, 18)
+        y = ops.nchw_to_nhwc_pad(x.to(DEV), 3, Wp, 4, dtype)
+        ref = torch.zeros(3, Hp, Wp, 4)
+        ref[:, 3:23, 3:21, :3] = nhwc(x)
+        assert (y.float().cpu() - rnd(ref, dtype)).abs().max() == 0
+
+
+# ---------------------------------------------------------------- convolution
+GEOMS = [
+    (P.ConvGeom(64, 64, 1, 1, 0), (4, 28, 28)),
+    (P.ConvGeom(64, 64, 3, 1, 1), (4, 28, 28)),
+    (P.ConvGeom(64, 256, 1, 1, 0), (2, 56, 56)),
+    (P.ConvGeom(128, 128, 3, 2, 1), (3, 28, 28)),
+    (P.ConvGeom(256, 512, 1, 2, 0), (3, 14, 14)),
+    (P.ConvGeom(512, 128, 1, 1, 0), (2, 7, 7)),       # M = 98 (ragged M tile)
+    (P.ConvGeom(256, 256, 3, 1, 1), (2, 14, 14)),
+    (P.ConvGeom(128, 64, 3, 1, 1), (1, 9, 11)),       # odd spatial
+    (P.ConvGeom(72, 136, 3, 2, 1), (2, 10, 10)),      # C not a multiple of the K tile (generic path)
+]
+
+
+def _run_plan(descs, a, packs_buf, packer, y, **kw):
+    for d in descs:
+        rows = d.NCOLS
+        ops.conv_igemm(d, a, packer.view(d.pack, rows), y, **kw)
+    return y
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('geom,nhw', GEOMS)
+def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
+    N, H, W = nhw
+    gen = torch.Generator().manual_seed(7)
+    x = rnd(torch.randn(N, geom.cin, H, W, generator=gen), dtype).requires_grad_(True)
+    w = rnd(torch.randn(geom.cout, geom.cin, geom.k, geom.k, generator=gen) * 0.1, dtype).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), None, geom.stride, geom.pad)
+    dy = rnd(torch.randn(y.shape, generator=gen), dtype)
+    y.backward(dy.double())
+    # master weights, physically KRSC fp32
+    w_krsc = w.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    fd = P.fwd_desc(geom, N, H, W)
+    dds, skipped = P.dgrad_plan(geom, N, H, W)
+    packer = WeightPacker()
+    for d in [fd] + dds:
+        packer.add(0, geom.cout, geom.k, geom.k, geom.cin, d.pack)
+    packer.build(DEV, dtype).run(w_krsc.view(-1))
+    # pack kernel vs emulator
+    for d in [fd] + dds:
+        got = packer.buffer[d.pack.dst_off:d.pack.dst_off + d.pack.size].float().cpu()
+        ref = emu.emu_pack(d.pack, w.detach().permute(0, 2, 3, 1).contiguous()).reshape(-1)
+        assert (got - rnd(ref, dtype)).abs().max() == 0
+    xa = nhwc(x.detach()).to(DEV).to(dtype)
+    yo = torch.empty(N, fd.OP, fd.OQ, geom.cout, dtype=dtype, device=DEV)
+    ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo)
+    assert relmax(yo.float(), nhwc(y.detach())) < tol(dtype)
+    # dgrad
+    dya = nhwc(dy).to(DEV).to(dtype)
+    dx = torch.full((N, H, W, geom.cin), float('nan'), dtype=dtype, device=DEV)
+    if skipped:
+        dx.zero_()
+    for d in dds:
+        ops.conv_igemm(d, dya, packer.view(d.pack, geom.cin), dx)
+    assert not torch.isnan(dx.float()).any()
+    assert relmax(dx.float(), nhwc(x.grad)) < tol(dtype)
+    # wgrad (fp32 accumulate, several split counts)
+    for splits in (None, 1, 3):
+        dw = torch.zeros(geom.cout, geom.k * geom.k * geom.cin, dtype=torch.float32, device=DEV)
+        ops.conv_wgrad(P.wgrad_desc(geom, N, H, W), xa, dya.view(-1, geom.cout), dw, splits)
+        ref = w.grad.permute(0, 2, 3, 1).reshape(geom.cout, -1)
+        assert relmax(dw, ref) < (1e-4 if dtype == torch.float32 else 2e-3), splits
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_epilogue_affine_residual_relu_f32out(dtype):
+    geom = P.ConvGeom(64, 128, 1, 1, 0)
+    N, H, W = 2, 12, 12
+    gen = torch.Generator().manual_seed(3)
+    x = rnd(torch.randn(N, 64, H, W, generator=gen), dtype)
+    w = rnd(torch.randn(128, 64, 1, 1, generator=gen) * 0.1, dtype)
+    scale = torch.rand(128, generator=gen) + 0.5
+    shift = torch.randn(128, generator=gen)
+    res = rnd(torch.randn(N, 128, H, W, generator=gen), dtype)
+    ref = F.relu(F.conv2d(x, w) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    fd = P.fwd_desc(geom, N, H, W)
+    packer = WeightPacker()
+    packer.add(0, 128, 1, 1, 64, fd.pack)
+    packer.build(DEV, dtype).run(w.permute(0, 2, 3, 1).contiguous().view(-1).to(DEV))
+    xa = nhwc(x).to(DEV).to(dtype)
+    y = torch.empty(N, H, W, 128, dtype=dtype, device=DEV)
+    ops.conv_igemm(fd, xa, packer.view(fd.pack, 128), y, scale=scale.to(DEV), shift=shift.to(DEV),
+                   residual=nhwc(res).to(DEV).to(dtype), relu=True)
+    assert relmax(y.float(), nhwc(ref)) < tol(dtype)
+    # fp32 output, shift only (Linear + bias)
+    y32 = torch.empty(N, H, W, 128, dtype=torch.float32, device=DEV)
+    ops.conv_igemm(fd, xa, packer.view(fd.pack, 128), y32, shift=shift.to(DEV), out_f32=True)
+    ref2 = F.conv2d(x, w) + shift.view(1, -1, 1, 1)
+    assert relmax(y32, nhwc(ref2)) < (1e-4 if dtype == torch.float32 else 1e-3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('hw', [(64, 64), (33, 47)])
+def test_stem_conv_and_wgrad(dtype, hw):
+    H, W = hw
+    N, cout = 4, 64
+    gen = torch.Generator().manual_seed(5)
+    x = rnd(torch.randn(N, 3, H, W, generator=gen), dtype).requires_grad_(True)
+    w = rnd(torch.randn(cout, 3, 7, 7, generator=gen) * 0.1, dtype).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), None, 2, 3)
+    dy = rnd(torch.randn(y.shape, generator=gen), dtype)
+    y.backward(dy.double())
+    d = P.stem_desc(cout, N, H, W)
+    Hp, Wp = P.stem_padded_hw(H, W)
+    xp = ops.nchw_to_nhwc_pad(x.detach().to(DEV), P.STEM_PAD, Wp, P.STEM_CP, dtype)
+    packer = WeightPacker()
+    packer.add(0, cout, 7, 7, 3, d.pack)
+    packer.build(DEV, dtype).run(w.detach().permute(0, 2, 3, 1).contiguous().view(-1).to(DEV))
+    yo = torch.empty(N, d.OP, d.OQ, cout, dtype=dtype, device=DEV)
+    ops.conv_igemm(d, xp, packer.view(d.pack, cout), yo)
+    assert relmax(yo.float(), nhwc(y.detach())) < tol(dtype)
+    dwp = torch.zeros(cout, 7 * 32, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(d, xp, nhwc(dy).to(DEV).to(dtype).view(-1, cout), dwp)
+    got = dwp.view(cout, 7, 8, 4)[:, :, :7, :3]
+    assert relmax(got, w.grad.permute(0, 2, 3, 1)) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_linear_as_conv(dtype):
+    """Linear 2048->128 with bias on [256, 2048] rows (projector), fwd + dgrad + wgrad."""
+    N, cin, cout = 256, 2048, 128
+    gen = torch.Generator().manual_seed(9)
+    x = rnd(torch.randn(N, cin, generator=gen), dtype)
+    w = rnd(torch.randn(cout, cin, generator=gen) * 0.02, dtype)
+    b = torch.randn(cout, generator=gen)
+    geom = P.ConvGeom(cin, cout, 1, 1, 0)
+    fd = P.fwd_desc(geom, N, 1, 1)
+    dds, _ = P.dgrad_plan(geom, N, 1, 1)
+    packer = WeightPacker()
+    for d in [fd] + dds:
+        packer.add(0, cout, 1, 1, cin, d.pack)
+    packer.build(DEV, dtype).run(w.contiguous().view(-1).to(DEV))
+    xa = x.to(DEV).to(dtype)
+    y = torch.empty(N, cout, dtype=torch.float32, device=DEV)
+    ops.conv_igemm(fd, xa, packer.view(fd.pack, cout), y, shift=b.to(DEV), out_f32=True)
+    assert relmax(y, x.double() @ w.double().t() + b.double()) < (1e-4 if dtype == torch.float32 else 2e-3)
+    dy = rnd(torch.randn(N, cout, generator=gen), dtype)
+    dx = torch.empty(N, cin, dtype=dtype, device=DEV)
+    ops.conv_igemm(dds[0], dy.to(DEV).to(dtype), packer.view(dds[0].pack, cin), dx)
+    assert relmax(dx.float(), dy.double() @ w.double()) < tol(dtype)
+    dw = torch.zeros(cout, cin, dtype=torch.float32, device=DEV)
+    ops.conv_wgrad(P.wgrad_desc(geom, N, 1, 1), xa, dy.to(DEV).to(dtype), dw)
+    assert relmax(dw, dy.double().t() @ x.double()) < (1e-4 if dtype == torch.float32 else 2e-3)
+    db = torch.empty(cout, dtype=torch.float32, device=DEV)
+    ops.colsum_into(dy.to(DEV).to(dtype), db)
+    assert relmax(db, dy.double().sum(0)) < 1e-5
+
+
+# ---------------------------------------------------------------- batch norm
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(4, 56, 56, 64), (2, 7, 7, 2048), (3, 5, 5, 24), (8, 14, 14, 256)])
+@pytest.mark.parametrize('with_res', [False, True])
+def test_bn_fwd_bwd(dtype, shape, with_res):
+    N, H, W, Cc = shape
+    gen = torch.Generator().manual_seed(11)
+    x = rnd(torch.randn(N, H, W, Cc, generator=gen) * 2 + 0.5, dtype).requires_grad_(True)
+    gamma = (torch.rand(Cc, generator=gen) + 0.5).requires_grad_(True)
+    beta = torch.randn(Cc, generator=gen).requires_grad_(True)
+    res = rnd(torch.randn(N, H, W, Cc, generator=gen), dtype).requires_grad_(True)
+    rm0 = torch.randn(Cc, generator=gen); rv0 = torch.rand(Cc, generator=gen) + 0.5
+    x64 = x.double()
+    mu = x64.mean(dim=(0, 1, 2)); var = x64.var(dim=(0, 1, 2), unbiased=False)
+    xh = (x64 - mu) / torch.sqrt(var + 1e-5)
+    pre = xh * gamma.double() + beta.double()
+    if with_res:
+        pre = pre + res.double()
+    z_ref = F.relu(pre)
+    dz = rnd(torch.randn(shape, generator=gen), dtype)
+    z_ref.backward(dz.double())
+    rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    xd = x.detach().to(DEV).to(dtype)
+    resd = res.detach().to(DEV).to(dtype) if with_res else None
+    z, mean, invstd = ops.bn_train_fwd(xd, gamma.detach().to(DEV), beta.detach().to(DEV), rm, rv,
+                                       residual=resd, relu=True)
+    assert relmax(z.float(), z_ref.detach()) < tol(dtype)
+    assert relmax(mean, mu) < 1e-5 and relmax(invstd, 1 / torch.sqrt(var + 1e-5)) < 1e-5
+    assert relmax(rm, 0.9 * rm0 + 0.1 * mu) < 1e-5
+    assert relmax(rv, 0.9 * rv0 + 0.1 * var) < 1e-5
+    dgamma = torch.zeros(Cc, device=DEV); dbeta = torch.zeros(Cc, device=DEV)
+    # the mask must come from the product's own z (bf16 rounding can flip tiny values)
+    dx, dres = ops.bn_bwd(dz.to(DEV).to(dtype), z, xd, gamma.detach().to(DEV), mean, invstd,
+                          dgamma, dbeta, relu=True, want_dres=with_res)
+    t = 1e-4 if dtype == torch.float32 else 3e-2
+    assert relmax(dx.float(), x.grad) < t
+    assert relmax(dgamma, gamma.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    assert relmax(dbeta, beta.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    if with_res:
+        assert relmax(dres.float(), res.grad) < t
+
+
+# ---------------------------------------------------------------- pooling
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 64, 112, 112), (3, 64, 33, 17), (1, 8, 5, 5)])
+def test_maxpool(dtype, shape):
+    gen = torch.Generator().manual_seed(13)
+    x = rnd(torch.randn(shape, generator=gen), dtype).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = rnd(torch.randn(y.shape, generator=gen), dtype)
+    y.backward(dy)
+    yo, idx = ops.maxpool_fwd(nhwc(x.detach()).to(DEV).to(dtype))
+    assert (yo.float().cpu() - nhwc(y.detach())).abs().max() == 0
+    dx = ops.maxpool_bwd(nhwc(dy).to(DEV).to(dtype), idx, shape[2], shape[3])
+    assert relmax(dx.float(), nhwc(x.grad)) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_avgpool(dtype):
+    gen = torch.Generator().manual_seed(14)
+    x = rnd(torch.randn(5, 7, 7, 2048, generator=gen), dtype)
+    y = ops.avgpool_fwd(x.to(DEV).to(dtype))
+    assert relmax(y.float(), x.mean(dim=(1, 2))) < (1e-6 if dtype == torch.float32 else 1e-2)
+    dy = rnd(torch.randn(5, 2048, generator=gen), dtype)
+    dx = ops.avgpool_bwd(dy.to(DEV).to(dtype), 7, 7)
+    ref = (dy / 49.0).view(5, 1, 1, 2048).expand(5, 7, 7, 2048)
+    assert relmax(dx.float(), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+# ---------------------------------------------------------------- head
+def test_l2norm_fwd_bwd():
+    gen = torch.Generator().manual_seed(15)
+    x = torch.randn(37, 128, generator=gen, requires_grad=True)
+    y = x / x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    dy = torch.randn(37, 128, generator=gen)
+    y.backward(dy)
+    yo, norm = ops.l2norm_fwd(x.detach().to(DEV))
+    assert relmax(yo, y.detach()) < 1e-6
+    dx = ops.l2norm_bwd(dy.to(DEV), yo, norm, torch.float32)
+    assert relmax(dx, x.grad) < 1e-5
+    dxb = ops.l2norm_bwd(dy.to(DEV), yo, norm, torch.bfloat16)
+    assert relmax(dxb.float(), x.grad) < 1e-2
+
+
+@pytest.mark.parametrize('N,K', [(256, 65536), (32, 65536), (8, 1024), (70, 2048)])
+def test_infonce_fwd_bwd(N, K):
+    gen = torch.Generator().manual_seed(16)
+    T = 0.2
+    q = F.normalize(torch.randn(N, 128, generator=gen), dim=1).requires_grad_(True)
+    k = F.normalize(q.detach() + 0.5 * torch.randn(N, 128, generator=gen), dim=1)
+    queue = F.normalize(torch.randn(128, K, generator=gen), dim=0)
+    # make a few negatives beat the positive so acc1/acc5 are non-trivial
+    queue[:, 3] = q.detach()[0]; queue[:, 9] = q.detach()[1]
+    q64 = q.double()
+    logits = torch.cat([(q64 * k.double()).sum(1, keepdim=True), q64 @ queue.double()], 1) / T
+    loss = F.cross_entropy(logits, torch.zeros(N, dtype=torch.long))
+    loss.backward()
+    rank = (logits[:, 1:] > logits[:, :1]).sum(1)
+    out, lse, lg = ops.infonce_fwd(q.detach().to(DEV), k.to(DEV), queue.to(DEV), T, want_logits=True)
+    out = out.cpu()
+    assert abs(out[0].item() - loss.item()) < 2e-5 * max(1.0, abs(loss.item()))
+    assert abs(out[1].item() - (rank < 1).double().mean().item() * 100) < 1e-3
+    assert abs(out[2].item() - (rank < 5).double().mean().item() * 100) < 1e-3
+    assert (lg.double().cpu() - logits.detach()).abs().max() < 1e-4
+    assert (lse.double().cpu() - torch.logsumexp(logits.detach(), 1)).abs().max() < 1e-4
+    gs = torch.tensor([1.0], device=DEV)
+    dq = ops.infonce_bwd(q.detach().to(DEV), k.to(DEV), queue.to(DEV), lse, gs, T)
+    assert relmax(dq, q.grad) < 1e-4
+    dq2 = ops.infonce_bwd(q.detach().to(DEV), k.to(DEV), queue.to(DEV), lse, None, T)
+    assert relmax(dq2, q.grad) < 1e-4
+
+
+def test_enqueue():
+    gen = torch.Generator().manual_seed(17)
+    queue = torch.randn(128, 1024, generator=gen)
+    keys = torch.randn(32, 128, generator=gen)
+    qd = queue.clone().to(DEV)
+    ops.enqueue(qd, keys.to(DEV), 96)
+    queue[:, 96:128] = keys.t()
+    assert (qd.cpu() - queue).abs().max() == 0
