@@ -1,0 +1,147 @@
+"""Data-parallel gradient / parameter synchronisation over RCCL (backend "nccl" on ROCm) or gloo.
+
+What it replaces in the reference:
+  * v110: ``fleet.distributed_model(model)`` = paddle.DataParallel — bucketed gradient all-reduce
+    (sum, then / nranks) overlapped with backward, parameters broadcast from rank 0 at wrap time
+    (passl_v110/engine/trainer.py:172-183, 218-219)
+  * v2:   ``grad_sync`` / ``param_sync`` (passl/core/sync_utils.py:18-69): blocking per-parameter
+    all_reduce after backward + scale by 1/nranks; broadcast of params and buffers from rank 0
+
+MI355X design: gradients already live in ONE flat fp32 buffer (EncoderArena.grads), so a bucket is
+a contiguous slice — no flatten/unflatten copies.  The backward kernels' host code reports each
+layer's parameters as ready (arena.grad_ready); when every parameter of a bucket is ready the
+slice is all-reduced asynchronously (RCCL runs on its own stream and waits on an event of the
+compute stream, so it overlaps with the remaining backward kernels).  Buckets are walked from the
+END of the buffer (the last layers finish first in backward).  The 1/world_size scale is folded
+into the optimizer kernel (no extra pass).  xGMI is point-to-point (7 links/GPU): 112 MB of fp32
+gradients in 4 x 28 MB buckets keeps every collective large enough to be bandwidth- rather than
+latency-bound while leaving 3/4 of the traffic overlappable with backward.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _ws(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+class GradReducer(object):
+    """Bucketed, overlapped all-reduce over a flat gradient buffer."""
+
+    def __init__(self, arena, optimizer=None, bucket_elems=7 * 1024 * 1024, group=None):
+        self.arena = arena
+        self.group = group
+        self.world = _ws(group)
+        self.grads = arena.grads
+        slices = arena.param_slices
+        # buckets = runs of consecutive parameters, built from the end of the buffer
+        self.buckets = []          # (start_elem, end_elem, [param indices])
+        cur, cur_n, end = [], 0, None
+        for idx in range(len(slices) - 1, -1, -1):
+            off, n = slices[idx]
+            if end is None:
+                end = off + n
+            cur.append(idx)
+            cur_n += n
+            if cur_n >= bucket_elems or idx == 0:
+                self.buckets.append((off, end, cur))
+                cur, cur_n, end = [], 0, None
+        self.bucket_of = {}
+        for b, (_s, _e, idxs) in enumerate(self.buckets):
+            for i in idxs:
+                self.bucket_of[i] = b
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._ready = set()
+        self._handles = []
+        self._active = False
+        arena.reducer = self
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+
+    def begin(self):
+        """Call right before loss.backward()."""
+        self._pending = [len(b[2]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._ready = set()
+        self._handles = []
+        self._active = True
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        if self.world > 1:
+            self._handles.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM,
+                                                 group=self.group, async_op=True))
+
+    def mark_ready(self, index):
+        if not self._active or index in self._ready:
+            return
+        self._ready.add(index)
+        b = self.bucket_of[index]
+        self._pending[b] -= 1
+        # launch in bucket order so that every rank issues the collectives in the same sequence
+        while True:
+            nxt = next((i for i, l in enumerate(self._launched) if not l), None)
+            if nxt is None or self._pending[nxt] > 0:
+                break
+            self._launch(nxt)
+
+    def finish(self):
+        """Call before the optimizer reads the gradients: launches what is left (parameters that
+        received no gradient this step) and waits for every collective."""
+        if not self._active:
+            return
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+        self._active = False
+
+
+@torch.no_grad()
+def grad_sync(param_groups, comm_group=None, grad_avg=True):
+    """v2 spelling (passl/core/sync_utils.py:18-43): blocking all_reduce of every parameter's
+    gradient (+ average).  Arena-backed parameters are reduced as ONE flat call per arena."""
+    nranks = _ws(comm_group)
+    if nranks < 2:
+        return
+    seen = []
+    for group in param_groups:
+        for p in group['params']:
+            if p.grad is None:
+                continue
+            a = getattr(p, '_passl_arena', None)
+            if a is not None:
+                if a not in seen:
+                    seen.append(a)
+                    dist.all_reduce(a.grads, group=comm_group)
+                    if grad_avg:
+                        a.grads.mul_(1.0 / nranks)
+                continue
+            dist.all_reduce(p.grad, group=comm_group)
+            if grad_avg:
+                p.grad.mul_(1.0 / nranks)
+
+
+@torch.no_grad()
+def param_sync(model, src_rank=0, comm_group=None):
+    """Broadcast parameters and buffers from ``src_rank`` (passl/core/sync_utils.py:46-69).
+    Arena-backed state is one broadcast per flat buffer."""
+    if _ws(comm_group) < 2:
+        return
+    arenas = [getattr(model, n) for n in ('arena_q', 'arena_k') if hasattr(model, n)]
+    flat_ptrs = set()
+    for a in arenas:
+        dist.broadcast(a.flat, src=src_rank, group=comm_group)
+        flat_ptrs.add(a.flat.untyped_storage().data_ptr())
+    seen = set()
+    for t in list(model.parameters()) + list(model.buffers()):
+        if t.untyped_storage().data_ptr() in flat_ptrs or id(t) in seen:
+            continue
+        seen.add(id(t))
+        dist.broadcast(t, src=src_rank, group=comm_group)
+    if hasattr(model, 'sync_runtime_state') and next(model.parameters()).is_cuda:
+        model.sync_runtime_state()

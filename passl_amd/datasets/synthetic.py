@@ -1,0 +1,56 @@
+"""Synthetic two-view image source: x_q, x_k ~ N(0,1) fp32 [N,3,S,S] drawn from
+``torch.Generator(seed = 1234 + rank)`` — post-NormalizeImage images are ~zero-mean/unit-variance
+(configs/moco/moco_v2_r50.yaml:57-60).  Batches are generated on the host once and kept resident
+in HBM, so the timed step never includes host->device copies."""
+import os
+
+import torch
+
+from .builder import DATASETS
+
+
+@DATASETS.register()
+class SyntheticTwoView(object):
+    def __init__(self, num_samples=1281167, image_size=224, seed=1234, num_batches_cached=1,
+                 **ignored):
+        self.num_samples = int(num_samples)
+        self.image_size = int(image_size)
+        self.seed = int(seed)
+        self.num_batches_cached = int(num_batches_cached)
+
+    def __len__(self):
+        return self.num_samples
+
+
+@DATASETS.register()
+class ImageNet(object):
+    def __init__(self, **kwargs):
+        raise NotImplementedError(
+            'The ImageNet folder dataset + CPU augmentation pipeline of the reference is outside '
+            'the MI355X hot path (SURVEY §2.1 row 9).  Use `-o dataloader.train.dataset.name='
+            'SyntheticTwoView` for benchmarking/parity runs.')
+
+
+class SyntheticLoader(object):
+    def __init__(self, dataset, batch_size, device, drop_last=True):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.device = device
+        world = int(os.environ.get('WORLD_SIZE', 1))
+        rank = int(os.environ.get('RANK', 0))
+        per_rank = len(dataset) // world
+        self._len = per_rank // self.batch_size if drop_last else -(-per_rank // self.batch_size)
+        gen = torch.Generator().manual_seed(dataset.seed + rank)
+        s = dataset.image_size
+        self._cache = []
+        for _ in range(max(1, dataset.num_batches_cached)):
+            xq = torch.randn(self.batch_size, 3, s, s, generator=gen)
+            xk = torch.randn(self.batch_size, 3, s, s, generator=gen)
+            self._cache.append((xq.to(device), xk.to(device)))
+
+    def __len__(self):
+        return max(self._len, 1)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self._cache[i % len(self._cache)]

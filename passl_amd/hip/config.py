@@ -1,0 +1,44 @@
+"""Process-wide settings of the HIP path: target device and compute dtype.
+
+``set_device`` plays the role of ``paddle.set_device`` in the reference's Trainer
+(passl_v110/engine/trainer.py:112-116): layers created afterwards allocate their parameters
+there.  ``cpu`` is accepted so that host-side logic (registries, config, Trainer/hook plumbing,
+gloo collectives) can be exercised without a GPU — the HIP layers themselves refuse to *run* on
+a host tensor (passl_amd/hip/lib.py: no CPU fallback).
+"""
+import os
+
+import torch
+
+_state = {'device': None, 'dtype': torch.bfloat16}
+
+
+def set_device(name):
+    if isinstance(name, torch.device):
+        _state['device'] = name
+    elif name in ('gpu', 'cuda'):
+        _state['device'] = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+        torch.cuda.set_device(_state['device'])
+    elif name == 'cpu':
+        _state['device'] = torch.device('cpu')
+    else:
+        raise ValueError("device must be 'gpu' or 'cpu', got %r" % (name,))
+    return _state['device']
+
+
+def get_device():
+    if _state['device'] is None:
+        set_device('gpu' if torch.cuda.is_available() else 'cpu')
+    return _state['device']
+
+
+def set_compute_dtype(dt):
+    if isinstance(dt, str):
+        dt = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'fp32': torch.float32,
+              'float32': torch.float32}[dt]
+    assert dt in (torch.bfloat16, torch.float32)
+    _state['dtype'] = dt
+
+
+def get_compute_dtype():
+    return _state['dtype']

@@ -1,0 +1,569 @@
+"""Layers of the MoCo-v2 R50 hot path, executed by libpassl_hip.so.
+
+PyTorch provides parameter storage and the autograd tape only: every ``autograd.Function``
+below launches hand-written HIP kernels through the C ABI (passl_amd/hip/ops.py) in both
+directions.  Activations are NHWC in the compute dtype (bf16, or fp32 for parity runs).
+
+Storage model (EncoderArena): all parameters and BN statistics of one encoder live in ONE flat
+fp32 buffer, each conv weight physically [K][R][S][C] and each Linear weight [out][in]
+(K-contiguous rows = the B operand of the implicit GEMM); the ``nn.Parameter`` objects are
+strided *views* with the reference's logical shapes ([Cout,Cin,kh,kw], Linear [in,out]) so
+``state_dict()`` matches the reference layout.  Gradients are written by the
+kernels straight into a flat fp32 gradient buffer (``p.grad`` are views of it), so the key-
+encoder EMA, the optimizer and the DP all-reduce are single launches over flat memory.
+
+Reference semantics mirrored here: paddle.nn.Conv2D(bias_attr=False), BatchNorm2D (momentum 0.9,
+eps 1e-5, biased running var, ``_use_global_stats``), MaxPool2D(3,2,1), AdaptiveAvgPool2D(1),
+Linear — as used by passl_v110/modeling/backbones/resnetimagenet.py:111-253 and
+passl_v110/modeling/necks/base_neck.py:68-97.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as tnn
+from torch.autograd import Function
+
+from . import config, ops
+from . import plan as P
+from .packer import WeightPacker
+
+
+class Layer(tnn.Module):
+    """torch Module with the few paddle.nn.Layer spellings the reference's code relies on."""
+
+    def sublayers(self, include_self=False):
+        mods = list(self.modules())
+        return mods if include_self else mods[1:]
+
+    def set_state_dict(self, sd, *a, **k):
+        return self.load_state_dict(sd, *a, **k)
+
+
+def _need_rt(layer):
+    if getattr(layer, '_rt', None) is None:
+        raise RuntimeError('%s is not attached to an EncoderArena (call EncoderArena(encoder) after '
+                           'building the model)' % type(layer).__name__)
+    return layer._rt
+
+
+# =============================================================================== conv
+class _ConvFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, layer, hw):
+        rt = _need_rt(layer)
+        N = x.shape[0]
+        pl = layer._plan(N, hw[0], hw[1])
+        y = torch.empty(N, pl.fd.OP, pl.fd.OQ, layer.geom.cout, dtype=x.dtype, device=x.device)
+        ops.conv_igemm(pl.fd, x, rt.w_fwd, y)
+        ctx.save_for_backward(x)
+        ctx.layer, ctx.pl, ctx.hw = layer, pl, hw
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        layer, pl = ctx.layer, ctx.pl
+        rt = layer._rt
+        g = layer.geom
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            N = x.shape[0]
+            alloc = torch.zeros if pl.dgrad_zero else torch.empty
+            dx = alloc(N, ctx.hw[0], ctx.hw[1], g.cin, dtype=dy.dtype, device=dy.device)
+            for d in pl.dds:
+                ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
+        if layer.is_stem:
+            tmp = torch.zeros(g.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dy.device)
+            ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), tmp)
+            rt.dw.view(g.cout, 7, 7, 3).add_(tmp.view(g.cout, 7, 8, 4)[:, :, :7, :3])
+        else:
+            ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
+        rt.arena.grad_ready(rt.indices)
+        return dx, None, None, None
+
+
+class Conv2D(Layer):
+    """Bias-free 2-D convolution, NHWC activations, weight logically [Cout,Cin,kh,kw]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias_attr=False, **_):
+        super().__init__()
+        assert bias_attr is False, 'only bias-free convs are on the hot path'
+        assert dilation == 1 and groups == 1
+        self.geom = P.ConvGeom(in_channels, out_channels, kernel_size, stride, padding)
+        self.is_stem = (in_channels, kernel_size, stride, padding) == (3, 7, 2, 3)
+        self.weight = tnn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size,
+                                                device=config.get_device()))
+        self._rt = None
+        self._plans = {}
+
+    def _plan(self, N, H, W):
+        key = (N, H, W)
+        pl = self._plans.get(key)
+        if pl is None:
+            rt = _need_rt(self)
+            g = self.geom
+            if self.is_stem:
+                fd = P.stem_desc(g.cout, N, H, W)
+                pl = SimpleNamespace(fd=fd, wd=fd, dds=[], dgrad_zero=False)
+            else:
+                dds, skipped = ([], False)
+                if rt.dgrad_packs is not None:
+                    dds, skipped = P.dgrad_plan(g, N, H, W, packs=rt.dgrad_packs)
+                pl = SimpleNamespace(fd=P.fwd_desc(g, N, H, W), wd=P.wgrad_desc(g, N, H, W),
+                                     dds=dds, dgrad_zero=skipped)
+            self._plans[key] = pl
+        return pl
+
+    def forward(self, x, hw=None):
+        """x: NHWC compute-dtype tensor (the stem takes the zero-padded image + hw=(H, W))."""
+        if hw is None:
+            hw = (x.shape[1], x.shape[2])
+        return _ConvFn.apply(x, self.weight, self, hw)
+
+    @torch.no_grad()
+    def infer(self, x, bn=None, residual=None, relu=False, hw=None):
+        """conv + (BatchNorm with running stats) + residual + ReLU in ONE kernel (epilogue)."""
+        rt = _need_rt(self)
+        if hw is None:
+            hw = (x.shape[1], x.shape[2])
+        N = x.shape[0]
+        pl = self._plan(N, hw[0], hw[1])
+        y = torch.empty(N, pl.fd.OP, pl.fd.OQ, self.geom.cout, dtype=x.dtype, device=x.device)
+        scale = shift = None
+        if bn is not None:
+            scale, shift = bn.infer_affine()
+        ops.conv_igemm(pl.fd, x, rt.w_fwd, y, scale=scale, shift=shift, residual=residual, relu=relu)
+        return y
+
+
+# =============================================================================== batch norm
+class _BNActFn(Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, residual, layer, relu):
+        z, mean, invstd = ops.bn_train_fwd(y, gamma.detach(), beta.detach(), layer._mean,
+                                           layer._variance, residual, relu, layer._momentum,
+                                           layer._epsilon)
+        ctx.save_for_backward(y, z, mean, invstd)
+        ctx.layer, ctx.relu, ctx.has_res = layer, relu, residual is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, z, mean, invstd = ctx.saved_tensors
+        layer = ctx.layer
+        for p in (layer.weight, layer.bias):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        dx, dres = ops.bn_bwd(dz.contiguous(), z, y, layer.weight.detach(), mean, invstd,
+                              layer.weight.grad, layer.bias.grad, relu=ctx.relu,
+                              want_dres=ctx.has_res and ctx.needs_input_grad[3])
+        if layer._rt is not None:
+            layer._rt.arena.grad_ready(layer._rt.indices)
+        return dx, None, None, dres, None, None
+
+
+class _BatchNormBase(Layer):
+    """BatchNorm over the channel (last) axis of NHWC rows.  ``_mean`` / ``_variance`` keep the
+    reference's state_dict key names; ``_use_global_stats`` is what freeze_batchnorm_statictis
+    (passl_v110/modules/freeze.py:18-23) flips on the key encoder."""
+
+    def __init__(self, num_features, momentum=0.9, epsilon=1e-05, weight_attr=None,
+                 bias_attr=None, data_format='NCHW', use_global_stats=None, name=None):
+        super().__init__()
+        dev = config.get_device()
+        self._momentum, self._epsilon = momentum, epsilon
+        self._use_global_stats = use_global_stats
+        self.num_features = num_features
+        self.weight = tnn.Parameter(torch.ones(num_features, device=dev))
+        self.bias = tnn.Parameter(torch.zeros(num_features, device=dev))
+        self.register_buffer('_mean', torch.zeros(num_features, device=dev))
+        self.register_buffer('_variance', torch.ones(num_features, device=dev))
+        self._rt = None
+
+    def uses_global_stats(self):
+        return bool(self._use_global_stats) if self._use_global_stats is not None \
+            else (not self.training)
+
+    def infer_affine(self):
+        """(scale, shift) of y = x*scale + shift with the running statistics."""
+        rt = self._rt
+        if rt is not None and rt.arena.bn_affine is not None:
+            s, e = rt.bn_slice
+            return rt.arena.bn_affine[0][s:e], rt.arena.bn_affine[1][s:e]
+        scale = self.weight.detach() * torch.rsqrt(self._variance + self._epsilon)
+        return scale, self.bias.detach() - self._mean * scale
+
+    def forward(self, y, residual=None, relu=False):
+        if self.uses_global_stats():
+            if torch.is_grad_enabled() and (y.requires_grad or self.weight.requires_grad):
+                raise NotImplementedError('frozen BatchNorm inside a differentiated graph is not on '
+                                          'the MoCo hot path (key encoder runs under no_grad)')
+            scale, shift = self.infer_affine()
+            return ops.bn_apply(y, scale, shift, residual, relu)
+        return _BNActFn.apply(y, self.weight, self.bias, residual, self, relu)
+
+
+class BatchNorm2D(_BatchNormBase):
+    pass
+
+
+class BatchNorm1D(_BatchNormBase):
+    pass
+
+
+# =============================================================================== pooling
+class _MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y, idx = ops.maxpool_fwd(x)
+        ctx.save_for_backward(idx)
+        ctx.hw = (x.shape[1], x.shape[2])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool_bwd(dy.contiguous(), idx, ctx.hw[0], ctx.hw[1])
+
+
+class MaxPool2D(Layer):
+    def __init__(self, kernel_size=3, stride=2, padding=1):
+        super().__init__()
+        assert (kernel_size, stride, padding) == (3, 2, 1), 'only the ResNet stem pool is built'
+
+    def forward(self, x):
+        return _MaxPoolFn.apply(x)
+
+
+class _AvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.avgpool_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.avgpool_bwd(dy.contiguous(), ctx.hw[0], ctx.hw[1])
+
+
+class AdaptiveAvgPool2D(Layer):
+    def __init__(self, output_size=(1, 1)):
+        super().__init__()
+        assert tuple(output_size) == (1, 1) if not isinstance(output_size, int) else output_size == 1
+
+    def forward(self, x):
+        """[N,H,W,C] -> [N,C]"""
+        return _AvgPoolFn.apply(x)
+
+
+class ReLU(Layer):
+    """Marker layer: ReLU is always fused into the producing kernel's epilogue
+    (BatchNorm-apply, conv epilogue or Linear epilogue)."""
+
+    def forward(self, x):
+        raise RuntimeError('ReLU is fused into the preceding layer on the HIP path')
+
+
+# =============================================================================== linear
+class _LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer, relu, out_f32):
+        rt = _need_rt(layer)
+        N = x.shape[0]
+        pl = layer._plan(N)
+        y = torch.empty(N, layer.out_features, dtype=torch.float32 if out_f32 else x.dtype,
+                        device=x.device)
+        ops.conv_igemm(pl.fd, x, rt.w_fwd, y, shift=bias.detach() if bias is not None else None,
+                       relu=relu, out_f32=out_f32)
+        ctx.save_for_backward(x, y if relu else None)
+        ctx.layer, ctx.pl, ctx.relu = layer, pl, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        layer, pl = ctx.layer, ctx.pl
+        rt = layer._rt
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if ctx.relu:
+            dy = ops.relu_bwd(dy, y)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape[0], layer.in_features, dtype=x.dtype, device=x.device)
+            d = pl.dds[0]
+            ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
+        ops.conv_wgrad(pl.wd, x, dy, rt.dw)
+        if layer.bias is not None:
+            tmp = torch.empty(layer.out_features, dtype=torch.float32, device=dy.device)
+            ops.colsum_into(dy, tmp)
+            layer.bias.grad.add_(tmp)
+        rt.arena.grad_ready(rt.indices)
+        return dx, None, None, None, None, None
+
+
+class Linear(Layer):
+    """y = x W + b with W logically [in, out] (the reference's paddle.nn.Linear layout)."""
+
+    def __init__(self, in_features, out_features, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        dev = config.get_device()
+        self.in_features, self.out_features = in_features, out_features
+        self.geom = P.ConvGeom(in_features, out_features, 1, 1, 0)
+        self.weight = tnn.Parameter(torch.empty(in_features, out_features, device=dev))
+        self.bias = None if bias_attr is False else tnn.Parameter(torch.zeros(out_features, device=dev))
+        self._rt = None
+        self._plans = {}
+
+    def _plan(self, N):
+        pl = self._plans.get(N)
+        if pl is None:
+            rt = _need_rt(self)
+            dds = []
+            if rt.dgrad_packs is not None:
+                dds, _ = P.dgrad_plan(self.geom, N, 1, 1, packs=rt.dgrad_packs)
+            pl = SimpleNamespace(fd=P.fwd_desc(self.geom, N, 1, 1), wd=P.wgrad_desc(self.geom, N, 1, 1),
+                                 dds=dds)
+            self._plans[N] = pl
+        return pl
+
+    def forward(self, x, relu=False, out_f32=False):
+        return _LinearFn.apply(x, self.weight, self.bias, self, relu, out_f32)
+
+
+# =============================================================================== head pieces
+class _L2NormFn(Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, norm = ops.l2norm_fwd(x.contiguous(), eps)
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        return ops.l2norm_bwd(dy.contiguous(), y, norm, torch.float32), None
+
+
+def normalize(x, axis=1, epsilon=1e-12):
+    """paddle.nn.functional.normalize(x, axis=1) for [N, D] fp32 rows."""
+    assert x.dim() == 2 and axis in (1, -1)
+    return _L2NormFn.apply(x, epsilon)
+
+
+class _InfoNCEFn(Function):
+    """loss = mean_i CE([q_i.k_i | q_i.queue] / T, label 0); returns (loss[1], acc1[1], acc5[1])."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, T):
+        out, lse, _ = ops.infonce_fwd(q.contiguous(), k.contiguous(), queue, T, want_logits=False)
+        ctx.save_for_backward(q, k, queue, lse)
+        ctx.T = T
+        loss, acc1, acc5 = out[0:1], out[1:2], out[2:3]
+        ctx.mark_non_differentiable(acc1, acc5)
+        return loss, acc1, acc5
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g5):
+        q, k, queue, lse = ctx.saved_tensors
+        dq = ops.infonce_bwd(q, k, queue, lse, gloss.contiguous().float(), ctx.T)
+        return dq, None, None, None
+
+
+def infonce(q, k, queue, T):
+    return _InfoNCEFn.apply(q, k, queue, float(T))
+
+
+# =============================================================================== arena
+class EncoderArena:
+    """Flat fp32 storage for one encoder (see module docstring)."""
+
+    ALIGN = 8   # elements; keeps every slot 32-byte aligned in fp32 and 16-byte aligned in bf16
+
+    def __init__(self, module, trainable=True, dtype=None):
+        self.module = module
+        self.trainable = trainable
+        self.dtype = dtype or config.get_compute_dtype()
+        self.reducer = None
+        self.bn_affine = None
+        params = []      # (owner, name, kind)
+        seen = set()
+        for mod in module.modules():
+            for name, p in mod._parameters.items():
+                if p is None or id(p) in seen:
+                    continue
+                seen.add(id(p))
+                kind = 'conv' if isinstance(mod, Conv2D) else \
+                    ('linw' if isinstance(mod, Linear) and name == 'weight' else 'vec')
+                params.append((mod, name, kind))
+        stats = [(mod, n) for mod in module.modules() if isinstance(mod, _BatchNormBase)
+                 for n in ('_mean', '_variance')]
+        dev = params[0][0]._parameters[params[0][1]].device
+        self.device = dev
+
+        def aligned(n):
+            return (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+
+        off = 0
+        self.param_slices = []   # (off, numel) per trainable parameter, registration order
+        slots = []
+        for mod, name, kind in params:
+            n = mod._parameters[name].numel()
+            slots.append((mod, name, kind, off, n))
+            self.param_slices.append((off, n))
+            off += aligned(n)
+        self.n_train = off
+        stat_slots = []
+        for mod, name in stats:
+            n = mod._buffers[name].numel()
+            stat_slots.append((mod, name, off, n))
+            off += aligned(n)
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=dev) if trainable else None
+        self.lp = torch.zeros(self.total, dtype=torch.bfloat16, device=dev) \
+            if self.dtype == torch.bfloat16 else None
+        self.packer = WeightPacker()
+        owners = {}
+        for index, (mod, name, kind, o, n) in enumerate(slots):
+            old = mod._parameters[name].detach()
+            seg = self.flat[o:o + n]
+            if kind == 'conv':
+                K, Cc, R, S = old.shape
+                seg.view(K, R, S, Cc).copy_(old.permute(0, 2, 3, 1))
+                view = seg.view(K, R, S, Cc).permute(0, 3, 1, 2)
+                gview = self.grads[o:o + n].view(K, R, S, Cc).permute(0, 3, 1, 2) if trainable else None
+            elif kind == 'linw':
+                i, oo = old.shape
+                seg.view(oo, i).copy_(old.t())
+                view = seg.view(oo, i).t()
+                gview = self.grads[o:o + n].view(oo, i).t() if trainable else None
+            else:
+                seg.copy_(old.reshape(-1))
+                view = seg.view(old.shape)
+                gview = self.grads[o:o + n].view(old.shape) if trainable else None
+            p = tnn.Parameter(view, requires_grad=trainable)
+            p._passl_arena = self
+            if trainable:
+                p.grad = gview
+            mod._parameters[name] = p
+            rt = owners.get(id(mod))
+            if rt is None:
+                rt = SimpleNamespace(arena=self, indices=[], dgrad_packs=None, w_dgrad={},
+                                     bn_slice=None)
+                owners[id(mod)] = rt
+                mod._rt = rt
+            rt.indices.append(index)
+            if kind in ('conv', 'linw'):
+                self._attach_gemm_layer(mod, rt, o, n)
+        for mod, name, o, n in stat_slots:
+            seg = self.flat[o:o + n]
+            seg.copy_(mod._buffers[name])
+            mod._buffers[name] = seg
+        # index tensors for the one-shot inference-BN affine of all layers
+        gi, bi, mi, vi, pos = [], [], [], [], 0
+        slot_of = {(id(m), nm): (o, n) for m, nm, _k, o, n in slots}
+        slot_of.update({(id(m), nm): (o, n) for m, nm, o, n in stat_slots})
+        self._bn_eps = 1e-5
+        for mod in module.modules():
+            if isinstance(mod, _BatchNormBase):
+                Cc = mod.num_features
+                for lst, nm in ((gi, 'weight'), (bi, 'bias'), (mi, '_mean'), (vi, '_variance')):
+                    o, _ = slot_of[(id(mod), nm)]
+                    lst.append(torch.arange(o, o + Cc))
+                mod._rt.bn_slice = (pos, pos + Cc)
+                pos += (Cc + 7) // 8 * 8          # keep every slice 32-byte aligned
+                self._bn_eps = mod._epsilon
+        self._bn_idx = None
+        if gi:
+            def cat_pad(lst):
+                outs = []
+                for t in lst:
+                    padn = (-len(t)) % 8
+                    outs.append(t)
+                    if padn:
+                        outs.append(t[:1].expand(padn))
+                return torch.cat(outs).to(dev)
+            self._bn_idx = tuple(cat_pad(lst) for lst in (gi, bi, mi, vi))
+        self.packer.build(dev, self.dtype)
+        # resolve packed-operand views now that the packer buffer exists
+        for rt in owners.values():
+            if getattr(rt, '_pending', None):
+                rt._pending()
+                rt._pending = None
+        self._refresh_if_on_device()
+
+    def _attach_gemm_layer(self, mod, rt, off, n):
+        g = mod.geom
+        rows = g.cout
+        is_stem = getattr(mod, 'is_stem', False)
+        rt.dw = self.grads[off:off + n].view(rows, -1) if self.trainable else None
+        stem_pack = None
+        if is_stem:
+            stem_pack = P.stem_desc(g.cout, 1, 8, 8).pack
+            self.packer.add(off, g.cout, g.k, g.k, g.cin, stem_pack)
+        elif self.trainable:
+            rt.dgrad_packs = P.dgrad_packs(g)
+            for pk in rt.dgrad_packs.values():
+                self.packer.add(off, g.cout, g.k, g.k, g.cin, pk)
+
+        def resolve():
+            if is_stem:
+                rt.w_fwd = self.packer.view(stem_pack, g.cout)
+            elif self.lp is not None:
+                rt.w_fwd = self.lp[off:off + n].view(rows, -1)
+            else:
+                rt.w_fwd = self.flat[off:off + n].view(rows, -1)
+            if rt.dgrad_packs:
+                rt.w_dgrad = {id(pk): self.packer.view(pk, g.cin) for pk in rt.dgrad_packs.values()}
+        rt._pending = resolve
+
+    # ---- per-step maintenance
+    @torch.no_grad()
+    def refresh(self):
+        """Recompute the compute-dtype operand copies from the fp32 master weights."""
+        if self.lp is not None:
+            ops.cast_bf16(self.flat[:self.n_train], self.lp[:self.n_train])
+        self.packer.run(self.flat)
+
+    @torch.no_grad()
+    def ema_from(self, other, m):
+        """self = self*m + other*(1-m) over parameters AND BN statistics (one launch), then refresh
+        the stem pack and the fused-BN affine.  moco.py:82-90 semantics (SURVEY §3.1 note A)."""
+        ops.ema_update(self.flat, other.flat, m, self.lp)
+        self.packer.run(self.flat)
+        self.update_bn_affine()
+
+    def _refresh_if_on_device(self):
+        # Building a model on the host is allowed (config / registry / checkpoint tooling);
+        # *running* it is not: refresh() and every layer raise on host tensors.
+        if self.device.type == 'cuda':
+            self.refresh()
+
+    @torch.no_grad()
+    def copy_from(self, other):
+        self.flat.copy_(other.flat)
+        self._refresh_if_on_device()
+        self.update_bn_affine()
+
+    @torch.no_grad()
+    def update_bn_affine(self):
+        if self._bn_idx is None:
+            return
+        g, b, m, v = (self.flat[i] for i in self._bn_idx)
+        scale = g * torch.rsqrt(v + self._bn_eps)
+        self.bn_affine = (scale, b - m * scale)
+
+    def clear_grad(self):
+        if self.grads is not None:
+            self.grads.zero_()
+
+    def grad_ready(self, indices):
+        """Called from the backward kernels' host code once the gradients of parameters
+        `indices` (positions in param_slices) are enqueued on the compute stream."""
+        if self.reducer is not None:
+            for i in indices:
+                self.reducer.mark_ready(i)

@@ -106,6 +106,17 @@ def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum
     return z, stats[0], stats[1]
 
 
+def bn_apply(x, scale, shift, residual=None, relu=False):
+    """z = relu?(x*scale + shift + residual) with given per-channel affine (inference BN)."""
+    Cch = x.shape[-1]
+    M = x.numel() // Cch
+    z = torch.empty_like(x)
+    L.check(_lib().passl_hip_bn_apply(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(residual),
+                                      L.ptr(z), M, Cch, 1 if relu else 0, L.dt(x), L.stream()),
+            'bn_apply')
+    return z
+
+
 def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=False):
     """Returns dx (and dres).  dgamma/dbeta (fp32 [C]) are accumulated into."""
     Cch = x.shape[-1]

@@ -1,0 +1,2 @@
+from .builder import MODELS, build_model
+from .moco import MoCo

@@ -1,0 +1,151 @@
+"""MoCo (v1/v2) on the MI355X HIP path.
+
+Constructor, registry name, attribute names (``encoder_q``, ``encoder_k``, ``backbone``, ``head``,
+buffers ``queue`` [dim,K] and ``queue_ptr`` int64[1]) and the ``forward(*inputs, mode=...)``
+contract are the reference's (passl_v110/modeling/architectures/moco.py:25-195).  The step does
+what moco.py:154-185 does, in this order:
+
+  q = normalize(encoder_q(img_q))                         train-mode BN (batch statistics)
+  no_grad: key-encoder EMA over ALL parameters incl. BN statistics (moco.py:82-90; the key
+           encoder's BN runs on those running statistics, modules/freeze.py — SURVEY §3.1 note A)
+           k = normalize(encoder_k(img_k))
+  loss/acc = InfoNCE([q.k | q@queue]/T)                   fused, no [N,K+1] logits in HBM
+  queue[:, ptr:ptr+B] = all_gather(k)^T ; ptr = (ptr+B) % K
+
+Differences by design (output-neutral): (1) batch shuffle (moco.py:107-152) is off by default
+because a key encoder with frozen-statistics BN is per-sample independent, so shuffling changes no
+output; ``shuffle_bn=True`` restores the collective pattern.  (2) the EMA is one launch over a flat
+buffer instead of 269 ``paddle.assign`` calls.  (3) encoders keep their state in EncoderArenas.
+"""
+import torch
+import torch.distributed as dist
+
+from ...hip import nn, ops
+from ...hip.nn import EncoderArena
+from ...modules import freeze_batchnorm_statictis
+from ..backbones import build_backbone
+from ..heads import build_head
+from ..necks import build_neck
+from .builder import MODELS
+
+
+def _world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+@torch.no_grad()
+def concat_all_gather(tensor):
+    """all_gather + concat along dim 0 (identity for a single process) — moco.py:198-210."""
+    ws = _world_size()
+    if ws < 2:
+        return tensor
+    out = torch.empty((ws * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
+                      device=tensor.device)
+    dist.all_gather_into_tensor(out, tensor.contiguous())
+    return out
+
+
+@MODELS.register()
+class MoCo(nn.Layer):
+    def __init__(self, backbone, neck=None, head=None, dim=128, K=65536, m=0.999, T=0.07,
+                 shuffle_bn=False):
+        super().__init__()
+        self.K, self.m, self.T = K, m, T
+        self.shuffle_bn = shuffle_bn
+        self.encoder_q = torch.nn.Sequential(build_backbone(backbone), build_neck(neck))
+        self.encoder_k = torch.nn.Sequential(build_backbone(backbone), build_neck(neck))
+        self.backbone = self.encoder_q[0]
+        self.head = build_head(head)
+        # flat storage; key encoder = copy of the query encoder, no gradients, frozen-statistics BN
+        self.arena_q = EncoderArena(self.encoder_q, trainable=True)
+        self.arena_k = EncoderArena(self.encoder_k, trainable=False)
+        self.arena_k.copy_from(self.arena_q)              # param_k.set_value(param_q), moco.py:69-72
+        freeze_batchnorm_statictis(self.encoder_k)        # moco.py:74
+        dev = self.arena_q.device
+        queue = torch.randn(dim, K)                       # host RNG (seeded by the Trainer)
+        queue = queue / queue.norm(dim=0, keepdim=True).clamp_min(1e-12)
+        self.register_buffer('queue', queue.to(dev))
+        self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.int64, device=dev))
+        self._ptr = 0     # host mirror of queue_ptr: no device->host sync in the step
+
+    # -- state ------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.sync_runtime_state()
+        return r
+
+    def sync_runtime_state(self):
+        """Call after parameters/buffers were written from outside (checkpoint load, tests)."""
+        self._ptr = int(self.queue_ptr[0].item())
+        self.arena_q.refresh()
+        self.arena_k.refresh()
+        self.arena_k.update_bn_affine()
+
+    # -- moco.py:82-90 ----------------------------------------------------------------------
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        self.arena_k.ema_from(self.arena_q, self.m)
+
+    # -- moco.py:92-105 ---------------------------------------------------------------------
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys):
+        keys = concat_all_gather(keys)
+        batch_size = keys.shape[0]
+        ptr = self._ptr
+        assert self.K % batch_size == 0  # for simplicity
+        ops.enqueue(self.queue, keys.contiguous(), ptr)
+        self._ptr = (ptr + batch_size) % self.K
+        self.queue_ptr.fill_(self._ptr)
+
+    # -- moco.py:107-152 (output-neutral here; see module docstring) -------------------------
+    @torch.no_grad()
+    def _batch_shuffle_ddp(self, x):
+        bs = x.shape[0]
+        x_gather = concat_all_gather(x)
+        n_all = x_gather.shape[0]
+        idx_shuffle = torch.randperm(n_all, device=x.device)
+        if _world_size() > 1:
+            dist.broadcast(idx_shuffle, src=0)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        rank = dist.get_rank() if _world_size() > 1 else 0
+        idx_this = idx_shuffle.view(n_all // bs, -1)[rank]
+        return x_gather[idx_this], idx_unshuffle
+
+    @torch.no_grad()
+    def _batch_unshuffle_ddp(self, x, idx_unshuffle):
+        bs = x.shape[0]
+        x_gather = concat_all_gather(x)
+        rank = dist.get_rank() if _world_size() > 1 else 0
+        idx_this = idx_unshuffle.view(x_gather.shape[0] // bs, -1)[rank]
+        return x_gather[idx_this]
+
+    # -- moco.py:154-185 --------------------------------------------------------------------
+    def train_iter(self, *inputs, **kwargs):
+        img_q, img_k = inputs
+        self.arena_q.refresh()                      # compute-dtype copies of the updated weights
+        q = self.encoder_q(img_q)                   # queries: NxC (fp32)
+        q = nn.normalize(q, axis=1)
+        with torch.no_grad():
+            self._momentum_update_key_encoder()
+            if self.shuffle_bn:
+                img_k, idx_unshuffle = self._batch_shuffle_ddp(img_k)
+            k = self.encoder_k(img_k)
+            k = nn.normalize(k, axis=1)
+            if self.shuffle_bn:
+                k = self._batch_unshuffle_ddp(k, idx_unshuffle)
+            queue_snapshot = self.queue.clone()     # `self.queue.clone().detach()`, moco.py:180
+        outputs = self.head.fused(q, k, queue_snapshot)
+        self._dequeue_and_enqueue(k)
+        return outputs
+
+    def forward(self, *inputs, mode='train', **kwargs):
+        if mode == 'train':
+            return self.train_iter(*inputs, **kwargs)
+        elif mode == 'test':
+            return self.test_iter(*inputs, **kwargs)
+        elif mode == 'extract':
+            with torch.no_grad():
+                self.arena_q.refresh()
+                return self.backbone(*inputs).permute(0, 3, 1, 2).float()
+        else:
+            raise Exception('No such mode: {}'.format(mode))

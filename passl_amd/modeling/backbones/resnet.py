@@ -1,0 +1,153 @@
+"""ResNet backbone on the HIP path (depth 50/101/152, bottleneck blocks).
+
+API and state_dict keys follow the reference's ``ResNet`` (passl_v110/modeling/backbones/
+resnet.py:25-104, a subclass of paddle.vision's ResNet whose topology is stated in-tree at
+passl_v110/modeling/backbones/resnetimagenet.py:111-253): ``ResNet(depth, num_classes=0,
+with_pool=False, zero_init_residual=False, frozen_stages=-1, pretrained=None)``; stride on
+conv2; bias-free convs; downsample = 1x1 conv(stride)+BN on the first block of a stage; init =
+kaiming-normal(fan_out, relu) for convs, BN gamma=1 beta=0.
+
+Execution differs from the reference by design: activations are NHWC in the compute dtype; in
+training mode each conv is one implicit-GEMM kernel and BN+ReLU(+residual) three streaming
+kernels; with frozen BN under no_grad (the key encoder) BN+ReLU+residual are folded into the conv
+epilogue, i.e. one kernel per conv and no extra pass over the activations.
+``forward`` takes the reference's NCHW fp32 image batch and returns the NHWC layer4 feature map.
+"""
+import torch
+
+from ...hip import nn, ops, plan as P
+from ...modules import init, freeze
+from ...utils.logger import get_logger
+from .builder import BACKBONES
+
+
+class BottleneckBlock(nn.Layer):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64,
+                 dilation=1, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2D
+        width = int(planes * (base_width / 64.)) * groups
+        self.conv1 = nn.Conv2D(inplanes, width, 1, bias_attr=False)
+        self.bn1 = norm_layer(width)
+        self.conv2 = nn.Conv2D(width, width, 3, padding=dilation, stride=stride, groups=groups,
+                               dilation=dilation, bias_attr=False)
+        self.bn2 = norm_layer(width)
+        self.conv3 = nn.Conv2D(width, planes * self.expansion, 1, bias_attr=False)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU()
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        out = self.conv3(out)
+        if self.downsample is not None:
+            identity = self.downsample[1](self.downsample[0](x), relu=False)
+        return self.bn3(out, residual=identity, relu=True)      # out += identity; relu
+
+    def forward_frozen(self, x):
+        """Same block with running-stat BN folded into the conv epilogues (3-4 kernels)."""
+        out = self.conv1.infer(x, self.bn1, relu=True)
+        out = self.conv2.infer(out, self.bn2, relu=True)
+        identity = x
+        if self.downsample is not None:
+            identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
+        return self.conv3.infer(out, self.bn3, residual=identity, relu=True)
+
+
+@BACKBONES.register()
+class ResNet(nn.Layer):
+    def __init__(self, depth, num_classes=0, with_pool=False, zero_init_residual=False,
+                 frozen_stages=-1, pretrained=None):
+        super().__init__()
+        layer_cfg = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+        if depth not in layer_cfg:
+            raise NotImplementedError('HIP path builds bottleneck ResNets only (depth 50/101/152)')
+        if num_classes > 0:
+            raise NotImplementedError('classification fc is outside the MoCo hot path')
+        layers = layer_cfg[depth]
+        self.num_classes = num_classes
+        self.with_pool = with_pool
+        self._norm_layer = nn.BatchNorm2D
+        self.inplanes = 64
+        self.dilation = 1
+        self.conv1 = nn.Conv2D(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias_attr=False)
+        self.bn1 = self._norm_layer(self.inplanes)
+        self.relu = nn.ReLU()
+        self.maxpool = nn.MaxPool2D(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(BottleneckBlock, 64, layers[0])
+        self.layer2 = self._make_layer(BottleneckBlock, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(BottleneckBlock, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(BottleneckBlock, 512, layers[3], stride=2)
+        if with_pool:
+            self.avgpool = nn.AdaptiveAvgPool2D((1, 1))
+        self.zero_init_residual = zero_init_residual
+        self.frozen_stages = frozen_stages
+        self.init_parameters()
+        if pretrained is not None:
+            state_dict = torch.load(pretrained, map_location='cpu')
+            if 'state_dict' in state_dict:
+                state_dict = state_dict['state_dict']
+            self.set_state_dict(state_dict)
+            get_logger().info('Load pretrained backbone weight from {} success!'.format(pretrained))
+        self._freeze_stages()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        norm_layer = self._norm_layer
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = torch.nn.Sequential(
+                nn.Conv2D(self.inplanes, planes * block.expansion, 1, stride=stride, bias_attr=False),
+                norm_layer(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample, 1, 64, 1, norm_layer)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, norm_layer=norm_layer))
+        return torch.nn.Sequential(*layers)
+
+    def init_parameters(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2D):
+                init.kaiming_init(m, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn._BatchNormBase):
+                init.constant_init(m, 1)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BottleneckBlock):
+                    init.constant_init(m.bn3, 0)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            raise NotImplementedError('frozen_stages>=0 (linear-probe configs) is outside the '
+                                      'MoCo pre-training hot path')
+
+    def _all_bn_frozen(self):
+        return all(m.uses_global_stats() for m in self.modules() if isinstance(m, nn._BatchNormBase))
+
+    def forward(self, x):
+        """x: [N,3,H,W] fp32 (reference layout) -> [N,H/32,W/32,2048] NHWC in the compute dtype."""
+        rt = nn._need_rt(self.conv1)
+        dtype = rt.arena.dtype
+        N, _, H, W = x.shape
+        _Hp, Wp = P.stem_padded_hw(H, W)
+        xp = ops.nchw_to_nhwc_pad(x.contiguous().float(), P.STEM_PAD, Wp, P.STEM_CP, dtype)
+        frozen = self._all_bn_frozen()
+        if frozen and not torch.is_grad_enabled():
+            y = self.conv1.infer(xp, self.bn1, relu=True, hw=(H, W))
+            y = self.maxpool(y)
+            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in stage:
+                    y = blk.forward_frozen(y)
+        else:
+            y = self.bn1(self.conv1(xp, hw=(H, W)), relu=True)
+            y = self.maxpool(y)
+            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for blk in stage:
+                    y = blk(y)
+        if self.with_pool:
+            y = self.avgpool(y)
+        return y

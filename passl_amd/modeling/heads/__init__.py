@@ -1,0 +1,2 @@
+from .builder import HEADS, build_head
+from .contrastive_head import ContrastiveHead

@@ -1,0 +1,2 @@
+from .builder import build_lr_scheduler, build_optimizer, LRSCHEDULERS, OPTIMIZERS
+from . import lr_scheduler, optimizer

@@ -1,0 +1,79 @@
+"""Learning-rate schedulers with paddle.optimizer.lr semantics (the reference registers Paddle's
+own classes, passl_v110/solver/lr_scheduler.py:20-28): the constructor performs the first
+``step()`` (last_epoch 0 -> base lr), ``step()`` advances one unit, ``get_lr()``/``__call__``
+return the current value.  CosineAnnealingDecay uses the closed form
+``eta_min + (lr-eta_min)*(1+cos(pi*t/T_max))/2`` (Paddle's recursive form agrees to fp error)."""
+import math
+
+from .builder import LRSCHEDULERS
+
+
+class LRScheduler(object):
+    def __init__(self, learning_rate=0.1, last_epoch=-1, verbose=False):
+        self.base_lr = float(learning_rate)
+        self.last_lr = float(learning_rate)
+        self.last_epoch = last_epoch
+        self.verbose = verbose
+        self.step()
+
+    def __call__(self):
+        return self.last_lr
+
+    def get_lr(self):
+        raise NotImplementedError
+
+    def step(self, epoch=None):
+        if epoch is None:
+            self.last_epoch += 1
+        else:
+            self.last_epoch = epoch
+        self.last_lr = self.get_lr()
+
+    def state_dict(self):
+        return {'last_epoch': self.last_epoch, 'last_lr': self.last_lr}
+
+    def set_state_dict(self, sd):
+        self.last_epoch = sd['last_epoch']
+        self.last_lr = sd['last_lr']
+
+
+@LRSCHEDULERS.register()
+class CosineAnnealingDecay(LRScheduler):
+    def __init__(self, learning_rate, T_max, eta_min=0, last_epoch=-1, verbose=False):
+        self.T_max = T_max
+        self.eta_min = float(eta_min)
+        super().__init__(learning_rate, last_epoch, verbose)
+
+    def get_lr(self):
+        return self.eta_min + (self.base_lr - self.eta_min) * \
+            (1 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+
+
+@LRSCHEDULERS.register()
+class MultiStepDecay(LRScheduler):
+    def __init__(self, learning_rate, milestones, gamma=0.1, last_epoch=-1, verbose=False):
+        self.milestones = list(milestones)
+        self.gamma = gamma
+        super().__init__(learning_rate, last_epoch, verbose)
+
+    def get_lr(self):
+        n = sum(1 for m in self.milestones if self.last_epoch >= m)
+        return self.base_lr * (self.gamma ** n)
+
+
+@LRSCHEDULERS.register()
+class LinearWarmup(LRScheduler):
+    def __init__(self, learning_rate, warmup_steps, start_lr, end_lr, last_epoch=-1, verbose=False):
+        self.learning_rate = learning_rate      # float or LRScheduler
+        self.warmup_steps = warmup_steps
+        self.start_lr, self.end_lr = start_lr, end_lr
+        super().__init__(start_lr, last_epoch, verbose)
+
+    def get_lr(self):
+        if self.last_epoch < self.warmup_steps:
+            return (self.end_lr - self.start_lr) * float(self.last_epoch) / float(self.warmup_steps) \
+                + self.start_lr
+        if isinstance(self.learning_rate, LRScheduler):
+            self.learning_rate.step(self.last_epoch - self.warmup_steps)
+            return self.learning_rate()
+        return self.learning_rate

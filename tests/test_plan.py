@@ -7,7 +7,14 @@ import torch.nn.functional as F
 import emu
 from passl_amd.hip import plan as P
 
-torch.set_default_dtype(torch.float64)
+
+
+@pytest.fixture(autouse=True)
+def _fp64_default():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(old)
 
 GEOMS = [
     P.ConvGeom(cin=8, cout=16, k=3, stride=1, pad=1),
