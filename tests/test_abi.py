@@ -1,0 +1,75 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/passl_hip.h declares,
+the ctypes structs have the C layout, and argument errors are reported before any launch."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from passl_amd.hip import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'passl_hip.h')
+
+
+@pytest.fixture(scope='module')
+def lib():
+    if not os.path.exists(L.LIB_PATH):
+        from passl_amd.csrc.build import build
+        build()
+    return L.load()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(passl_hip_\w+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 29
+    for s in syms:
+        assert hasattr(lib, s), 'not exported: ' + s
+        assert s in L.SIGNATURES, 'declared in the header but not bound in lib.py: ' + s
+    assert sorted(L.SIGNATURES) == syms, 'lib.py binds symbols the header does not declare'
+
+
+def test_abi_version_and_strerror(lib):
+    assert lib.passl_hip_abi_version() == 1
+    assert b'invalid' in lib.passl_hip_strerror(-1)
+    assert lib.passl_hip_strerror(0) == b'ok'
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    src = tmp_path / 'sz.c'
+    src.write_text('#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){'
+                   'printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(passl_pack_job), sizeof(passl_conv_desc),'
+                   'sizeof(passl_wgrad_desc), offsetof(passl_conv_desc, a_sn), offsetof(passl_conv_desc, relu),'
+                   'offsetof(passl_wgrad_desc, dy_ld)); return 0; }\n' % HEADER)
+    exe = tmp_path / 'sz'
+    subprocess.check_call(['gcc', str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert [int(v) for v in out] == [ctypes.sizeof(L.PackJob), ctypes.sizeof(L.ConvDesc),
+                                     ctypes.sizeof(L.WgradDesc), L.ConvDesc.a_sn.offset,
+                                     L.ConvDesc.relu.offset, L.WgradDesc.dy_ld.offset]
+
+
+def test_argument_errors_are_reported_without_a_gpu(lib):
+    # null pointers / bad shapes are rejected before anything is launched
+    assert lib.passl_hip_ema_update(None, None, None, 16, 0.999, None) == -1
+    assert lib.passl_hip_momentum_sgd(None, None, None, 16, 0.1, 0.9, 0.0, 1.0, None) == -1
+    assert lib.passl_hip_infonce_fwd(None, None, None, 8, 128, 1024, 0.2, None, None, None, None, None) == -1
+    d = L.ConvDesc()
+    assert lib.passl_hip_conv_igemm(ctypes.byref(d), None) == -1
+    w = L.WgradDesc()
+    assert lib.passl_hip_conv_wgrad(ctypes.byref(w), None) == -1
+    assert lib.passl_hip_infonce_workspace_bytes(256, 65536) == 512 * 256 * 16
+
+
+def test_host_tensors_are_refused():
+    import torch
+    from passl_amd.hip import ops
+    with pytest.raises(L.PasslHipError):
+        ops.ema_update(torch.zeros(16), torch.zeros(16), 0.9)

@@ -1,0 +1,143 @@
+"""N>1 path on CPU: two gloo processes exercise the GradReducer (bucketed, order-safe,
+overlappable all-reduce over the flat gradient buffer), grad_sync / param_sync, the key
+all-gather used by the queue update, and the Trainer's replica initialisation."""
+import os
+import socket
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+def _fake_arena(sizes):
+    off, slices = 0, []
+    for n in sizes:
+        slices.append((off, n))
+        off += (n + 7) // 8 * 8
+    return SimpleNamespace(grads=torch.zeros(off), param_slices=slices, reducer=None)
+
+
+def _reducer_case(rank, world):
+    from passl_amd.core.sync_utils import GradReducer
+    sizes = [40, 8, 8, 100, 16, 16, 200, 8, 64, 24]
+    arena = _fake_arena(sizes)
+    opt = SimpleNamespace(grad_scale=1.0)
+    red = GradReducer(arena, opt, bucket_elems=128)
+    assert opt.grad_scale == 1.0 / world
+    assert len(red.buckets) >= 3
+    covered = sorted(i for b in red.buckets for i in b[2])
+    assert covered == list(range(len(sizes)))                 # every parameter in exactly one bucket
+    results = []
+    for step in range(2):
+        arena.grads.zero_()
+        red.begin()
+        # "backward": last layer first, but ranks report readiness in different interleavings
+        order = list(range(len(sizes) - 1, -1, -1))
+        if rank == 1:
+            order[0], order[1] = order[1], order[0]
+            order[4], order[6] = order[6], order[4]
+        for i in order:
+            off, n = arena.param_slices[i]
+            arena.grads[off:off + n] = float((rank + 1) * (i + 1) + step)
+            if i != 3 or step == 0:      # parameter 3 gets no gradient in step 1 (finish() covers it)
+                red.mark_ready(i)
+        red.finish()
+        results.append(arena.grads.clone())
+    return results
+
+
+def test_grad_reducer_bucketed_allreduce():
+    out = _spawn(_reducer_case)
+    sizes = [40, 8, 8, 100, 16, 16, 200, 8, 64, 24]
+    arena = _fake_arena(sizes)
+    for step in range(2):
+        assert torch.equal(out[0][step], out[1][step])
+        for i, (off, n) in enumerate(arena.param_slices):
+            expect = sum((r + 1) * (i + 1) + step for r in range(2))
+            assert torch.all(out[0][step][off:off + n] == expect), (step, i)
+
+
+def _sync_case(rank, world):
+    from passl_amd.core.sync_utils import grad_sync, param_sync
+    from passl_amd.modeling.architectures.moco import concat_all_gather
+    torch.manual_seed(rank)
+    lin = torch.nn.Linear(4, 3)
+    lin.register_buffer('buf', torch.full((2,), float(rank)))
+    param_sync(lin, src_rank=0)
+    w_after = lin.weight.detach().clone()
+    for p in lin.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))
+    grad_sync([{'params': list(lin.parameters())}])
+    keys = torch.full((2, 3), float(rank))
+    gathered = concat_all_gather(keys)
+    return w_after, lin.buf.clone(), lin.weight.grad.clone(), gathered
+
+
+def test_param_sync_grad_sync_and_key_gather():
+    out = _spawn(_sync_case)
+    assert torch.equal(out[0][0], out[1][0])                # weights broadcast from rank 0
+    assert torch.all(out[1][1] == 0)                        # buffers too
+    assert torch.all(out[0][2] == 1.5) and torch.all(out[1][2] == 1.5)   # mean of (1, 2)
+    for r in (0, 1):
+        assert out[r][3].shape == (4, 3)
+        assert torch.all(out[r][3][:2] == 0) and torch.all(out[r][3][2:] == 1)
+
+
+def _trainer_case(rank, world):
+    """Two Trainer replicas on CPU with a host-only model whose parameters live in an arena-like
+    flat buffer: checks rank-dependent seeding + flat broadcast + reducer wiring."""
+    from passl_amd.hip import config as hip_config
+    hip_config.set_device('cpu')
+    from passl_amd.hip.nn import EncoderArena, Linear
+    from passl_amd.core.sync_utils import GradReducer, param_sync
+    torch.manual_seed(100 + rank)
+    enc = torch.nn.Sequential(Linear(8, 16), Linear(16, 8))
+    for m in enc:
+        torch.nn.init.normal_(m.weight)
+    arena = EncoderArena(enc, trainable=True, dtype=torch.float32)
+    holder = SimpleNamespace(arena_q=arena, parameters=lambda: enc.parameters(),
+                             buffers=lambda: enc.buffers())
+    before = arena.flat.clone()
+    param_sync(holder, src_rank=0)
+    red = GradReducer(arena, None, bucket_elems=64)
+    red.begin()
+    arena.grads.fill_(float(rank + 1))
+    for i in range(len(arena.param_slices) - 1, -1, -1):
+        arena.grad_ready([i])
+    red.finish()
+    return before, arena.flat.clone(), arena.grads.clone(), [p.grad.sum().item() for p in enc.parameters()]
+
+
+def test_arena_replicas_and_reducer_via_arena_hooks():
+    out = _spawn(_trainer_case)
+    assert not torch.equal(out[0][0], out[1][0])             # different seeds before the sync
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1], out[0][0])
+    assert torch.all(out[0][2] == 3.0) and torch.all(out[1][2] == 3.0)
+    assert out[0][3] == out[1][3] and out[0][3][0] == 3.0 * 8 * 16   # p.grad views see the reduced buffer

@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference interface, exercised on CPU: registries, config +
+overrides, lr schedule, hook bus order, Trainer loop, model construction / state_dict layout.
+(The HIP layers are built but not run here; running them needs the GPU tests.)"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from passl_amd.hip import config as hip_config
+from passl_amd.utils.config import AttrDict, get_config, override_config
+from passl_amd.utils.registry import Registry, build_from_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CFG = '/root/reference/configs/moco/moco_v2_r50.yaml'
+OUR_CFG = os.path.join(ROOT, 'configs/moco/moco_v2_r50_synthetic.yaml')
+
+
+def test_registry_contract():
+    R = Registry('T')
+
+    @R.register()
+    class A(object):
+        def __init__(self, x=1):
+            self.x = x
+    R.register(dict, name='D')
+    assert R.get('A') is A and R.get('D') is dict
+    with pytest.raises(AssertionError):
+        R.register(A)                         # duplicate name
+    with pytest.raises(KeyError):
+        R.get('missing')
+    assert build_from_config({'name': 'A', 'x': 3}, R).x == 3
+    assert build_from_config({'x': 5}, R, default_args={'name': 'A'}).x == 5
+    with pytest.raises(KeyError):
+        build_from_config({'x': 5}, R)
+    with pytest.raises(TypeError):
+        build_from_config({'name': 'A', 'bogus': 1}, R)      # constructor error is re-raised
+    with pytest.raises(TypeError):
+        build_from_config(['name'], R)
+
+
+def test_config_overrides():
+    cfg = get_config(OUR_CFG, ['optimizer.weight_decay=0.5', 'epochs=3',
+                               'dataloader.train.sampler.batch_size=64'])
+    assert cfg.optimizer.weight_decay == 0.5 and cfg.epochs == 3
+    assert cfg.dataloader.train.sampler.batch_size == 64
+    assert isinstance(cfg.model.backbone, AttrDict) and cfg.model.backbone.depth == 50
+    with pytest.raises(AssertionError):
+        override_config(cfg, ['model.nonexistent=1'])
+    with pytest.raises(AssertionError):
+        get_config('/nonexistent.yaml')
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason='reference tree not present')
+def test_reference_moco_config_loads_and_builds_unchanged():
+    hip_config.set_device('cpu')
+    from passl_amd.modeling import build_model
+    cfg = get_config(REF_CFG, ['dataloader.train.dataset.name=SyntheticTwoView'])
+    assert cfg.model.head.temperature == 0.2 and cfg.lr_scheduler.T_max == 200
+    assert cfg.dataloader.train.dataset.view_trans1[5].scale == '1.0/255.0'   # literal_eval keeps it
+    model = build_model(cfg.model)
+    assert model.K == 65536 and model.m == 0.999 and model.head.temperature == 0.2
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 27966656
+
+
+def test_model_state_layout_matches_reference_naming():
+    """state_dict keys/shapes = SURVEY appendix A (and the oracle's, which is checked against the
+    reference's own state_dict order in oracle/ref_runner.load_oracle_state)."""
+    hip_config.set_device('cpu')
+    from oracle.resnet50 import init_encoder_state
+    from passl_amd.modeling import build_model
+    import moco_util as U
+    cfg = dict(U.MODEL_CFG)
+    cfg.update(K=256)
+    model = build_model(cfg)
+    ost = init_encoder_state(torch.Generator().manual_seed(0))
+    qsd = model.encoder_q.state_dict()
+    assert list(qsd.keys()) == list(ost.keys())
+    for k in ost:
+        assert tuple(qsd[k].shape) == tuple(ost[k].shape), k
+    full = model.state_dict()
+    assert 'queue' in full and 'queue_ptr' in full and full['queue'].shape == (128, 256)
+    assert 'backbone.conv1.weight' in full and 'encoder_k.1.mlp.2.bias' in full
+    np.testing.assert_allclose(full['queue'].norm(dim=0).numpy(), 1.0, atol=1e-5)
+    # physical layouts: conv [K][R][S][C], linear [out][in]; grads alias the flat buffer
+    w = model.encoder_q[0].layer1[0].conv2.weight
+    assert w.shape == (64, 64, 3, 3) and w.stride() == (576, 1, 192, 64)
+    lw = model.encoder_q[1].mlp[0].weight
+    assert lw.shape == (2048, 2048) and lw.stride() == (1, 2048)
+    a = model.arena_q
+    assert w.grad.untyped_storage().data_ptr() == a.grads.untyped_storage().data_ptr()
+    assert a.n_train == 27966656 and a.total - a.n_train == 2 * 26560
+    # key encoder: copy of q, no grads, frozen-statistics BN
+    assert torch.equal(model.arena_k.flat, model.arena_q.flat)
+    assert all(not p.requires_grad for p in model.encoder_k.parameters())
+    assert all(m._use_global_stats for m in model.encoder_k.modules() if hasattr(m, '_use_global_stats'))
+    # load_state_dict round trip through the strided views
+    sd = {k: torch.randn_like(v) for k, v in qsd.items()}
+    model.encoder_q.load_state_dict(sd)
+    for k, v in model.encoder_q.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # and the flat buffer holds conv weights physically as KRSC
+    off, n = a.param_slices[0]
+    assert torch.equal(a.flat[off:off + n].view(64, 7, 7, 3), sd['0.conv1.weight'].permute(0, 2, 3, 1))
+
+
+def test_cosine_schedule_and_momentum_spelling():
+    from passl_amd.solver import build_lr_scheduler, LRSCHEDULERS, OPTIMIZERS
+    cfg = AttrDict(name='CosineAnnealingDecay', learning_rate=0.015, T_max=200)
+    s = build_lr_scheduler(cfg, iters_per_epoch=10)
+    assert s.T_max == 2000 and s.get_lr() == 0.015 and s.last_epoch == 0
+    for t in range(1, 5):
+        s.step()
+        assert abs(s() - 0.015 * 0.5 * (1 + math.cos(math.pi * t / 2000))) < 1e-15
+    assert 'Momentum' in OPTIMIZERS and 'LinearWarmup' in LRSCHEDULERS and 'MultiStepDecay' in LRSCHEDULERS
+    with pytest.raises(NotImplementedError):
+        OPTIMIZERS.get('Momentum')(0.1, parameters=[torch.nn.Parameter(torch.zeros(3))])
+
+
+def _register_dummies():
+    """A tiny CPU model / optimizer registered the way a third-party user would."""
+    from passl_amd.modeling.architectures.builder import MODELS
+    from passl_amd.solver.builder import OPTIMIZERS
+    if 'DummySSL' in MODELS:
+        return
+
+    @MODELS.register()
+    class DummySSL(torch.nn.Module):
+        def __init__(self, dim=4):
+            super().__init__()
+            self.fc = torch.nn.Linear(3, dim)
+            self.calls = []
+
+        def forward(self, xq, xk, mode='train', **kw):
+            self.calls.append(sorted(kw))
+            return {'loss': (self.fc(xq.mean((2, 3))) - self.fc(xk.mean((2, 3)))).pow(2).mean().reshape(1),
+                    'acc1': torch.tensor([50.0])}
+
+    @OPTIMIZERS.register()
+    class PlainSGD(object):
+        type = 'sgd'
+
+        def __init__(self, learning_rate, parameters=None, **kw):
+            self.lr, self.params = learning_rate, list(parameters)
+
+        def clear_grad(self):
+            for p in self.params:
+                p.grad = None
+
+        def step(self):
+            with torch.no_grad():
+                for p in self.params:
+                    p -= float(self.lr()) * p.grad
+
+        def get_lr(self):
+            return float(self.lr())
+
+        def state_dict(self):
+            return {}
+
+
+def test_trainer_loop_hooks_and_checkpoint(tmp_path):
+    _register_dummies()
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.hooks import Hook, HOOKS
+    events = []
+    if 'SpyHook' not in HOOKS:
+        @HOOKS.register()
+        class SpyHook(Hook):
+            def __init__(self, priority=1):
+                self.priority = priority
+
+            def train_iter_begin(self, t):
+                events.append(('begin', t.current_iter, t.inner_iter))
+
+            def train_iter_end(self, t):
+                events.append(('end', t.current_iter, float(t.lr_scheduler.get_lr())))
+        HOOKS.get('SpyHook').events = events
+    else:
+        events = HOOKS.get('SpyHook').events
+        del events[:]
+    cfg = get_config(OUR_CFG, ['device=cpu', 'epochs=2', 'dataloader.train.sampler.batch_size=4',
+                               'dataloader.train.dataset.num_samples=12',
+                               'dataloader.train.dataset.image_size=8',
+                               'log_config.interval=1', 'checkpoint.interval=1'])
+    cfg.model = AttrDict(name='DummySSL', dim=4)
+    cfg.optimizer = AttrDict(name='PlainSGD')
+    cfg.custom_config = [AttrDict(name='SpyHook')]
+    cfg.output_dir = str(tmp_path)
+    cfg.timestamp = '-t'
+    tr = Trainer(cfg)
+    names = [type(h).__name__ for h in tr.hooks]
+    assert names == ['OptimizerHook', 'IterTimerHook', 'CheckpointHook', 'LogHook',
+                     'LRSchedulerHook', 'SpyHook']       # trainer.py:235-263 order, stable sort
+    assert tr.iters_per_epoch == 3 and tr.total_iters == 6
+    w0 = tr.model.fc.weight.detach().clone()
+    tr.train()
+    assert tr.current_iter == 6 and tr.current_epoch == 2
+    assert not torch.equal(w0, tr.model.fc.weight)
+    assert [e[:2] for e in events if e[0] == 'begin'] == [('begin', i + 1) for i in range(6)]
+    assert [e[2] for e in events if e[0] == 'begin'] == [0, 1, 2, 0, 1, 2]
+    # model call contract: total_iters / current_iter / mixup_fn kwargs (trainer.py:326-330)
+    assert tr.model.calls[0] == ['current_iter', 'mixup_fn', 'total_iters']
+    # cosine lr stepped per iteration: lr seen by the spy at iter i is lr(i) (spy runs after LR hook)
+    lrs = [e[2] for e in events if e[0] == 'end']
+    assert abs(lrs[0] - 0.015 * 0.5 * (1 + math.cos(math.pi * 1 / 600))) < 1e-12
+    # LogHook flushed the deferred device scalars into AverageMeters
+    assert os.path.exists(os.path.join(str(tmp_path), 'epoch_2.pd'))
+    assert os.path.islink(os.path.join(str(tmp_path), 'latest.pd'))
+
+
+def test_v2_train_one_step_facade():
+    """ContrastiveLearningTrainingEpochLoop.train_one_step(batch) -> (None, loss_dict)
+    (passl/engine/loops/contrastive_learning_loop.py:67-88), with gradient accumulation."""
+    _register_dummies()
+    from types import SimpleNamespace
+    from passl_amd.engine.loops import ContrastiveLearningTrainingEpochLoop
+    from passl_amd.modeling.architectures.builder import MODELS
+    from passl_amd.solver.builder import OPTIMIZERS
+    from passl_amd.solver.lr_scheduler import CosineAnnealingDecay
+    model = MODELS.get('DummySSL')()
+    sched = CosineAnnealingDecay(0.1, T_max=10)
+    opt = OPTIMIZERS.get('PlainSGD')(sched, parameters=model.parameters())
+    opt._parameter_list = opt.params
+    tr = SimpleNamespace(model=model, optimizer=opt, lr_scheduler=sched, accum_steps=2,
+                         lr_decay_unit='step')
+    loop = ContrastiveLearningTrainingEpochLoop(tr, epochs=1)
+    batch = [[torch.randn(4, 3, 8, 8), torch.randn(4, 3, 8, 8)], torch.zeros(4)]
+    w0 = model.fc.weight.detach().clone()
+    out, loss_dict = loop.train_one_step(batch)
+    assert out is None and 'loss' in loss_dict and loop.global_step == 1
+    assert not torch.equal(w0, model.fc.weight) and sched.last_epoch == 1
