@@ -18,13 +18,14 @@ static inline hipStream_t as_stream(passl_stream_t s) { return reinterpret_cast<
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // round-to-nearest-even; NaN stays NaN
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f));
 }
+// two floats -> packed bf16 pair, RNE, one v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+  const bf2_t v = __builtin_convertvector(f2_t{lo, hi}, bf2_t);
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct ElemTraits;

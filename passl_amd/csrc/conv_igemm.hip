@@ -14,10 +14,17 @@
 //   (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct slots of the 256-byte
 //   bank row (conflict-free), global->register->LDS staging with the next tile's loads issued
 //   before the current tile's MFMAs (one barrier per K-tile).
-// Epilogue: accumulators -> LDS (fp32) -> coalesced 16/32-byte row stores with the fused
-//   per-channel affine (BatchNorm in inference form), residual add and ReLU.
+// Epilogue: accumulators -> LDS -> coalesced 16/32-byte row stores with the fused per-channel
+//   affine (BatchNorm in inference form), residual add and ReLU.  bf16 outputs are staged as
+//   packed bf16 pairs (34 KB instead of 66 KB of LDS); fp32 outputs / the fp32 path stage fp32.
+// Pipelining: STAGES=2 double-buffers the LDS tiles (one barrier per K-tile, 64 KB of LDS, 2
+//   workgroups per CU); STAGES=1 keeps ONE LDS tile and prefetches the next K-tile into registers
+//   while the MFMAs run (two barriers per K-tile, 35 KB of LDS, 3 workgroups per CU) — the better
+//   trade for the short-K, store-heavy 1x1 convolutions that are HBM/latency- rather than
+//   MFMA-bound.
 // Grid: one workgroup per output tile, N-tiles fastest, remapped so that every XCD (private L2)
 //   walks a contiguous range of tiles: the N-tiles that share an A row-panel hit the same L2.
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 
@@ -27,6 +34,26 @@ constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+// exact n / d for all 32-bit n by multiply-high (Granlund-Montgomery); d is launch-invariant
+struct FastDiv {
+  uint32_t mul, sh1, sh2;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f = {0, 0, 0};
+  if (d > 1) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = 1;
+    f.sh2 = l - 1;
+  }
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv f) {
+  const uint32_t t = __umulhi(f.mul, (uint32_t)n);
+  return (int)((t + (((uint32_t)n - t) >> f.sh1)) >> f.sh2);
+}
 
 struct Params {
   const char* a;
@@ -41,12 +68,17 @@ struct Params {
   int64_t y_sn, y_sh, y_sw;
   int relu, out_f32;
   int tiles_n, ntiles;
+  FastDiv d_opq, d_oq, d_tn;
+  int dbg;   // ablation switches for tuning runs (PASSL_IGEMM_DBG): 1 no stores, 2 no epilogue, 4 no A loads, 8 no MFMA
 };
 
 __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
-template <typename T, int BM, int BN, bool GENERIC>
-__global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
+// DENSE: 1x1 / stride 1 / no padding with dense A and Y: row m lives at m*C resp. m*NCOLS, no
+// (n,op,oq) decomposition at all.
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE>
+__global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
+    igemm_kernel(const Params p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;          // elements per 16-byte slot
   constexpr int BK = kRowBytes / ES;    // elements per K-tile
@@ -55,14 +87,15 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
   constexpr int ACH = BM * 8 / kThreads;  // A chunks per thread
   constexpr int BCH = BN * 8 / kThreads;  // B chunks per thread
   constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
-  constexpr int LDO = BN + 4;
+  constexpr int LDO = BN + 4;    // fp32 epilogue pitch (floats)
+  constexpr int LDOB = BN + 8;   // bf16 epilogue pitch (elements): 272-byte rows, 16-byte aligned
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [A0][A1][B0][B1] ; epilogue reuses the front as float out[BM][LDO]; row offsets at the end
   char* As = smem;
-  char* Bs = smem + 2 * A_BYTES;
-  constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES);
-  constexpr int EPI_BYTES = BM * LDO * 4;
+  char* Bs = smem + STAGES * A_BYTES;
+  constexpr int STAGE_BYTES = STAGES * (A_BYTES + B_BYTES);
+  constexpr int EPI_BYTES = EPI32 ? BM * LDO * 4 : BM * LDOB * 2;
   constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   int64_t* rowoff = reinterpret_cast<int64_t*>(smem + MAIN_BYTES);
 
@@ -75,7 +108,7 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     tile = start + local;
   }
-  const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+  const int mt = fdiv(tile, p.d_tn), nt = tile - mt * p.tiles_n;
   const int m0 = mt * BM, n0 = nt * BN;
 
   const int tid = threadIdx.x;
@@ -91,10 +124,14 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
   for (int i = 0; i < ACH; ++i) {
     const int row = (tid >> 3) + 32 * i;
     const int m = m0 + row;
-    if (m < p.M) {
-      const int n = m / opq;
+    if (DENSE) {
+      a_base[i] = (int64_t)m * p.C;
+      ih0[i] = m < p.M ? 0 : -(1 << 28);
+      iw0[i] = 0;
+    } else if (m < p.M) {
+      const int n = fdiv(m, p.d_opq);
       const int rem = m - n * opq;
-      const int op = rem / p.OQ;
+      const int op = fdiv(rem, p.d_oq);
       const int oq = rem - op * p.OQ;
       a_base[i] = (int64_t)n * p.a_sn;
       ih0[i] = op * p.sh - p.ph;
@@ -110,11 +147,15 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
     const int m = m0 + tid;
     int64_t off = -1;
     if (m < p.M) {
-      const int n = m / opq;
-      const int rem = m - n * opq;
-      const int op = rem / p.OQ;
-      const int oq = rem - op * p.OQ;
-      off = (int64_t)n * p.y_sn + (int64_t)op * p.y_sh + (int64_t)oq * p.y_sw;
+      if (DENSE) {
+        off = (int64_t)m * p.NCOLS;
+      } else {
+        const int n = fdiv(m, p.d_opq);
+        const int rem = m - n * opq;
+        const int op = fdiv(rem, p.d_oq);
+        const int oq = rem - op * p.OQ;
+        off = (int64_t)n * p.y_sn + (int64_t)op * p.y_sh + (int64_t)oq * p.y_sw;
+      }
     }
     rowoff[tid] = off;
   }
@@ -142,10 +183,12 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int ih = ih0[i] + r, iw = iw0[i] + s;
-      const bool ok = kvalid && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW;
+      const bool ok = DENSE ? (ih0[i] >= 0)
+                            : (kvalid && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW);
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const int64_t off = a_base[i] + (int64_t)ih * p.a_sh + (int64_t)iw * p.a_sw + c;
+      if (ok && !(p.dbg & 4)) {
+        const int64_t off = DENSE ? a_base[i] + c
+                                  : a_base[i] + (int64_t)ih * p.a_sh + (int64_t)iw * p.a_sw + c;
         v = *reinterpret_cast<const uint4*>(p.a + off * ES);
       }
       ra[i] = v;
@@ -179,16 +222,8 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
   const int l15 = lane & 15, l4 = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const char* Ab = As + buf * A_BYTES;
-    const char* Bb = Bs + buf * B_BYTES;
+  auto compute_tile = [&](const char* Ab, const char* Bb) {
     if constexpr (ES == 2) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -209,7 +244,10 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            // operands swapped (A := weight fragment, B := activation fragment) so that a lane
+            // ends up with 4 CONSECUTIVE output channels of one pixel:
+            //   acc[i][j][r] = C[row = wm*WM + i*16 + l15][col = wn*WN + j*16 + l4*4 + r]
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -229,101 +267,197 @@ __global__ void __launch_bounds__(kThreads, 2) igemm_kernel(const Params p) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+
+  load_tile(0);
+  if constexpr (STAGES == 2) {
+    store_tile(0);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_tile(kt + 1);
+      compute_tile(As + buf * A_BYTES, Bs + buf * B_BYTES);
+      if (kt + 1 < nk) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tile(0);
+      __syncthreads();
+      if (kt + 1 < nk) load_tile(kt + 1);      // in flight while the MFMAs run
+      if (!(p.dbg & 8)) compute_tile(As, Bs);
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue phase 1: accumulators -> LDS fp32 tile
-  float* out = reinterpret_cast<float*>(smem);
+  constexpr int CPR = BN / 8;  // 8-column chunks per row
+  if (p.dbg & 2) return;
+  if constexpr (EPI32) {
+    // ---- epilogue phase 1: accumulators -> LDS fp32 tile
+    float* out = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * WM + i * 16 + l4 * 4 + r;
-        const int col = wn * WN + j * 16 + l15;
-        out[row * LDO + col] = acc[i][j][r];
+      for (int j = 0; j < FN; ++j) {
+        const int row = wm * WM + i * 16 + l15;
+        const int col = wn * WN + j * 16 + l4 * 4;
+        *reinterpret_cast<f32x4*>(out + row * LDO + col) = acc[i][j];
       }
-  __syncthreads();
-
-  // ---- phase 2: coalesced row stores, 8 columns per thread-chunk
-  constexpr int CPR = BN / 8;  // chunks per row
+    __syncthreads();
+    // ---- phase 2: coalesced row stores, 8 columns per thread-chunk
 #pragma unroll
-  for (int t = 0; t < BM * CPR / kThreads; ++t) {
-    const int chunk = tid + t * kThreads;
-    const int row = chunk / CPR, cc = chunk - row * CPR;
-    const int gcol = n0 + cc * 8;
-    const int64_t roff = rowoff[row];
-    if (roff < 0 || gcol >= p.NCOLS) continue;
-    float v[8];
-    const float4 v0 = *reinterpret_cast<const float4*>(out + row * LDO + cc * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(out + row * LDO + cc * 8 + 4);
-    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-    v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    if (p.scale) {
+    for (int t = 0; t < BM * CPR / kThreads; ++t) {
+      const int chunk = tid + t * kThreads;
+      const int row = chunk / CPR, cc = chunk - row * CPR;
+      const int gcol = n0 + cc * 8;
+      const int64_t roff = rowoff[row];
+      if (roff < 0 || gcol >= p.NCOLS) continue;
+      float v[8];
+      const float4 v0 = *reinterpret_cast<const float4*>(out + row * LDO + cc * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(out + row * LDO + cc * 8 + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+      v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      if (p.scale) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= p.scale[gcol + e];
+        for (int e = 0; e < 8; ++e) v[e] *= p.scale[gcol + e];
+      }
+      if (p.shift) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p.shift[gcol + e];
+      }
+      const int64_t o = roff + gcol;
+      if (p.out_f32) {
+        if (p.res) {
+          float rr[8];
+          ElemTraits<float>::load8(reinterpret_cast<const float*>(p.res) + o, rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        ElemTraits<float>::store8(reinterpret_cast<float*>(p.y) + o, v);
+      } else {
+        if (p.res) {
+          float rr[8];
+          ElemTraits<T>::load8(reinterpret_cast<const T*>(p.res) + o, rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        ElemTraits<T>::store8(reinterpret_cast<T*>(p.y) + o, v);
+      }
     }
-    if (p.shift) {
+  } else {
+    // ---- bf16 epilogue.  phase 1: affine (+ReLU when there is no residual) on the fp32
+    // accumulators; each lane packs its 4 consecutive channels and writes 8 bytes (ds_write_b64)
+    // into out[BM][LDOB].
+    char* outc = smem;
+    const bool relu_now = p.relu && !p.res;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += p.shift[gcol + e];
+    for (int j = 0; j < FN; ++j) {
+      const int col = wn * WN + j * 16 + l4 * 4;
+      const int gcol = n0 + col;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gcol < p.NCOLS) {
+        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + gcol);
+        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + gcol);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        f32x4 a = acc[i][j];
+        a[0] = a[0] * sc.x + sh.x; a[1] = a[1] * sc.y + sh.y;
+        a[2] = a[2] * sc.z + sh.z; a[3] = a[3] * sc.w + sh.w;
+        if (relu_now) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+        }
+        const int row = wm * WM + i * 16 + l15;
+        *reinterpret_cast<uint2*>(outc + row * (LDOB * 2) + col * 2) =
+            make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+      }
     }
-    const int64_t o = roff + gcol;
-    if (p.out_f32) {
+    __syncthreads();
+    const bf16_t* outb = reinterpret_cast<const bf16_t*>(smem);
+#pragma unroll
+    for (int t = 0; t < BM * CPR / kThreads; ++t) {
+      const int chunk = tid + t * kThreads;
+      const int row = chunk / CPR, cc = chunk - row * CPR;
+      const int gcol = n0 + cc * 8;
+      const int64_t roff = rowoff[row];
+      if (roff < 0 || gcol >= p.NCOLS) continue;
+      const int64_t o = roff + gcol;
+      uint4 v = *reinterpret_cast<const uint4*>(outb + row * LDOB + cc * 8);
       if (p.res) {
-        float rr[8];
-        ElemTraits<float>::load8(reinterpret_cast<const float*>(p.res) + o, rr);
+        float a[8], rr[8];
+        a[0] = __uint_as_float(v.x << 16); a[1] = __uint_as_float(v.x & 0xffff0000u);
+        a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
+        a[4] = __uint_as_float(v.z << 16); a[5] = __uint_as_float(v.z & 0xffff0000u);
+        a[6] = __uint_as_float(v.w << 16); a[7] = __uint_as_float(v.w & 0xffff0000u);
+        ElemTraits<bf16_t>::load8(reinterpret_cast<const bf16_t*>(p.res) + o, rr);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        for (int e = 0; e < 8; ++e) {
+          a[e] += rr[e];
+          if (p.relu) a[e] = fmaxf(a[e], 0.f);
+        }
+        ElemTraits<bf16_t>::store8(reinterpret_cast<bf16_t*>(p.y) + o, a);
+      } else {
+        if (!(p.dbg & 1)) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
       }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      ElemTraits<float>::store8(reinterpret_cast<float*>(p.y) + o, v);
-    } else {
-      if (p.res) {
-        float rr[8];
-        ElemTraits<T>::load8(reinterpret_cast<const T*>(p.res) + o, rr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rr[e];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      ElemTraits<T>::store8(reinterpret_cast<T*>(p.y) + o, v);
     }
   }
 }
 
-template <typename T, int BM, int BN>
-int launch(const Params& p, bool generic, hipStream_t st) {
-  constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
-  constexpr int STAGE = 2 * (A_BYTES + B_BYTES);
-  constexpr int EPI = BM * (BN + 4) * 4;
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE>
+int launch(const Params& p, hipStream_t st) {
+  constexpr int STAGE = STAGES * (BM + BN) * kRowBytes;
+  constexpr int EPI = EPI32 ? BM * (BN + 4) * 4 : BM * (BN + 8) * 2;
   constexpr int LDS = (STAGE > EPI ? STAGE : EPI) + BM * 8;
-  static bool attr_set[2] = {false, false};
-  if (generic) {
-    if (!attr_set[1]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr_set[1] = true;
-    }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, true>), dim3(p.ntiles), dim3(kThreads), LDS, st, p);
-  } else {
-    if (!attr_set[0]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr_set[0] = true;
-    }
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, false>), dim3(p.ntiles), dim3(kThreads), LDS, st, p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
   }
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE>), dim3(p.ntiles),
+                     dim3(kThreads), LDS, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+// K-tiles up to which the single-LDS-stage variant is used (tunable: PASSL_IGEMM_NK1)
+int nk1_threshold() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PASSL_IGEMM_NK1");
+    v = e ? atoi(e) : 24;
+  }
+  return v;
+}
+
+template <typename T, int BN>
+int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    return generic ? launch<T, 128, BN, true, 2, true, false>(p, st)
+                   : launch<T, 128, BN, false, 2, true, false>(p, st);
+  } else {
+    if (out_f32)
+      return generic ? PASSL_EUNSUPPORTED : launch<T, 128, BN, false, 2, true, false>(p, st);
+    if (generic) return launch<T, 128, BN, true, 2, false, false>(p, st);
+    const bool one = nk <= nk1_threshold();
+    if (dense)
+      return one ? launch<T, 128, BN, false, 1, false, true>(p, st)
+                 : launch<T, 128, BN, false, 2, false, true>(p, st);
+    return one ? launch<T, 128, BN, false, 1, false, false>(p, st)
+               : launch<T, 128, BN, false, 2, false, false>(p, st);
+  }
 }
 
 }  // namespace
@@ -359,19 +493,34 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   p.a_sn = d->a_sn; p.a_sh = d->a_sh; p.a_sw = d->a_sw;
   p.y_sn = d->y_sn; p.y_sh = d->y_sh; p.y_sw = d->y_sw;
   p.relu = d->relu; p.out_f32 = d->out_f32;
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("PASSL_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
   const bool generic = (d->C % bk) != 0;
   const bool narrow = d->NCOLS <= 64;
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (d->NCOLS + bn - 1) / bn;
   const int tiles_m = (p.M + 127) / 128;
   p.ntiles = tiles_m * p.tiles_n;
+  p.d_opq = make_fastdiv((uint32_t)(d->OP * d->OQ));
+  p.d_oq = make_fastdiv((uint32_t)d->OQ);
+  p.d_tn = make_fastdiv((uint32_t)p.tiles_n);
+  const bool dense = d->R == 1 && d->S == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 &&
+                     d->pw == 0 && d->IH == d->OP && d->IW == d->OQ && d->a_sw == d->C &&
+                     d->a_sh == (int64_t)d->IW * d->C && d->a_sn == (int64_t)d->IH * d->IW * d->C &&
+                     d->y_sw == d->NCOLS && d->y_sh == (int64_t)d->OQ * d->NCOLS &&
+                     d->y_sn == (int64_t)d->OP * d->OQ * d->NCOLS;
   hipStream_t st = as_stream(stream);
   passl_prof_begin(0, st);
   int rc;
+  const int nk = (p.KDIM + bk - 1) / bk;
+  const bool of32 = d->out_f32 != 0;
   if (d->dtype == PASSL_BF16)
-    rc = narrow ? launch<bf16_t, 128, 64>(p, generic, st) : launch<bf16_t, 128, 128>(p, generic, st);
+    rc = narrow ? dispatch<bf16_t, 64>(p, generic, of32, dense, nk, st) : dispatch<bf16_t, 128>(p, generic, of32, dense, nk, st);
   else
-    rc = narrow ? launch<float, 128, 64>(p, generic, st) : launch<float, 128, 128>(p, generic, st);
+    rc = narrow ? dispatch<float, 64>(p, generic, of32, dense, nk, st) : dispatch<float, 128>(p, generic, of32, dense, nk, st);
   passl_prof_end(0, st);
   return rc;
 }
