@@ -109,7 +109,11 @@ typedef struct passl_conv_desc {
   const float* scale;      /* [NCOLS] or NULL (=1) */
   const float* shift;      /* [NCOLS] or NULL (=0) */
   const void* residual;    /* addressed like y, dtype = out dtype; or NULL */
-  float* stats;            /* reserved (fused BN partial sums), must be NULL */
+  float* stats;            /* NULL, or fused BatchNorm statistics of the STORED output values:
+                              stats[rep][col][0..1] += (sum, sum of squares) over the rows of each
+                              output tile, rep = tile_row % stats_replicas; fp32 atomics, caller
+                              zeroes; bf16 output without residual only.  Feed it to
+                              passl_hip_bn_finalize as `partial` with nblocks = replicas. */
   int32_t N, OP, OQ;       /* M = N*OP*OQ */
   int32_t NCOLS;
   int32_t R, S, C;
@@ -120,6 +124,7 @@ typedef struct passl_conv_desc {
   int32_t relu;
   int32_t dtype;           /* passl_dtype of A, B */
   int32_t out_f32;         /* 1: y (and residual) are fp32 regardless of dtype */
+  int32_t stats_replicas;  /* number of accumulator replicas behind `stats` (spreads the atomics) */
 } passl_conv_desc;
 int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream);
 
@@ -158,22 +163,29 @@ int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t M, int C, c
                           const float* beta, float* running_mean, float* running_var,
                           float momentum, float eps, float* mean, float* invstd, float* scale,
                           float* shift, passl_stream_t stream);
+/* relu_mask (optional, needs relu): one bit per element of z (bit e of byte i <-> element 8*i+e,
+ * set where z > 0), M*C/8 bytes — the ReLU mask the backward kernels can read instead of z. */
 int passl_hip_bn_apply(const void* x, const float* scale, const float* shift, const void* residual,
-                       void* z, int64_t M, int C, int relu, int dtype, passl_stream_t stream);
-/* Backward.  g = dz * (z > 0 if relu);   reduce: partial[b][c] = (sum g, sum g*xhat);
+                       void* z, uint8_t* relu_mask, int64_t M, int C, int relu, int dtype,
+                       passl_stream_t stream);
+/* Backward.  g = dz * relu-mask;   reduce: partial[b][c] = (sum g, sum g*xhat);
  * finalize: dgamma += .., dbeta += .. (accumulated) and the per-channel coefficients (A,B,Cc)
  *           of dx = A*g + B*x + Cc;
- * apply: writes dx and, if dres != NULL, dres = g (gradient of the residual branch). */
+ * apply: writes dx and, if dres != NULL, dres = g (gradient of the residual branch).
+ * `relu` selects where the ReLU mask comes from: 0 no ReLU; 1 `z` is the forward output
+ * (mask z > 0); 2 recomputed as x*scale + shift > 0 from the forward's scale/shift (BN+ReLU
+ * without residual: z is never read); 3 `z` is the bit mask written by passl_hip_bn_apply. */
 int passl_hip_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean,
-                            const float* invstd, float* partial, int64_t M, int C, int nblocks,
-                            int relu, int dtype, passl_stream_t stream);
+                            const float* invstd, const float* scale, const float* shift,
+                            float* partial, int64_t M, int C, int nblocks, int relu, int dtype,
+                            passl_stream_t stream);
 int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int64_t M, int C,
                               const float* gamma, const float* mean, const float* invstd,
                               float* dgamma, float* dbeta, float* coef /* [3][C] */,
                               passl_stream_t stream);
 int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* coef,
-                           void* dx, void* dres, int64_t M, int C, int relu, int dtype,
-                           passl_stream_t stream);
+                           const float* scale, const float* shift, void* dx, void* dres, int64_t M,
+                           int C, int relu, int dtype, passl_stream_t stream);
 
 /* ---------------------------------------------------------------- pooling */
 

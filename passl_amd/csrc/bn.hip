@@ -15,11 +15,34 @@ constexpr int kThreads = 256;
 // are spread over threadIdx % cols; the remaining threads stride over rows.
 // C/8 may exceed 256 (not on this path: C <= 2048) -> column loop.
 
+// ReLU mask sources of the backward kernels (relu argument):
+//   0 none   1 z > 0 (z tensor)   2 x*scale + shift > 0 (recomputed; BN+ReLU without residual)
+//   3 bit mask written by bn_apply (bit e of byte i <-> element 8*i + e)
+template <typename T>
+__device__ __forceinline__ void apply_relu_mask(float (&g)[8], const float (&xv)[8], int relu,
+                                                const void* zsrc, int64_t chunk,
+                                                const float* sc, const float* sh) {
+  if (relu == 1) {
+    float zz[8];
+    ElemTraits<T>::load8(reinterpret_cast<const T*>(zsrc) + chunk * 8, zz);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+  } else if (relu == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+  } else if (relu == 3) {
+    const uint32_t bits = reinterpret_cast<const uint8_t*>(zsrc)[chunk];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = ((bits >> e) & 1u) ? g[e] : 0.f;
+  }
+}
+
 template <typename T, int MODE>
-// MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat) with g = dz * (z>0 | 1)
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum g, sum g*xhat) with g = dz * relu-mask
 __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
-    const T* __restrict__ x, const T* __restrict__ dz, const T* __restrict__ z,
-    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
+    const T* __restrict__ x, const T* __restrict__ dz, const void* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ partial,
     int64_t M, int C, int rows_per_block, int relu) {
   extern __shared__ float red[];  // [kThreads][16]
   const int cols = C >> 3;
@@ -34,10 +57,14 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
     float a0[8], a1[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-    float mu[8], is[8];
+    float mu[8], is[8], sc[8], sh[8];
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { mu[e] = mean[col * 8 + e]; is[e] = invstd[col * 8 + e]; }
+      if (relu == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale[col * 8 + e]; sh[e] = shift[col * 8 + e]; }
+      }
     }
     if (rl < lanes) {
       for (int64_t r = row0 + rl; r < row1; r += lanes) {
@@ -49,12 +76,7 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
         } else {
           float g[8];
           ElemTraits<T>::load8(dz + r * C + col * 8, g);
-          if (relu) {
-            float zz[8];
-            ElemTraits<T>::load8(z + r * C + col * 8, zz);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
-          }
+          apply_relu_mask<T>(g, v, relu, z, r * cols + col, sc, sh);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { a0[e] += g[e]; a1[e] += g[e] * (v[e] - mu[e]) * is[e]; }
         }
@@ -158,8 +180,9 @@ __global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict_
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const T* __restrict__ res,
-                                                            T* __restrict__ z, int64_t nchunks,
-                                                            int cols, int relu) {
+                                                            T* __restrict__ z,
+                                                            uint8_t* __restrict__ mask,
+                                                            int64_t nchunks, int cols, int relu) {
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
     const int col = (int)(i % cols);
@@ -180,6 +203,12 @@ __global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict_
       for (int e = 0; e < 8; ++e) v[e] += r[e];
     }
     if (relu) {
+      if (mask) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bits |= (v[e] > 0.f ? 1u : 0u) << e;
+        mask[i] = (uint8_t)bits;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
@@ -190,8 +219,9 @@ __global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict_
 // dx = A*g + B*x + Cc ; dres = g
 template <typename T>
 __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(
-    const T* __restrict__ dz, const T* __restrict__ z, const T* __restrict__ x,
-    const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ dres, int64_t nchunks,
+    const T* __restrict__ dz, const void* __restrict__ z, const T* __restrict__ x,
+    const float* __restrict__ coef, const float* __restrict__ scale,
+    const float* __restrict__ shift, T* __restrict__ dx, T* __restrict__ dres, int64_t nchunks,
     int cols, int C, int relu) {
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
@@ -199,11 +229,13 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(
     float g[8], v[8];
     ElemTraits<T>::load8(dz + i * 8, g);
     ElemTraits<T>::load8(x + i * 8, v);
-    if (relu) {
-      float zz[8];
-      ElemTraits<T>::load8(z + i * 8, zz);
+    if (relu == 2) {
+      float sc[8], sh[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+      for (int e = 0; e < 8; ++e) { sc[e] = scale[col * 8 + e]; sh[e] = shift[col * 8 + e]; }
+      apply_relu_mask<T>(g, v, 2, nullptr, i, sc, sh);
+    } else if (relu) {
+      apply_relu_mask<T>(g, v, relu, z, i, nullptr, nullptr);
     }
     float o[8];
 #pragma unroll
@@ -238,7 +270,7 @@ extern "C" int passl_hip_bn_stats(const void* x, float* partial, int64_t M, int 
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(nblocks), dim3(kThreads),
                                            kThreads * 16 * sizeof(float), as_stream(stream),
                                            reinterpret_cast<const T*>(x), nullptr, nullptr, nullptr,
-                                           nullptr, partial, M, C, rows, 0);)
+                                           nullptr, nullptr, nullptr, partial, M, C, rows, 0);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -259,35 +291,45 @@ extern "C" int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t 
 }
 
 extern "C" int passl_hip_bn_apply(const void* x, const float* scale, const float* shift,
-                                  const void* residual, void* z, int64_t M, int C, int relu,
-                                  int dtype, passl_stream_t stream) {
+                                  const void* residual, void* z, uint8_t* relu_mask, int64_t M,
+                                  int C, int relu, int dtype, passl_stream_t stream) {
   if (!x || !scale || !shift || !z || M <= 0 || C <= 0 || (C & 7) || !aligned16(x) ||
       !aligned16(z) || (residual && !aligned16(residual)) || !aligned16(scale) || !aligned16(shift))
     return PASSL_EINVAL;
+  if (relu_mask && !relu) return PASSL_EINVAL;
   const int64_t nchunks = M * (C >> 3);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(nchunks)),
                                            dim3(kThreads), 0, as_stream(stream),
                                            reinterpret_cast<const T*>(x), scale, shift,
                                            reinterpret_cast<const T*>(residual),
-                                           reinterpret_cast<T*>(z), nchunks, C >> 3, relu);)
+                                           reinterpret_cast<T*>(z), relu_mask, nchunks, C >> 3,
+                                           relu);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
 
+static bool relu_args_ok(int relu, const void* z, const float* scale, const float* shift) {
+  if (relu < 0 || relu > 3) return false;
+  if (relu == 1 && (!z || !aligned16(z))) return false;
+  if (relu == 2 && (!scale || !shift)) return false;
+  if (relu == 3 && !z) return false;
+  return true;
+}
+
 extern "C" int passl_hip_bn_bwd_reduce(const void* dz, const void* z, const void* x,
-                                       const float* mean, const float* invstd, float* partial,
+                                       const float* mean, const float* invstd,
+                                       const float* scale, const float* shift, float* partial,
                                        int64_t M, int C, int nblocks, int relu, int dtype,
                                        passl_stream_t stream) {
-  if (!dz || !x || !mean || !invstd || !partial || (relu && !z) || M <= 0 || C <= 0 || (C & 7) ||
-      nblocks <= 0 || !aligned16(dz) || !aligned16(x) || (z && !aligned16(z)))
+  if (!dz || !x || !mean || !invstd || !partial || !relu_args_ok(relu, z, scale, shift) ||
+      M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || !aligned16(dz) || !aligned16(x))
     return PASSL_EINVAL;
   const int rows = (int)((M + nblocks - 1) / nblocks);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(nblocks), dim3(kThreads),
                                            kThreads * 16 * sizeof(float), as_stream(stream),
                                            reinterpret_cast<const T*>(x),
-                                           reinterpret_cast<const T*>(dz),
-                                           reinterpret_cast<const T*>(z), mean, invstd, partial, M,
-                                           C, rows, relu);)
+                                           reinterpret_cast<const T*>(dz), z, mean, invstd, scale,
+                                           shift, partial, M, C, rows, relu);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -306,18 +348,17 @@ extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int6
 }
 
 extern "C" int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void* x,
-                                      const float* coef, void* dx, void* dres, int64_t M, int C,
-                                      int relu, int dtype, passl_stream_t stream) {
-  if (!dz || !x || !coef || !dx || (relu && !z) || M <= 0 || C <= 0 || (C & 7) ||
-      !aligned16(dz) || !aligned16(x) || !aligned16(dx) || (z && !aligned16(z)) ||
-      (dres && !aligned16(dres)))
+                                      const float* coef, const float* scale, const float* shift,
+                                      void* dx, void* dres, int64_t M, int C, int relu, int dtype,
+                                      passl_stream_t stream) {
+  if (!dz || !x || !coef || !dx || !relu_args_ok(relu, z, scale, shift) || M <= 0 || C <= 0 ||
+      (C & 7) || !aligned16(dz) || !aligned16(x) || !aligned16(dx) || (dres && !aligned16(dres)))
     return PASSL_EINVAL;
   const int64_t nchunks = M * (C >> 3);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(nchunks)),
                                            dim3(kThreads), 0, as_stream(stream),
-                                           reinterpret_cast<const T*>(dz),
-                                           reinterpret_cast<const T*>(z),
-                                           reinterpret_cast<const T*>(x), coef,
+                                           reinterpret_cast<const T*>(dz), z,
+                                           reinterpret_cast<const T*>(x), coef, scale, shift,
                                            reinterpret_cast<T*>(dx), reinterpret_cast<T*>(dres),
                                            nchunks, C >> 3, C, relu);)
   PASSL_RETURN_IF_LAUNCH_FAILED();

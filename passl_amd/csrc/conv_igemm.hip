@@ -62,6 +62,8 @@ struct Params {
   const float* scale;
   const float* shift;
   const char* res;
+  float* stats;      // fused BatchNorm statistics: [stats_rep][NCOLS][2] (sum, sum of squares), atomics
+  int stats_rep;
   int M, NCOLS, KDIM;
   int OP, OQ, R, S, C, IH, IW, sh, sw, ph, pw;
   int64_t a_sn, a_sh, a_sw;
@@ -384,8 +386,26 @@ __global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
             make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
       }
     }
+    // residual rows of this thread's phase-2 chunks: issued before the barrier (the accumulators are dead by now), consumed after it
+    constexpr int NT = BM * CPR / kThreads;
+    uint4 rres[NT];
+    if (p.res) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int chunk = tid + t * kThreads;
+        const int row = chunk / CPR, cc = chunk - row * CPR;
+        const int gcol = n0 + cc * 8;
+        const int64_t roff = rowoff[row];
+        rres[t] = make_uint4(0, 0, 0, 0);
+        if (roff >= 0 && gcol < p.NCOLS)
+          rres[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.res) + roff + gcol);
+      }
+    }
     __syncthreads();
     const bf16_t* outb = reinterpret_cast<const bf16_t*>(smem);
+    float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    static_assert(kThreads % CPR == 0, "a thread must keep its column chunk across iterations");
 #pragma unroll
     for (int t = 0; t < BM * CPR / kThreads; ++t) {
       const int chunk = tid + t * kThreads;
@@ -401,7 +421,10 @@ __global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
         a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
         a[4] = __uint_as_float(v.z << 16); a[5] = __uint_as_float(v.z & 0xffff0000u);
         a[6] = __uint_as_float(v.w << 16); a[7] = __uint_as_float(v.w & 0xffff0000u);
-        ElemTraits<bf16_t>::load8(reinterpret_cast<const bf16_t*>(p.res) + o, rr);
+        rr[0] = __uint_as_float(rres[t].x << 16); rr[1] = __uint_as_float(rres[t].x & 0xffff0000u);
+        rr[2] = __uint_as_float(rres[t].y << 16); rr[3] = __uint_as_float(rres[t].y & 0xffff0000u);
+        rr[4] = __uint_as_float(rres[t].z << 16); rr[5] = __uint_as_float(rres[t].z & 0xffff0000u);
+        rr[6] = __uint_as_float(rres[t].w << 16); rr[7] = __uint_as_float(rres[t].w & 0xffff0000u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           a[e] += rr[e];
@@ -410,6 +433,41 @@ __global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
         ElemTraits<bf16_t>::store8(reinterpret_cast<bf16_t*>(p.y) + o, a);
       } else {
         if (!(p.dbg & 1)) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
+        if (p.stats) {
+          // fused BatchNorm statistics of the STORED (bf16) values: this thread owns the same 8
+          // columns in every iteration t, so it accumulates them in registers
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
+            ssum[2 * e] += lo; ssq[2 * e] += lo * lo;
+            ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * hi;
+          }
+        }
+      }
+    }
+    if (p.stats) {
+      // threads tid, tid+CPR, ... share a column chunk: each writes its 16 partial values to
+      // red[tid / CPR][BN][2] (the epilogue tile is dead by now), 2*BN threads add the
+      // kThreads/CPR partials and issue ONE global atomic per (column, statistic) of the tile.
+      constexpr int J = kThreads / CPR;
+      static_assert(J * BN * 2 * 4 <= MAIN_BYTES, "reduction scratch must fit the tile buffers");
+      __syncthreads();                       // every thread is done reading the output tile
+      float* red = reinterpret_cast<float*>(smem);
+      {
+        float* dst = red + (tid / CPR) * (BN * 2) + (tid % CPR) * 16;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2)
+          *reinterpret_cast<float4*>(dst + e * 2) = make_float4(ssum[e], ssq[e], ssum[e + 1], ssq[e + 1]);
+      }
+      __syncthreads();
+      if (tid < 2 * BN && n0 + (tid >> 1) < p.NCOLS) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) a += red[j * (BN * 2) + tid];
+        const int rep = mt % p.stats_rep;
+        if (!(p.dbg & 16))
+          atomicAdd(p.stats + ((int64_t)rep * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1), a);
       }
     }
   }
@@ -463,7 +521,11 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
 }  // namespace
 
 extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream) {
-  if (!d || !d->a || !d->b || !d->y || d->stats) return PASSL_EINVAL;
+  if (!d || !d->a || !d->b || !d->y) return PASSL_EINVAL;
+  // fused BN statistics live in the bf16-output epilogue only
+  if (d->stats && (d->dtype != PASSL_BF16 || d->out_f32 || d->residual || d->stats_replicas <= 0 ||
+                   (reinterpret_cast<uintptr_t>(d->stats) & 3)))
+    return PASSL_EUNSUPPORTED;
   if (d->N <= 0 || d->OP <= 0 || d->OQ <= 0 || d->NCOLS <= 0 || d->R <= 0 || d->S <= 0 ||
       d->C <= 0 || d->IH <= 0 || d->IW <= 0)
     return PASSL_EINVAL;
@@ -487,6 +549,7 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   p.y = reinterpret_cast<char*>(d->y);
   p.scale = d->scale; p.shift = d->shift;
   p.res = reinterpret_cast<const char*>(d->residual);
+  p.stats = d->stats; p.stats_rep = d->stats ? d->stats_replicas : 1;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.R = d->R; p.S = d->S; p.C = d->C;
   p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
@@ -495,7 +558,9 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   p.relu = d->relu; p.out_f32 = d->out_f32;
   {
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("PASSL_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    static int dyn = -1;
+    if (dyn < 0) dyn = getenv("PASSL_IGEMM_DBG_DYNAMIC") ? 1 : 0;
+    if (dbg < 0 || dyn) { const char* e = getenv("PASSL_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;
   }
   const bool generic = (d->C % bk) != 0;

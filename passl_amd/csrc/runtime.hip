@@ -59,7 +59,7 @@ extern "C" int passl_hip_prof_collect(int cls, double* total_ms, int64_t* launch
   return PASSL_OK;
 }
 
-extern "C" int passl_hip_abi_version(void) { return 1; }
+extern "C" int passl_hip_abi_version(void) { return 2; }
 
 extern "C" const char* passl_hip_strerror(int status) {
   switch (status) {

@@ -10,7 +10,9 @@ import os
 
 import torch
 
-_state = {'device': None, 'dtype': torch.bfloat16}
+_state = {'device': None, 'dtype': torch.bfloat16,
+          'fused_bn_stats': os.environ.get('PASSL_FUSED_BN_STATS', '1') != '0',
+          'fuse_residual_grad': os.environ.get('PASSL_FUSE_RESIDUAL_GRAD', '1') != '0'}
 
 
 def set_device(name):
@@ -42,3 +44,20 @@ def set_compute_dtype(dt):
 
 def get_compute_dtype():
     return _state['dtype']
+
+
+def fused_bn_stats():
+    """BatchNorm statistics accumulated by the producing conv's epilogue (bf16 only) instead of a
+    separate pass over the conv output."""
+    return _state['fused_bn_stats']
+
+
+def fuse_residual_grad():
+    """Residual-fork gradient added in conv1's data-gradient epilogue (nn.GradSlot) instead of an
+    autograd add kernel."""
+    return _state['fuse_residual_grad']
+
+
+def set_flag(name, value):
+    assert name in ('fused_bn_stats', 'fuse_residual_grad')
+    _state[name] = bool(value)

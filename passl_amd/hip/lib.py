@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ('sh', C.c_int32), ('sw', C.c_int32), ('ph', C.c_int32), ('pw', C.c_int32),
                 ('a_sn', c_l), ('a_sh', c_l), ('a_sw', c_l),
                 ('y_sn', c_l), ('y_sh', c_l), ('y_sw', c_l),
-                ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32)]
+                ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32),
+                ('stats_replicas', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -65,10 +66,12 @@ SIGNATURES = {
     'passl_hip_bn_stats': (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     'passl_hip_bn_finalize': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p,
                                     c_p, c_p, c_p]),
-    'passl_hip_bn_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
-    'passl_hip_bn_bwd_reduce': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_bwd_reduce': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i,
+                                      c_i, c_p]),
     'passl_hip_bn_bwd_finalize': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    'passl_hip_bn_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i,
+                                     c_p]),
     'passl_hip_maxpool3x3s2_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_maxpool3x3s2_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

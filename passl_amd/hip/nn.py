@@ -46,17 +46,53 @@ def _need_rt(layer):
     return layer._rt
 
 
+class GradSlot:
+    """Hand-off of ONE gradient tensor between two backward nodes of a residual fork.
+
+    A block input x feeds conv1 and the identity (or downsample) branch, so autograd would add the
+    two input gradients with an extra elementwise kernel.  Instead the branch whose backward runs
+    first (bn3's identity gradient, or the downsample conv's dx) `put`s its tensor here and
+    returns None to autograd; conv1's backward `take`s it and the data-gradient kernel adds it in
+    its epilogue.  The order is fixed by the graph (conv1's backward depends on bn3's), and it is
+    checked: a `take` from a slot that was armed but never filled raises instead of silently
+    dropping a gradient."""
+
+    __slots__ = ('armed', 'grad')
+
+    def __init__(self):
+        self.armed = False
+        self.grad = None
+
+    def arm(self):
+        self.armed = True
+
+    def put(self, g):
+        if not self.armed or self.grad is not None:
+            raise RuntimeError('GradSlot.put: slot not armed or already filled')
+        self.grad = g
+
+    def take(self):
+        if not self.armed:
+            return None
+        if self.grad is None:
+            raise RuntimeError('GradSlot.take: the residual-branch gradient has not been produced '
+                               'yet (autograd executed the fork in an unexpected order)')
+        g, self.grad, self.armed = self.grad, None, False
+        return g
+
+
 # =============================================================================== conv
 class _ConvFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, layer, hw):
+    def forward(ctx, x, weight, layer, hw, stats, add_slot, sink_slot):
         rt = _need_rt(layer)
         N = x.shape[0]
         pl = layer._plan(N, hw[0], hw[1])
         y = torch.empty(N, pl.fd.OP, pl.fd.OQ, layer.geom.cout, dtype=x.dtype, device=x.device)
-        ops.conv_igemm(pl.fd, x, rt.w_fwd, y)
+        ops.conv_igemm(pl.fd, x, rt.w_fwd, y, stats=stats)
         ctx.save_for_backward(x)
         ctx.layer, ctx.pl, ctx.hw = layer, pl, hw
+        ctx.add_slot, ctx.sink_slot = add_slot, sink_slot
         return y
 
     @staticmethod
@@ -71,8 +107,14 @@ class _ConvFn(Function):
             N = x.shape[0]
             alloc = torch.zeros if pl.dgrad_zero else torch.empty
             dx = alloc(N, ctx.hw[0], ctx.hw[1], g.cin, dtype=dy.dtype, device=dy.device)
+            extra = ctx.add_slot.take() if ctx.add_slot is not None else None
+            if extra is not None and (len(pl.dds) != 1 or pl.dgrad_zero):
+                raise RuntimeError('residual-gradient fusion needs a single dense data-gradient conv')
             for d in pl.dds:
-                ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
+                ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx, residual=extra)
+            if ctx.sink_slot is not None:
+                ctx.sink_slot.put(dx)
+                dx = None
         if layer.is_stem:
             tmp = torch.zeros(g.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dy.device)
             ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), tmp)
@@ -80,7 +122,7 @@ class _ConvFn(Function):
         else:
             ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
         rt.arena.grad_ready(rt.indices)
-        return dx, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class Conv2D(Layer):
@@ -116,11 +158,22 @@ class Conv2D(Layer):
             self._plans[key] = pl
         return pl
 
-    def forward(self, x, hw=None):
-        """x: NHWC compute-dtype tensor (the stem takes the zero-padded image + hw=(H, W))."""
+    def forward(self, x, hw=None, want_stats=False, add_slot=None, sink_slot=None):
+        """x: NHWC compute-dtype tensor (the stem takes the zero-padded image + hw=(H, W)).
+        want_stats: also return the fused BatchNorm statistics accumulated by the conv epilogue
+        (None when the dtype has no fused path) -> (y, stats).
+        add_slot / sink_slot: residual-fork gradient hand-off (GradSlot): this conv's backward adds
+        the slot's tensor to dx in the kernel epilogue / deposits its dx there instead of
+        returning it."""
         if hw is None:
             hw = (x.shape[1], x.shape[2])
-        return _ConvFn.apply(x, self.weight, self, hw)
+        stats = None
+        if want_stats and x.dtype == torch.bfloat16 and config.fused_bn_stats():
+            g = self.geom
+            P_, Q_ = ((hw[0] + 2 * g.pad - g.k) // g.stride + 1, (hw[1] + 2 * g.pad - g.k) // g.stride + 1)
+            stats = ops.conv_stats_buffer(x.shape[0] * P_ * Q_, g.cout, x.device, pooled=True)
+        y = _ConvFn.apply(x, self.weight, self, hw, stats, add_slot, sink_slot)
+        return (y, stats) if want_stats else y
 
     @torch.no_grad()
     def infer(self, x, bn=None, residual=None, relu=False, hw=None):
@@ -141,27 +194,36 @@ class Conv2D(Layer):
 # =============================================================================== batch norm
 class _BNActFn(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, layer, relu):
-        z, mean, invstd = ops.bn_train_fwd(y, gamma.detach(), beta.detach(), layer._mean,
-                                           layer._variance, residual, relu, layer._momentum,
-                                           layer._epsilon)
-        ctx.save_for_backward(y, z, mean, invstd)
-        ctx.layer, ctx.relu, ctx.has_res = layer, relu, residual is not None
+    def forward(ctx, y, gamma, beta, residual, layer, relu, partial, res_slot):
+        has_res = residual is not None
+        z, st, mask = ops.bn_train_fwd(y, gamma.detach(), beta.detach(), layer._mean,
+                                       layer._variance, residual, relu, layer._momentum,
+                                       layer._epsilon, partial=partial,
+                                       want_mask=relu and has_res)
+        # ReLU mask for the backward: recomputed from y (no residual) or the bit mask (residual):
+        # the output z is never re-read by this layer's backward.
+        ctx.relu_mode = 0 if not relu else (3 if has_res else 2)
+        ctx.save_for_backward(y, st, mask)
+        ctx.layer, ctx.has_res, ctx.res_slot = layer, has_res, res_slot
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        y, z, mean, invstd = ctx.saved_tensors
+        y, st, mask = ctx.saved_tensors
         layer = ctx.layer
         for p in (layer.weight, layer.bias):
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-        dx, dres = ops.bn_bwd(dz.contiguous(), z, y, layer.weight.detach(), mean, invstd,
-                              layer.weight.grad, layer.bias.grad, relu=ctx.relu,
-                              want_dres=ctx.has_res and ctx.needs_input_grad[3])
+        want_dres = ctx.has_res and (ctx.needs_input_grad[3] or ctx.res_slot is not None)
+        dx, dres = ops.bn_bwd(dz.contiguous(), mask, y, layer.weight.detach(), st[0], st[1],
+                              layer.weight.grad, layer.bias.grad, relu=ctx.relu_mode,
+                              want_dres=want_dres, scale=st[2], shift=st[3])
+        if ctx.res_slot is not None:
+            ctx.res_slot.put(dres)
+            dres = None
         if layer._rt is not None:
             layer._rt.arena.grad_ready(layer._rt.indices)
-        return dx, None, None, dres, None, None
+        return dx, None, None, dres, None, None, None, None
 
 
 class _BatchNormBase(Layer):
@@ -195,14 +257,16 @@ class _BatchNormBase(Layer):
         scale = self.weight.detach() * torch.rsqrt(self._variance + self._epsilon)
         return scale, self.bias.detach() - self._mean * scale
 
-    def forward(self, y, residual=None, relu=False):
+    def forward(self, y, residual=None, relu=False, stats=None, res_slot=None):
+        """stats: fused statistics from the producing conv's epilogue (Conv2D.forward(...,
+        want_stats=True)); res_slot: GradSlot that receives the residual branch's gradient."""
         if self.uses_global_stats():
             if torch.is_grad_enabled() and (y.requires_grad or self.weight.requires_grad):
                 raise NotImplementedError('frozen BatchNorm inside a differentiated graph is not on '
                                           'the MoCo hot path (key encoder runs under no_grad)')
             scale, shift = self.infer_affine()
             return ops.bn_apply(y, scale, shift, residual, relu)
-        return _BNActFn.apply(y, self.weight, self.bias, residual, self, relu)
+        return _BNActFn.apply(y, self.weight, self.bias, residual, self, relu, stats, res_slot)
 
 
 class BatchNorm2D(_BatchNormBase):

@@ -29,15 +29,17 @@ def _conv_struct(d: P.Desc):
               'a_sn', 'a_sh', 'a_sw', 'y_sn', 'y_sh', 'y_sw'):
         setattr(s, f, getattr(d, f))
     s.stats = None
+    s.stats_replicas = 0
     _desc_cache[key] = (d, s)
     return s
 
 
 def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=False,
-               out_f32=False):
+               out_f32=False, stats=None):
     """Launch one implicit-GEMM conv described by `d` (plan.Desc).  `a` activation tensor,
     `b` packed weights [NCOLS, R*S*C] (same dtype as a), `y` output tensor (written in place at
-    d.y_off with d's strides)."""
+    d.y_off with d's strides).  `stats`: zeroed fp32 [R, NCOLS, 2] accumulator of the fused
+    BatchNorm statistics (sum, sum of squares of the raw conv output), bf16 only."""
     s = _conv_struct(d)
     esz = 4 if out_f32 else y.element_size()
     s.a = L.ptr(a)
@@ -49,6 +51,8 @@ def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=F
     s.relu = 1 if relu else 0
     s.dtype = L.dt(a)
     s.out_f32 = 1 if out_f32 else 0
+    s.stats = L.ptr(stats)
+    s.stats_replicas = stats.shape[0] if stats is not None else 0
     L.check(_lib().passl_hip_conv_igemm(C.byref(s), L.stream()), 'conv_igemm')
     return y
 
@@ -86,24 +90,74 @@ def _bn_blocks(M, Cch):
     return int(max(1, min(1024, -(-M // (16 * lanes)))))
 
 
-def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum=0.9, eps=1e-5):
-    """x: [..., C] NHWC rows.  Returns z, mean, invstd; updates rmean/rvar in place."""
+class _StatsPool:
+    """Bump allocator over ONE fp32 workspace for the conv epilogues' fused BN statistics.
+    `reset()` zeroes the part handed out so far with a single fill and rewinds; buffers are only
+    valid until the next reset on the same stream (a backbone forward resets once at its start:
+    every statistic is consumed by bn_finalize inside that forward)."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+        self.dirty = 0
+
+    def reset(self):
+        if self.buf is not None and self.dirty:
+            self.buf[:self.dirty].zero_()
+        self.used = 0
+        self.dirty = 0
+
+    def take(self, n, device):
+        n = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device or self.used + n > self.buf.numel():
+            # grow: earlier views stay alive through their own storage
+            self.buf = torch.zeros(max(4 << 20, 2 * n), dtype=torch.float32, device=device)
+            self.used = self.dirty = 0
+        v = self.buf[self.used:self.used + n]
+        self.used += n
+        self.dirty = self.used
+        return v
+
+
+stats_pool = _StatsPool()
+
+
+def conv_stats_buffer(M, Cch, device, pooled=False):
+    """Zeroed accumulator for the conv epilogue's fused BN statistics: [R, C, 2] fp32, the R
+    replicas spread the atomics of the M/128 row tiles.  pooled: carve it from `stats_pool`."""
+    R = max(1, min(64, (M + 127) // 128 // 8))
+    if pooled:
+        return stats_pool.take(R * Cch * 2, device)[:R * Cch * 2].view(R, Cch, 2)
+    return torch.zeros(R, Cch, 2, dtype=torch.float32, device=device)
+
+
+def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum=0.9, eps=1e-5,
+                 partial=None, want_mask=False):
+    """x: [..., C] NHWC rows.  Returns z, stats[4,C] (mean, invstd, scale, shift), relu bit mask
+    (or None); updates rmean/rvar in place.  `partial` = the fused statistics a conv epilogue
+    already accumulated ([R, C, 2]); without it a stats pass over x is launched."""
     Cch = x.shape[-1]
     M = x.numel() // Cch
-    nb = _bn_blocks(M, Cch)
     dev = x.device
-    partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
     stats = torch.empty(4, Cch, dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
     lib, st, dtc = _lib(), L.stream(), L.dt(x)
-    L.check(lib.passl_hip_bn_stats(L.ptr(x), L.ptr(partial), M, Cch, nb, dtc, st), 'bn_stats')
+    if partial is None:
+        nb = _bn_blocks(M, Cch)
+        partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
+        L.check(lib.passl_hip_bn_stats(L.ptr(x), L.ptr(partial), M, Cch, nb, dtc, st), 'bn_stats')
+    else:
+        nb = partial.shape[0]
     L.check(lib.passl_hip_bn_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(beta),
                                       L.ptr(rmean), L.ptr(rvar), momentum, eps,
                                       L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
                                       L.ptr(stats[3]), st), 'bn_finalize')
     z = torch.empty_like(x)
+    mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (want_mask and relu) \
+        else None
     L.check(lib.passl_hip_bn_apply(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(residual),
-                                   L.ptr(z), M, Cch, 1 if relu else 0, dtc, st), 'bn_apply')
-    return z, stats[0], stats[1]
+                                   L.ptr(z), L.ptr(mask), M, Cch, 1 if relu else 0, dtc, st),
+            'bn_apply')
+    return z, stats, mask
 
 
 def bn_apply(x, scale, shift, residual=None, relu=False):
@@ -112,13 +166,16 @@ def bn_apply(x, scale, shift, residual=None, relu=False):
     M = x.numel() // Cch
     z = torch.empty_like(x)
     L.check(_lib().passl_hip_bn_apply(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(residual),
-                                      L.ptr(z), M, Cch, 1 if relu else 0, L.dt(x), L.stream()),
-            'bn_apply')
+                                      L.ptr(z), None, M, Cch, 1 if relu else 0, L.dt(x),
+                                      L.stream()), 'bn_apply')
     return z
 
 
-def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=False):
-    """Returns dx (and dres).  dgamma/dbeta (fp32 [C]) are accumulated into."""
+def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=False,
+           scale=None, shift=None):
+    """Returns dx (and dres).  dgamma/dbeta (fp32 [C]) are accumulated into.
+    `relu`: False/0 none, True/1 mask = z > 0, 2 mask recomputed from x*scale+shift (z unused),
+    3 `z` is the bit mask written by the forward's bn_apply."""
     Cch = x.shape[-1]
     M = x.numel() // Cch
     nb = _bn_blocks(M, Cch)
@@ -126,17 +183,18 @@ def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=Fa
     partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
     coef = torch.empty(3 * Cch, dtype=torch.float32, device=dev)
     lib, st, dtc = _lib(), L.stream(), L.dt(x)
-    r = 1 if relu else 0
-    L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), L.ptr(z) if relu else None, L.ptr(x),
-                                        L.ptr(mean), L.ptr(invstd), L.ptr(partial), M, Cch, nb, r,
+    r = int(relu)
+    zp = L.ptr(z) if r in (1, 3) else None
+    L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), zp, L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                        L.ptr(scale), L.ptr(shift), L.ptr(partial), M, Cch, nb, r,
                                         dtc, st), 'bn_bwd_reduce')
     L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(mean),
                                           L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
                                           st), 'bn_bwd_finalize')
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    L.check(lib.passl_hip_bn_bwd_apply(L.ptr(dz), L.ptr(z) if relu else None, L.ptr(x),
-                                       L.ptr(coef), L.ptr(dx), L.ptr(dres), M, Cch, r, dtc, st),
+    L.check(lib.passl_hip_bn_bwd_apply(L.ptr(dz), zp, L.ptr(x), L.ptr(coef), L.ptr(scale),
+                                       L.ptr(shift), L.ptr(dx), L.ptr(dres), M, Cch, r, dtc, st),
             'bn_bwd_apply')
     return dx, dres
 

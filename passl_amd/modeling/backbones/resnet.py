@@ -15,7 +15,7 @@ epilogue, i.e. one kernel per conv and no extra pass over the activations.
 """
 import torch
 
-from ...hip import nn, ops, plan as P
+from ...hip import config, nn, ops, plan as P
 from ...modules import init, freeze
 from ...utils.logger import get_logger
 from .builder import BACKBONES
@@ -41,13 +41,23 @@ class BottleneckBlock(nn.Layer):
         self.stride = stride
 
     def forward(self, x):
-        identity = x
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        out = self.conv3(out)
+        # x forks into conv1 and the identity/downsample branch: the branch gradient is handed to
+        # conv1's data-gradient kernel through a GradSlot (added in its epilogue) instead of an
+        # autograd add kernel.
+        slot = None
+        if config.fuse_residual_grad() and torch.is_grad_enabled() and x.requires_grad:
+            slot = nn.GradSlot()
+            slot.arm()
+        out, st = self.conv1(x, want_stats=True, add_slot=slot)
+        out = self.bn1(out, relu=True, stats=st)
+        out, st = self.conv2(out, want_stats=True)
+        out = self.bn2(out, relu=True, stats=st)
+        out, st3 = self.conv3(out, want_stats=True)
         if self.downsample is not None:
-            identity = self.downsample[1](self.downsample[0](x), relu=False)
-        return self.bn3(out, residual=identity, relu=True)      # out += identity; relu
+            idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
+            identity = self.downsample[1](idn, relu=False, stats=st)
+            return self.bn3(out, residual=identity, relu=True, stats=st3)
+        return self.bn3(out, residual=x, relu=True, stats=st3, res_slot=slot)   # out += identity; relu
 
     def forward_frozen(self, x):
         """Same block with running-stat BN folded into the conv epilogues (3-4 kernels)."""
@@ -143,7 +153,9 @@ class ResNet(nn.Layer):
                 for blk in stage:
                     y = blk.forward_frozen(y)
         else:
-            y = self.bn1(self.conv1(xp, hw=(H, W)), relu=True)
+            ops.stats_pool.reset()        # one fill for all fused-BN accumulators of this pass
+            y, st = self.conv1(xp, hw=(H, W), want_stats=True)
+            y = self.bn1(y, relu=True, stats=st)
             y = self.maxpool(y)
             for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in stage:

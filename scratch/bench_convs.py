@@ -30,8 +30,8 @@ def timeit(fn, iters=10):
 
 tot = {'fwd': [0, 0], 'dgrad': [0, 0], 'wgrad': [0, 0]}
 print('%-28s %8s | %8s %7s | %8s %7s | %8s %7s' % ('shape', 'GFLOP', 'fwd us', 'TF', 'dgrad us', 'TF', 'wgrad us', 'TF'))
-for cin, cout, k, st, pad, H, cnt in SHAPES:
-    g = P.ConvGeom(cin, cout, k, st, pad)
+for cin, cout, k, stv, pad, H, cnt in SHAPES:
+    g = P.ConvGeom(cin, cout, k, stv, pad)
     fd = P.fwd_desc(g, N, H, H)
     dds, skipped = P.dgrad_plan(g, N, H, H)
     wd = P.wgrad_desc(g, N, H, H)
@@ -47,13 +47,16 @@ for cin, cout, k, st, pad, H, cnt in SHAPES:
     dw = torch.zeros(cout, k * k * cin, device=DEV)
     fl = 2.0 * N * fd.OP * fd.OQ * cout * k * k * cin
     t_f = timeit(lambda: ops.conv_igemm(fd, x, packer.view(fd.pack, cout), y))
+    st = ops.conv_stats_buffer(N * fd.OP * fd.OQ, cout, DEV)
+    t_fs = timeit(lambda: ops.conv_igemm(fd, x, packer.view(fd.pack, cout), y, stats=st)) if dtype == torch.bfloat16 else 0
     def dg():
         for d in dds: ops.conv_igemm(d, dy, packer.view(d.pack, cin), dx)
     t_d = timeit(dg)
     t_w = timeit(lambda: ops.conv_wgrad(wd, x, dy.view(-1, cout), dw))
     for nm, t in (('fwd', t_f), ('dgrad', t_d), ('wgrad', t_w)):
         tot[nm][0] += t * cnt; tot[nm][1] += fl * cnt
-    print('%4d->%4d k%d s%d @%3d x%d       %8.2f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f' % (
-        cin, cout, k, st, H, cnt, fl / 1e9, t_f * 1e3, fl / t_f / 1e9, t_d * 1e3, fl / t_d / 1e9, t_w * 1e3, fl / t_w / 1e9))
+    tot.setdefault('fwd+stats', [0, 0]); tot['fwd+stats'][0] += t_fs * cnt; tot['fwd+stats'][1] += fl * cnt
+    print('%4d->%4d k%d s%d @%3d x%d       %8.2f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f | stats %8.1f R=%d' % (
+        cin, cout, k, stv, H, cnt, fl / 1e9, t_f * 1e3, fl / t_f / 1e9, t_d * 1e3, fl / t_d / 1e9, t_w * 1e3, fl / t_w / 1e9, t_fs * 1e3, st.shape[0]))
 for nm in tot:
     print('%s total: %.2f ms per pass, %.1f TF avg' % (nm, tot[nm][0], tot[nm][1] / tot[nm][0] / 1e9))

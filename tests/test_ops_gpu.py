@@ -127,6 +127,18 @@ def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
     yo = torch.empty(N, fd.OP, fd.OQ, geom.cout, dtype=dtype, device=DEV)
     ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo)
     assert relmax(yo.float(), nhwc(y.detach())) < tol(dtype)
+    if dtype == torch.bfloat16:
+        # fused BatchNorm statistics of the conv epilogue: per-channel (sum, sum of squares) of the
+        # fp32 accumulators, spread over R replicas; same output as without statistics
+        for R in (1, 3):
+            st = torch.zeros(R, geom.cout, 2, dtype=torch.float32, device=DEV)
+            yo2 = torch.empty_like(yo)
+            ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo2, stats=st)
+            assert torch.equal(yo2, yo)
+            y64 = yo.double().cpu().reshape(-1, geom.cout)       # statistics of the STORED values
+            tot = st.sum(0).double().cpu()
+            assert relmax(tot[:, 0], y64.sum(0)) < 1e-5 * max(1.0, float(y64.abs().sum(0).max() / y64.sum(0).abs().max()))
+            assert relmax(tot[:, 1], (y64 * y64).sum(0)) < 1e-5
     # dgrad
     dya = nhwc(dy).to(DEV).to(dtype)
     dx = torch.full((N, H, W, geom.cin), float('nan'), dtype=dtype, device=DEV)
@@ -136,6 +148,13 @@ def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
         ops.conv_igemm(d, dya, packer.view(d.pack, geom.cin), dx)
     assert not torch.isnan(dx.float()).any()
     assert relmax(dx.float(), nhwc(x.grad)) < tol(dtype)
+    if len(dds) == 1 and not skipped:
+        # residual-fork gradient added in the data-gradient epilogue (nn.GradSlot path)
+        extra = rnd(torch.randn(N, H, W, geom.cin, generator=gen), dtype)
+        dx2 = torch.empty_like(dx)
+        ops.conv_igemm(dds[0], dya, packer.view(dds[0].pack, geom.cin), dx2,
+                       residual=extra.to(DEV).to(dtype))
+        assert relmax(dx2.float(), nhwc(x.grad) + extra.double()) < tol(dtype)
     # wgrad (fp32 accumulate, several split counts)
     for splits in (None, 1, 3):
         dw = torch.zeros(geom.cout, geom.k * geom.k * geom.cin, dtype=torch.float32, device=DEV)
@@ -252,9 +271,13 @@ def test_bn_fwd_bwd(dtype, shape, with_res):
     rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
     xd = x.detach().to(DEV).to(dtype)
     resd = res.detach().to(DEV).to(dtype) if with_res else None
-    z, mean, invstd = ops.bn_train_fwd(xd, gamma.detach().to(DEV), beta.detach().to(DEV), rm, rv,
-                                       residual=resd, relu=True)
+    z, st, mask = ops.bn_train_fwd(xd, gamma.detach().to(DEV), beta.detach().to(DEV), rm, rv,
+                                   residual=resd, relu=True, want_mask=True)
+    mean, invstd = st[0], st[1]
     assert relmax(z.float(), z_ref.detach()) < tol(dtype)
+    # the bit mask is exactly (z > 0), bit e of byte i <-> element 8*i + e
+    bits = (z.reshape(-1, 8) > 0).to(torch.int32) * (1 << torch.arange(8, device=DEV, dtype=torch.int32))
+    assert torch.equal(bits.sum(1).to(torch.uint8), mask)
     assert relmax(mean, mu) < 1e-5 and relmax(invstd, 1 / torch.sqrt(var + 1e-5)) < 1e-5
     assert relmax(rm, 0.9 * rm0 + 0.1 * mu) < 1e-5
     assert relmax(rv, 0.9 * rv0 + 0.1 * var) < 1e-5
@@ -268,6 +291,16 @@ def test_bn_fwd_bwd(dtype, shape, with_res):
     assert relmax(dbeta, beta.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
     if with_res:
         assert relmax(dres.float(), res.grad) < t
+    # the other mask sources must reproduce the z-based result bit for bit: 3 = bit mask,
+    # 2 = recomputed from x*scale+shift (BN+ReLU without residual only)
+    for mode in ([3] if with_res else [3, 2]):
+        dg2 = torch.zeros(Cc, device=DEV); db2 = torch.zeros(Cc, device=DEV)
+        dx2, dres2 = ops.bn_bwd(dz.to(DEV).to(dtype), mask if mode == 3 else None, xd,
+                                gamma.detach().to(DEV), mean, invstd, dg2, db2, relu=mode,
+                                want_dres=with_res, scale=st[2], shift=st[3])
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+        if with_res:
+            assert torch.equal(dres2, dres)
 
 
 # ---------------------------------------------------------------- pooling
