@@ -13,6 +13,7 @@
 // The reduction over M is split over blockIdx.z; partial tiles are accumulated with fp32
 // global atomics (dW is zeroed by the caller).  Per-row gather info (image base, ih0, iw0) for
 // the next reduction tile is computed by 64 threads into a double-buffered LDS table.
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 
@@ -29,6 +30,7 @@ struct WParams {
   int OP, OQ, R, S, C, IH, IW, sh, sw, ph, pw;
   int64_t a_sn, a_sh, a_sw, dy_ld;
   int tiles_per_split, nk_total;
+  int dbg;   // tuning switches (PASSL_WGRAD_DBG): 1 = skip the atomic epilogue
 };
 
 struct RowInfo {
@@ -287,6 +289,226 @@ int dispatch(const WParams& p, int splits, hipStream_t st) {
   return launch<T, 128, 128>(p, splits, st);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 fast path: LDS-DMA staging + hardware transpose reads.
+//
+// Both operands keep their NATURAL layout in LDS ([64 reduction rows m][channels], 16-byte chunks
+// XOR-swizzled within a row), written by `buffer_load_dwordx4 ... lds` (no VGPR staging, no
+// ds_write, out-of-range lanes fetch zeros through the buffer bounds check), and the MFMA
+// fragments (8 consecutive m per lane) come from two `ds_read_b64_tr_b16` each: a 16-lane group
+// addresses a [4 m][16 ch] block (lane j -> row j>>2, 4 channels at 4*(j&3)) and lane i receives
+// channel i of the 4 rows.  Swizzle: the 32-byte chunk pair index is XORed with h(row), chosen so
+// that the 8 row segments a 32-lane group touches fall on disjoint banks (see hswz).
+// Pipeline: 2 LDS stages (64 KB) -> 2 workgroups per CU; the DMA of tile t+1 is in flight while
+// tile t is multiplied; one barrier per tile.
+struct RowInfo2 {
+  uint32_t base;   // byte offset of image n
+  int ih0, iw0;
+  int valid;
+};
+
+template <int CPR>   // 16-byte chunks per LDS row (16: 128 channels, 8: 64 channels)
+__device__ __forceinline__ int hswz(int row) {
+  return CPR == 16 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+
+constexpr uint32_t kOOB = 0x7ffffff0u;   // beyond every buffer's num_records -> the load returns 0
+
+template <int BMo, int BNo>
+__global__ void __launch_bounds__(kThreads, 2) wgrad_dma_kernel(const WParams p, uint32_t a_bytes,
+                                                                uint32_t dy_bytes) {
+  constexpr int BKM = 64;
+  constexpr int WM = BMo / 2, WN = BNo / 2;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int CPA = BMo / 8, CPB = BNo / 8;          // chunks per row
+  constexpr int PA = BMo * 2, PB = BNo * 2;            // row pitch (bytes)
+  constexpr int A_BYTES = BKM * PA, B_BYTES = BKM * PB;
+  constexpr int NIA = A_BYTES / 1024 / 4, NIB = B_BYTES / 1024 / 4;   // DMA instructions per wave
+  constexpr int RPA = 1024 / PA, RPB = 1024 / PB;      // rows per DMA instruction
+  constexpr int STAGE = A_BYTES + B_BYTES;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  RowInfo2* rinfo = reinterpret_cast<RowInfo2*>(smem + 2 * STAGE);   // [2][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int oc0 = blockIdx.y * BMo;
+  const int j0 = blockIdx.x * BNo;
+  const int opq = p.OP * p.OQ;
+  const int kt_begin = blockIdx.z * p.tiles_per_split;
+  int kt_end = kt_begin + p.tiles_per_split;
+  if (kt_end > p.nk_total) kt_end = p.nk_total;
+  if (kt_begin >= kt_end) return;
+
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, dy_bytes, 0x00020000);
+
+  // ---- static per-thread DMA geometry (tile invariant: rows advance by 64 = 0 mod 16)
+  int a_row[NIA]; uint32_t a_col[NIA];                 // dy tile
+#pragma unroll
+  for (int i = 0; i < NIA; ++i) {
+    const int q = i * 4 + wave;
+    const int row = q * RPA + lane / CPA;
+    const int chunk = (lane % CPA) ^ (hswz<CPA>(row) << 1);
+    const int oc = oc0 + chunk * 8;
+    a_row[i] = row;
+    a_col[i] = oc < p.NCOLS ? (uint32_t)oc * 2u : kOOB;
+  }
+  int b_row[NIB], b_r[NIB], b_s[NIB]; uint32_t b_c[NIB];   // x tile
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int q = i * 4 + wave;
+    const int row = q * RPB + lane / CPB;
+    const int chunk = (lane % CPB) ^ (hswz<CPB>(row) << 1);
+    const int j = j0 + chunk * 8;
+    const int rs = j / p.C;
+    b_row[i] = row;
+    b_r[i] = rs / p.S;
+    b_s[i] = rs - b_r[i] * p.S;
+    b_c[i] = j < p.KDIM ? (uint32_t)(j - rs * p.C) * 2u : kOOB;
+  }
+
+  auto fill_rowinfo = [&](int kt, int buf) {
+    if (tid < BKM) {
+      const int m = kt * BKM + tid;
+      RowInfo2 ri;
+      if (m < p.M) {
+        const int n = m / opq;
+        const int rem = m - n * opq;
+        const int op = rem / p.OQ;
+        const int oq = rem - op * p.OQ;
+        ri.base = (uint32_t)((int64_t)n * p.a_sn * 2);
+        ri.ih0 = op * p.sh - p.ph;
+        ri.iw0 = oq * p.sw - p.pw;
+        ri.valid = 1;
+      } else {
+        ri.base = 0; ri.ih0 = 0; ri.iw0 = 0; ri.valid = 0;
+      }
+      rinfo[buf * 64 + tid] = ri;
+    }
+  };
+
+  auto issue_tile = [&](int kt, int sbuf, int ibuf) {
+    char* Ab = smem + sbuf * STAGE;
+    char* Bb = Ab + A_BYTES;
+    const int mbase = kt * BKM;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int m = mbase + a_row[i];
+      uint32_t off = kOOB;
+      if (m < p.M && a_col[i] != kOOB) off = (uint32_t)m * (uint32_t)(p.dy_ld * 2) + a_col[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_dy, (__attribute__((address_space(3))) void*)(Ab + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const RowInfo2 ri = rinfo[ibuf * 64 + b_row[i]];
+      const int ih = ri.ih0 + b_r[i], iw = ri.iw0 + b_s[i];
+      uint32_t off = kOOB;
+      if (ri.valid && b_c[i] != kOOB && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
+        off = ri.base + (uint32_t)(ih * (int)(p.a_sh * 2) + iw * (int)(p.a_sw * 2)) + b_c[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_a, (__attribute__((address_space(3))) void*)(Bb + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fill_rowinfo(kt_begin, 0);
+  __syncthreads();
+  issue_tile(kt_begin, 0, 0);
+  if (kt_begin + 1 < kt_end) fill_rowinfo(kt_begin + 1, 1);
+
+  // transpose-read addressing: 16-lane group g reads rows 8g + 4*half + (lane>>2)&3, lane's own
+  // 8 bytes sit at channel 4*(lane&3) of the fragment's 16-channel block
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int r4 = (lane >> 2) & 3, c4 = lane & 3;
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const char* Ab = smem + buf * STAGE;
+    const char* Bb = Ab + A_BYTES;
+    // ALL fragment reads of this tile are issued BEFORE the next tile's DMA: hipcc orders every
+    // LDS read that follows an LDS-DMA behind a full `s_waitcnt vmcnt(0)` (it cannot prove the
+    // two touch different stages), which would serialise the DMA with the MFMAs.
+    bf16x8_t af[2][FM], bfr[2][FN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = ks * 32 + 8 * l4 + 4 * h + r4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int pair = (wm * WM) / 16 + i;
+          const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4_t*)(Ab + row * PA + ((pair ^ hswz<CPA>(row)) << 5) + c4 * 8));
+          af[ks][i][4 * h + 0] = v[0]; af[ks][i][4 * h + 1] = v[1];
+          af[ks][i][4 * h + 2] = v[2]; af[ks][i][4 * h + 3] = v[3];
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int pair = (wn * WN) / 16 + j;
+          const bf16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4_t*)(Bb + row * PB + ((pair ^ hswz<CPB>(row)) << 5) + c4 * 8));
+          bfr[ks][j][4 * h + 0] = v[0]; bfr[ks][j][4 * h + 1] = v[1];
+          bfr[ks][j][4 * h + 2] = v[2]; bfr[ks][j][4 * h + 3] = v[3];
+        }
+      }
+    }
+    if (kt + 1 < kt_end) issue_tile(kt + 1, buf ^ 1, buf ^ 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    if (kt + 2 < kt_end) fill_rowinfo(kt + 2, buf);
+  }
+
+  // ---- epilogue: fp32 atomics into dW[oc][j]
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oc = oc0 + wm * WM + i * 16 + l4 * 4 + r;
+        const int jj = j0 + wn * WN + j * 16 + l15;
+        if (oc < p.NCOLS && jj < p.KDIM && !(p.dbg & 1)) atomicAdd(p.dw + (int64_t)oc * p.KDIM + jj, acc[i][j][r]);
+      }
+}
+
+template <int BMo, int BNo>
+int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
+  constexpr int LDS = 2 * 64 * (BMo + BNo) * 2 + 2 * 64 * (int)sizeof(RowInfo2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<BMo, BNo>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  dim3 grid((p.KDIM + BNo - 1) / BNo, (p.NCOLS + BMo - 1) / BMo, splits);
+  hipLaunchKernelGGL((wgrad_dma_kernel<BMo, BNo>), grid, dim3(kThreads), LDS, st, p, a_bytes, dy_bytes);
+  return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
+  const bool m64 = p.NCOLS <= 64, n64 = p.KDIM <= 64;
+  if (m64 && n64) return launch_dma<64, 64>(p, splits, a_bytes, dy_bytes, st);
+  if (m64) return launch_dma<64, 128>(p, splits, a_bytes, dy_bytes, st);
+  if (n64) return launch_dma<128, 64>(p, splits, a_bytes, dy_bytes, st);
+  return launch_dma<128, 128>(p, splits, a_bytes, dy_bytes, st);
+}
+
 }  // namespace
 
 extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t stream) {
@@ -318,9 +540,27 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
   if (splits > p.nk_total) splits = p.nk_total;
   p.tiles_per_split = (p.nk_total + splits - 1) / splits;
   splits = (p.nk_total + p.tiles_per_split - 1) / p.tiles_per_split;
+  {
+    static int dyn = -1;
+    static int dbg = 0;
+    if (dyn < 0) dyn = getenv("PASSL_WGRAD_DBG_DYNAMIC") ? 1 : 0;
+    if (dyn || dbg == 0) { const char* e = getenv("PASSL_WGRAD_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
   hipStream_t st = as_stream(stream);
   passl_prof_begin(1, st);
-  const int rc = d->dtype == PASSL_BF16 ? dispatch<bf16_t>(p, splits, st) : dispatch<float>(p, splits, st);
+  int rc;
+  // bf16: LDS-DMA + transpose-read kernel when both operands are addressable with 32-bit byte
+  // offsets (buffer addressing); the register-staged kernel otherwise and for fp32
+  static int use_dma = -1;
+  if (use_dma < 0) { const char* e = getenv("PASSL_WGRAD_DMA"); use_dma = e ? atoi(e) : 1; }
+  const int64_t a_bytes = ((int64_t)d->N * d->a_sn) * 2;
+  const int64_t dy_bytes = (M64 * d->dy_ld) * 2;
+  const int64_t lim = 0x7ffffff0ll;
+  if (d->dtype == PASSL_BF16 && use_dma && a_bytes < lim && dy_bytes < lim && a_bytes > 0)
+    rc = dispatch_dma(p, splits, (uint32_t)a_bytes, (uint32_t)dy_bytes, st);
+  else
+    rc = d->dtype == PASSL_BF16 ? dispatch<bf16_t>(p, splits, st) : dispatch<float>(p, splits, st);
   passl_prof_end(1, st);
   return rc;
 }
