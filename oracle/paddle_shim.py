@@ -61,6 +61,10 @@ def _dtype(dt):
             'int32': torch.int32, 'bool': torch.bool, None: torch.float32}[dt]
 
 
+def _set_default_dtype_hook():
+    pass
+
+
 # ------------------------------------------------------------------ nn
 class Layer(torch.nn.Module):
     def sublayers(self, include_self=False):
@@ -161,7 +165,7 @@ class MaxPool2D(Layer):
 
 
 class AdaptiveAvgPool2D(Layer):
-    def __init__(self, output_size):
+    def __init__(self, output_size, data_format='NCHW'):
         super().__init__()
         self.o = output_size
 
@@ -218,7 +222,24 @@ def install():
     paddle.to_tensor = lambda x, dtype=None, **k: torch.as_tensor(
         x, dtype=None if dtype is None else _dtype(dtype))
     paddle.concat = lambda xs, axis=0: torch.cat(list(xs), dim=axis)
-    paddle.matmul = torch.matmul
+
+    def matmul(x, y, transpose_x=False, transpose_y=False):
+        if transpose_x:
+            x = x.transpose(-1, -2)
+        if transpose_y:
+            y = y.transpose(-1, -2)
+        return torch.matmul(x, y)
+    paddle.matmul = matmul
+    paddle.arange = lambda start, end=None, step=1, dtype=None: torch.arange(
+        start, end, step, dtype=_dtype(dtype) if dtype else None)
+    paddle.reshape = lambda x, shape: x.reshape(list(shape))
+    paddle.unsqueeze = lambda x, axis: x.unsqueeze(axis)
+    paddle.argmax = lambda x, axis=None: x.argmax() if axis is None else x.argmax(dim=axis)
+
+    class ParamAttr(object):
+        def __init__(self, *a, **k):
+            pass
+    paddle.ParamAttr = ParamAttr
     paddle.sum = lambda x, axis=None, keepdim=False: x.sum() if axis is None \
         else x.sum(dim=axis, keepdim=keepdim)
     paddle.cast = lambda x, dt: x.to(_dtype(dt))
@@ -245,6 +266,19 @@ def install():
     nn.functional = F
     F.normalize = _normalize
     F.relu = TF.relu
+    F.one_hot = lambda x, num_classes: TF.one_hot(x.long(), num_classes).float()
+    F.softmax = lambda x, axis=-1: torch.softmax(x, dim=axis)
+    F.log_softmax = lambda x, axis=-1: torch.log_softmax(x, dim=axis)
+    # softmax_with_cross_entropy(soft_label=True): -sum(label*log_softmax) per row, shape [N,1]
+    F.softmax_with_cross_entropy = lambda logits, label, soft_label=False, axis=-1: \
+        -(label * torch.log_softmax(logits, dim=axis)).sum(dim=axis, keepdim=True)
+    # kl_div: the kldiv_loss op has no gradient for `label`  [Paddle-semantics]
+    F.kl_div = lambda input, label, reduction='mean': TF.kl_div(input, label.detach(),
+                                                                reduction=reduction)
+    init_mod = mod('paddle.nn.initializer')
+    nn.initializer = init_mod
+    for nm in ('XavierNormal', 'Constant', 'Normal', 'KaimingNormal'):
+        setattr(init_mod, nm, type(nm, (object,), {'__init__': lambda self, *a, **k: None}))
     layer = mod('paddle.nn.layer')
     nn.layer = layer
     norm = mod('paddle.nn.layer.norm')
@@ -265,8 +299,24 @@ def install():
     paddle.fluid = fluid
     fl = mod('paddle.fluid.layers')
     fluid.layers = fl
-    fl.l2_normalize = lambda x, axis: _normalize(x, axis=axis)
-    fl.squeeze = lambda x, axes: x
+    # fluid.layers.l2_normalize: x / sqrt(sum(x^2) + eps)   [Paddle-semantics]
+    fl.l2_normalize = lambda x, axis, epsilon=1e-12: x * torch.rsqrt(
+        x.pow(2).sum(dim=axis, keepdim=True) + epsilon)
+
+    def squeeze(x, axes):
+        if not axes:
+            return x.reshape([d for d in x.shape if d != 1] or [1]) if x.dim() > 2 else x
+        for a in sorted(axes, reverse=True):
+            x = x.squeeze(a)
+        return x
+    fl.squeeze = squeeze
+    fl.split = lambda x, num_or_sections, dim=-1: list(torch.chunk(x, num_or_sections, dim=dim))
+    fl.reduce_mean = lambda x, dim=None: x.mean() if dim is None else x.mean(dim=dim)
+
+    def fl_accuracy(input, label, k=1):
+        top = input.topk(k, dim=1).indices
+        return (top == label.reshape(-1, 1)).any(dim=1).float().mean()
+    fl.accuracy = fl_accuracy
 
     utils = mod('paddle.utils')
     paddle.utils = utils

@@ -74,6 +74,11 @@ def load():
     imp(PKG + '.modeling.heads.contrastive_head')
     imp(PKG + '.modeling.architectures.builder')
     imp(PKG + '.modeling.architectures.moco')
+    # SimCLR row: resnetcifar/resnetsimclr backbone, SimCLRContrastiveHead, SimCLR architecture
+    imp(PKG + '.modeling.backbones.resnetcifar')
+    imp(PKG + '.modeling.backbones.resnetsimclr')
+    imp(PKG + '.modeling.heads.simclr_contrastive_head')
+    imp(PKG + '.modeling.architectures.simclr')
     return _namespace()
 
 
@@ -89,6 +94,9 @@ def _namespace():
     ns.BACKBONES = sys.modules[PKG + '.modeling.backbones.builder'].BACKBONES
     ns.NECKS = sys.modules[PKG + '.modeling.necks.builder'].NECKS
     ns.HEADS = sys.modules[PKG + '.modeling.heads.builder'].HEADS
+    ns.SimCLR = sys.modules[PKG + '.modeling.architectures.simclr'].SimCLR
+    ns.SimCLRContrastiveHead = sys.modules[
+        PKG + '.modeling.heads.simclr_contrastive_head'].SimCLRContrastiveHead
     return ns
 
 
@@ -125,3 +133,33 @@ def load_oracle_state(model, oracle):
                 sd[n].copy_(t.detach())
         model.queue.copy_(oracle.queue)
         model.queue_ptr[0] = oracle.queue_ptr
+
+
+SIMCLR_CFG = dict(
+    name='SimCLR',
+    backbone=dict(name='ResNetsimclr', depth=50),
+    neck=dict(name='NonLinearNeckfc3', in_channels=2048, hid_channels=2048, out_channels=128,
+              with_avg_pool=False),
+    head=dict(name='SimCLRContrastiveHead', temperature=0.1),
+)
+
+
+def build_reference_simclr(T=0.1):
+    """SimCLR built by the reference's registries from the `model:` block of
+    configs/simclr/simclr_r50_IM.yaml (restated in SIMCLR_CFG)."""
+    import copy
+    ns = load()
+    cfg = copy.deepcopy(SIMCLR_CFG)
+    cfg['head']['temperature'] = T
+    return ns.build_model(cfg)
+
+
+def load_simclr_state(model, oracle):
+    """Copy a SimCLROracle's encoder state into a reference SimCLR instance."""
+    import torch
+    with torch.no_grad():
+        sd = model.encoder.state_dict()
+        assert list(sd.keys()) == list(oracle.st.keys()), 'state_dict key order differs'
+        for n, t in oracle.st.items():
+            assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)
+            sd[n].copy_(t.detach())

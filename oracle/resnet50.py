@@ -96,22 +96,26 @@ def batch_norm(x, st, prefix, use_global_stats, new_stats=None):
     in ``new_stats`` (applied by the caller after the forward, functionally)."""
     w, b = st[prefix + '.weight'], st[prefix + '.bias']
     rm, rv = st[prefix + '._mean'], st[prefix + '._variance']
+    dims = (0, 2, 3) if x.dim() == 4 else (0,)          # BatchNorm2D / BatchNorm1D on [N, C]
     if use_global_stats:
         mean, var = rm, rv
     else:
-        mean = x.mean(dim=(0, 2, 3))
-        var = x.var(dim=(0, 2, 3), unbiased=False)
+        mean = x.mean(dim=dims)
+        var = x.var(dim=dims, unbiased=False)
         if new_stats is not None:
             with torch.no_grad():
                 new_stats[prefix + '._mean'] = BN_MOMENTUM * rm + (1 - BN_MOMENTUM) * mean.detach()
                 new_stats[prefix + '._variance'] = BN_MOMENTUM * rv + (1 - BN_MOMENTUM) * var.detach()
     inv = torch.rsqrt(var + BN_EPS)
+    if x.dim() == 2:
+        return (x - mean[None, :]) * (inv * w)[None, :] + b[None, :]
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def encoder_forward(st, x, use_global_stats, new_stats=None, taps=None):
-    """nn.Sequential(ResNet(depth=50,num_classes=0,with_pool=False),
-    NonLinearNeckV1(...)) forward; ``st`` keys as in init_encoder_state."""
+def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=True):
+    """ResNet-50 trunk (keys '0.*'): [N,3,H,W] -> layer4 map.  ``maxpool=False`` is the
+    SimCLR variant (passl_v110/modeling/backbones/resnetcifar.py:275 comments the stem pool
+    out, forward :321-333)."""
     def conv(name, x, stride, pad):
         return F.conv2d(x, st['0.' + name + '.weight'], None, stride, pad)
 
@@ -119,7 +123,8 @@ def encoder_forward(st, x, use_global_stats, new_stats=None, taps=None):
         return batch_norm(x, st, '0.' + name, use_global_stats, new_stats)
 
     x = F.relu(bn('bn1', conv('conv1', x, 2, 3)))
-    x = F.max_pool2d(x, 3, 2, 1)
+    if maxpool:
+        x = F.max_pool2d(x, 3, 2, 1)
     if taps is not None:
         taps['stem'] = x
     for li, blocks in enumerate(LAYERS, start=1):
@@ -135,6 +140,13 @@ def encoder_forward(st, x, use_global_stats, new_stats=None, taps=None):
             x = F.relu(out + identity)
         if taps is not None:
             taps['layer%d' % li] = x
+    return x
+
+
+def encoder_forward(st, x, use_global_stats, new_stats=None, taps=None):
+    """nn.Sequential(ResNet(depth=50,num_classes=0,with_pool=False),
+    NonLinearNeckV1(...)) forward; ``st`` keys as in init_encoder_state."""
+    x = trunk_forward(st, x, use_global_stats, new_stats, taps, maxpool=True)
     # NonLinearNeckV1.forward (base_neck.py:93-97)
     x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)
     x = F.relu(x @ st['1.mlp.0.weight'] + st['1.mlp.0.bias'])
