@@ -60,6 +60,21 @@ int passl_hip_ema_update(float* k, const float* q, void* k_lp, int64_t n, float 
 int passl_hip_momentum_sgd(float* p, const float* g, float* v, int64_t n, float lr, float mu,
                            float wd, float grad_scale, passl_stream_t stream);
 
+/* LARS momentum over a flat fp32 buffer holding many parameter tensors ("segments").
+ * The buffer is cut into blocks of at most 4096 elements, each inside ONE segment
+ * (blk_off: element offset, 4-aligned; blk_len; blk_seg: segment index); per segment s:
+ *   local_lr = lr*lars_coeff*|p_s| / (|g_s| + wd_s*|p_s| + epsilon)   if wd_s > 0, |p_s| > 0, |g_s| > 0
+ *            = lr                                                     otherwise
+ *   v = mu*v + local_lr*(g*grad_scale + wd_s*p);   p = p - v
+ * norms: workspace [n_seg][2] (zeroed inside).  Two launches (norms, update).
+ * Replaces paddle.fluid.optimizer.LarsMomentumOptimizer.minimize called from
+ * passl_v110/hooks/optimizer_hook.py:44-45 (registered at passl_v110/solver/optimizer.py:25). */
+int passl_hip_lars_momentum(float* p, const float* g, float* v, const int64_t* blk_off,
+                            const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
+                            const float* seg_wd, int n_seg, float* norms, float lr, float mu,
+                            float lars_coeff, float epsilon, float grad_scale,
+                            passl_stream_t stream);
+
 /* dst_bf16[i] = bf16(src[i]) (round-to-nearest-even). */
 int passl_hip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, passl_stream_t stream);
 
@@ -239,6 +254,26 @@ int passl_hip_infonce_bwd(const float* q, const float* k, const float* queue,
  * MoCo._dequeue_and_enqueue, moco.py:101-102 (the pointer arithmetic stays on the host). */
 int passl_hip_enqueue(float* queue, const float* keys, int D, int K, int ptr, int B,
                       passl_stream_t stream);
+
+/* Fused NT-Xent + CO2 head of SimCLR (passl_v110/modeling/heads/simclr_contrastive_head.py:42-102).
+ * a, b: [B][D] fp32 rows of this rank (hidden1, hidden2); a_all, b_all: [BL][D] the column sets
+ * (a_all = a, b_all = b, BL = B, row_offset = 0 reproduces the reference, which never gathers;
+ * with all-gathered embeddings row i's positive column is row_offset + i).  D must be 128, BL >= 2.
+ *   loss = mean_i( LSE([ab_i|aa_i]) - ab_i,pos + LSE([ba_i|bb_i]) - ba_i,pos )
+ *          + co2_weight * sum_i( KL(Pb_i||Pa_i) + KL(Pa_i||Pb_i) ) / B          (self/positive masks
+ *   as in the reference), acc1 = fraction of rows whose positive is the arg-max of ab_i.
+ * out[0..1] = loss, acc1; rowstats [B][8] = (lse_ce_a, lse_ce_b, lse_Pa, lse_Pb, co2_i, pos, rank, 0)
+ * is what the backward needs.  The B x BL logits are never written. */
+int passl_hip_ntxent_fwd(const float* a, const float* b, const float* a_all, const float* b_all,
+                         int B, int BL, int row_offset, int D, float T, float co2_weight,
+                         float* out, float* rowstats, passl_stream_t stream);
+/* Gradients (accumulated with atomics into zeroed buffers): da, db [B][D] = through the row role,
+ * da_all, db_all [BL][D] = through the column role (the caller adds / reduce-scatters them).
+ * The kl_div target carries no gradient (Paddle's kldiv_loss_grad). gscale: device scalar or NULL. */
+int passl_hip_ntxent_bwd(const float* a, const float* b, const float* a_all, const float* b_all,
+                         const float* rowstats, const float* gscale, int B, int BL, int row_offset,
+                         int D, float T, float co2_weight, float* da, float* db, float* da_all,
+                         float* db_all, passl_stream_t stream);
 
 /* ---------------------------------------------------------------- measurement hooks */
 

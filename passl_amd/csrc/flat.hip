@@ -87,6 +87,81 @@ __global__ void __launch_bounds__(kThreads) cast_kernel(const float* __restrict_
   }
 }
 
+// ---- LARS (multi-tensor): one block = one chunk (<= kLarsChunk elements) of ONE parameter tensor.
+constexpr int kLarsChunk = 4096;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// norms[seg][0] += sum p^2, norms[seg][1] += sum (g*gs)^2 over the block's chunk
+__global__ void __launch_bounds__(kThreads) lars_norm_kernel(
+    const float* __restrict__ p, const float* __restrict__ g, const int64_t* __restrict__ blk_off,
+    const int32_t* __restrict__ blk_len, const int32_t* __restrict__ blk_seg, float gs,
+    float* __restrict__ norms) {
+  __shared__ float red[4];
+  const int64_t off = blk_off[blockIdx.x];
+  const int len = blk_len[blockIdx.x];
+  float sp = 0.f, sg = 0.f;
+  for (int i = threadIdx.x * 4; i < len; i += kThreads * 4) {
+    if (i + 4 <= len) {
+      const float4 pv = *reinterpret_cast<const float4*>(p + off + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + off + i);
+      sp += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
+      sg += (gv.x * gv.x + gv.y * gv.y + gv.z * gv.z + gv.w * gv.w) * gs * gs;
+    } else {
+      for (int e = i; e < len; ++e) { sp += p[off + e] * p[off + e]; sg += g[off + e] * g[off + e] * gs * gs; }
+    }
+  }
+  sp = block_sum(sp, red);
+  sg = block_sum(sg, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(norms + 2 * blk_seg[blockIdx.x], sp);
+    atomicAdd(norms + 2 * blk_seg[blockIdx.x] + 1, sg);
+  }
+}
+
+// lars_momentum op:  local_lr = lr*coeff*|p| / (|g| + wd*|p| + eps)  if wd > 0, |p| > 0, |g| > 0
+//                    (else lr);   v = mu*v + local_lr*(g + wd*p);   p -= v
+__global__ void __launch_bounds__(kThreads) lars_update_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+    const int64_t* __restrict__ blk_off, const int32_t* __restrict__ blk_len,
+    const int32_t* __restrict__ blk_seg, const float* __restrict__ seg_wd,
+    const float* __restrict__ norms, float lr, float mu, float coeff, float eps, float gs) {
+  const int seg = blk_seg[blockIdx.x];
+  const float wd = seg_wd[seg];
+  const float pn = sqrtf(norms[2 * seg]), gn = sqrtf(norms[2 * seg + 1]);
+  float llr = lr;
+  if (wd > 0.f && pn > 0.f && gn > 0.f) llr = lr * coeff * pn / (gn + wd * pn + eps);
+  const int64_t off = blk_off[blockIdx.x];
+  const int len = blk_len[blockIdx.x];
+  for (int i = threadIdx.x * 4; i < len; i += kThreads * 4) {
+    if (i + 4 <= len) {
+      float4 pv = *reinterpret_cast<float4*>(p + off + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + off + i);
+      float4 vv = *reinterpret_cast<float4*>(v + off + i);
+      vv.x = mu * vv.x + llr * (gv.x * gs + wd * pv.x);
+      vv.y = mu * vv.y + llr * (gv.y * gs + wd * pv.y);
+      vv.z = mu * vv.z + llr * (gv.z * gs + wd * pv.z);
+      vv.w = mu * vv.w + llr * (gv.w * gs + wd * pv.w);
+      pv.x -= vv.x; pv.y -= vv.y; pv.z -= vv.z; pv.w -= vv.w;
+      *reinterpret_cast<float4*>(v + off + i) = vv;
+      *reinterpret_cast<float4*>(p + off + i) = pv;
+    } else {
+      for (int e = i; e < len; ++e) {
+        const float vv = mu * v[off + e] + llr * (g[off + e] * gs + wd * p[off + e]);
+        v[off + e] = vv;
+        p[off + e] -= vv;
+      }
+    }
+  }
+}
+
 // One block = up to 1024 consecutive destination elements of one job.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) pack_kernel(const float* __restrict__ src,
@@ -177,6 +252,27 @@ extern "C" int passl_hip_pack_weights(const float* src, void* dst, int dtype,
                        src, reinterpret_cast<float*>(dst), jobs, block_job, block_start);
   else
     return PASSL_EUNSUPPORTED;
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_lars_momentum(float* p, const float* g, float* v, const int64_t* blk_off,
+                                       const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
+                                       const float* seg_wd, int n_seg, float* norms, float lr,
+                                       float mu, float lars_coeff, float epsilon, float grad_scale,
+                                       passl_stream_t stream) {
+  if (!p || !g || !v || !blk_off || !blk_len || !blk_seg || !seg_wd || !norms || n_blocks < 0 ||
+      n_seg <= 0 || !aligned16(p) || !aligned16(g) || !aligned16(v))
+    return PASSL_EINVAL;
+  if (n_blocks == 0) return PASSL_OK;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(norms, 0, 2 * sizeof(float) * (size_t)n_seg, st) != hipSuccess)
+    return PASSL_ELAUNCH;
+  hipLaunchKernelGGL(lars_norm_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, blk_off, blk_len,
+                     blk_seg, grad_scale, norms);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(lars_update_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, v, blk_off,
+                     blk_len, blk_seg, seg_wd, norms, lr, mu, lars_coeff, epsilon, grad_scale);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

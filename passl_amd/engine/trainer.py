@@ -29,7 +29,7 @@ from ..datasets import build_dataloader
 from ..hip import config as hip_config
 from ..hooks import Hook, build_hook
 from ..modeling.architectures import build_model
-from ..solver import build_lr_scheduler, build_optimizer
+from ..solver import build_lr_scheduler, build_lr_scheduler_simclr, build_optimizer
 
 
 class IterLoader:
@@ -105,7 +105,15 @@ class Trainer:
         self.train_dataloader, self.mixup_fn = build_dataloader(cfg.dataloader.train, self.device)
         self.iters_per_epoch = len(self.train_dataloader)
 
-        self.lr_scheduler = build_lr_scheduler(cfg.lr_scheduler, self.iters_per_epoch)
+        self.use_simclr_iters = cfg.get('use_simclr_iters', False)
+        if self.use_simclr_iters:                 # trainer.py:157-163 (the x8 is the reference's)
+            self.batch_size = cfg.dataloader.train.sampler.batch_size
+            self.global_batch_size = cfg.global_batch_size
+            self.lr_scheduler = build_lr_scheduler_simclr(
+                cfg.lr_scheduler, self.iters_per_epoch, self.batch_size * 8, cfg.epochs,
+                self.current_iter)
+        else:
+            self.lr_scheduler = build_lr_scheduler(cfg.lr_scheduler, self.iters_per_epoch)
         self.optimizer = build_optimizer(cfg.optimizer, self.lr_scheduler, [self.model])
 
         self.use_amp = cfg.get('use_amp', False)

@@ -84,6 +84,11 @@ SIGNATURES = {
     'passl_hip_infonce_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
     'passl_hip_infonce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
     'passl_hip_enqueue': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_lars_momentum': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_f, c_f,
+                                      c_f, c_f, c_f, c_p]),
+    'passl_hip_ntxent_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
+    'passl_hip_ntxent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p,
+                                   c_p, c_p, c_p, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),
     'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),
 }

@@ -398,6 +398,27 @@ class Linear(Layer):
         return _LinearFn.apply(x, self.weight, self.bias, self, relu, out_f32)
 
 
+class _ToComputeFn(Function):
+    """fp32 rows -> compute dtype (bf16) with a HIP cast kernel; gradient comes back as fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        ops.cast_bf16(x.contiguous().view(-1), y.view(-1))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.float()
+
+
+def to_compute(x, dtype):
+    """Cast an fp32 activation to the compute dtype (identity for fp32 compute)."""
+    if dtype == torch.float32 or x.dtype == dtype:
+        return x
+    return _ToComputeFn.apply(x)
+
+
 # =============================================================================== head pieces
 class _L2NormFn(Function):
     @staticmethod

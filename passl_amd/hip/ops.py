@@ -327,3 +327,37 @@ def pack_weights(src, dst, jobs_dev, block_job, block_start, n_blocks):
     L.check(_lib().passl_hip_pack_weights(L.ptr(src), L.ptr(dst), L.dt(dst), L.ptr(jobs_dev),
                                           L.ptr(block_job), L.ptr(block_start), n_blocks,
                                           L.stream()), 'pack_weights')
+
+
+# ------------------------------------------------------------------ SimCLR head / LARS
+def ntxent_fwd(a, b, a_all, b_all, row_offset, T, co2_weight=3.0):
+    """Returns out[2] (loss, acc1) and rowstats [B, 8] (saved for the backward)."""
+    B, Dd = a.shape
+    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    rowstats = torch.empty(B, 8, dtype=torch.float32, device=a.device)
+    L.check(_lib().passl_hip_ntxent_fwd(L.ptr(a), L.ptr(b), L.ptr(a_all), L.ptr(b_all), B,
+                                        a_all.shape[0], int(row_offset), Dd, T, co2_weight,
+                                        L.ptr(out), L.ptr(rowstats), L.stream()), 'ntxent_fwd')
+    return out, rowstats
+
+
+def ntxent_bwd(a, b, a_all, b_all, rowstats, gscale, row_offset, T, co2_weight=3.0):
+    """Returns (da, db, da_all, db_all): row-role and column-role gradients."""
+    B, Dd = a.shape
+    da, db = torch.zeros_like(a), torch.zeros_like(b)
+    da_all, db_all = torch.zeros_like(a_all), torch.zeros_like(b_all)
+    L.check(_lib().passl_hip_ntxent_bwd(L.ptr(a), L.ptr(b), L.ptr(a_all), L.ptr(b_all),
+                                        L.ptr(rowstats), L.ptr(gscale), B, a_all.shape[0],
+                                        int(row_offset), Dd, T, co2_weight, L.ptr(da), L.ptr(db),
+                                        L.ptr(da_all), L.ptr(db_all), L.stream()), 'ntxent_bwd')
+    return da, db, da_all, db_all
+
+
+def lars_momentum(p, g, v, table, lr, mu, coeff, eps, grad_scale=1.0):
+    """`table` = dict(blk_off int64[nb], blk_len int32[nb], blk_seg int32[nb], seg_wd float[ns],
+    norms float[ns,2]) on the device (built once by the optimizer)."""
+    L.check(_lib().passl_hip_lars_momentum(L.ptr(p), L.ptr(g), L.ptr(v), L.ptr(table['blk_off']),
+                                           L.ptr(table['blk_len']), L.ptr(table['blk_seg']),
+                                           table['blk_off'].numel(), L.ptr(table['seg_wd']),
+                                           table['seg_wd'].numel(), L.ptr(table['norms']), lr, mu,
+                                           coeff, eps, grad_scale, L.stream()), 'lars_momentum')

@@ -1,2 +1,3 @@
 from .builder import MODELS, build_model
 from .moco import MoCo
+from .simclr import SimCLR

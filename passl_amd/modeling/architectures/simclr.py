@@ -1,0 +1,57 @@
+"""SimCLR on the MI355X HIP path — reference passl_v110/modeling/architectures/simclr.py:30-76.
+
+train_iter = concat the two views -> ONE encoder pass over 2N images (train-mode BN statistics
+over both views, as in the reference) -> l2_normalize -> split -> SimCLRContrastiveHead.
+Attribute names (``encoder``, ``backbone``, ``head``) and the ``forward(*inputs, mode=...)``
+contract are the reference's; the encoder's parameters live in one EncoderArena (flat fp32 buffer
++ flat gradient buffer) so LARS is a two-launch multi-tensor update."""
+import torch
+
+from ...hip import nn
+from ...hip.nn import EncoderArena
+from ..backbones import build_backbone
+from ..heads import build_head
+from ..necks import build_neck
+from .builder import MODELS
+
+
+@MODELS.register()
+class SimCLR(nn.Layer):
+    def __init__(self, backbone, neck=None, head=None, dim=128, T=0.5):
+        super().__init__()
+        self.T = T
+        self.encoder = torch.nn.Sequential(build_backbone(backbone), build_neck(neck))
+        self.backbone = self.encoder[0]
+        self.head = build_head(head)
+        self.arena_q = EncoderArena(self.encoder, trainable=True)    # name shared with MoCo (DP reducer)
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.sync_runtime_state()
+        return r
+
+    def sync_runtime_state(self):
+        self.arena_q.refresh()
+
+    def train_iter(self, *inputs, **kwargs):
+        img_q, img_k = inputs
+        self.arena_q.refresh()
+        img_con = torch.cat([img_q, img_k])
+        con = self.encoder(img_con)
+        con = nn.normalize(con, axis=1)                    # layers.l2_normalize(con, -1)
+        n = img_q.shape[0]
+        q, k = con[:n], con[n:]
+        return self.head(q, k)
+
+    def forward(self, *inputs, mode='train', **kwargs):
+        if mode == 'train':
+            return self.train_iter(*inputs, **kwargs)
+        elif mode == 'extract':
+            with torch.no_grad():
+                self.arena_q.refresh()
+                return self.backbone(*inputs)
+        elif mode == 'test':
+            raise NotImplementedError('SimCLR.test_iter is broken in the reference (simclr.py:62-68 '
+                                      'calls an undefined backbone_forward)')
+        else:
+            raise Exception('No such mode: {}'.format(mode))

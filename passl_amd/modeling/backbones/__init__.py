@@ -1,2 +1,3 @@
 from .builder import BACKBONES, build_backbone
 from .resnet import ResNet, BottleneckBlock
+from .resnetsimclr import ResNetsimclr

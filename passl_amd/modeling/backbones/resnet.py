@@ -71,6 +71,8 @@ class BottleneckBlock(nn.Layer):
 
 @BACKBONES.register()
 class ResNet(nn.Layer):
+    stem_pool = True          # ResNetsimclr (resnetcifar.py:275) drops the stem max-pool
+
     def __init__(self, depth, num_classes=0, with_pool=False, zero_init_residual=False,
                  frozen_stages=-1, pretrained=None):
         super().__init__()
@@ -88,7 +90,8 @@ class ResNet(nn.Layer):
         self.conv1 = nn.Conv2D(3, self.inplanes, kernel_size=7, stride=2, padding=3, bias_attr=False)
         self.bn1 = self._norm_layer(self.inplanes)
         self.relu = nn.ReLU()
-        self.maxpool = nn.MaxPool2D(kernel_size=3, stride=2, padding=1)
+        if self.stem_pool:
+            self.maxpool = nn.MaxPool2D(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(BottleneckBlock, 64, layers[0])
         self.layer2 = self._make_layer(BottleneckBlock, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(BottleneckBlock, 256, layers[2], stride=2)
@@ -148,7 +151,8 @@ class ResNet(nn.Layer):
         frozen = self._all_bn_frozen()
         if frozen and not torch.is_grad_enabled():
             y = self.conv1.infer(xp, self.bn1, relu=True, hw=(H, W))
-            y = self.maxpool(y)
+            if self.stem_pool:
+                y = self.maxpool(y)
             for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in stage:
                     y = blk.forward_frozen(y)
@@ -156,7 +160,8 @@ class ResNet(nn.Layer):
             ops.stats_pool.reset()        # one fill for all fused-BN accumulators of this pass
             y, st = self.conv1(xp, hw=(H, W), want_stats=True)
             y = self.bn1(y, relu=True, stats=st)
-            y = self.maxpool(y)
+            if self.stem_pool:
+                y = self.maxpool(y)
             for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for blk in stage:
                     y = blk(y)

@@ -1,0 +1,39 @@
+"""ResNetsimclr: the SimCLR backbone of the reference (passl_v110/modeling/backbones/
+resnetsimclr.py:25-91 over resnetcifar.py:216-333) on the HIP path.
+
+Same bottleneck topology and state_dict keys as ``ResNet`` but (1) NO stem max-pool
+(resnetcifar.py:275 is commented out; forward :321-333) — ~3.9x the FLOPs of a standard R50 at
+224^2; (2) ``with_pool`` defaults to True: the backbone returns the globally pooled [N, 2048]
+features; (3) convs initialised XavierNormal(fan_in=None, fan_out=0) = N(0, sqrt(2/fan_in))
+(resnetcifar.py:62-70 ...), ``init_parameters()`` is NOT called (resnetsimclr.py:63 comments it
+out); BN gamma=1, beta=0.
+"""
+import math
+
+import torch
+
+from ...hip import nn
+from ...modules import init
+from .builder import BACKBONES
+from .resnet import ResNet
+
+
+@BACKBONES.register()
+class ResNetsimclr(ResNet):
+    stem_pool = False
+
+    def __init__(self, depth, num_classes=0, with_pool=True, zero_init_residual=False,
+                 frozen_stages=-1, pretrained=None):
+        if depth in (18, 34):
+            raise NotImplementedError('BasicBlock ResNets (depth 18/34) are not built on the HIP path')
+        super().__init__(depth, num_classes=num_classes, with_pool=with_pool,
+                         zero_init_residual=zero_init_residual, frozen_stages=frozen_stages,
+                         pretrained=pretrained)
+
+    def init_parameters(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2D):
+                fan_in, _ = init._calculate_fan_in_and_fan_out(m.weight)
+                init.normal_(m.weight, 0.0, math.sqrt(2.0 / fan_in))     # XavierNormal, fan_out=0
+            elif isinstance(m, nn._BatchNormBase):
+                init.constant_init(m, 1)

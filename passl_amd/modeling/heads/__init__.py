@@ -1,2 +1,3 @@
 from .builder import HEADS, build_head
 from .contrastive_head import ContrastiveHead
+from .simclr_contrastive_head import SimCLRContrastiveHead

@@ -1,2 +1,2 @@
 from .builder import NECKS, build_neck
-from .base_neck import LinearNeck, NonLinearNeckV1
+from .base_neck import LinearNeck, NonLinearNeckV1, NonLinearNeckfc3

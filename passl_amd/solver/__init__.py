@@ -1,2 +1,3 @@
-from .builder import build_lr_scheduler, build_optimizer, LRSCHEDULERS, OPTIMIZERS
+from .builder import (build_lr_scheduler, build_lr_scheduler_simclr, build_optimizer, LRSCHEDULERS,
+                      OPTIMIZERS)
 from . import lr_scheduler, optimizer

@@ -21,6 +21,27 @@ def build_lr_scheduler(cfg, iters_per_epoch):
     raise NotImplementedError(cfg.name)
 
 
+def build_lr_scheduler_simclr(cfg, iters_per_epoch, batch_size, epochs, current_iter):
+    """passl_v110/solver/builder.py:41-66 (``batch_size`` is the trainer's per-GPU batch x 8)."""
+    import math
+    if cfg.name == 'CosineAnnealingDecay':
+        cfg.T_max *= iters_per_epoch
+    elif cfg.name == 'MultiStepDecay':
+        cfg.milestones = [x * iters_per_epoch for x in cfg.milestones]
+    elif cfg.name == 'simclrCosineWarmup':
+        cfg.step_each_epoch = iters_per_epoch
+        cfg.epochs = epochs
+        cfg.warmup_steps = int(round(cfg.warmup_epochs * cfg.total_images // batch_size))
+        cfg.total_steps = cfg.total_images * epochs // batch_size + 1
+        cfg.T_max = cfg.total_steps - cfg.warmup_steps
+        cfg.current_iter = current_iter
+        if cfg.learning_rate_scaling == 'linear':
+            cfg.lr = cfg.end_lr * batch_size / 256.
+        elif cfg.learning_rate_scaling == 'sqrt':
+            cfg.lr = cfg.end_lr * math.sqrt(batch_size)
+    return build_from_config(cfg, LRSCHEDULERS)
+
+
 def build_optimizer(cfg, lr_scheduler, model_list=None):
     cfg = copy.deepcopy(cfg)
     name = cfg.pop('name')

@@ -77,3 +77,29 @@ class LinearWarmup(LRScheduler):
             self.learning_rate.step(self.last_epoch - self.warmup_steps)
             return self.learning_rate()
         return self.learning_rate
+
+
+@LRSCHEDULERS.register()
+class Cosinesimclr(LRScheduler):
+    """passl_v110/solver/lr_scheduler.py:105-114."""
+
+    def __init__(self, learning_rate, T_max, last_epoch=-1, verbose=False):
+        self.T_max = T_max
+        super().__init__(learning_rate, last_epoch, verbose)
+
+    def get_lr(self):
+        return self.base_lr * (1 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+
+
+@LRSCHEDULERS.register()
+class simclrCosineWarmup(LinearWarmup):
+    """Linear warm-up 0 -> lr over ``warmup_steps`` iterations, then Cosinesimclr counted from the
+    end of the warm-up — passl_v110/solver/lr_scheduler.py:117-139 (extra yaml keys such as
+    total_images / learning_rate_scaling arrive as **kwargs exactly like in the reference)."""
+
+    def __init__(self, lr, warmup_steps, T_max, current_iter=0, last_epoch=-1, warmup_epoch=10,
+                 **kwargs):
+        lr_sch = Cosinesimclr(lr, T_max, last_epoch=-1)
+        super().__init__(learning_rate=lr_sch, warmup_steps=warmup_steps, start_lr=0.0, end_lr=lr,
+                         last_epoch=last_epoch)
+        self.update_specified = False

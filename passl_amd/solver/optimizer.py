@@ -77,3 +77,130 @@ class Momentum(object):
             v.copy_(sd['velocity_%d' % i])
         if 'LR_Scheduler' in sd and isinstance(self._learning_rate, LRScheduler):
             self._learning_rate.set_state_dict(sd['LR_Scheduler'])
+
+
+def _paddle_auto_names(arena):
+    """Dygraph auto-generated parameter names ('conv2d_3.w_0', 'batch_norm2d_1.b_0', 'linear_0.w_0')
+    in construction order — what LarsMomentumOptimizer matches ``exclude_from_weight_decay``
+    against (param.name, not the state_dict key)  [Paddle-semantics]."""
+    from ..hip import nn as hnn
+    counters, names = {}, []
+    for mod in arena.module.modules():
+        own = [n for n, p in mod._parameters.items() if p is not None]
+        if not own:
+            continue
+        if isinstance(mod, hnn.Conv2D):
+            kind = 'conv2d'
+        elif isinstance(mod, hnn.BatchNorm1D):
+            kind = 'batch_norm1d'
+        elif isinstance(mod, hnn._BatchNormBase):
+            kind = 'batch_norm2d'
+        elif isinstance(mod, hnn.Linear):
+            kind = 'linear'
+        else:
+            kind = type(mod).__name__.lower()
+        idx = counters.get(kind, 0)
+        counters[kind] = idx + 1
+        for n in own:
+            names.append('%s_%d.%s' % (kind, idx, 'w_0' if n == 'weight' else 'b_0'))
+    return names
+
+
+@OPTIMIZERS.register()
+class LarsMomentumOptimizer(object):
+    """paddle.fluid.optimizer.LarsMomentumOptimizer (registered by the reference at
+    passl_v110/solver/optimizer.py:25, built with ``parameter_list=`` at solver/builder.py:198-201,
+    driven through ``minimize(loss)`` / ``clear_gradients()`` by hooks/optimizer_hook.py:26-45)
+    as a two-launch multi-tensor update over the flat arena (passl_hip_lars_momentum).
+
+    Rule per parameter tensor (lars_momentum op)  [Paddle-semantics]:
+        local_lr = lr * lars_coeff * |p| / (|g| + wd*|p| + epsilon)   if wd > 0, |p| > 0, |g| > 0
+                 = lr                                                otherwise
+        v = mu*v + local_lr*(g + wd*p);  p = p - v
+    ``exclude_from_weight_decay``: wd = 0 for parameters whose *Paddle name* contains one of the
+    strings — the yaml's ["scale","offset",".bias"] match none of the dygraph auto-names."""
+    type = 'lars_momentum'
+
+    def __init__(self, learning_rate, momentum, lars_coeff=0.001, lars_weight_decay=0.0005,
+                 parameter_list=None, regularization=None, grad_clip=None, name=None,
+                 exclude_from_weight_decay=None, epsilon=0, multi_precision=False,
+                 rescale_grad=1.0):
+        if regularization is not None or grad_clip is not None:
+            raise NotImplementedError('regularization / grad_clip are not used by configs/simclr')
+        self._learning_rate = learning_rate
+        self._momentum = float(momentum)
+        self._coeff = float(lars_coeff)
+        self._wd = float(lars_weight_decay)
+        self._eps = float(epsilon)
+        self._rescale = float(rescale_grad)
+        self._exclude = list(exclude_from_weight_decay or [])
+        params = [p for p in (parameter_list or []) if p.requires_grad]
+        arenas = []
+        for p in params:
+            a = getattr(p, '_passl_arena', None)
+            if a is None:
+                raise NotImplementedError('LarsMomentumOptimizer optimises parameters that live in '
+                                          'an EncoderArena (flat buffer); got a free tensor')
+            if a not in arenas:
+                arenas.append(a)
+        for a in arenas:
+            if sum(1 for p in params if p._passl_arena is a) != len(a.param_slices):
+                raise NotImplementedError('optimising a subset of an arena is not supported')
+        self._parameter_list = params
+        self._arenas = arenas
+        self._velocity = [torch.zeros_like(a.flat[:a.n_train]) for a in arenas]
+        self._tables = [self._build_table(a) for a in arenas]
+        self.grad_scale = 1.0
+
+    def _build_table(self, arena, chunk=4096):
+        names = _paddle_auto_names(arena)
+        assert len(names) == len(arena.param_slices)
+        blk_off, blk_len, blk_seg, seg_wd = [], [], [], []
+        self.param_names = names
+        for si, ((off, n), name) in enumerate(zip(arena.param_slices, names)):
+            seg_wd.append(0.0 if any(e in name for e in self._exclude) else self._wd)
+            for c in range(0, n, chunk):
+                blk_off.append(off + c)
+                blk_len.append(min(chunk, n - c))
+                blk_seg.append(si)
+        dev = arena.device
+        return dict(blk_off=torch.tensor(blk_off, dtype=torch.int64, device=dev),
+                    blk_len=torch.tensor(blk_len, dtype=torch.int32, device=dev),
+                    blk_seg=torch.tensor(blk_seg, dtype=torch.int32, device=dev),
+                    seg_wd=torch.tensor(seg_wd, dtype=torch.float32, device=dev),
+                    norms=torch.zeros(len(seg_wd), 2, dtype=torch.float32, device=dev))
+
+    def get_lr(self):
+        lr = self._learning_rate
+        return float(lr()) if isinstance(lr, LRScheduler) else float(lr)
+
+    def clear_gradients(self, set_to_zero=True):
+        for a in self._arenas:
+            a.clear_grad()
+
+    clear_grad = clear_gradients
+
+    @torch.no_grad()
+    def step(self):
+        lr = self.get_lr()
+        for a, v, t in zip(self._arenas, self._velocity, self._tables):
+            if a.reducer is not None:
+                a.reducer.finish()
+            ops.lars_momentum(a.flat[:a.n_train], a.grads, v, t, lr, self._momentum, self._coeff,
+                              self._eps, self.grad_scale * self._rescale)
+
+    def minimize(self, loss=None, startup_program=None, parameters=None, no_grad_set=None):
+        """Dygraph ``minimize``: the gradients already exist (the hook called backward())."""
+        self.step()
+
+    def state_dict(self):
+        sd = {'velocity_%d' % i: v.detach().cpu() for i, v in enumerate(self._velocity)}
+        if isinstance(self._learning_rate, LRScheduler):
+            sd['LR_Scheduler'] = self._learning_rate.state_dict()
+        return sd
+
+    def set_state_dict(self, sd):
+        for i, v in enumerate(self._velocity):
+            v.copy_(sd['velocity_%d' % i])
+        if 'LR_Scheduler' in sd and isinstance(self._learning_rate, LRScheduler):
+            self._learning_rate.set_state_dict(sd['LR_Scheduler'])

@@ -231,3 +231,63 @@ def test_v2_train_one_step_facade():
     out, loss_dict = loop.train_one_step(batch)
     assert out is None and 'loss' in loss_dict and loop.global_step == 1
     assert not torch.equal(w0, model.fc.weight) and sched.last_epoch == 1
+
+
+# ------------------------------------------------------------------ SimCLR row (host side)
+REF_SIMCLR_CFG = '/root/reference/configs/simclr/simclr_r50_IM.yaml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SIMCLR_CFG), reason='reference tree not present')
+def test_reference_simclr_config_loads_and_builds_unchanged():
+    hip_config.set_device('cpu')
+    from passl_amd.modeling import build_model
+    from passl_amd.solver import build_lr_scheduler_simclr, build_optimizer
+    from oracle.simclr import init_encoder_state
+    cfg = get_config(REF_SIMCLR_CFG, [])
+    assert cfg.use_simclr_iters and cfg.global_batch_size == 4096
+    model = build_model(cfg.model)
+    assert model.head.temperature == 0.1 and model.head.multi_rank is False
+    assert not hasattr(model.backbone, 'maxpool') and model.backbone.with_pool
+    # state_dict layout = the oracle's (= the reference's own, checked in oracle/ref_runner)
+    ost = init_encoder_state(torch.Generator().manual_seed(0))
+    sd = model.encoder.state_dict()
+    assert list(sd.keys()) == list(ost.keys())
+    assert all(tuple(sd[k].shape) == tuple(ost[k].shape) for k in ost)
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 32171456
+    # trainer.py:157-163 passes batch_size*8 ; builder.py:54-66
+    sched = build_lr_scheduler_simclr(cfg.lr_scheduler, 2502, 512 * 8, cfg.epochs, 0)
+    assert (sched.warmup_steps, sched.learning_rate.T_max, sched.end_lr) == (3127, 28152, 64.0)
+    assert sched() == 0.0
+    for _ in range(3127):
+        sched.step()
+    assert abs(sched() - 64.0) < 1e-9
+    sched.step()
+    assert abs(sched() - 64.0 * (1 + math.cos(math.pi * 1 / 28152)) / 2) < 1e-9
+    opt = build_optimizer(cfg.optimizer, sched, [model])
+    assert 'lars' in opt.type and opt._wd == 1e-4 and opt._coeff == 0.001 and opt._momentum == 0.9
+    # exclude_from_weight_decay is matched against Paddle auto-names: nothing matches
+    assert opt.param_names[0] == 'conv2d_0.w_0' and opt.param_names[1] == 'batch_norm2d_0.w_0'
+    assert float(opt._tables[0]['seg_wd'].min()) > 0
+    t = opt._tables[0]
+    assert int(t['blk_len'].sum()) == sum(n for _o, n in model.arena_q.param_slices)
+    assert int(t['blk_len'].max()) <= 4096 and int((t['blk_off'] % 4).sum()) == 0
+
+
+def test_simclr_registry_names_and_kwargs():
+    from passl_amd.modeling.architectures import MODELS
+    from passl_amd.modeling.backbones import BACKBONES
+    from passl_amd.modeling.heads import HEADS
+    from passl_amd.modeling.necks import NECKS
+    from passl_amd.solver import LRSCHEDULERS, OPTIMIZERS
+    for reg, names in ((MODELS, ['MoCo', 'SimCLR']), (BACKBONES, ['ResNet', 'ResNetsimclr']),
+                       (NECKS, ['LinearNeck', 'NonLinearNeckV1', 'NonLinearNeckfc3']),
+                       (HEADS, ['ContrastiveHead', 'SimCLRContrastiveHead']),
+                       (OPTIMIZERS, ['Momentum', 'LarsMomentumOptimizer']),
+                       (LRSCHEDULERS, ['CosineAnnealingDecay', 'simclrCosineWarmup', 'Cosinesimclr'])):
+        for n in names:
+            assert n in reg, n
+    h = HEADS.get('SimCLRContrastiveHead')(temperature=0.5, return_accuracy=True, multi_rank=False)
+    assert h.temperature == 0.5 and h.co2_weight == 3.0
+    with pytest.raises(NotImplementedError):
+        hip_config.set_device('cpu')
+        BACKBONES.get('ResNetsimclr')(depth=18)

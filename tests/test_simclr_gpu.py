@@ -1,0 +1,264 @@
+"""SimCLR path on a real MI355X, through the registries and the C ABI: (1) the fused NT-Xent+CO2
+kernel forward/backward against the CPU oracle's head (fp32 autograd and fp64), ragged sizes and
+the gathered-columns extension; (2) the multi-tensor LARS kernel against the oracle's rule;
+(3) whole training steps against the golden vectors produced by the reference's own SimCLR
+sources (tests/golden/simclr_*.npz) and against the oracle run live.
+
+Tolerances: fp32 compute must meet 1e-3 on loss / embeddings / logits (BASELINE.json); bf16 is
+compared with the same fp32 goldens at stated looser bounds (the reference has no bf16 path)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import simclr_util as U                        # noqa: E402
+from oracle import simclr as S                 # noqa: E402
+from passl_amd.hip import ops                  # noqa: E402
+
+DEV = 'cuda'
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _unit(B, gen, scale=1.0):
+    return torch.nn.functional.normalize(torch.randn(B, 128, generator=gen), dim=1) * scale
+
+
+def _head_general(h1, h2, a_all, b_all, roff, T, w=3.0):
+    """Oracle head generalised to a gathered column set (fp64 torch, explicit masks); with
+    a_all = h1, b_all = h2, roff = 0 it is oracle.simclr.simclr_head."""
+    B, BL = h1.shape[0], a_all.shape[0]
+    pos = torch.zeros(B, BL, dtype=torch.bool)
+    pos[torch.arange(B), roff + torch.arange(B)] = True
+    ninf = float('-inf')
+    aa, ab = h1 @ a_all.t() / T, h1 @ b_all.t() / T
+    ba, bb = h2 @ a_all.t() / T, h2 @ b_all.t() / T
+    aam, bbm = aa.masked_fill(pos, ninf), bb.masked_fill(pos, ninf)
+    abm, bam = ab.masked_fill(pos, ninf), ba.masked_fill(pos, ninf)
+    ce = (torch.logsumexp(torch.cat([ab, aam], 1), 1) - ab[pos]) + \
+        (torch.logsumexp(torch.cat([ba, bbm], 1), 1) - ba[pos])
+    x, y = torch.cat([aam, abm], 1), torch.cat([bam, bbm], 1)
+    la, lb = torch.log_softmax(x, 1), torch.log_softmax(y, 1)
+    pa, pb = la.exp().detach(), lb.exp().detach()
+    fin = torch.isfinite(x)
+    kl1 = (pb * (torch.where(fin, lb, torch.zeros_like(lb)).detach() - torch.where(fin, la, torch.zeros_like(la)))).sum() / B
+    kl2 = (pa * (torch.where(fin, la, torch.zeros_like(la)).detach() - torch.where(fin, lb, torch.zeros_like(lb)))).sum() / B
+    acc = (ab.argmax(1) == roff + torch.arange(B)).double().mean()
+    return ce.mean() + w * (kl1 + kl2), acc
+
+
+@pytest.mark.parametrize('B', [8, 33, 512])
+def test_ntxent_fwd_bwd_vs_oracle(B):
+    gen = torch.Generator().manual_seed(B)
+    a = _unit(B, gen).requires_grad_(True)
+    b = _unit(B, gen).requires_grad_(True)
+    loss, acc1, _ = S.simclr_head(a, b, 0.1)
+    gscale = torch.tensor([0.7])
+    (loss * 0.7).backward()
+    l64, a64 = S.simclr_head_f64(a.detach().numpy(), b.detach().numpy(), 0.1)
+    ad, bd = a.detach().to(DEV), b.detach().to(DEV)
+    out, rs = ops.ntxent_fwd(ad, bd, ad, bd, 0, 0.1, 3.0)
+    assert abs(float(out[0]) - l64) < 1e-4 and abs(float(out[0]) - float(loss)) < 1e-4
+    assert abs(float(out[1]) - a64) < 1e-6
+    da, db, dA, dB = ops.ntxent_bwd(ad, bd, ad, bd, rs, gscale.to(DEV), 0, 0.1, 3.0)
+    ga, gb = (da + dA).cpu(), (db + dB).cpu()
+    s = max(float(a.grad.abs().max()), 1e-12)
+    assert float((ga - a.grad).abs().max()) / s < 2e-4
+    assert float((gb - b.grad).abs().max()) / s < 2e-4
+
+
+def test_ntxent_unnormalised_and_gathered_columns():
+    """Inputs far from unit norm (online max rescaling) and the cross-rank extension: this rank
+    owns rows [roff, roff+B) of a larger column set."""
+    gen = torch.Generator().manual_seed(7)
+    B, BL, roff, T = 24, 72, 24, 0.2
+    a_all = (_unit(BL, gen) * 1.7).double()
+    b_all = (_unit(BL, gen) * 0.6).double()
+    h1 = a_all[roff:roff + B].clone().requires_grad_(True)
+    h2 = b_all[roff:roff + B].clone().requires_grad_(True)
+    A = a_all.clone().requires_grad_(True)
+    Bm = b_all.clone().requires_grad_(True)
+    loss, acc = _head_general(h1, h2, A, Bm, roff, T)
+    loss.backward()
+    f = lambda t: t.detach().float().to(DEV).contiguous()
+    out, rs = ops.ntxent_fwd(f(h1), f(h2), f(A), f(Bm), roff, T, 3.0)
+    assert abs(float(out[0]) - float(loss)) < 2e-4 * max(1.0, abs(float(loss)))
+    assert abs(float(out[1]) - float(acc)) < 1e-6
+    da, db, dA, dB = ops.ntxent_bwd(f(h1), f(h2), f(A), f(Bm), rs, None, roff, T, 3.0)
+    for got, ref in ((da, h1.grad), (db, h2.grad), (dA, A.grad), (dB, Bm.grad)):
+        s = max(float(ref.abs().max()), 1e-12)
+        assert float((got.cpu().double() - ref).abs().max()) / s < 3e-4
+
+
+def test_lars_kernel_vs_oracle_rule():
+    gen = torch.Generator().manual_seed(1)
+    sizes = [9408, 64, 64, 4096 * 3 + 40, 8, 2048 * 128]
+    offs, total = [], 0
+    for n in sizes:
+        offs.append(total)
+        total += (n + 7) // 8 * 8
+    p = torch.randn(total, generator=gen)
+    g = torch.randn(total, generator=gen) * 0.01
+    g[offs[2]:offs[2] + sizes[2]] = 0.0                   # |g| = 0 -> plain lr branch
+    v = torch.randn(total, generator=gen) * 0.001
+    wd = [1e-4, 1e-4, 1e-4, 0.0, 1e-4, 1e-4]               # one excluded tensor
+    lr, mu, coeff, gs = 0.8, 0.9, 0.001, 0.5
+    blk_off, blk_len, blk_seg = [], [], []
+    for si, (o, n) in enumerate(zip(offs, sizes)):
+        for c in range(0, n, 4096):
+            blk_off.append(o + c); blk_len.append(min(4096, n - c)); blk_seg.append(si)
+    table = dict(blk_off=torch.tensor(blk_off, dtype=torch.int64, device=DEV),
+                 blk_len=torch.tensor(blk_len, dtype=torch.int32, device=DEV),
+                 blk_seg=torch.tensor(blk_seg, dtype=torch.int32, device=DEV),
+                 seg_wd=torch.tensor(wd, dtype=torch.float32, device=DEV),
+                 norms=torch.zeros(len(sizes), 2, device=DEV))
+    pd, gd, vd = p.to(DEV), g.to(DEV), v.to(DEV)
+    ops.lars_momentum(pd, gd, vd, table, lr, mu, coeff, 0.0, gs)
+    pr, vr = p.clone(), v.clone()
+    for o, n, w in zip(offs, sizes, wd):
+        ps, gsn = p[o:o + n].double(), (g[o:o + n] * gs).double()
+        pn, gn = ps.norm().item(), gsn.norm().item()
+        llr = lr
+        if w > 0 and pn > 0 and gn > 0:
+            llr = lr * coeff * pn / (gn + w * pn)
+        vv = mu * v[o:o + n].double() + llr * (gsn + w * ps)
+        vr[o:o + n] = vv.float()
+        pr[o:o + n] = (ps - vv).float()
+    assert float((pd.cpu() - pr).abs().max()) < 1e-6
+    assert float((vd.cpu() - vr).abs().max()) < 1e-7
+    # padding between segments is untouched
+    assert torch.equal(pd.cpu()[offs[0] + sizes[0]:offs[1]], p[offs[0] + sizes[0]:offs[1]])
+
+
+WATCH = ['0.conv1.weight', '0.layer1.0.conv2.weight', '0.layer2.0.downsample.0.weight',
+         '0.layer4.2.conv3.weight', '0.layer3.5.bn2.weight', '0.bn1.bias',
+         '1.mlp.0.weight', '1.mlp.3.bias', '1.mlp.6.weight', '1.mlp.7.weight']
+WATCH_STATS = ['0.bn1._mean', '0.bn1._variance', '1.mlp.7._mean', '1.mlp.7._variance']
+TOL_F32 = dict(loss=1e-3, emb=1e-3, logits=1e-3, grad=1e-2, param=1e-3, stat=1e-3)
+# bf16 (the benchmark dtype; the reference has no bf16 path, so these are stated sanity bounds, NOT
+# parity claims — parity is the fp32 tests above).  At random init SimCLR's projector
+# (fc-BN1D-ReLU x2, fc-BN1D over a batch of 16-64 rows) amplifies backbone noise: ONE bf16 rounding
+# of the pooled features already moves the fp32 oracle's embeddings by 6e-3 (|q_i| ~ 0.07), and
+# 53 bf16 conv layers give 3-5 % feature noise (cf. the MoCo keys: 7.5e-3 through a BN-free
+# projector).  Measured on MI355X: embeddings within 0.25, logits (cos/T, T = 0.1) within 2.9,
+# loss (9-14) within 0.65, gradient norms within 13 %.
+# The loss itself (sum of log-sum-exps of those logits) is the most sensitive scalar: two bf16 runs
+# that differ only in the summation order of the BN statistics land 0.6-1.3 from the fp32 value.
+# What IS exact in bf16 mode is the head given the embeddings: checked against the fp64 oracle.
+TOL_BF16 = dict(loss=3.0, emb=4e-1, logits=4.0, grad=3e-1, param=3e-1, stat=1e-1)
+
+
+def _run_against_golden(name, dtype, steps_cap, tol):
+    """|hip - ref32| <= max(nominal, k*|ref32 - ref64|), k = 4 for the first two steps, 8 after:
+    the goldens carry the same steps evaluated in float64, and a random-init network with
+    batch-statistics BN amplifies rounding differences after every update."""
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    N, hw, steps = [int(v) for v in z['meta']]
+    oracle0 = S.SimCLROracle(seed=0, **U.SOLVER)
+    model, opt, sched = U.build_product(dtype)
+    U.load_oracle_state(model, oracle0)
+    model.train()
+    captured = {}
+    head_fwd = model.head.forward
+
+    def spy(q, k):
+        captured.update(q=q.detach(), k=k.detach())
+        return head_fwd(q, k)
+    model.head.forward = spy
+    gen = torch.Generator().manual_seed(4321)
+    report, bad = [], []
+
+    def check(what, got, ref32, ref64, nominal, step, rel=False):
+        got, ref32 = np.asarray(got, dtype=np.float64), np.asarray(ref32, dtype=np.float64)
+        scale = max(float(np.max(np.abs(ref32))), 1e-12) if rel else 1.0
+        err = float(np.max(np.abs(got - ref32))) / scale
+        noise = 0.0 if ref64 is None else float(np.max(np.abs(ref32 - np.asarray(ref64, dtype=np.float64)))) / scale
+        bound = max(nominal, (4.0 if step < 2 else 8.0) * noise)
+        line = '%-44s err %.3e  bound %.3e (nominal %.1e, ref32-vs-ref64 %.3e)' % (what, err, bound, nominal, noise)
+        report.append(line)
+        if not err <= bound:
+            bad.append(line)
+
+    for s in range(min(steps, steps_cap)):
+        xq = torch.randn(N, 3, hw, hw, generator=gen)
+        xk = torch.randn(N, 3, hw, hw, generator=gen)
+        assert abs(sched() - float(z['s%d_lr' % s])) < 1e-9
+        out = U.product_step(model, opt, sched, xq.to(DEV), xk.to(DEV))
+        pre, p64 = 's%d_' % s, 's%d_f64_' % s
+        check(pre + 'loss', float(out['loss'].detach()), z[pre + 'loss'], z[p64 + 'loss'], tol['loss'], s)
+        q, k = captured['q'].float().cpu(), captured['k'].float().cpu()
+        l64, a64 = S.simclr_head_f64(q.numpy(), k.numpy(), U.SOLVER['T'])
+        check(pre + 'loss vs fp64 head(own q,k)', float(out['loss'].detach()), l64, None, 1e-3, s)
+        check(pre + 'acc1 vs fp64 head(own q,k)', float(out['acc1']), a64, None, 1e-6, s)
+        check(pre + 'q[:, :8]', q[:, :8].numpy(), z[pre + 'q_head'], z[p64 + 'q_head'], tol['emb'], s)
+        check(pre + 'ab[:, :8]', (q @ k.t() / U.SOLVER['T'])[:, :8].numpy(), z[pre + 'ab_head'],
+              z[p64 + 'ab_head'], tol['logits'], s)
+        psd = dict(model.encoder.named_parameters())
+        sd = model.encoder.state_dict()
+        gmax = max(float(z[pre + 'gradnorm/' + n]) for n in WATCH)
+        for n in WATCH:
+            if float(z[pre + 'gradnorm/' + n]) < 1e-6 * gmax:
+                # analytically zero gradient (a Linear bias in front of a BatchNorm): the stored
+                # value is rounding noise; require "still negligible" instead of a relative match
+                got = psd[n].grad.double().norm().item()
+                line = '%-44s |grad| %.3e  (reference %.3e, noise-only; bound %.1e)' % (
+                    pre + 'gradnorm/' + n, got, float(z[pre + 'gradnorm/' + n]), 1e-3 * gmax)
+                report.append(line)
+                if not got <= 1e-3 * gmax:
+                    bad.append(line)
+                continue
+            check(pre + 'gradnorm/' + n, psd[n].grad.double().norm().item(), z[pre + 'gradnorm/' + n],
+                  z[p64 + 'gradnorm/' + n], tol['grad'], s, rel=True)
+            check(pre + 'pnorm/' + n, psd[n].detach().double().norm().item(), z[pre + 'pnorm/' + n],
+                  z[p64 + 'pnorm/' + n], tol['param'], s, rel=True)
+        for n in WATCH_STATS:
+            check(pre + 'stat/' + n, sd[n][:8].cpu().numpy(), z[pre + 'stat/' + n],
+                  z[p64 + 'stat/' + n], tol['stat'] * (1.0 + s), s)
+    print('\n'.join(report))
+    try:
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/parity_%s_%s.txt' % (name, str(dtype).split('.')[-1]), 'w') as f:
+            f.write('\n'.join(report) + '\n\nVIOLATIONS (%d)\n' % len(bad) + '\n'.join(bad) + '\n')
+    except OSError:
+        pass
+    assert not bad, 'parity violations:\n' + '\n'.join(bad)
+
+
+def test_golden_small_fp32():
+    _run_against_golden('simclr_r50_small', torch.float32, 3, TOL_F32)
+
+
+def test_golden_b32_fp32():
+    _run_against_golden('simclr_r50_b32', torch.float32, 2, TOL_F32)
+
+
+def test_golden_small_bf16():
+    _run_against_golden('simclr_r50_small', torch.bfloat16, 1, TOL_BF16)
+
+
+def test_golden_b32_bf16():
+    _run_against_golden('simclr_r50_b32', torch.bfloat16, 2, TOL_BF16)
+
+
+def test_live_oracle_fp32_two_steps():
+    """Oracle on the host cores vs HIP path, N=6, 80x48 (non-square), incl. one real LARS update."""
+    solver = dict(T=0.1, lr=1.0, warmup_steps=1, t_max=50)
+    oracle = S.SimCLROracle(seed=3, **solver)
+    model, opt, sched = U.build_product(torch.float32, solver=solver)
+    U.load_oracle_state(model, oracle)
+    model.train()
+    gen = torch.Generator().manual_seed(11)
+    for s in range(2):
+        xq = torch.randn(6, 3, 80, 48, generator=gen)
+        xk = torch.randn(6, 3, 80, 48, generator=gen)
+        ref = oracle.train_step(xq, xk)
+        out = U.product_step(model, opt, sched, xq.to(DEV), xk.to(DEV))
+        assert abs(float(out['loss'].detach()) - float(ref['loss'])) < (1e-3 if s == 0 else 2e-2)
+        assert abs(float(out['acc1']) - float(ref['acc1'])) < 1e-6 or s > 0
+    # the LARS update itself: parameters after step 0 (lr = 0) are unchanged, after step 1 they moved
+    sd = model.encoder.state_dict()
+    n = '0.layer4.2.conv3.weight'
+    rel = float((sd[n].cpu() - oracle.st[n]).norm() / oracle.st[n].norm())
+    assert rel < 5e-3, rel
