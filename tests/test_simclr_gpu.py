@@ -262,3 +262,27 @@ def test_live_oracle_fp32_two_steps():
     n = '0.layer4.2.conv3.weight'
     rel = float((sd[n].cpu() - oracle.st[n]).norm() / oracle.st[n].norm())
     assert rel < 5e-3, rel
+
+
+def test_trainer_runs_simclr_config_end_to_end(tmp_path):
+    """The v110 Trainer + hook bus drive the SimCLR config (LARS branch of OptimizerHook,
+    simclrCosineWarmup through use_simclr_iters) for a few iterations on synthetic data."""
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_config(os.path.join(root, 'configs/simclr/simclr_r50_synthetic.yaml'),
+                     ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+                      'dataloader.train.dataset.num_samples=64', 'epochs=1',
+                      'lr_scheduler.total_images=64', 'lr_scheduler.warmup_epochs=1',
+                      'output_dir=%s' % tmp_path, 'log_config.interval=2'])
+    cfg.timestamp = ''
+    tr = Trainer(cfg)
+    assert tr.use_simclr_iters and 'lars' in tr.optimizer.type
+    assert tr.lr_scheduler.warmup_steps == 1 and tr.iters_per_epoch == 8
+    w0 = tr.model.encoder[0].conv1.weight.detach().clone()
+    tr.train()
+    assert tr.current_iter == 8
+    loss = float(tr.outputs['loss'].detach())
+    assert np.isfinite(loss) and 0 < loss < 40
+    assert float((tr.model.encoder[0].conv1.weight.detach() - w0).abs().max()) > 0     # LARS moved it
+    assert abs(tr.lr_scheduler() - tr.optimizer.get_lr()) < 1e-12
