@@ -40,6 +40,14 @@ enum passl_status {
 enum passl_dtype { PASSL_F32 = 0, PASSL_BF16 = 1 };
 
 int passl_hip_abi_version(void);
+/* Kernel-selection knobs (defaults are tuned for MI355X; tests use them to force a path):
+ *   "igemm_ring" 0/1            use the LDS-DMA ring conv kernel when it applies (1)
+ *   "igemm_ring_min_nk" n       ... only for reductions of at least n 64-element K-tiles (8)
+ *   "igemm_ring_min_tiles" n    ... and launches with at least n output tiles (1)
+ *   "igemm_ring_bm" 128|256     row-tile of the ring kernel: 128 (4 waves, 2 LDS stages, two
+ *                               workgroups per CU; default) or 256 (8 waves, 3 stages, one)
+ * Returns PASSL_EINVAL for an unknown name. */
+int passl_hip_set_option(const char* name, int value);
 /* Human readable text for a passl_status. */
 const char* passl_hip_strerror(int status);
 

@@ -520,6 +520,8 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
 
 }  // namespace
 
+int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st);   // conv_igemm_ring.hip
+
 extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream) {
   if (!d || !d->a || !d->b || !d->y) return PASSL_EINVAL;
   // fused BN statistics live in the bf16-output epilogue only
@@ -579,7 +581,11 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
                      d->y_sn == (int64_t)d->OP * d->OQ * d->NCOLS;
   hipStream_t st = as_stream(stream);
   passl_prof_begin(0, st);
-  int rc;
+  int rc = passl_igemm_ring_try(d, st);        // large-tile LDS-DMA ring kernel when it applies
+  if (rc != PASSL_EUNSUPPORTED) {
+    passl_prof_end(0, st);
+    return rc;
+  }
   const int nk = (p.KDIM + bk - 1) / bk;
   const bool of32 = d->out_f32 != 0;
   if (d->dtype == PASSL_BF16)

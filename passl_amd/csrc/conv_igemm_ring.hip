@@ -1,0 +1,482 @@
+// Implicit-GEMM convolution, bf16, large tiles + LDS-DMA ring (gfx950).
+//
+// Same contract as igemm_kernel (conv_igemm.hip): Y[m][col] = epi(sum_k A[m][k] B[col][k]) with
+// m = (n,op,oq) gathered from an NHWC tensor, k = (r,s,c), fused affine / residual / ReLU /
+// BatchNorm statistics in the epilogue.  What differs is how the operands reach the MFMAs:
+//
+//  * block tile 256 x BN (BN = 128: 8 waves as 4 x 2; BN = 64: 8 waves as 8 x 1), K-tile 64;
+//    one workgroup per CU (512 threads, two waves per SIMD);
+//  * staging by `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging VGPRs, no ds_write; the
+//    im2col gather is the per-lane buffer offset, padding / ragged rows use an out-of-range
+//    offset that the buffer bounds check turns into zeros; the XOR slot swizzle of the tile rows
+//    is applied to the SOURCE chunk each lane fetches (LDS-DMA writes lane-linear);
+//  * a 3-stage LDS ring (3 x (256 + BN) x 128 B): while tile t is multiplied, tiles t+1 and t+2
+//    are in flight.  hipcc orders every LDS read it can see behind ALL pending LDS-DMA
+//    (s_waitcnt vmcnt(0)), which would collapse the ring to depth 1, so the fragment reads are
+//    inline-asm ds_read_b128 and the waits are explicit: counted `s_waitcnt vmcnt(IPT)` (IPT =
+//    DMA instructions per tile per wave: the newest tile stays in flight across the barrier),
+//    raw s_barrier, `s_waitcnt lgkmcnt(0)` + sched_barrier before the MFMAs.
+//  * ring protocol per K-tile t (stage t % 3):  wait own DMA of tile t -> barrier (all waves'
+//    tile-t DMA landed AND all waves finished reading stage (t-1) % 3) -> issue DMA of tile t+2
+//    into stage (t-1) % 3 -> read fragments of tile t -> MFMA.
+//
+// Used when the launch has enough 256-row tiles to fill the chip and the operands are addressable
+// with 32-bit byte offsets; passl_hip_conv_igemm falls back to igemm_kernel otherwise.
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "common.h"
+
+namespace ring {
+
+constexpr int kRowBytes = 128;
+constexpr uint32_t kOOB = 0x7ffffff0u;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct FastDiv { uint32_t mul, sh1, sh2; };
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f = {0, 0, 0};
+  if (d > 1) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = 1;
+    f.sh2 = l - 1;
+  }
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv f) {
+  const uint32_t t = __umulhi(f.mul, (uint32_t)n);
+  return (int)((t + (((uint32_t)n - t) >> f.sh1)) >> f.sh2);
+}
+
+struct Params {
+  const char* a;
+  const char* b;
+  char* y;
+  const float* scale;
+  const float* shift;
+  const char* res;
+  float* stats;
+  int stats_rep;
+  uint32_t a_bytes, b_bytes;
+  int M, NCOLS, KDIM;
+  int OP, OQ, S, C, IH, IW, sh, sw, ph, pw;
+  int a_sn2, a_sh2, a_sw2;      // BYTE strides of A (fit 32 bits, checked on the host)
+  int64_t y_sn, y_sh, y_sw;
+  int relu, dense;
+  int tiles_n, ntiles;
+  FastDiv d_opq, d_oq, d_tn;
+};
+
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <int BM, int BN, int STAGES>
+__global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
+  constexpr int kThreads = BM * 2;          // 4 waves for 128-row tiles, 8 for 256-row tiles
+  constexpr int WAVES = kThreads / 64;
+  constexpr int WAVES_N = BN == 128 ? 2 : 1;
+  constexpr int WAVES_M = WAVES / WAVES_N;
+  constexpr int WM = BM / WAVES_M;          // 64 or 32 rows per wave
+  constexpr int WN = BN / WAVES_N;          // 64 columns per wave
+  constexpr int FM = WM / 16, FN = WN / 16;
+  static_assert(FN == 4 && (FM == 4 || FM == 2), "wave tile is 64 or 32 rows x 64 columns");
+  constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NIA = A_BYTES / 1024 / WAVES;   // A DMA instructions per wave per tile (4)
+  constexpr int NIB = B_BYTES / 1024 / WAVES;   // 1, 2 or 4
+  constexpr int IPT = NIA + NIB;
+  constexpr int LDOB = BN + 8;              // bf16 epilogue pitch (elements)
+  constexpr int CPR = BN / 8;
+  static_assert(BM * LDOB * 2 <= STAGES * STAGE, "epilogue tile must fit the ring");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t* rowoff = reinterpret_cast<int64_t*>(smem + STAGES * STAGE);
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(
+      (__attribute__((address_space(3))) char*)smem);
+
+  // ---- XCD-aware tile mapping (bijective for any ntiles)
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = p.ntiles >> 3, r = p.ntiles & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    tile = start + local;
+  }
+  const int mt = fdiv(tile, p.d_tn), nt = tile - mt * p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int opq = p.OP * p.OQ;
+
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.b), 0, p.b_bytes, 0x00020000);
+
+  // ---- static DMA geometry.  Instruction q = i*WAVES + wave covers tile rows 8q .. 8q+7;
+  // lane -> row 8q + (lane >> 3), LDS slot lane & 7, SOURCE chunk (lane & 7) ^ ((row >> 1) & 7).
+  // A byte offset of (row, tap r/s, channel c0) = a_base + r*a_sh2 + s*a_sw2 + 2*c0 with
+  // a_base = n*a_sn2 + ih0*a_sh2 + iw0*a_sw2 + chunk (may be "negative" mod 2^32 for padding
+  // taps: those lanes are redirected to the out-of-range offset), valid iff
+  // 0 <= ih0 + r < IH and 0 <= iw0 + s < IW (unsigned compares; invalid rows carry ih0 = -2^28).
+  uint32_t a_base[NIA];
+  int ih0[NIA], iw0[NIA];
+#pragma unroll
+  for (int i = 0; i < NIA; ++i) {
+    const int row = (i * WAVES + wave) * 8 + (lane >> 3);
+    const int m = m0 + row;
+    const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    if (m < p.M) {
+      if (p.dense) {
+        a_base[i] = (uint32_t)m * (uint32_t)(p.C * 2) + chunk;
+        ih0[i] = 0; iw0[i] = 0;
+      } else {
+        const int n = fdiv(m, p.d_opq);
+        const int rem = m - n * opq;
+        const int op = fdiv(rem, p.d_oq);
+        const int oq = rem - op * p.OQ;
+        ih0[i] = op * p.sh - p.ph;
+        iw0[i] = oq * p.sw - p.pw;
+        a_base[i] = (uint32_t)n * (uint32_t)p.a_sn2 + (uint32_t)(ih0[i] * p.a_sh2) +
+                    (uint32_t)(iw0[i] * p.a_sw2) + chunk;
+      }
+    } else {
+      a_base[i] = 0; ih0[i] = -(1 << 28); iw0[i] = 0;
+    }
+  }
+  uint32_t b_off[NIB];
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int row = (i * WAVES + wave) * 8 + (lane >> 3);
+    const int col = n0 + row;
+    const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    b_off[i] = col < p.NCOLS ? (uint32_t)col * (uint32_t)(p.KDIM * 2) + chunk : kOOB;
+  }
+  // output row offsets (elements) for the epilogue; -1 = row out of range
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int64_t off = -1;
+    if (m < p.M) {
+      if (p.dense) {
+        off = (int64_t)m * p.NCOLS;
+      } else {
+        const int n = fdiv(m, p.d_opq);
+        const int rem = m - n * opq;
+        const int op = fdiv(rem, p.d_oq);
+        const int oq = rem - op * p.OQ;
+        off = (int64_t)n * p.y_sn + (int64_t)op * p.y_sh + (int64_t)oq * p.y_sw;
+      }
+    }
+    rowoff[tid] = off;
+  }
+
+  const int nk = p.KDIM / 64;
+  // (r, s, c0) of the NEXT tile to issue, advanced incrementally (wave-uniform scalars)
+  int ir = 0, is = 0, ic = 0;
+  int issued = 0;
+  auto issue_tile = [&]() {
+    char* Ab = smem + (issued % STAGES) * STAGE;
+    char* Bb = Ab + A_BYTES;
+    const uint32_t koff = (uint32_t)issued * 128u;        // byte offset of the K-tile in a B row
+    const uint32_t tap = (uint32_t)(ir * p.a_sh2 + is * p.a_sw2 + ic * 2);   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const bool ok = (uint32_t)(ih0[i] + ir) < (uint32_t)p.IH && (uint32_t)(iw0[i] + is) < (uint32_t)p.IW;
+      const uint32_t off = ok ? a_base[i] + tap : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_a, (__attribute__((address_space(3))) void*)(Ab + (i * WAVES + wave) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const uint32_t off = b_off[i] == kOOB ? kOOB : b_off[i] + koff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_b, (__attribute__((address_space(3))) void*)(Bb + (i * WAVES + wave) * 1024), 16, off, 0, 0, 0);
+    }
+    ++issued;
+    ic += 64;
+    if (ic == p.C) { ic = 0; if (++is == p.S) { is = 0; ++ir; } }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses (bytes from the stage base): row r, slot (ks*4 + l4) ^ ((r >> 1) & 7);
+  // rows of the other fragments differ by multiples of 16 -> same swizzle term, immediate offsets
+  uint32_t a_rd[2], b_rd[2];
+  {
+    const int ra = wm * WM + l15, rb = wn * WN + l15;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a_rd[ks] = (uint32_t)(ra * kRowBytes + (((ks * 4 + l4) ^ ((ra >> 1) & 7)) << 4));
+      b_rd[ks] = (uint32_t)(A_BYTES + rb * kRowBytes + (((ks * 4 + l4) ^ ((rb >> 1) & 7)) << 4));
+    }
+  }
+
+  // two register sets of fragments: tile t is multiplied from one set while tile t+1 is read
+  // from LDS into the other (the reads overlap the MFMAs; waited at the end of the iteration)
+  u32x4 af[2][2][FM], bfr[2][2][FN];
+  auto read_frags = [&](auto SET, int t) {
+    constexpr int S_ = decltype(SET)::value;
+    const uint32_t sb = lds0 + (uint32_t)((t % STAGES) * STAGE);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      af[S_][ks][0] = lds_read_b128<0>(sb + a_rd[ks]);
+      af[S_][ks][1] = lds_read_b128<2048>(sb + a_rd[ks]);
+      if constexpr (FM == 4) {
+        af[S_][ks][2] = lds_read_b128<4096>(sb + a_rd[ks]);
+        af[S_][ks][3] = lds_read_b128<6144>(sb + a_rd[ks]);
+      }
+      bfr[S_][ks][0] = lds_read_b128<0>(sb + b_rd[ks]);
+      bfr[S_][ks][1] = lds_read_b128<2048>(sb + b_rd[ks]);
+      bfr[S_][ks][2] = lds_read_b128<4096>(sb + b_rd[ks]);
+      bfr[S_][ks][3] = lds_read_b128<6144>(sb + b_rd[ks]);
+    }
+  };
+  // Ring protocol.  Before iteration t: tiles <= t+STAGES-1 are issued, tile t sits in
+  // registers (set t & 1).  Iteration t: wait own DMA of tile t+1 (the newest tile may stay in
+  // flight) -> barrier (everybody's tile t+1 landed; everybody finished reading stage t % STAGES
+  // in iteration t-1) -> issue tile t+STAGES into stage t % STAGES -> start reading tile t+1 into
+  // the other register set -> MFMAs of tile t -> lgkmcnt(0).
+  auto iteration = [&](auto SET, int t) {
+    constexpr int S_ = decltype(SET)::value;
+    if (t + 1 < nk) {
+      if (t + 2 < nk && STAGES > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * IPT + 0) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + STAGES < nk) issue_tile();
+      read_frags(std::integral_constant<int, 1 - S_>{}, t + 1);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          // operands swapped (A := weight fragment): acc[i][j][r] = C[row][col = .. + l4*4 + r]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8_t, bfr[S_][ks][j]), __builtin_bit_cast(bf16x8_t, af[S_][ks][i]),
+              acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  static_assert(STAGES == 2 || STAGES == 3, "vmcnt bookkeeping below covers 2 or 3 stages");
+  for (int t = 0; t < STAGES && t < nk; ++t) issue_tile();
+  // tile 0 landed: at most min(STAGES, nk) - 1 newer tiles may stay in flight
+  if (nk >= STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * IPT) : "memory");
+  else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(std::integral_constant<int, 0>{}, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    iteration(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) iteration(std::integral_constant<int, 1>{}, kt + 1);
+  }
+  __syncthreads();      // all fragment reads done before the ring is reused as the output tile
+
+  // ---- epilogue (same as igemm_kernel's bf16 path).  phase 1: affine (+ReLU when there is no
+  // residual), packed bf16 pairs into out[BM][LDOB]
+  char* outc = smem;
+  const bool relu_now = p.relu && !p.res;
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int col = wn * WN + j * 16 + l4 * 4;
+    const int gcol = n0 + col;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gcol < p.NCOLS) {
+      if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + gcol);
+      if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + gcol);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      f32x4 a = acc[i][j];
+      a[0] = a[0] * sc.x + sh.x; a[1] = a[1] * sc.y + sh.y;
+      a[2] = a[2] * sc.z + sh.z; a[3] = a[3] * sc.w + sh.w;
+      if (relu_now) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+      }
+      const int row = wm * WM + i * 16 + l15;
+      *reinterpret_cast<uint2*>(outc + row * (LDOB * 2) + col * 2) =
+          make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+    }
+  }
+  constexpr int NT = BM * CPR / kThreads;
+  uint4 rres[NT];
+  if (p.res) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int chunk = tid + t * kThreads;
+      const int row = chunk / CPR, cc = chunk - row * CPR;
+      const int gcol = n0 + cc * 8;
+      const int64_t roff = rowoff[row];
+      rres[t] = make_uint4(0, 0, 0, 0);
+      if (roff >= 0 && gcol < p.NCOLS)
+        rres[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.res) + roff + gcol);
+    }
+  }
+  __syncthreads();
+  const bf16_t* outb = reinterpret_cast<const bf16_t*>(smem);
+  float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  static_assert(kThreads % CPR == 0, "a thread must keep its column chunk across iterations");
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int chunk = tid + t * kThreads;
+    const int row = chunk / CPR, cc = chunk - row * CPR;
+    const int gcol = n0 + cc * 8;
+    const int64_t roff = rowoff[row];
+    if (roff < 0 || gcol >= p.NCOLS) continue;
+    const int64_t o = roff + gcol;
+    uint4 v = *reinterpret_cast<const uint4*>(outb + row * LDOB + cc * 8);
+    if (p.res) {
+      float a[8], rr[8];
+      a[0] = __uint_as_float(v.x << 16); a[1] = __uint_as_float(v.x & 0xffff0000u);
+      a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
+      a[4] = __uint_as_float(v.z << 16); a[5] = __uint_as_float(v.z & 0xffff0000u);
+      a[6] = __uint_as_float(v.w << 16); a[7] = __uint_as_float(v.w & 0xffff0000u);
+      rr[0] = __uint_as_float(rres[t].x << 16); rr[1] = __uint_as_float(rres[t].x & 0xffff0000u);
+      rr[2] = __uint_as_float(rres[t].y << 16); rr[3] = __uint_as_float(rres[t].y & 0xffff0000u);
+      rr[4] = __uint_as_float(rres[t].z << 16); rr[5] = __uint_as_float(rres[t].z & 0xffff0000u);
+      rr[6] = __uint_as_float(rres[t].w << 16); rr[7] = __uint_as_float(rres[t].w & 0xffff0000u);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a[e] += rr[e];
+        if (p.relu) a[e] = fmaxf(a[e], 0.f);
+      }
+      ElemTraits<bf16_t>::store8(reinterpret_cast<bf16_t*>(p.y) + o, a);
+    } else {
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
+      if (p.stats) {
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
+          ssum[2 * e] += lo; ssq[2 * e] += lo * lo;
+          ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * hi;
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    constexpr int J = kThreads / CPR;
+    static_assert(J * BN * 2 * 4 <= STAGES * STAGE, "reduction scratch must fit the ring");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    {
+      float* dst = red + (tid / CPR) * (BN * 2) + (tid % CPR) * 16;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        *reinterpret_cast<float4*>(dst + e * 2) = make_float4(ssum[e], ssq[e], ssum[e + 1], ssq[e + 1]);
+    }
+    __syncthreads();
+    if (tid < 2 * BN && n0 + (tid >> 1) < p.NCOLS) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) a += red[j * (BN * 2) + tid];
+      // 256-row tiles: two consecutive tiles share the replica slot of igemm_kernel's 128-row tiles
+      const int rep = mt % p.stats_rep;
+      atomicAdd(p.stats + ((int64_t)rep * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1), a);
+    }
+  }
+}
+
+template <int BM, int BN, int STAGES>
+int launch(const Params& p, hipStream_t st) {
+  constexpr int LDS = STAGES * (BM + BN) * kRowBytes + BM * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, STAGES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, STAGES>), dim3(p.ntiles), dim3(BM * 2), LDS, st, p);
+  return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+}  // namespace ring
+
+// Returns PASSL_EUNSUPPORTED when the descriptor is outside this kernel's envelope (the caller
+// then uses igemm_kernel); the descriptor has already been validated by passl_hip_conv_igemm.
+static int g_ring_enabled = -1, g_ring_min_tiles = 1, g_ring_bm = 128, g_ring_min_nk = 8;
+
+// passl_hip_set_option("igemm_ring", 0/1) / ("igemm_ring_min_tiles", n)   (runtime.hip dispatches)
+int passl_igemm_ring_option(const char* name, int value) {
+  if (!strcmp(name, "igemm_ring")) { g_ring_enabled = value != 0; return PASSL_OK; }
+  if (!strcmp(name, "igemm_ring_min_tiles")) { g_ring_min_tiles = value; return PASSL_OK; }
+  if (!strcmp(name, "igemm_ring_min_nk")) { g_ring_min_nk = value; return PASSL_OK; }
+  if (!strcmp(name, "igemm_ring_bm")) {
+    if (value != 128 && value != 256) return PASSL_EINVAL;
+    g_ring_bm = value;
+    return PASSL_OK;
+  }
+  return PASSL_EINVAL;
+}
+
+int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
+  if (g_ring_enabled < 0) {
+    const char* e = getenv("PASSL_IGEMM_RING");
+    g_ring_enabled = e ? atoi(e) : 1;
+    const char* t = getenv("PASSL_IGEMM_RING_MIN_TILES");
+    if (t) g_ring_min_tiles = atoi(t);
+  }
+  const int enabled = g_ring_enabled, min_tiles = g_ring_min_tiles;
+  if (!enabled || d->dtype != PASSL_BF16 || d->out_f32) return PASSL_EUNSUPPORTED;
+  if ((d->C % 64) != 0) return PASSL_EUNSUPPORTED;
+  // short reductions are dominated by the prologue/epilogue: igemm_kernel's single-stage variant
+  // (3 workgroups per CU) wins there (measured per layer: profiles/r01_ring_vs_igemm_bs256.txt)
+  if ((int64_t)d->R * d->S * d->C < 64ll * g_ring_min_nk) return PASSL_EUNSUPPORTED;
+  const int64_t M64 = (int64_t)d->N * d->OP * d->OQ;
+  const int64_t K64 = (int64_t)d->R * d->S * d->C;
+  const int64_t a_bytes = (int64_t)d->N * d->a_sn * 2;
+  const int64_t b_bytes = (int64_t)d->NCOLS * K64 * 2;
+  const int64_t lim = 0x7ffffff0ll;
+  if (a_bytes <= 0 || a_bytes >= lim || b_bytes >= lim) return PASSL_EUNSUPPORTED;
+  const int bn = d->NCOLS <= 64 ? 64 : 128;
+  const int tiles_n = (d->NCOLS + bn - 1) / bn;
+  const int bm = g_ring_bm;
+  const int64_t tiles_m = (M64 + bm - 1) / bm;
+  if (tiles_m * tiles_n < min_tiles) return PASSL_EUNSUPPORTED;
+
+  ring::Params p;
+  p.a = reinterpret_cast<const char*>(d->a);
+  p.b = reinterpret_cast<const char*>(d->b);
+  p.y = reinterpret_cast<char*>(d->y);
+  p.scale = d->scale; p.shift = d->shift;
+  p.res = reinterpret_cast<const char*>(d->residual);
+  p.stats = d->stats; p.stats_rep = d->stats ? d->stats_replicas : 1;
+  p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
+  p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
+  p.OP = d->OP; p.OQ = d->OQ; p.S = d->S; p.C = d->C;
+  p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
+  p.a_sn2 = (int)(d->a_sn * 2); p.a_sh2 = (int)(d->a_sh * 2); p.a_sw2 = (int)(d->a_sw * 2);
+  p.y_sn = d->y_sn; p.y_sh = d->y_sh; p.y_sw = d->y_sw;
+  p.relu = d->relu;
+  p.dense = d->R == 1 && d->S == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 &&
+            d->IH == d->OP && d->IW == d->OQ && d->a_sw == d->C &&
+            d->a_sh == (int64_t)d->IW * d->C && d->a_sn == (int64_t)d->IH * d->IW * d->C &&
+            d->y_sw == d->NCOLS && d->y_sh == (int64_t)d->OQ * d->NCOLS &&
+            d->y_sn == (int64_t)d->OP * d->OQ * d->NCOLS;
+  p.tiles_n = tiles_n;
+  p.ntiles = (int)(tiles_m * tiles_n);
+  p.d_opq = ring::make_fastdiv((uint32_t)(d->OP * d->OQ));
+  p.d_oq = ring::make_fastdiv((uint32_t)d->OQ);
+  p.d_tn = ring::make_fastdiv((uint32_t)tiles_n);
+  if (bm == 256) return bn == 64 ? ring::launch<256, 64, 3>(p, st) : ring::launch<256, 128, 3>(p, st);
+  return bn == 64 ? ring::launch<128, 64, 2>(p, st) : ring::launch<128, 128, 2>(p, st);
+}

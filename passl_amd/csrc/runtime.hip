@@ -59,7 +59,14 @@ extern "C" int passl_hip_prof_collect(int cls, double* total_ms, int64_t* launch
   return PASSL_OK;
 }
 
-extern "C" int passl_hip_abi_version(void) { return 2; }
+int passl_igemm_ring_option(const char* name, int value);    // conv_igemm_ring.hip
+
+extern "C" int passl_hip_set_option(const char* name, int value) {
+  if (!name) return PASSL_EINVAL;
+  return passl_igemm_ring_option(name, value);
+}
+
+extern "C" int passl_hip_abi_version(void) { return 3; }
 
 extern "C" const char* passl_hip_strerror(int status) {
   switch (status) {

@@ -92,12 +92,18 @@ def _run_against_golden(name, dtype, steps_cap, tol):
         nq = max(group_noise(s, 'qnorm'), ng_hist)
         nk = max(group_noise(s, 'knorm'), ng_hist)
         for n in G.WATCH:
+            # BatchNorm/Linear biases start at zero and their gradient is a plain sum over all
+            # positions (heavy cancellation): in bf16 it is noise dominated — identical runs of the
+            # same build differ by 0.015 ... 0.30 in the stem bias (atomics reorder the BN
+            # statistics, which flips bf16 roundings downstream) — hence the separate bound
+            tg = tol.get('grad_bias', tol['grad']) if n.endswith('.bias') else tol['grad']
+            tp = tol.get('grad_bias', tol['param']) if n.endswith('.bias') else tol['param']
             check(pre + 'gradnorm/' + n, qsd[n].grad.double().norm().item(),
-                  z[pre + 'gradnorm/' + n], None, tol['grad'], rel=True, noise=ng, step=s)
+                  z[pre + 'gradnorm/' + n], None, tg, rel=True, noise=ng, step=s)
             check(pre + 'qnorm/' + n, qsd[n].detach().double().norm().item(),
-                  z[pre + 'qnorm/' + n], None, tol['param'], rel=True, noise=nq, step=s)
+                  z[pre + 'qnorm/' + n], None, tp, rel=True, noise=nq, step=s)
             check(pre + 'knorm/' + n, ksd[n].double().norm().item(),
-                  z[pre + 'knorm/' + n], None, tol['param'], rel=True, noise=nk, step=s)
+                  z[pre + 'knorm/' + n], None, tp, rel=True, noise=nk, step=s)
         for n in G.WATCH_STATS:
             # running statistics integrate the per-step activation error AND the weight drift of
             # the steps so far: the nominal bound grows linearly with the step index where the
@@ -125,7 +131,7 @@ TOL_F32 = dict(loss=1e-3, logits=1e-3, queue=1e-3, grad=1e-2, param=1e-3, stat=1
 # running statistics: 5e-2 at the first step, +5e-2 per further step (two valid bf16 evaluations
 # of the same step — BN statistics from the fp32 accumulators vs from the bf16-rounded conv
 # output — already differ by 3e-2 in the stem's running variance after three updates).
-TOL_BF16 = dict(loss=6e-2, logits=4e-1, queue=3e-2, grad=2e-1, param=2e-1, stat=5e-2,
+TOL_BF16 = dict(loss=6e-2, logits=4e-1, queue=3e-2, grad=2e-1, param=2e-1, grad_bias=6e-1, stat=5e-2,
                 stat_growth=1.0, exact_acc=False)
 
 

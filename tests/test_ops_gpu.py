@@ -100,6 +100,35 @@ def _run_plan(descs, a, packs_buf, packer, y, **kw):
     return y
 
 
+@pytest.fixture
+def force_ring_kernel():
+    """Route every eligible bf16 conv through the LDS-DMA ring kernel (normally only reductions
+    of >= 8 K-tiles use it), in both tile configurations."""
+    from passl_amd.hip import lib as L
+    lib = L.load()
+    assert lib.passl_hip_set_option(b'igemm_ring_min_nk', 1) == 0
+
+    def select(bm):
+        assert lib.passl_hip_set_option(b'igemm_ring_bm', bm) == 0
+    yield select
+    assert lib.passl_hip_set_option(b'igemm_ring_min_nk', 8) == 0
+    assert lib.passl_hip_set_option(b'igemm_ring_bm', 128) == 0
+    assert lib.passl_hip_set_option(b'bogus', 1) != 0 and lib.passl_hip_set_option(b'igemm_ring_bm', 7) != 0
+
+
+@pytest.mark.parametrize('bm', [128, 256])
+@pytest.mark.parametrize('geom,nhw', [g for g in GEOMS if g[0].cin % 64 == 0])
+def test_conv_ring_kernel(geom, nhw, bm, force_ring_kernel):
+    force_ring_kernel(bm)
+    test_conv_fwd_dgrad_wgrad(geom, nhw, torch.bfloat16)
+
+
+@pytest.mark.parametrize('bm', [128, 256])
+def test_conv_ring_kernel_epilogue(bm, force_ring_kernel):
+    force_ring_kernel(bm)
+    test_conv_epilogue_affine_residual_relu_f32out(torch.bfloat16)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('geom,nhw', GEOMS)
 def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
