@@ -31,6 +31,7 @@ struct WParams {
   int64_t a_sn, a_sh, a_sw, dy_ld;
   int tiles_per_split, nk_total;
   int dbg;   // tuning switches (PASSL_WGRAD_DBG): 1 = skip the atomic epilogue
+  int grid_j, grid_oc;   // tile counts of the 1-D launch of wgrad_dma_kernel
 };
 
 struct RowInfo {
@@ -334,10 +335,22 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_dma_kernel(const WParams p,
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int oc0 = blockIdx.y * BMo;
-  const int j0 = blockIdx.x * BNo;
+  // 1-D grid, XCD-aware: hardware block b runs on XCD b % 8 (private L2); give every XCD a
+  // contiguous range of virtual blocks, j-tiles fastest, so that the j-tiles sharing one dy tile
+  // (same oc-tile, same M-slice) and the oc-tiles sharing one x tile hit the same L2.  Pure speed:
+  // any placement is correct (bijective for every grid size).
+  int vb;
+  {
+    const int bid = blockIdx.x, nb = gridDim.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int bx = vb % p.grid_j, by = (vb / p.grid_j) % p.grid_oc, bz = vb / (p.grid_j * p.grid_oc);
+  const int oc0 = by * BMo;
+  const int j0 = bx * BNo;
   const int opq = p.OP * p.OQ;
-  const int kt_begin = blockIdx.z * p.tiles_per_split;
+  const int kt_begin = bz * p.tiles_per_split;
   int kt_end = kt_begin + p.tiles_per_split;
   if (kt_end > p.nk_total) kt_end = p.nk_total;
   if (kt_begin >= kt_end) return;
@@ -496,8 +509,11 @@ int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  dim3 grid((p.KDIM + BNo - 1) / BNo, (p.NCOLS + BMo - 1) / BMo, splits);
-  hipLaunchKernelGGL((wgrad_dma_kernel<BMo, BNo>), grid, dim3(kThreads), LDS, st, p, a_bytes, dy_bytes);
+  WParams q = p;
+  q.grid_j = (p.KDIM + BNo - 1) / BNo;
+  q.grid_oc = (p.NCOLS + BMo - 1) / BMo;
+  hipLaunchKernelGGL((wgrad_dma_kernel<BMo, BNo>), dim3(q.grid_j * q.grid_oc * splits), dim3(kThreads),
+                     LDS, st, q, a_bytes, dy_bytes);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
