@@ -141,3 +141,74 @@ def test_arena_replicas_and_reducer_via_arena_hooks():
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][1], out[0][0])
     assert torch.all(out[0][2] == 3.0) and torch.all(out[1][2] == 3.0)
     assert out[0][3] == out[1][3] and out[0][3][0] == 3.0 * 8 * 16   # p.grad views see the reduced buffer
+
+
+def _simclr_gather_case(rank, world):
+    """SimCLRContrastiveHead(multi_rank=True) on two gloo ranks: the collective pattern
+    (all-gather embeddings, positives offset by rank*N, reduce-scatter of the column-role
+    gradients) with the HIP kernels replaced by a torch restatement of their contract, compared
+    with ONE process evaluating the loss of all 2N rows (mean over ranks of per-rank losses)."""
+    from passl_amd.hip import ops
+    from passl_amd.modeling.heads.simclr_contrastive_head import SimCLRContrastiveHead
+
+    def head_terms(h1, h2, A, B_, roff, T, w):
+        n, bl = h1.shape[0], A.shape[0]
+        pos = torch.zeros(n, bl, dtype=torch.bool)
+        pos[torch.arange(n), roff + torch.arange(n)] = True
+        ninf = float('-inf')
+        aa, ab, ba, bb = h1 @ A.t() / T, h1 @ B_.t() / T, h2 @ A.t() / T, h2 @ B_.t() / T
+        aam, bbm = aa.masked_fill(pos, ninf), bb.masked_fill(pos, ninf)
+        abm, bam = ab.masked_fill(pos, ninf), ba.masked_fill(pos, ninf)
+        ce = (torch.logsumexp(torch.cat([ab, aam], 1), 1) - ab[pos]) + \
+            (torch.logsumexp(torch.cat([ba, bbm], 1), 1) - ba[pos])
+        x, y = torch.cat([aam, abm], 1), torch.cat([bam, bbm], 1)
+        la, lb = torch.log_softmax(x, 1), torch.log_softmax(y, 1)
+        fin = torch.isfinite(x)
+        z = torch.zeros_like(la)
+        kl = (lb.exp().detach() * (torch.where(fin, lb, z).detach() - torch.where(fin, la, z))).sum() + \
+            (la.exp().detach() * (torch.where(fin, la, z).detach() - torch.where(fin, lb, z))).sum()
+        return ce.mean() + w * kl / n
+
+    saved = {}
+
+    def fake_fwd(a, b, a_all, b_all, roff, T, w=3.0):
+        loss = head_terms(a, b, a_all, b_all, roff, T, w)
+        saved['args'] = (roff, T, w)
+        return torch.stack([loss.detach(), torch.zeros(())]), torch.zeros(a.shape[0], 8)
+
+    def fake_bwd(a, b, a_all, b_all, rowstats, gscale, roff, T, w=3.0):
+        with torch.enable_grad():           # autograd.Function.backward runs under no_grad
+            leaves = [t.detach().clone().requires_grad_(True) for t in (a, b, a_all, b_all)]
+            (head_terms(*leaves, roff, T, w) * gscale.reshape(())).backward()
+        return tuple(l.grad for l in leaves)
+
+    ops.ntxent_fwd, ops.ntxent_bwd = fake_fwd, fake_bwd
+    gen = torch.Generator().manual_seed(5)
+    N, T = 6, 0.2
+    full1 = torch.nn.functional.normalize(torch.randn(world * N, 128, generator=gen), dim=1)
+    full2 = torch.nn.functional.normalize(torch.randn(world * N, 128, generator=gen), dim=1)
+    h1 = full1[rank * N:(rank + 1) * N].clone().requires_grad_(True)
+    h2 = full2[rank * N:(rank + 1) * N].clone().requires_grad_(True)
+    head = SimCLRContrastiveHead(temperature=T, multi_rank=True)
+    out = head(h1, h2)
+    out['loss'].backward()
+    assert saved['args'][0] == rank * N
+    # single-process reference: DP averages the per-rank losses; every rank's loss depends on all rows
+    f1 = full1.clone().requires_grad_(True)
+    f2 = full2.clone().requires_grad_(True)
+    tot = sum(head_terms(f1[r * N:(r + 1) * N], f2[r * N:(r + 1) * N], f1, f2, r * N, T, 3.0)
+              for r in range(world))
+    tot.backward()
+    # this rank's gradient = d(sum of all ranks' losses)/d(own rows)  (reduce-scatter sums the
+    # column-role parts contributed by the other ranks)
+    e1 = float((h1.grad - f1.grad[rank * N:(rank + 1) * N]).abs().max())
+    e2 = float((h2.grad - f2.grad[rank * N:(rank + 1) * N]).abs().max())
+    return e1, e2, float(out['loss'].detach())
+
+
+def test_simclr_head_cross_rank_gather():
+    ret = _spawn(_simclr_gather_case)
+    for rank in (0, 1):
+        e1, e2, loss = ret[rank]
+        assert e1 < 1e-5 and e2 < 1e-5, (rank, e1, e2)
+        assert loss > 0
