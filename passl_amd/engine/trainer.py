@@ -186,23 +186,29 @@ class Trainer:
                 self.current_epoch += 1
         self.call_hook('run_end')
 
-    # ---- checkpoint plumbing (scope row §8f-3, minimal)
+    # ---- checkpoint plumbing (scope row §8f-3) — reference trainer.py:419-444
     def resume(self, checkpoint_path):
-        import pickle
-        with open(checkpoint_path, 'rb') as f:
-            ck = pickle.load(f)
-        self.load_numpy_state(ck['state_dict'])
-        self.optimizer.set_state_dict({k: torch.as_tensor(v) if isinstance(v, np.ndarray) else v
-                                       for k, v in ck['optimizer'].items()})
-        self.lr_scheduler.set_state_dict(ck['lr_scheduler'])
-        self.start_epoch = self.current_epoch = ck['epoch']
-        self.current_iter = self.current_epoch * self.iters_per_epoch
+        from ..utils.checkpoint import load_pickle, to_tensors
+        checkpoint = load_pickle(checkpoint_path)
+        if checkpoint.get('epoch', None) is not None:
+            self.start_epoch = checkpoint['epoch']
+            self.current_epoch = checkpoint['epoch']
+            # as in the reference (trainer.py:424): the iteration counter restarts one epoch early
+            self.current_iter = (self.start_epoch - 1) * self.iters_per_epoch
+        self.load_numpy_state(checkpoint['state_dict'])
+        self.optimizer.set_state_dict(to_tensors(checkpoint['optimizer']))
+        self.lr_scheduler.set_state_dict(checkpoint['lr_scheduler'])
+        self.logger.info('Resume training from {} success!'.format(checkpoint_path))
 
     def load(self, weight_path, export=False):
-        import pickle
-        with open(weight_path, 'rb') as f:
-            ck = pickle.load(f)
-        self.load_numpy_state(ck.get('state_dict', ck))
+        from ..utils.checkpoint import load_pickle
+        state_dict = load_pickle(weight_path)
+        if 'state_dict' in state_dict:
+            state_dict = state_dict['state_dict']
+        if export:
+            raise NotImplementedError('export (paddle.jit inference model) is outside the hot path')
+        self.load_numpy_state(state_dict)
 
     def load_numpy_state(self, sd):
-        self.model.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=False)
+        from ..utils.checkpoint import to_tensors
+        self.model.load_state_dict(to_tensors(sd), strict=False)

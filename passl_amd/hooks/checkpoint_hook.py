@@ -4,19 +4,11 @@ as the reference (passl_v110/hooks/checkpoint_hook.py:23-141).  Scope row §8f-3
 import os
 import pickle
 
-import torch
-
 from .builder import HOOKS
 from .hook import Hook
 
 
-def _to_numpy(obj):
-    if torch.is_tensor(obj):
-        return obj.detach().float().cpu().contiguous().numpy() if obj.is_floating_point() \
-            else obj.detach().cpu().numpy()
-    if isinstance(obj, dict):
-        return {k: _to_numpy(v) for k, v in obj.items()}
-    return obj
+from ..utils.checkpoint import to_numpy as _to_numpy
 
 
 def save_checkpoint(path, trainer):

@@ -1,0 +1,43 @@
+"""Checkpoint / weight-exchange helpers.
+
+File format = a pickled dict of numpy arrays, the layout of the reference's ``save`` helper
+(passl_v110/hooks/checkpoint_hook.py:23-50) and of ``paddle.save`` for a dygraph ``state_dict``
+(which adds the bookkeeping key ``StructuredToParameterName@@``  [Paddle-semantics]).  Because
+``state_dict()`` here uses the reference's key names and logical shapes, a published ``.pdparams``
+loads without any transposition."""
+import pickle
+
+import numpy as np
+import torch
+
+PADDLE_META_KEYS = ('StructuredToParameterName@@',)
+
+
+def load_pickle(path):
+    with open(path, 'rb') as f:
+        obj = pickle.load(f, encoding='latin1')
+    if isinstance(obj, dict):
+        for k in PADDLE_META_KEYS:
+            obj.pop(k, None)
+    return obj
+
+
+def to_numpy(obj):
+    if torch.is_tensor(obj):
+        t = obj.detach().cpu()
+        return t.float().contiguous().numpy() if t.is_floating_point() else t.numpy()
+    if isinstance(obj, dict):
+        return {k: to_numpy(v) for k, v in obj.items()}
+    return obj
+
+
+def to_tensors(sd):
+    return {k: torch.as_tensor(np.asarray(v)) if isinstance(v, (np.ndarray, np.generic)) else v
+            for k, v in sd.items()}
+
+
+def load_state_into(model, state_dict, strict=False):
+    """state_dict: name -> numpy array (or tensor).  A bare backbone dict (as written by
+    tools/extract_weight.py --remove_prefix) can be loaded into ``model.backbone``."""
+    sd = to_tensors(state_dict)
+    return model.load_state_dict(sd, strict=strict)

@@ -291,3 +291,76 @@ def test_simclr_registry_names_and_kwargs():
     with pytest.raises(NotImplementedError):
         hip_config.set_device('cpu')
         BACKBONES.get('ResNetsimclr')(depth=18)
+
+
+# ------------------------------------------------------------------ checkpoint / weight exchange
+def test_checkpoint_file_format_and_extract_weight(tmp_path):
+    """CheckpointHook writes the reference's pickle-of-numpy layout (hooks/checkpoint_hook.py:23-50);
+    tools/extract_weight.py applies the reference's prefix rules (tools_v110/extract_weight.py)."""
+    import pickle
+    import sys
+    from types import SimpleNamespace
+    hip_config.set_device('cpu')
+    import moco_util as U
+    from passl_amd.hooks.checkpoint_hook import CheckpointHook
+    from passl_amd.modeling import build_model
+    from passl_amd.solver.lr_scheduler import CosineAnnealingDecay
+    from passl_amd.solver.optimizer import Momentum
+    from passl_amd.utils.checkpoint import load_pickle, load_state_into
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import extract_weight as EW
+    cfg = dict(U.MODEL_CFG)
+    cfg.update(K=256)
+    torch.manual_seed(3)
+    model = build_model(cfg)
+    sched = CosineAnnealingDecay(0.015, T_max=100)
+    opt = Momentum(sched, parameters=list(model.parameters()), weight_decay=1e-4)
+    tr = SimpleNamespace(model=model, optimizer=opt, lr_scheduler=sched, current_epoch=0, rank=0,
+                         output_dir=str(tmp_path), logger=SimpleNamespace(info=lambda *a: None))
+    hook = CheckpointHook(interval=1)
+    hook.every_n_epochs = lambda t, n: True
+    for ep in range(7):                       # max_keep_ckpts = 5
+        tr.current_epoch = ep
+        hook.train_epoch_end(tr)
+    files = sorted(os.listdir(tmp_path))
+    assert files == ['epoch_3.pd', 'epoch_4.pd', 'epoch_5.pd', 'epoch_6.pd', 'epoch_7.pd', 'latest.pd']
+    assert os.readlink(os.path.join(tmp_path, 'latest.pd')) == 'epoch_7.pd'
+    with open(os.path.join(tmp_path, 'latest.pd'), 'rb') as f:
+        ck = pickle.load(f)
+    assert set(ck) == {'epoch', 'state_dict', 'optimizer', 'lr_scheduler'} and ck['epoch'] == 7
+    sd = ck['state_dict']
+    assert all(isinstance(v, np.ndarray) for v in sd.values())
+    assert sd['encoder_q.0.conv1.weight'].shape == (64, 3, 7, 7)
+    assert sd['encoder_q.1.mlp.0.weight'].shape == (2048, 2048)            # Paddle Linear [in, out]
+    assert sd['encoder_q.0.bn1._variance'].shape == (64,) and sd['queue'].shape == (128, 256)
+    assert sd['queue_ptr'].dtype == np.int64
+    np.testing.assert_array_equal(sd['backbone.conv1.weight'], sd['encoder_q.0.conv1.weight'])  # moco.py:65 alias
+    # extract_weight: prefix filter, --remove_prefix, error when the prefix is absent
+    out = EW.extract(ck, 'backbone', remove_prefix=True)
+    assert 'conv1.weight' in out and 'layer4.2.bn3._mean' in out and not any(k.startswith('backbone') for k in out)
+    assert set(EW.extract(ck, 'encoder_k')) == {k for k in sd if k.startswith('encoder_k')}
+    with pytest.raises(Exception, match='Cannot find a nothere layer'):
+        EW.extract(ck, 'nothere')
+    EW.main([os.path.join(tmp_path, 'latest.pd'), '--prefix', 'backbone', '--remove_prefix', '--output',
+             os.path.join(tmp_path, 'bb.pdparams')])
+    # a paddle.save()-style file (bookkeeping key) loads into a fresh backbone without transposes
+    with open(os.path.join(tmp_path, 'bb.pdparams'), 'rb') as f:
+        bb = pickle.load(f)
+    bb['StructuredToParameterName@@'] = {'conv1.weight': 'conv2d_0.w_0'}
+    with open(os.path.join(tmp_path, 'bb2.pdparams'), 'wb') as f:
+        pickle.dump(bb, f, protocol=2)
+    torch.manual_seed(9)
+    model2 = build_model(cfg)
+    missing, unexpected = load_state_into(model2.backbone, load_pickle(os.path.join(tmp_path, 'bb2.pdparams')))
+    assert not missing and not unexpected
+    for k, v in model.backbone.state_dict().items():
+        assert torch.equal(model2.backbone.state_dict()[k], v), k
+    # optimizer / scheduler round trip
+    opt._velocity[0].normal_()
+    for _ in range(5):
+        sched.step()
+    sched2 = CosineAnnealingDecay(0.015, T_max=100)
+    opt2 = Momentum(sched2, parameters=list(model2.parameters()), weight_decay=1e-4)
+    from passl_amd.utils.checkpoint import to_numpy, to_tensors
+    opt2.set_state_dict(to_tensors(to_numpy(opt.state_dict())))
+    assert torch.equal(opt2._velocity[0], opt._velocity[0]) and sched2.last_epoch == 5 and sched2() == sched()

@@ -213,3 +213,53 @@ def test_key_encoder_has_no_grad_and_extract_mode():
     assert feat.shape == (4, 2048, 2, 2) and feat.dtype == torch.float32
     with pytest.raises(AssertionError):
         model(torch.randn(6, 3, 64, 64).to(DEV), torch.randn(6, 3, 64, 64).to(DEV))  # 256 % 6 != 0
+
+
+def test_checkpoint_resume_continues_identically(tmp_path):
+    """Trainer + CheckpointHook: save after epoch 1, resume in a fresh Trainer, the next steps
+    reproduce the uninterrupted run (fp32 compute; only the atomics' summation order differs)."""
+    import os
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.hooks import OptimizerHook, LRSchedulerHook
+    from passl_amd.utils.config import get_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def make(out):
+        cfg = get_config(os.path.join(root, 'configs/moco/moco_v2_r50_synthetic.yaml'),
+                         ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+                          'dataloader.train.dataset.num_samples=16', 'epochs=2', 'compute_dtype=fp32',
+                          'output_dir=%s' % out, 'checkpoint.interval=1',
+                          'lr_scheduler.learning_rate=0.5'])
+        cfg.model.K = 256                  # v110 overrides only replace existing keys
+        cfg.timestamp = ''
+        return Trainer(cfg)
+
+    def manual_steps(tr, n):
+        opt = next(h for h in tr.hooks if isinstance(h, OptimizerHook))
+        lrh = next(h for h in tr.hooks if isinstance(h, LRSchedulerHook))
+        data = next(iter(tr.train_dataloader))
+        losses = []
+        tr.model.train()
+        for _ in range(n):
+            tr.outputs = tr.model(*data, total_iters=4, current_iter=1, mixup_fn=None)
+            opt.train_iter_end(tr)
+            lrh.train_iter_end(tr)
+            losses.append(float(tr.outputs['loss'].detach()))
+        return losses
+
+    a = make(tmp_path / 'a')
+    assert a.iters_per_epoch == 2
+    a.total_iters = 2                      # run exactly one epoch through the hook bus
+    a.train()
+    ck = os.path.join(str(tmp_path / 'a'), 'epoch_1.pd')
+    assert os.path.exists(ck) and os.path.islink(os.path.join(str(tmp_path / 'a'), 'latest.pd'))
+    ref_losses = manual_steps(a, 2)
+    b = make(tmp_path / 'b')
+    b.resume(ck)
+    assert b.start_epoch == 1 and b.current_epoch == 1 and b.current_iter == 0    # trainer.py:421-424
+    assert b.lr_scheduler.last_epoch == 2 and int(b.model.queue_ptr[0]) == 16
+    got = manual_steps(b, 2)
+    assert abs(got[0] - ref_losses[0]) < 1e-4 and abs(got[1] - ref_losses[1]) < 5e-3, (got, ref_losses)
+    w_a = a.model.encoder_q[0].layer4[2].conv3.weight.detach()
+    w_b = b.model.encoder_q[0].layer4[2].conv3.weight.detach()
+    assert float((w_a - w_b).abs().max() / w_a.abs().max()) < 1e-3
