@@ -184,6 +184,86 @@ class Linear(Layer):
         return y if self.bias is None else y + self.bias
 
 
+class LayerNorm(Layer):
+    def __init__(self, normalized_shape, epsilon=1e-05, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        n = normalized_shape if isinstance(normalized_shape, int) else normalized_shape[-1]
+        self._epsilon = epsilon
+        self.weight = torch.nn.Parameter(torch.ones(n))
+        self.bias = torch.nn.Parameter(torch.zeros(n))
+
+    def forward(self, x):
+        return TF.layer_norm(x, (x.shape[-1],), self.weight, self.bias, self._epsilon)
+
+
+class GELU(Layer):
+    def __init__(self, approximate=False, name=None):
+        super().__init__()
+        self._approximate = approximate
+
+    def forward(self, x):
+        return TF.gelu(x, approximate='tanh' if self._approximate else 'none')
+
+
+class Dropout(Layer):
+    def __init__(self, p=0.5, axis=None, mode='upscale_in_train', name=None):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        assert self.p == 0.0 or not self.training, 'shim: dropout > 0 is not on the oracle path'
+        return x
+
+
+class LayerList(torch.nn.ModuleList, Layer):
+    pass
+
+
+class _Initializer(object):
+    """Callable initialisers (paddle.nn.initializer.*): in dygraph `init(param)` fills in place.
+    `reshape` returns a view sharing storage, so initialising a reshaped weight initialises it."""
+
+    def __call__(self, t, block=None):
+        with torch.no_grad():
+            t.copy_(self.sample(t))
+        return t
+
+
+class _Constant(_Initializer):
+    def __init__(self, value=0.0):
+        self.value = value
+
+    def sample(self, t):
+        return torch.full_like(t, self.value)
+
+
+class _TruncatedNormal(_Initializer):
+    def __init__(self, mean=0.0, std=1.0, name=None):
+        self.mean, self.std = mean, std
+
+    def sample(self, t):
+        return torch.fmod(torch.randn_like(t), 2.0) * self.std + self.mean
+
+
+class _XavierUniform(_Initializer):
+    def __init__(self, fan_in=None, fan_out=None, name=None):
+        self.fan_in, self.fan_out = fan_in, fan_out
+
+    def sample(self, t):
+        fi = t.shape[0] if t.dim() == 2 else t.shape[1] * t[0][0].numel()
+        fo = t.shape[1] if t.dim() == 2 else t.shape[0] * t[0][0].numel()
+        a = (6.0 / (fi + fo)) ** 0.5
+        return (torch.rand_like(t) * 2 - 1) * a
+
+
+class _Noop(_Initializer):
+    def __init__(self, *a, **k):
+        pass
+
+    def sample(self, t):
+        return t
+
+
 class CrossEntropyLoss(Layer):
     def forward(self, logits, labels):
         return TF.cross_entropy(logits, labels)
@@ -230,8 +310,20 @@ def install():
             y = y.transpose(-1, -2)
         return torch.matmul(x, y)
     paddle.matmul = matmul
-    paddle.arange = lambda start, end=None, step=1, dtype=None: torch.arange(
-        start, end, step, dtype=_dtype(dtype) if dtype else None)
+    def arange(start, end=None, step=1, dtype=None):
+        dt = _dtype(dtype) if dtype else None
+        return torch.arange(start, dtype=dt) if end is None else torch.arange(start, end, step, dtype=dt)
+    paddle.arange = arange
+    paddle.einsum = torch.einsum
+    paddle.rand = lambda shape, dtype=None: torch.rand(*shape)
+
+    def create_parameter(shape, dtype='float32', name=None, attr=None, is_bias=False,
+                         default_initializer=None):
+        p = torch.nn.Parameter(torch.zeros(*shape, dtype=_dtype(dtype)))
+        if default_initializer is not None:
+            default_initializer(p)
+        return p
+    paddle.create_parameter = create_parameter
     paddle.reshape = lambda x, shape: x.reshape(list(shape))
     paddle.unsqueeze = lambda x, axis: x.unsqueeze(axis)
     paddle.argmax = lambda x, axis=None: x.argmax() if axis is None else x.argmax(dim=axis)
@@ -260,7 +352,7 @@ def install():
     paddle.nn = nn
     for cls in (Layer, Sequential, ReLU, Conv2D, BatchNorm2D, BatchNorm1D, BatchNorm,
                 SyncBatchNorm, GroupNorm, MaxPool2D, AdaptiveAvgPool2D, Linear,
-                CrossEntropyLoss):
+                CrossEntropyLoss, LayerNorm, GELU, Dropout, LayerList):
         setattr(nn, cls.__name__, cls)
     F = mod('paddle.nn.functional')
     nn.functional = F
@@ -277,8 +369,11 @@ def install():
                                                                 reduction=reduction)
     init_mod = mod('paddle.nn.initializer')
     nn.initializer = init_mod
-    for nm in ('XavierNormal', 'Constant', 'Normal', 'KaimingNormal'):
-        setattr(init_mod, nm, type(nm, (object,), {'__init__': lambda self, *a, **k: None}))
+    for nm in ('XavierNormal', 'Normal', 'KaimingNormal'):
+        setattr(init_mod, nm, type(nm, (_Noop,), {}))
+    init_mod.Constant = _Constant
+    init_mod.TruncatedNormal = _TruncatedNormal
+    init_mod.XavierUniform = _XavierUniform
     layer = mod('paddle.nn.layer')
     nn.layer = layer
     norm = mod('paddle.nn.layer.norm')

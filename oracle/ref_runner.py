@@ -79,6 +79,14 @@ def load():
     imp(PKG + '.modeling.backbones.resnetsimclr')
     imp(PKG + '.modeling.heads.simclr_contrastive_head')
     imp(PKG + '.modeling.architectures.simclr')
+    # MAE row: backbones/mae.py (class MAE) over modules/get_sincos_pe.py, architectures/MAE.py.
+    # get_sincos_pe.py:25 uses the `np.float` alias that NumPy >= 1.24 removed
+    import numpy as _np
+    if not hasattr(_np, 'float'):
+        _np.float = float
+    imp(PKG + '.modules.get_sincos_pe')
+    imp(PKG + '.modeling.backbones.mae')
+    imp(PKG + '.modeling.architectures.MAE')
     return _namespace()
 
 
@@ -94,6 +102,9 @@ def _namespace():
     ns.BACKBONES = sys.modules[PKG + '.modeling.backbones.builder'].BACKBONES
     ns.NECKS = sys.modules[PKG + '.modeling.necks.builder'].NECKS
     ns.HEADS = sys.modules[PKG + '.modeling.heads.builder'].HEADS
+    ns.mae = sys.modules[PKG + '.modeling.backbones.mae']
+    ns.MAE = ns.mae.MAE
+    ns.MAE_PRETRAIN = sys.modules[PKG + '.modeling.architectures.MAE'].MAE_PRETRAIN
     ns.SimCLR = sys.modules[PKG + '.modeling.architectures.simclr'].SimCLR
     ns.SimCLRContrastiveHead = sys.modules[
         PKG + '.modeling.heads.simclr_contrastive_head'].SimCLRContrastiveHead
@@ -160,6 +171,28 @@ def load_simclr_state(model, oracle):
     with torch.no_grad():
         sd = model.encoder.state_dict()
         assert list(sd.keys()) == list(oracle.st.keys()), 'state_dict key order differs'
+        for n, t in oracle.st.items():
+            assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)
+            sd[n].copy_(t.detach())
+
+
+def build_reference_mae(cfg, norm_pix_loss=False):
+    """The reference's MAE backbone (passl_v110/modeling/backbones/mae.py:318) built through its
+    BACKBONES registry with the architecture block of configs/mae/mae_vit_b_pretrain.yaml."""
+    ns = load()
+    arch = dict(name='MAE', img_size=cfg['img_size'], patch_size=cfg['patch_size'],
+                embed_dim=cfg['embed_dim'], depth=cfg['depth'], num_heads=cfg['num_heads'],
+                decoder_embed_dim=cfg['decoder_embed_dim'], decoder_depth=cfg['decoder_depth'],
+                decoder_num_heads=cfg['decoder_num_heads'], mlp_ratio=cfg['mlp_ratio'],
+                norm_pix_loss=norm_pix_loss)
+    return ns.BACKBONES.get('MAE')(**{k: v for k, v in arch.items() if k != 'name'})
+
+
+def load_mae_state(model, oracle):
+    import torch
+    with torch.no_grad():
+        sd = model.state_dict()
+        assert set(sd.keys()) == set(oracle.st.keys()), set(sd.keys()) ^ set(oracle.st.keys())
         for n, t in oracle.st.items():
             assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)
             sd[n].copy_(t.detach())
