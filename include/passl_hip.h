@@ -283,6 +283,71 @@ int passl_hip_ntxent_bwd(const float* a, const float* b, const float* a_all, con
                          int D, float T, float co2_weight, float* da, float* db, float* da_all,
                          float* db_all, passl_stream_t stream);
 
+/* ---------------------------------------------------------------- ViT / MAE
+ * Reference: class MAE, passl_v110/modeling/backbones/mae.py:318-564 (= passl/models/mae.py:37-290),
+ * Mlp/Attention/Block :61-189.  Activations [rows][C] in `dtype`, C % 8 == 0. */
+
+/* y = (x - mean)/sqrt(var + eps) * gamma + beta per row (biased var); saves mean, rstd [M]. */
+int passl_hip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                            float* mean, float* rstd, int64_t M, int C, float eps, int dtype,
+                            passl_stream_t stream);
+/* dx; dgamma/dbeta (fp32 [C]) are ACCUMULATED into (atomics).  C <= 2048. */
+int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t M,
+                            int C, int dtype, passl_stream_t stream);
+/* exact (erf) GELU and its backward dx = dy * gelu'(x); n % 8 == 0. */
+int passl_hip_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream);
+int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,
+                       passl_stream_t stream);
+/* Fused softmax(q k^T * scale) v per (image, head) on the fused projection qkv [B,T,3,H,DH];
+ * out [B,T,H,DH]; lse [B,H,T] (row log-sum-exp, saved for the backward).  DH in {32, 64},
+ * T <= 208 (PASSL_EUNSUPPORTED otherwise).  Replaces Attention.forward, mae.py:141-155. */
+int passl_hip_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int DH,
+                            float scale, int dtype, passl_stream_t stream);
+/* dqkv [B,T,3,H,DH] (fully written) from dout [B,T,H,DH]. */
+int passl_hip_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                            void* dqkv, int B, int T, int H, int DH, float scale, int dtype,
+                            passl_stream_t stream);
+/* random_masking (mae.py:461-488) without the sort: ids_restore[b,l] = rank of noise[b,l] in its row
+ * (ties by index), ids_keep[b,rank] = l for rank < len_keep, mask[b,l] = rank >= len_keep. */
+int passl_hip_mae_mask(const float* noise, int B, int L, int len_keep, int32_t* ids_keep,
+                       int32_t* ids_restore, float* mask, passl_stream_t stream);
+/* encoder input (mae.py:494-503): out[b,0] = cls + pos[0]; out[b,1+k] = x[b,ids_keep[b,k]] +
+ * pos[1+ids_keep[b,k]];  x [B,L,D], pos [L+1,D], out [B,K+1,D]. */
+int passl_hip_mae_gather(const void* x, const float* cls, const float* pos, const int32_t* ids_keep,
+                         void* out, int B, int L, int K, int D, int dtype, passl_stream_t stream);
+/* its backward: dx [B,L,D] fully written (zeros at masked patches), dcls += sum_b dout[b,0]. */
+int passl_hip_mae_gather_bwd(const void* dout, const int32_t* ids_restore, void* dx, float* dcls,
+                             int B, int L, int K, int D, int dtype, passl_stream_t stream);
+/* decoder input (mae.py:516-527): out[b,0] = x[b,0] + pos[0]; out[b,1+l] = (r = ids_restore[b,l]) < K
+ * ? x[b,1+r] : mask_token, + pos[1+l];  x [B,K+1,D], out [B,L+1,D]. */
+int passl_hip_mae_unshuffle(const void* x, const float* mask_token, const float* pos,
+                            const int32_t* ids_restore, void* out, int B, int L, int K, int D,
+                            int dtype, passl_stream_t stream);
+/* its backward: dx [B,K+1,D] fully written, dmask_token += sum over masked positions. */
+int passl_hip_mae_unshuffle_bwd(const void* dout, const int32_t* ids_keep, const int32_t* ids_restore,
+                                void* dx, float* dmask_token, int B, int L, int K, int D, int dtype,
+                                passl_stream_t stream);
+/* imgs fp32 NCHW -> out [B*L, p*p*C] in `dtype`, column order (ph, pw, c): the patch-embed conv
+ * (mae.py:87-121) as a GEMM, and MAE.patchify's order (mae.py:433-445). */
+int passl_hip_patchify(const float* img, void* out, int B, int C, int H, int W, int p, int dtype,
+                       passl_stream_t stream);
+/* forward_loss (mae.py:541-557): pred fp32 [B, L+1, P] (row 0 of every image = cls, ignored);
+ * loss[0] = sum_l mask * mean_P (pred - target)^2 / denom, target = patches of img, normalised per
+ * patch ((x - mean)/sqrt(var_unbiased + 1e-6)) when norm_pix.  denom = sum(mask). */
+int passl_hip_mae_loss_fwd(const float* img, const float* pred, const float* mask, float* loss, int B,
+                           int C, int H, int W, int p, int norm_pix, float denom,
+                           passl_stream_t stream);
+int passl_hip_mae_loss_bwd(const float* img, const float* pred, const float* mask,
+                           const float* gscale, float* dpred, int B, int C, int H, int W, int p,
+                           int norm_pix, float denom, passl_stream_t stream);
+/* AdamW over a flat fp32 buffer (paddle adamw op): p *= 1 - lr*wd; m = b1 m + (1-b1) g;
+ * v = b2 v + (1-b2) g^2; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps*sqrt(1-b2^t)), with
+ * g scaled by grad_scale.  Replaces paddle.optimizer.AdamW.step (solver/optimizer.py:22). */
+int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                    float beta2, float epsilon, float weight_decay, float beta1_pow, float beta2_pow,
+                    float grad_scale, passl_stream_t stream);
+
 /* ---------------------------------------------------------------- measurement hooks */
 
 /* When enabled, every passl_hip_conv_igemm / passl_hip_conv_wgrad launch is bracketed by HIP

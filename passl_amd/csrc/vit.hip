@@ -1,0 +1,590 @@
+// ViT / MAE streaming kernels for gfx950: LayerNorm, GELU, MAE token plumbing (masking ranks,
+// keep-gather + cls/pos, decoder unshuffle + mask tokens), patchify, masked-patch reconstruction
+// loss, multi-tensor AdamW.  All HBM-bound: 16-byte accesses per lane, one wave per row where a
+// row reduction is needed (wave shuffles), fp32 arithmetic, activations in `dtype`.
+//
+// Reference call sites: passl_v110/modeling/backbones/mae.py (= passl/models/mae.py):
+//   LayerNorm/GELU  :61-85,158-189      random_masking :461-488     forward_encoder :490-510
+//   forward_decoder :512-539            patchify/forward_loss :433-445,541-557
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]) {
+  ElemTraits<T>::load8(p, v);
+}
+
+// ------------------------------------------------------------------ LayerNorm (one wave per row)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) layernorm_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* xr = x + (int64_t)row * C;
+  float s = 0.f, ss = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    float v[8];
+    ld8(xr + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s += v[e]; ss += v[e] * v[e]; }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const float mu = s / (float)C;
+  float var = ss / (float)C - mu * mu;
+  var = var < 0.f ? 0.f : var;
+  const float rs = rsqrtf(var + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  T* yr = y + (int64_t)row * C;
+  for (int c = lane * 8; c < C; c += 512) {
+    float v[8], g[8], b[8];
+    ld8(xr + c, v);
+    ElemTraits<float>::load8(gamma + c, g);
+    ElemTraits<float>::load8(beta + c, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu) * rs * g[e] + b[e];
+    ElemTraits<T>::store8(yr + c, v);
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  The column sums of dy*xhat
+// and dy are kept in registers (a lane owns the same column chunks for every row its wave visits),
+// combined across the 4 waves through LDS and flushed with one atomic per column per block.
+constexpr int kLnMaxChunks = 4;            // C <= 2048
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int rows_per_block) {
+  extern __shared__ float col[];            // [4 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float ag[kLnMaxChunks][8], ab[kLnMaxChunks][8];
+#pragma unroll
+  for (int k = 0; k < kLnMaxChunks; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const T* xr = x + (int64_t)row * C;
+    const T* gr = dy + (int64_t)row * C;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLnMaxChunks; ++k) {
+      const int c = lane * 8 + k * 512;
+      if (c < C) {
+        float v[8], d[8], g[8];
+        ld8(xr + c, v);
+        ld8(gr + c, d);
+        ElemTraits<float>::load8(gamma + c, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[e] - mu) * rs, gg = d[e] * g[e];
+          s1 += gg;
+          s2 += gg * xh;
+          ag[k][e] += d[e] * xh;
+          ab[k][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    T* dr = dx + (int64_t)row * C;
+#pragma unroll
+    for (int k = 0; k < kLnMaxChunks; ++k) {
+      const int c = lane * 8 + k * 512;
+      if (c < C) {
+        float v[8], d[8], g[8], o[8];
+        ld8(xr + c, v);
+        ld8(gr + c, d);
+        ElemTraits<float>::load8(gamma + c, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (v[e] - mu) * rs;
+          o[e] = rs * (d[e] * g[e] - s1 - xh * s2);
+        }
+        ElemTraits<T>::store8(dr + c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kLnMaxChunks; ++k) {
+    const int c = lane * 8 + k * 512;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        col[(wave * 2 + 0) * C + c + e] = ag[k][e];
+        col[(wave * 2 + 1) * C + c + e] = ab[k][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    atomicAdd(dgamma + c, col[c] + col[2 * C + c] + col[4 * C + c] + col[6 * C + c]);
+    atomicAdd(dbeta + c, col[C + c] + col[3 * C + c] + col[5 * C + c] + col[7 * C + c]);
+  }
+}
+
+// ------------------------------------------------------------------ GELU (exact erf form)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(kThreads) gelu_kernel(const T* __restrict__ x,
+                                                        const T* __restrict__ dy,
+                                                        T* __restrict__ out, int64_t nchunks) {
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
+    float v[8], o[8];
+    ld8(x + i * 8, v);
+    if (BWD) {
+      float d[8];
+      ld8(dy + i * 8, d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_grad_f(v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = gelu_f(v[e]);
+    }
+    ElemTraits<T>::store8(out + i * 8, o);
+  }
+}
+
+// ------------------------------------------------------------------ MAE masking
+// rank[i] = #{j : noise[j] < noise[i] or (== and j < i)}  (= ids_restore of argsort(argsort));
+// ids_keep[rank] = i for rank < K; mask[i] = rank >= K.   One block per row, L <= 4096.
+__global__ void __launch_bounds__(kThreads) mae_mask_kernel(const float* __restrict__ noise, int L,
+                                                            int K, int32_t* __restrict__ ids_keep,
+                                                            int32_t* __restrict__ ids_restore,
+                                                            float* __restrict__ mask) {
+  extern __shared__ float nz[];
+  const float* nr = noise + (int64_t)blockIdx.x * L;
+  for (int i = threadIdx.x; i < L; i += kThreads) nz[i] = nr[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < L; i += kThreads) {
+    const float v = nz[i];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) rank += (nz[j] < v || (nz[j] == v && j < i)) ? 1 : 0;
+    ids_restore[(int64_t)blockIdx.x * L + i] = rank;
+    mask[(int64_t)blockIdx.x * L + i] = rank >= K ? 1.f : 0.f;
+    if (rank < K) ids_keep[(int64_t)blockIdx.x * K + rank] = i;
+  }
+}
+
+// encoder input: out[b,0] = cls + pos[0]; out[b,1+k] = x[b, ids_keep[b,k]] + pos[1 + ids_keep[b,k]]
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mae_gather_kernel(
+    const T* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+    const int32_t* __restrict__ ids_keep, T* __restrict__ out, int B, int L, int K, int D) {
+  const int cpr = D >> 3;
+  const int64_t total = (int64_t)B * (K + 1) * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int c = (int)(i % cpr) * 8;
+    const int64_t tok = i / cpr;
+    const int t = (int)(tok % (K + 1)), b = (int)(tok / (K + 1));
+    float v[8], p[8];
+    int src = 0;
+    if (t == 0) {
+      ElemTraits<float>::load8(cls + c, v);
+    } else {
+      src = ids_keep[(int64_t)b * K + t - 1];
+      ld8(x + ((int64_t)b * L + src) * D + c, v);
+      src += 1;
+    }
+    ElemTraits<float>::load8(pos + (int64_t)src * D + c, p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += p[e];
+    ElemTraits<T>::store8(out + tok * D + c, v);
+  }
+}
+
+// backward of the gather: dx[b, l] = dout[b, 1 + rank] if rank < K else 0 (rank = ids_restore);
+// dcls += sum_b dout[b, 0]
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mae_gather_bwd_kernel(
+    const T* __restrict__ dout, const int32_t* __restrict__ ids_restore, T* __restrict__ dx,
+    float* __restrict__ dcls, int B, int L, int K, int D) {
+  const int cpr = D >> 3;
+  const int64_t total = (int64_t)B * (L + 1) * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int c = (int)(i % cpr) * 8;
+    const int64_t tok = i / cpr;
+    const int l = (int)(tok % (L + 1)), b = (int)(tok / (L + 1));
+    float v[8];
+    if (l == L) {               // the extra slot handles the cls row of image b
+      ld8(dout + ((int64_t)b * (K + 1)) * D + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(dcls + c + e, v[e]);
+      continue;
+    }
+    const int rank = ids_restore[(int64_t)b * L + l];
+    if (rank < K) ld8(dout + ((int64_t)b * (K + 1) + 1 + rank) * D + c, v);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    ElemTraits<T>::store8(dx + ((int64_t)b * L + l) * D + c, v);
+  }
+}
+
+// decoder input: out[b,0] = x[b,0] + pos[0]; out[b,1+l] = (r < K ? x[b,1+r] : mask_token) + pos[1+l]
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mae_unshuffle_kernel(
+    const T* __restrict__ x, const float* __restrict__ mask_token, const float* __restrict__ pos,
+    const int32_t* __restrict__ ids_restore, T* __restrict__ out, int B, int L, int K, int D) {
+  const int cpr = D >> 3;
+  const int64_t total = (int64_t)B * (L + 1) * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int c = (int)(i % cpr) * 8;
+    const int64_t tok = i / cpr;
+    const int t = (int)(tok % (L + 1)), b = (int)(tok / (L + 1));
+    float v[8], p[8];
+    int r = 0;
+    if (t > 0) r = ids_restore[(int64_t)b * L + t - 1] + 1;
+    if (r <= K) ld8(x + ((int64_t)b * (K + 1) + r) * D + c, v);
+    else ElemTraits<float>::load8(mask_token + c, v);
+    ElemTraits<float>::load8(pos + (int64_t)t * D + c, p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += p[e];
+    ElemTraits<T>::store8(out + tok * D + c, v);
+  }
+}
+
+// backward: dx[b,0] = dout[b,0]; dx[b,1+r] = dout[b,1+l] where ids_restore[b,l] = r < K (the kept
+// token k sits at position l = ids_keep[b,k]); dmask_token += sum over masked positions
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mae_unshuffle_bwd_kernel(
+    const T* __restrict__ dout, const int32_t* __restrict__ ids_keep,
+    const int32_t* __restrict__ ids_restore, T* __restrict__ dx, float* __restrict__ dmask,
+    int B, int L, int K, int D) {
+  const int cpr = D >> 3;
+  const int64_t total = (int64_t)B * (L + 1) * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int c = (int)(i % cpr) * 8;
+    const int64_t tok = i / cpr;
+    const int t = (int)(tok % (L + 1)), b = (int)(tok / (L + 1));
+    float v[8];
+    if (t <= K) {       // destination row t of dx: source position in dout
+      const int src = t == 0 ? 0 : 1 + ids_keep[(int64_t)b * K + t - 1];
+      ld8(dout + ((int64_t)b * (L + 1) + src) * D + c, v);
+      ElemTraits<T>::store8(dx + ((int64_t)b * (K + 1) + t) * D + c, v);
+    }
+    if (t > 0 && ids_restore[(int64_t)b * L + t - 1] >= K) {
+      ld8(dout + tok * D + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(dmask + c + e, v[e]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ patchify
+// imgs fp32 NCHW [B,C,H,W] -> out [B*L, p*p*C] with column order (ph, pw, c): the K-order of the
+// patch-embed weight stored [Cout][p][p][C] and of MAE.patchify ('nchpwq->nhwpqc')
+template <typename T>
+__global__ void __launch_bounds__(kThreads) patchify_kernel(const float* __restrict__ img,
+                                                            T* __restrict__ out, int B, int C, int H,
+                                                            int W, int p) {
+  const int gh = H / p, gw = W / p;
+  const int P = p * p * C;
+  const int64_t total = (int64_t)B * gh * gw * P;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int col = (int)(i % P);
+    const int64_t patch = i / P;
+    const int c = col % C, pw = (col / C) % p, ph = col / (C * p);
+    const int w_ = (int)(patch % gw), h_ = (int)((patch / gw) % gh), b = (int)(patch / (gw * gh));
+    const float v = img[(((int64_t)b * C + c) * H + h_ * p + ph) * W + w_ * p + pw];
+    ElemTraits<T>::st(out + i, v);
+  }
+}
+
+// ------------------------------------------------------------------ masked-patch loss
+// one wave per patch.  pred fp32 [B, L+1, P] (row 0 of every image = cls, skipped), target from the
+// image: optional per-patch (mean, unbiased var) normalisation, loss = sum_l mask * mean_P (pred -
+// target)^2 / denom.  BWD writes dpred (zeros on cls rows and kept patches).
+template <bool BWD>
+__global__ void __launch_bounds__(kThreads) mae_loss_kernel(
+    const float* __restrict__ img, const float* __restrict__ pred, const float* __restrict__ mask,
+    const float* __restrict__ gscale, float* __restrict__ out, float* __restrict__ dpred, int B, int C,
+    int H, int W, int p, int norm_pix, float inv_denom) {
+  const int gh = H / p, gw = W / p, L = gh * gw, P = p * p * C;
+  const int lane = threadIdx.x & 63;
+  const int64_t patch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (patch >= (int64_t)B * (L + 1)) return;
+  const int t = (int)(patch % (L + 1)), b = (int)(patch / (L + 1));
+  float* dr = BWD ? dpred + patch * P : nullptr;
+  const float m = t == 0 ? 0.f : mask[(int64_t)b * L + t - 1];
+  if (m == 0.f) {
+    if (BWD) for (int i = lane; i < P; i += 64) dr[i] = 0.f;
+    return;
+  }
+  const int l = t - 1, w_ = l % gw, h_ = l / gw;
+  // first pass: patch statistics
+  float s = 0.f, ss = 0.f;
+  for (int i = lane; i < P; i += 64) {
+    const int c = i % C, pw = (i / C) % p, ph = i / (C * p);
+    const float v = img[(((int64_t)b * C + c) * H + h_ * p + ph) * W + w_ * p + pw];
+    s += v; ss += v * v;
+  }
+  s = wave_sum(s); ss = wave_sum(ss);
+  float mu = 0.f, rs = 1.f;
+  if (norm_pix) {
+    mu = s / (float)P;
+    float var = (ss - (float)P * mu * mu) / (float)(P - 1);      // unbiased (paddle var default)
+    var = var < 0.f ? 0.f : var;
+    rs = rsqrtf(var + 1e-6f);
+  }
+  const float* pr = pred + patch * P;
+  const float g = BWD ? (gscale ? *gscale : 1.f) * 2.f * inv_denom / (float)P : 0.f;
+  float acc = 0.f;
+  for (int i = lane; i < P; i += 64) {
+    const int c = i % C, pw = (i / C) % p, ph = i / (C * p);
+    const float v = img[(((int64_t)b * C + c) * H + h_ * p + ph) * W + w_ * p + pw];
+    const float d = pr[i] - (v - mu) * rs;
+    if (BWD) dr[i] = g * d;
+    else acc += d * d;
+  }
+  if (!BWD) {
+    acc = wave_sum(acc);
+    if (lane == 0) atomicAdd(out, acc / (float)P * inv_denom);
+  }
+}
+
+// ------------------------------------------------------------------ AdamW (flat buffer)
+// p *= 1 - lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr_t * m / (sqrt(v) + eps_t),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t), eps_t = eps*sqrt(1-b2^t)
+__global__ void __launch_bounds__(kThreads) adamw_kernel(float* __restrict__ p,
+                                                         const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         int64_t n, float decay, float b1, float b2,
+                                                         float lr_t, float eps_t, float gs) {
+  const int64_t nv = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kThreads;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pp = &pv.x; const float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = gp[e] * gs;
+      mp[e] = b1 * mp[e] + (1.f - b1) * gg;
+      vp[e] = b2 * vp[e] + (1.f - b2) * gg * gg;
+      pp[e] = pp[e] * decay - lr_t * (mp[e] / (sqrtf(vp[e]) + eps_t));
+    }
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nv << 2) + threadIdx.x;
+    const float gg = g[i] * gs;
+    m[i] = b1 * m[i] + (1.f - b1) * gg;
+    v[i] = b2 * v[i] + (1.f - b2) * gg * gg;
+    p[i] = p[i] * decay - lr_t * (m[i] / (sqrtf(v[i]) + eps_t));
+  }
+}
+
+static inline int grid_for(int64_t n) {
+  int64_t b = (n + kThreads - 1) / kThreads;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+#define VIT_DISPATCH(dtype, ...)                                \
+  if ((dtype) == PASSL_BF16) { using T = bf16_t; __VA_ARGS__ }  \
+  else if ((dtype) == PASSL_F32) { using T = float; __VA_ARGS__ } \
+  else return PASSL_EUNSUPPORTED;
+
+extern "C" int passl_hip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                                       float* mean, float* rstd, int64_t M, int C, float eps,
+                                       int dtype, passl_stream_t stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || M <= 0 || C <= 0 || (C & 7) ||
+      !aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_fwd_kernel<T>, dim3((unsigned)((M + 3) / 4)),
+                                         dim3(kThreads), 0, as_stream(stream),
+                                         reinterpret_cast<const T*>(x), gamma, beta,
+                                         reinterpret_cast<T*>(y), mean, rstd, (int)M, C, eps);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma,
+                                       const float* mean, const float* rstd, void* dx,
+                                       float* dgamma, float* dbeta, int64_t M, int C, int dtype,
+                                       passl_stream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0 || C <= 0 ||
+      (C & 7) || C > 512 * kLnMaxChunks || !aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma))
+    return PASSL_EINVAL;
+  int nb = (int)((M + 63) / 64);
+  if (nb > 1024) nb = 1024;
+  const int rows = (int)((M + nb - 1) / nb);
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nb), dim3(kThreads),
+                                         8 * C * sizeof(float), as_stream(stream),
+                                         reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x),
+                                         gamma, mean, rstd, reinterpret_cast<T*>(dx), dgamma, dbeta,
+                                         (int)M, C, rows);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream) {
+  if (!x || !y || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(y)) return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL((gelu_kernel<T, false>), dim3(grid_for(n >> 3)), dim3(kThreads),
+                                         0, as_stream(stream), reinterpret_cast<const T*>(x), nullptr,
+                                         reinterpret_cast<T*>(y), n >> 3);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,
+                                  passl_stream_t stream) {
+  if (!dy || !x || !dx || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(dy) || !aligned16(dx))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL((gelu_kernel<T, true>), dim3(grid_for(n >> 3)), dim3(kThreads),
+                                         0, as_stream(stream), reinterpret_cast<const T*>(x),
+                                         reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx),
+                                         n >> 3);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_mae_mask(const float* noise, int B, int L, int len_keep, int32_t* ids_keep,
+                                  int32_t* ids_restore, float* mask, passl_stream_t stream) {
+  if (!noise || !ids_keep || !ids_restore || !mask || B <= 0 || L <= 0 || L > 4096 || len_keep <= 0 ||
+      len_keep > L)
+    return PASSL_EINVAL;
+  hipLaunchKernelGGL(mae_mask_kernel, dim3(B), dim3(kThreads), L * sizeof(float), as_stream(stream),
+                     noise, L, len_keep, ids_keep, ids_restore, mask);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_mae_gather(const void* x, const float* cls, const float* pos,
+                                    const int32_t* ids_keep, void* out, int B, int L, int K, int D,
+                                    int dtype, passl_stream_t stream) {
+  if (!x || !cls || !pos || !ids_keep || !out || B <= 0 || L <= 0 || K <= 0 || K > L || D <= 0 || (D & 7))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_gather_kernel<T>, dim3(grid_for((int64_t)B * (K + 1) * (D >> 3))),
+                                         dim3(kThreads), 0, as_stream(stream),
+                                         reinterpret_cast<const T*>(x), cls, pos, ids_keep,
+                                         reinterpret_cast<T*>(out), B, L, K, D);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_mae_gather_bwd(const void* dout, const int32_t* ids_restore, void* dx,
+                                        float* dcls, int B, int L, int K, int D, int dtype,
+                                        passl_stream_t stream) {
+  if (!dout || !ids_restore || !dx || !dcls || B <= 0 || L <= 0 || K <= 0 || K > L || D <= 0 || (D & 7))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_gather_bwd_kernel<T>,
+                                         dim3(grid_for((int64_t)B * (L + 1) * (D >> 3))), dim3(kThreads), 0,
+                                         as_stream(stream), reinterpret_cast<const T*>(dout), ids_restore,
+                                         reinterpret_cast<T*>(dx), dcls, B, L, K, D);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_mae_unshuffle(const void* x, const float* mask_token, const float* pos,
+                                       const int32_t* ids_restore, void* out, int B, int L, int K,
+                                       int D, int dtype, passl_stream_t stream) {
+  if (!x || !mask_token || !pos || !ids_restore || !out || B <= 0 || L <= 0 || K <= 0 || K > L ||
+      D <= 0 || (D & 7))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_unshuffle_kernel<T>,
+                                         dim3(grid_for((int64_t)B * (L + 1) * (D >> 3))), dim3(kThreads), 0,
+                                         as_stream(stream), reinterpret_cast<const T*>(x), mask_token, pos,
+                                         ids_restore, reinterpret_cast<T*>(out), B, L, K, D);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_mae_unshuffle_bwd(const void* dout, const int32_t* ids_keep,
+                                           const int32_t* ids_restore, void* dx, float* dmask_token,
+                                           int B, int L, int K, int D, int dtype,
+                                           passl_stream_t stream) {
+  if (!dout || !ids_keep || !ids_restore || !dx || !dmask_token || B <= 0 || L <= 0 || K <= 0 ||
+      K > L || D <= 0 || (D & 7))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_unshuffle_bwd_kernel<T>,
+                                         dim3(grid_for((int64_t)B * (L + 1) * (D >> 3))), dim3(kThreads), 0,
+                                         as_stream(stream), reinterpret_cast<const T*>(dout), ids_keep,
+                                         ids_restore, reinterpret_cast<T*>(dx), dmask_token, B, L, K, D);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_patchify(const float* img, void* out, int B, int C, int H, int W, int p,
+                                  int dtype, passl_stream_t stream) {
+  if (!img || !out || B <= 0 || C <= 0 || p <= 0 || H <= 0 || W <= 0 || (H % p) || (W % p))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(grid_for((int64_t)B * C * H * W)),
+                                         dim3(kThreads), 0, as_stream(stream), img,
+                                         reinterpret_cast<T*>(out), B, C, H, W, p);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_mae_loss_fwd(const float* img, const float* pred, const float* mask,
+                                      float* loss, int B, int C, int H, int W, int p, int norm_pix,
+                                      float denom, passl_stream_t stream) {
+  if (!img || !pred || !mask || !loss || B <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p) || !(denom > 0.f))
+    return PASSL_EINVAL;
+  hipStream_t st = as_stream(stream);
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return PASSL_ELAUNCH;
+  const int64_t rows = (int64_t)B * ((H / p) * (W / p) + 1);
+  hipLaunchKernelGGL(mae_loss_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, st, img,
+                     pred, mask, nullptr, loss, nullptr, B, C, H, W, p, norm_pix, 1.0f / denom);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_mae_loss_bwd(const float* img, const float* pred, const float* mask,
+                                      const float* gscale, float* dpred, int B, int C, int H, int W,
+                                      int p, int norm_pix, float denom, passl_stream_t stream) {
+  if (!img || !pred || !mask || !dpred || B <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p) || !(denom > 0.f))
+    return PASSL_EINVAL;
+  const int64_t rows = (int64_t)B * ((H / p) * (W / p) + 1);
+  hipLaunchKernelGGL(mae_loss_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0,
+                     as_stream(stream), img, pred, mask, gscale, nullptr, dpred, B, C, H, W, p, norm_pix,
+                     1.0f / denom);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                               float beta1, float beta2, float epsilon, float weight_decay,
+                               float beta1_pow, float beta2_pow, float grad_scale,
+                               passl_stream_t stream) {
+  if (!p || !g || !m || !v || n < 0 || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v))
+    return PASSL_EINVAL;
+  if (n == 0) return PASSL_OK;
+  const float c2 = sqrtf(1.f - beta2_pow);
+  int64_t b = ((n >> 2) + kThreads - 1) / kThreads;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)b), dim3(kThreads), 0, as_stream(stream), p, g, m, v, n,
+                     1.f - lr * weight_decay, beta1, beta2, lr * c2 / (1.f - beta1_pow), epsilon * c2,
+                     grad_scale);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}

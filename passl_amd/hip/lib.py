@@ -90,6 +90,21 @@ SIGNATURES = {
     'passl_hip_ntxent_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
     'passl_hip_ntxent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p,
                                    c_p, c_p, c_p, c_p]),
+    'passl_hip_layernorm_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p]),
+    'passl_hip_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p]),
+    'passl_hip_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
+    'passl_hip_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
+    'passl_hip_attention_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    'passl_hip_attention_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    'passl_hip_mae_mask': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'passl_hip_mae_gather': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_mae_gather_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_mae_unshuffle': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_mae_unshuffle_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_patchify': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_mae_loss_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    'passl_hip_mae_loss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    'passl_hip_adamw': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),
     'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),
 }

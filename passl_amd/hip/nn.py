@@ -333,16 +333,17 @@ class ReLU(Layer):
 # =============================================================================== linear
 class _LinearFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, layer, relu, out_f32):
+    def forward(ctx, x, weight, bias, layer, relu, out_f32, residual):
         rt = _need_rt(layer)
         N = x.shape[0]
         pl = layer._plan(N)
         y = torch.empty(N, layer.out_features, dtype=torch.float32 if out_f32 else x.dtype,
                         device=x.device)
         ops.conv_igemm(pl.fd, x, rt.w_fwd, y, shift=bias.detach() if bias is not None else None,
-                       relu=relu, out_f32=out_f32)
+                       relu=relu, out_f32=out_f32, residual=residual)
         ctx.save_for_backward(x, y if relu else None)
         ctx.layer, ctx.pl, ctx.relu = layer, pl, relu
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
@@ -366,7 +367,8 @@ class _LinearFn(Function):
             ops.colsum_into(dy, tmp)
             layer.bias.grad.add_(tmp)
         rt.arena.grad_ready(rt.indices)
-        return dx, None, None, None, None, None
+        # y = x W + b + residual: the residual branch's gradient is dy itself
+        return dx, None, None, None, None, None, (dy if ctx.has_res else None)
 
 
 class Linear(Layer):
@@ -394,8 +396,9 @@ class Linear(Layer):
             self._plans[N] = pl
         return pl
 
-    def forward(self, x, relu=False, out_f32=False):
-        return _LinearFn.apply(x, self.weight, self.bias, self, relu, out_f32)
+    def forward(self, x, relu=False, out_f32=False, residual=None):
+        """residual: tensor shaped like the output, added in the GEMM epilogue (before the ReLU)."""
+        return _LinearFn.apply(x, self.weight, self.bias, self, relu, out_f32, residual)
 
 
 class _ToComputeFn(Function):
@@ -417,6 +420,88 @@ def to_compute(x, dtype):
     if dtype == torch.float32 or x.dtype == dtype:
         return x
     return _ToComputeFn.apply(x)
+
+
+# =============================================================================== ViT pieces
+class _LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, layer):
+        y, mean, rstd = ops.layernorm_fwd(x.contiguous(), gamma.detach(), beta.detach(), layer._epsilon)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.layer = layer
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        layer = ctx.layer
+        for p in (layer.weight, layer.bias):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        dx = ops.layernorm_bwd(dy.contiguous(), x, layer.weight.detach(), mean, rstd, layer.weight.grad,
+                               layer.bias.grad)
+        if layer._rt is not None:
+            layer._rt.arena.grad_ready(layer._rt.indices)
+        return dx, None, None, None
+
+
+class LayerNorm(Layer):
+    """paddle.nn.LayerNorm over the last axis (biased variance), rows [M, C] in the compute dtype."""
+
+    def __init__(self, normalized_shape, epsilon=1e-05, weight_attr=None, bias_attr=None, name=None):
+        super().__init__()
+        dev = config.get_device()
+        n = normalized_shape if isinstance(normalized_shape, int) else normalized_shape[-1]
+        self._epsilon = epsilon
+        self.weight = tnn.Parameter(torch.ones(n, device=dev))
+        self.bias = tnn.Parameter(torch.zeros(n, device=dev))
+        self._rt = None
+
+    def forward(self, x):
+        return _LayerNormFn.apply(x, self.weight, self.bias, self)
+
+
+class _GeluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(dy.contiguous(), x)
+
+
+def gelu(x):
+    return _GeluFn.apply(x)
+
+
+class GELU(Layer):
+    def forward(self, x):
+        return gelu(x)
+
+
+class _AttentionFn(Function):
+    """softmax(q k^T * scale) v per (image, head) on the fused qkv projection [B*T, 3*H*d]."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, T, H, DH, scale):
+        out, lse = ops.attention_fwd(qkv.contiguous(), B, T, H, DH, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.dims = (B, T, H, DH, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, T, H, DH, scale = ctx.dims
+        return ops.attention_bwd(qkv, out, dout.contiguous(), lse, B, T, H, DH, scale), None, None, None, \
+            None, None
+
+
+def attention(qkv, B, T, H, DH, scale):
+    return _AttentionFn.apply(qkv, B, T, H, DH, float(scale))
 
 
 # =============================================================================== head pieces
@@ -481,7 +566,8 @@ class EncoderArena:
                 if p is None or id(p) in seen:
                     continue
                 seen.add(id(p))
-                kind = 'conv' if isinstance(mod, Conv2D) else \
+                kind = 'conv' if ((isinstance(mod, Conv2D) or getattr(mod, 'krsc_weight', False))
+                                  and name == 'weight') else \
                     ('linw' if isinstance(mod, Linear) and name == 'weight' else 'vec')
                 params.append((mod, name, kind))
         stats = [(mod, n) for mod in module.modules() if isinstance(mod, _BatchNormBase)
@@ -590,7 +676,7 @@ class EncoderArena:
         if is_stem:
             stem_pack = P.stem_desc(g.cout, 1, 8, 8).pack
             self.packer.add(off, g.cout, g.k, g.k, g.cin, stem_pack)
-        elif self.trainable:
+        elif self.trainable and not getattr(mod, 'no_dgrad', False):
             rt.dgrad_packs = P.dgrad_packs(g)
             for pk in rt.dgrad_packs.values():
                 self.packer.add(off, g.cout, g.k, g.k, g.cin, pk)

@@ -361,3 +361,128 @@ def lars_momentum(p, g, v, table, lr, mu, coeff, eps, grad_scale=1.0):
                                            table['blk_off'].numel(), L.ptr(table['seg_wd']),
                                            table['seg_wd'].numel(), L.ptr(table['norms']), lr, mu,
                                            coeff, eps, grad_scale, L.stream()), 'lars_momentum')
+
+
+# ------------------------------------------------------------------ ViT / MAE
+def layernorm_fwd(x, gamma, beta, eps):
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    L.check(_lib().passl_hip_layernorm_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean),
+                                           L.ptr(rstd), M, Cc, eps, L.dt(x), L.stream()), 'layernorm_fwd')
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    dx = torch.empty_like(x)
+    L.check(_lib().passl_hip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                                           L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), M, Cc, L.dt(x),
+                                           L.stream()), 'layernorm_bwd')
+    return dx
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    L.check(_lib().passl_hip_gelu_fwd(L.ptr(x), L.ptr(y), x.numel(), L.dt(x), L.stream()), 'gelu_fwd')
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    L.check(_lib().passl_hip_gelu_bwd(L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.dt(x), L.stream()),
+            'gelu_bwd')
+    return dx
+
+
+def attention_fwd(qkv, B, T, H, DH, scale):
+    """qkv [B*T, 3*H*DH] -> out [B*T, H*DH], lse [B, H, T]."""
+    out = torch.empty(B * T, H * DH, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    L.check(_lib().passl_hip_attention_fwd(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, DH, scale,
+                                           L.dt(qkv), L.stream()), 'attention_fwd')
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, T, H, DH, scale):
+    dqkv = torch.empty_like(qkv)
+    L.check(_lib().passl_hip_attention_bwd(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(dqkv),
+                                           B, T, H, DH, scale, L.dt(qkv), L.stream()), 'attention_bwd')
+    return dqkv
+
+
+def mae_mask(noise, len_keep):
+    B, Ln = noise.shape
+    dev = noise.device
+    ids_keep = torch.empty(B, len_keep, dtype=torch.int32, device=dev)
+    ids_restore = torch.empty(B, Ln, dtype=torch.int32, device=dev)
+    mask = torch.empty(B, Ln, dtype=torch.float32, device=dev)
+    L.check(_lib().passl_hip_mae_mask(L.ptr(noise), B, Ln, len_keep, L.ptr(ids_keep), L.ptr(ids_restore),
+                                      L.ptr(mask), L.stream()), 'mae_mask')
+    return ids_keep, ids_restore, mask
+
+
+def mae_gather(x, cls, pos, ids_keep, B, Ln):
+    K, D = ids_keep.shape[1], x.shape[-1]
+    out = torch.empty(B * (K + 1), D, dtype=x.dtype, device=x.device)
+    L.check(_lib().passl_hip_mae_gather(L.ptr(x), L.ptr(cls), L.ptr(pos), L.ptr(ids_keep), L.ptr(out), B,
+                                        Ln, K, D, L.dt(x), L.stream()), 'mae_gather')
+    return out
+
+
+def mae_gather_bwd(dout, ids_restore, dcls, B, Ln, K):
+    D = dout.shape[-1]
+    dx = torch.empty(B * Ln, D, dtype=dout.dtype, device=dout.device)
+    L.check(_lib().passl_hip_mae_gather_bwd(L.ptr(dout), L.ptr(ids_restore), L.ptr(dx), L.ptr(dcls), B, Ln,
+                                            K, D, L.dt(dout), L.stream()), 'mae_gather_bwd')
+    return dx
+
+
+def mae_unshuffle(x, mask_token, pos, ids_restore, B, K):
+    Ln, D = ids_restore.shape[1], x.shape[-1]
+    out = torch.empty(B * (Ln + 1), D, dtype=x.dtype, device=x.device)
+    L.check(_lib().passl_hip_mae_unshuffle(L.ptr(x), L.ptr(mask_token), L.ptr(pos), L.ptr(ids_restore),
+                                           L.ptr(out), B, Ln, K, D, L.dt(x), L.stream()), 'mae_unshuffle')
+    return out
+
+
+def mae_unshuffle_bwd(dout, ids_keep, ids_restore, dmask_token, B):
+    K, Ln, D = ids_keep.shape[1], ids_restore.shape[1], dout.shape[-1]
+    dx = torch.empty(B * (K + 1), D, dtype=dout.dtype, device=dout.device)
+    L.check(_lib().passl_hip_mae_unshuffle_bwd(L.ptr(dout), L.ptr(ids_keep), L.ptr(ids_restore), L.ptr(dx),
+                                               L.ptr(dmask_token), B, Ln, K, D, L.dt(dout), L.stream()),
+            'mae_unshuffle_bwd')
+    return dx
+
+
+def patchify(img, p, dtype):
+    B, Cc, H, W = img.shape
+    out = torch.empty(B * (H // p) * (W // p), p * p * Cc, dtype=dtype, device=img.device)
+    L.check(_lib().passl_hip_patchify(L.ptr(img), L.ptr(out), B, Cc, H, W, p, L.dt(dtype), L.stream()),
+            'patchify')
+    return out
+
+
+def mae_loss_fwd(img, pred, mask, p, norm_pix, denom):
+    B, Cc, H, W = img.shape
+    loss = torch.empty(1, dtype=torch.float32, device=img.device)
+    L.check(_lib().passl_hip_mae_loss_fwd(L.ptr(img), L.ptr(pred), L.ptr(mask), L.ptr(loss), B, Cc, H, W, p,
+                                          1 if norm_pix else 0, denom, L.stream()), 'mae_loss_fwd')
+    return loss
+
+
+def mae_loss_bwd(img, pred, mask, gscale, p, norm_pix, denom):
+    B, Cc, H, W = img.shape
+    dpred = torch.empty_like(pred)
+    L.check(_lib().passl_hip_mae_loss_bwd(L.ptr(img), L.ptr(pred), L.ptr(mask), L.ptr(gscale), L.ptr(dpred),
+                                          B, Cc, H, W, p, 1 if norm_pix else 0, denom, L.stream()),
+            'mae_loss_bwd')
+    return dpred
+
+
+def adamw(p, g, m, v, lr, b1, b2, eps, wd, b1pow, b2pow, grad_scale=1.0):
+    L.check(_lib().passl_hip_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, wd,
+                                   b1pow, b2pow, grad_scale, L.stream()), 'adamw')

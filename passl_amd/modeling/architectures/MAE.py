@@ -1,0 +1,43 @@
+"""MAE_PRETRAIN wrapper — reference passl_v110/modeling/architectures/MAE.py:30-55.
+
+The reference's ``train_iter`` hands the whole ``(img, label)`` tuple to the backbone and returns
+the ``(loss, pred, mask)`` tuple, which OptimizerHook cannot index (``outputs['loss']``,
+hooks/optimizer_hook.py:32) — the wrapper as shipped never trains.  Here it takes
+``inputs[0]`` and returns ``{'loss': loss}`` so that configs/mae/mae_vit_b_pretrain.yaml runs
+unchanged through the v110 Trainer."""
+import torch
+
+from ...hip import nn
+from ...hip.nn import EncoderArena
+from ..backbones import build_backbone
+from .builder import MODELS
+
+
+@MODELS.register()
+class MAE_PRETRAIN(nn.Layer):
+    def __init__(self, architecture=None, mask_ratio=0.75):
+        super().__init__()
+        self.backbone = build_backbone(architecture)
+        self.mask_ratio = mask_ratio
+        self.arena_q = EncoderArena(self.backbone, trainable=True)    # flat params/grads (AdamW, DP)
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.arena_q.refresh()
+        return r
+
+    def train_iter(self, *inputs, **kwargs):
+        img = inputs[0]
+        self.arena_q.refresh()
+        loss, pred, mask = self.backbone(img, self.mask_ratio, noise=kwargs.get('noise', None))
+        return dict(loss=loss)
+
+    def forward(self, *inputs, mode='train', **kwargs):
+        if mode == 'train':
+            return self.train_iter(*inputs, **kwargs)
+        elif mode == 'extract':
+            with torch.no_grad():
+                self.arena_q.refresh()
+                return self.backbone(*inputs)
+        else:
+            raise Exception('No such mode: {}'.format(mode))

@@ -1,3 +1,4 @@
 from .builder import MODELS, build_model
 from .moco import MoCo
 from .simclr import SimCLR
+from .MAE import MAE_PRETRAIN

@@ -1,0 +1,279 @@
+"""MAE (masked autoencoder, ViT encoder + light decoder) on the MI355X HIP path.
+
+Constructor, registry name, sub-layer / state_dict names and the ``forward(imgs, mask_ratio)``
+-> ``(loss, pred, mask)`` contract are the reference's ``MAE`` (passl_v110/modeling/backbones/
+mae.py:318-564, twin of passl/models/mae.py:37-290); Mlp / Attention / Block follow :61-189.
+Execution: tokens are 2-D rows [B*T, C] in the compute dtype; every Linear is the implicit-GEMM
+kernel (bias, residual add in the epilogue; fp32 output for the pixel prediction), LayerNorm / GELU /
+attention / token gather-unshuffle / patchify / masked-patch loss are HIP kernels
+(csrc/vit.hip, csrc/attention.hip).  ``pos_embed`` / ``decoder_pos_embed`` are fixed sin-cos tables
+(reference: parameters with stop_gradient=True) kept as buffers under the same state_dict keys.
+The per-sample noise of random_masking comes from ``torch.rand`` on the device (``noise=`` lets
+tests inject the reference's draw); the argsort pair is replaced by a rank kernel."""
+import math
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as tnn
+from torch.autograd import Function
+
+from ...hip import config, nn, ops, plan as P
+from ...modules.get_sincos_pe import get_2d_sincos_pos_embed
+from .builder import BACKBONES
+
+
+@torch.no_grad()
+def xavier_uniform_(w, fan_in, fan_out):
+    a = math.sqrt(6.0 / (fan_in + fan_out))
+    w.copy_((torch.rand(w.shape) * 2 - 1) * a)
+
+
+@torch.no_grad()
+def trunc_normal_(w, std=0.02):
+    w.copy_(torch.fmod(torch.randn(w.shape), 2.0) * std)
+
+
+class Identity(nn.Layer):
+    def forward(self, x):
+        return x
+
+
+class Mlp(nn.Layer):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        assert drop == 0., 'dropout is not used by the MAE pre-training recipe'
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x, residual=None):
+        return self.fc2(self.act(self.fc1(x)), residual=residual)
+
+
+class _PatchProj(nn.Layer):
+    """The 16x16/stride-16 patch-embedding convolution as a GEMM over patchified rows.  ``weight`` is
+    logically [embed_dim, in_chans, p, p] (reference layout) and physically [embed_dim][p][p][in_chans]
+    = the K-order the patchify kernel writes."""
+    krsc_weight = True
+    no_dgrad = True           # the image needs no gradient
+
+    def __init__(self, in_chans, embed_dim, patch):
+        super().__init__()
+        dev = config.get_device()
+        self.patch, self.in_chans, self.out_features = patch, in_chans, embed_dim
+        self.in_features = in_chans * patch * patch
+        self.geom = P.ConvGeom(self.in_features, embed_dim, 1, 1, 0)
+        self.weight = tnn.Parameter(torch.empty(embed_dim, in_chans, patch, patch, device=dev))
+        self.bias = tnn.Parameter(torch.zeros(embed_dim, device=dev))
+        self._rt = None
+        self._plans = {}
+
+    _plan = nn.Linear._plan
+
+    def forward(self, rows):
+        return nn._LinearFn.apply(rows, self.weight, self.bias, self, False, False, None)
+
+
+class PatchEmbed(nn.Layer):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True):
+        super().__init__()
+        self.img_size = (img_size, img_size)
+        self.patch_size = (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = _PatchProj(in_chans, embed_dim, patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer else Identity()
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        assert H == self.img_size[0], f"Input image height ({H}) doesn't match model ({self.img_size[0]})."
+        assert W == self.img_size[1], f"Input image width ({W}) doesn't match model ({self.img_size[1]})."
+        dtype = nn._need_rt(self.proj).arena.dtype
+        rows = ops.patchify(x.contiguous().float(), self.patch_size[0], dtype)
+        return self.norm(self.proj(rows))                    # [B*L, embed_dim]
+
+
+class Attention(nn.Layer):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        assert attn_drop == 0. and proj_drop == 0.
+        self.num_heads = num_heads
+        self.head_dim = dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias_attr=None if qkv_bias else False)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, B, T, residual=None):
+        a = nn.attention(self.qkv(x), B, T, self.num_heads, self.head_dim, self.scale)
+        return self.proj(a, residual=residual)
+
+
+class Block(nn.Layer):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        assert drop_path == 0., 'stochastic depth is not used by the MAE pre-training recipe'
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x, B, T):
+        x = self.attn(self.norm1(x), B, T, residual=x)       # x + attn(norm1(x)): add in proj's epilogue
+        return self.mlp(self.norm2(x), residual=x)           # x + mlp(norm2(x)): add in fc2's epilogue
+
+
+class _GatherFn(Function):
+    @staticmethod
+    def forward(ctx, x, cls_token, pos, ids_keep, ids_restore, B, L):
+        ctx.save_for_backward(ids_restore)
+        ctx.cls, ctx.dims = cls_token, (B, L, ids_keep.shape[1])
+        return ops.mae_gather(x, cls_token.detach().view(-1), pos.view(-1, pos.shape[-1]), ids_keep, B, L)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids_restore,) = ctx.saved_tensors
+        B, L, K = ctx.dims
+        cls = ctx.cls
+        if cls.grad is None:
+            cls.grad = torch.zeros_like(cls)
+        dx = ops.mae_gather_bwd(dout.contiguous(), ids_restore, cls.grad, B, L, K)
+        return dx, None, None, None, None, None, None
+
+
+class _UnshuffleFn(Function):
+    @staticmethod
+    def forward(ctx, x, mask_token, pos, ids_keep, ids_restore, B):
+        ctx.save_for_backward(ids_keep, ids_restore)
+        ctx.tok, ctx.B = mask_token, B
+        return ops.mae_unshuffle(x, mask_token.detach().view(-1), pos.view(-1, pos.shape[-1]), ids_restore,
+                                 B, ids_keep.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids_keep, ids_restore = ctx.saved_tensors
+        tok = ctx.tok
+        if tok.grad is None:
+            tok.grad = torch.zeros_like(tok)
+        dx = ops.mae_unshuffle_bwd(dout.contiguous(), ids_keep, ids_restore, tok.grad, ctx.B)
+        return dx, None, None, None, None, None
+
+
+class _MAELossFn(Function):
+    @staticmethod
+    def forward(ctx, pred, imgs, mask, p, norm_pix, denom):
+        ctx.save_for_backward(pred, imgs, mask)
+        ctx.args = (p, norm_pix, denom)
+        return ops.mae_loss_fwd(imgs, pred, mask, p, norm_pix, denom)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, imgs, mask = ctx.saved_tensors
+        p, norm_pix, denom = ctx.args
+        return ops.mae_loss_bwd(imgs, pred, mask, gloss.contiguous().float(), p, norm_pix, denom), None, \
+            None, None, None, None
+
+
+@BACKBONES.register()
+class MAE(nn.Layer):
+    """Masked Autoencoder with VisionTransformer backbone."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
+                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.,
+                 norm_layer=partial(nn.LayerNorm, epsilon=1e-6), norm_pix_loss=False):
+        super().__init__()
+        dev = config.get_device()
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = tnn.Parameter(torch.zeros(1, 1, embed_dim, device=dev))
+        self.register_buffer('pos_embed', torch.zeros(1, num_patches + 1, embed_dim, device=dev))
+        self.blocks = tnn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer)
+                                      for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.decoder_embed = nn.Linear(embed_dim, decoder_embed_dim)
+        self.mask_token = tnn.Parameter(torch.zeros(1, 1, decoder_embed_dim, device=dev))
+        self.register_buffer('decoder_pos_embed', torch.zeros(1, num_patches + 1, decoder_embed_dim, device=dev))
+        self.decoder_blocks = tnn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio, qkv_bias=True,
+                                                    norm_layer=norm_layer) for _ in range(decoder_depth)])
+        self.decoder_norm = norm_layer(decoder_embed_dim)
+        self.decoder_pred = nn.Linear(decoder_embed_dim, patch_size ** 2 * in_chans)
+        self.norm_pix_loss = norm_pix_loss
+        self.in_chans = in_chans
+        self.initialize_weights()
+
+    @torch.no_grad()
+    def initialize_weights(self):
+        g = int(self.patch_embed.num_patches ** .5)
+        self.pos_embed.copy_(torch.from_numpy(
+            get_2d_sincos_pos_embed(self.pos_embed.shape[-1], g, cls_token=True)).float().unsqueeze(0))
+        self.decoder_pos_embed.copy_(torch.from_numpy(
+            get_2d_sincos_pos_embed(self.decoder_pos_embed.shape[-1], g, cls_token=True)).float().unsqueeze(0))
+        trunc_normal_(self.cls_token, std=0.02)              # create_parameter(default_initializer=trunc_normal_)
+        w = self.patch_embed.proj.weight                      # xavier_uniform_ on the [D, C*p*p] view
+        xavier_uniform_(w, w.shape[1] * w.shape[2] * w.shape[3], w.shape[0])
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                xavier_uniform_(m.weight, m.weight.shape[0], m.weight.shape[1])
+                if m.bias is not None:
+                    m.bias.zero_()
+            elif isinstance(m, nn.LayerNorm):
+                m.bias.zero_()
+                m.weight.fill_(1.0)
+
+    # -- reference helpers kept for API parity (host-side, not on the hot path) ------------------
+    def patchify(self, imgs):
+        p = self.patch_embed.patch_size[0]
+        h = w = imgs.shape[2] // p
+        x = imgs.reshape(imgs.shape[0], self.in_chans, h, p, w, p)
+        return torch.einsum('nchpwq->nhwpqc', x).reshape(imgs.shape[0], h * w, p ** 2 * self.in_chans)
+
+    def unpatchify(self, x):
+        p = self.patch_embed.patch_size[0]
+        h = w = int(x.shape[1] ** .5)
+        x = x.reshape(x.shape[0], h, w, p, p, self.in_chans)
+        return torch.einsum('nhwpqc->nchpwq', x).reshape(x.shape[0], self.in_chans, h * p, h * p)
+
+    def random_masking_ids(self, B, L, mask_ratio, noise=None):
+        len_keep = int(L * (1 - mask_ratio))
+        if noise is None:
+            noise = torch.rand(B, L, device=self.cls_token.device)     # paddle.rand([N, L])
+        ids_keep, ids_restore, mask = ops.mae_mask(noise.contiguous().float(), len_keep)
+        return ids_keep, ids_restore, mask, len_keep
+
+    def forward_encoder(self, imgs, mask_ratio, noise=None):
+        B = imgs.shape[0]
+        L = self.patch_embed.num_patches
+        x = self.patch_embed(imgs)                                       # [B*L, D]
+        ids_keep, ids_restore, mask, K = self.random_masking_ids(B, L, mask_ratio, noise)
+        x = _GatherFn.apply(x, self.cls_token, self.pos_embed, ids_keep, ids_restore, B, L)
+        for blk in self.blocks:
+            x = blk(x, B, K + 1)
+        return self.norm(x), mask, (ids_keep, ids_restore)
+
+    def forward_decoder(self, x, ids, B):
+        ids_keep, ids_restore = ids
+        L = ids_restore.shape[1]
+        x = self.decoder_embed(x)
+        x = _UnshuffleFn.apply(x, self.mask_token, self.decoder_pos_embed, ids_keep, ids_restore, B)
+        for blk in self.decoder_blocks:
+            x = blk(x, B, L + 1)
+        x = self.decoder_norm(x)
+        return self.decoder_pred(x, out_f32=True)                        # [B*(L+1), p*p*3] fp32, cls rows included
+
+    def forward_loss(self, imgs, pred_rows, mask):
+        denom = float(mask.shape[0] * (mask.shape[1] - int(self._len_keep)))
+        return _MAELossFn.apply(pred_rows, imgs.contiguous().float(), mask, self.patch_embed.patch_size[0],
+                                bool(self.norm_pix_loss), denom)
+
+    def forward(self, imgs, mask_ratio=0.75, noise=None):
+        B = imgs.shape[0]
+        L = self.patch_embed.num_patches
+        self._len_keep = int(L * (1 - mask_ratio))
+        latent, mask, ids = self.forward_encoder(imgs, mask_ratio, noise)
+        pred_rows = self.forward_decoder(latent, ids, B)
+        loss = self.forward_loss(imgs, pred_rows, mask)
+        pred = pred_rows.view(B, L + 1, -1)[:, 1:, :]                    # remove cls token
+        return loss, pred, mask

@@ -204,3 +204,79 @@ class LarsMomentumOptimizer(object):
             v.copy_(sd['velocity_%d' % i])
         if 'LR_Scheduler' in sd and isinstance(self._learning_rate, LRScheduler):
             self._learning_rate.set_state_dict(sd['LR_Scheduler'])
+
+
+@OPTIMIZERS.register()
+class AdamW(object):
+    """paddle.optimizer.AdamW (registered by the reference at passl_v110/solver/optimizer.py:22) as ONE
+    launch over the flat arena.  adamw op  [Paddle-semantics]:
+        p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+        p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps*sqrt(1-b2^t))
+    A float ``weight_decay`` decays EVERY trainable parameter (configs/mae/mae_vit_b_pretrain.yaml has no
+    exclusion list; fixed sin-cos embeddings are buffers and are not touched)."""
+    type = 'adamw'
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-08, parameters=None,
+                 weight_decay=0.01, lr_ratio=None, apply_decay_param_fun=None, grad_clip=None,
+                 lazy_mode=False, multi_precision=False, name=None):
+        if apply_decay_param_fun is not None or lr_ratio is not None or grad_clip is not None:
+            raise NotImplementedError('per-parameter decay / lr ratios / clipping are not used by the MAE '
+                                      'pre-training config and are not built')
+        self._learning_rate = learning_rate
+        self._b1, self._b2, self._eps = float(beta1), float(beta2), float(epsilon)
+        self._wd = float(weight_decay) if weight_decay else 0.0
+        params = [p for p in (parameters or []) if p.requires_grad]
+        arenas = []
+        for p in params:
+            a = getattr(p, '_passl_arena', None)
+            if a is None:
+                raise NotImplementedError('AdamW optimises parameters that live in an EncoderArena')
+            if a not in arenas:
+                arenas.append(a)
+        for a in arenas:
+            if sum(1 for p in params if p._passl_arena is a) != len(a.param_slices):
+                raise NotImplementedError('optimising a subset of an arena is not supported')
+        self._parameter_list = params
+        self._arenas = arenas
+        self._m = [torch.zeros_like(a.flat[:a.n_train]) for a in arenas]
+        self._v = [torch.zeros_like(a.flat[:a.n_train]) for a in arenas]
+        self._t = 0
+        self.grad_scale = 1.0
+
+    def get_lr(self):
+        lr = self._learning_rate
+        return float(lr()) if isinstance(lr, LRScheduler) else float(lr)
+
+    def clear_grad(self, set_to_zero=True):
+        for a in self._arenas:
+            a.clear_grad()
+
+    clear_gradients = clear_grad
+
+    @torch.no_grad()
+    def step(self):
+        lr = self.get_lr()
+        self._t += 1
+        b1p, b2p = self._b1 ** self._t, self._b2 ** self._t
+        for a, m, v in zip(self._arenas, self._m, self._v):
+            if a.reducer is not None:
+                a.reducer.finish()
+            ops.adamw(a.flat[:a.n_train], a.grads, m, v, lr, self._b1, self._b2, self._eps, self._wd, b1p, b2p,
+                      self.grad_scale)
+
+    def state_dict(self):
+        sd = {'t': self._t}
+        for i, (m, v) in enumerate(zip(self._m, self._v)):
+            sd['moment1_%d' % i] = m.detach().cpu()
+            sd['moment2_%d' % i] = v.detach().cpu()
+        if isinstance(self._learning_rate, LRScheduler):
+            sd['LR_Scheduler'] = self._learning_rate.state_dict()
+        return sd
+
+    def set_state_dict(self, sd):
+        self._t = int(sd['t'])
+        for i, (m, v) in enumerate(zip(self._m, self._v)):
+            m.copy_(torch.as_tensor(sd['moment1_%d' % i]))
+            v.copy_(torch.as_tensor(sd['moment2_%d' % i]))
+        if 'LR_Scheduler' in sd and isinstance(self._learning_rate, LRScheduler):
+            self._learning_rate.set_state_dict(sd['LR_Scheduler'])

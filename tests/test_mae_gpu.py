@@ -1,0 +1,265 @@
+"""MAE path on a real MI355X through the registries and the C ABI: per-kernel parity against plain
+PyTorch fp32/fp64 references (LayerNorm, GELU, fused attention, masking ranks, token gather /
+unshuffle, patchify, masked-patch loss, AdamW) and whole training steps against the golden vectors
+produced by the reference's own MAE sources (tests/golden/mae_*.npz)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import mae_util as U                           # noqa: E402
+from oracle import mae as M                    # noqa: E402
+from passl_amd.hip import ops                  # noqa: E402
+
+DEV = 'cuda'
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rnd(t, dtype):
+    return t.to(dtype).float()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M_,C', [(100, 768), (37, 512), (5, 64), (300, 2048)])
+def test_layernorm_fwd_bwd(dtype, M_, C):
+    gen = torch.Generator().manual_seed(C)
+    x = rnd(torch.randn(M_, C, generator=gen) * 2 + 0.3, dtype).requires_grad_(True)
+    g = (torch.rand(C, generator=gen) + 0.5).requires_grad_(True)
+    b = torch.randn(C, generator=gen).requires_grad_(True)
+    y = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-6)
+    dy = rnd(torch.randn(M_, C, generator=gen), dtype)
+    y.backward(dy.double())
+    yd, mean, rstd = ops.layernorm_fwd(x.detach().to(DEV).to(dtype), g.detach().to(DEV), b.detach().to(DEV), 1e-6)
+    t = 1e-5 if dtype == torch.float32 else 2e-2
+    assert relmax(yd.float(), y.detach()) < t
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV).to(dtype), x.detach().to(DEV).to(dtype), g.detach().to(DEV), mean, rstd, dg, db)
+    assert relmax(dx.float(), x.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert relmax(dg, g.grad) < 1e-4 and relmax(db, b.grad) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_gelu(dtype):
+    gen = torch.Generator().manual_seed(1)
+    x = rnd(torch.randn(64, 3072, generator=gen) * 2, dtype).requires_grad_(True)
+    y = F.gelu(x.double())
+    dy = rnd(torch.randn(64, 3072, generator=gen), dtype)
+    y.backward(dy.double())
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    assert relmax(ops.gelu_fwd(x.detach().to(DEV).to(dtype)).float(), y.detach()) < t
+    assert relmax(ops.gelu_bwd(dy.to(DEV).to(dtype), x.detach().to(DEV).to(dtype)).float(), x.grad) < t
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,T,H,DH', [(3, 50, 12, 64), (2, 197, 16, 32), (4, 5, 4, 32), (2, 17, 2, 32),
+                                      (1, 197, 3, 64), (1, 208, 2, 64)])
+def test_attention_fwd_bwd(dtype, B, T, H, DH):
+    gen = torch.Generator().manual_seed(T)
+    qkv = rnd(torch.randn(B, T, 3, H, DH, generator=gen), dtype).requires_grad_(True)
+    q, k, v = [qkv.double()[:, :, i].permute(0, 2, 1, 3) for i in range(3)]      # [B,H,T,d]
+    scale = DH ** -0.5
+    att = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    out = (att @ v).permute(0, 2, 1, 3).reshape(B * T, H * DH)
+    dout = rnd(torch.randn(B * T, H * DH, generator=gen), dtype)
+    out.backward(dout.double())
+    qd = qkv.detach().reshape(B * T, 3 * H * DH).to(DEV).to(dtype)
+    od, lse = ops.attention_fwd(qd, B, T, H, DH, scale)
+    t = 2e-5 if dtype == torch.float32 else 2e-2
+    assert relmax(od.float(), out.detach()) < t
+    ref_lse = torch.logsumexp(q @ k.transpose(-1, -2) * scale, dim=-1)
+    assert float((lse.cpu().double() - ref_lse).abs().max()) < 1e-4
+    dq = ops.attention_bwd(qd, od, dout.to(DEV).to(dtype), lse, B, T, H, DH, scale)
+    assert relmax(dq.float().reshape(B, T, 3, H, DH), qkv.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+
+
+def test_attention_rejects_unsupported_shapes():
+    from passl_amd.hip.lib import PasslHipError
+    x = torch.zeros(2 * 300, 3 * 2 * 64, device=DEV)
+    with pytest.raises(PasslHipError):
+        ops.attention_fwd(x, 2, 300, 2, 64, 0.125)           # T > 208
+    with pytest.raises(PasslHipError):
+        ops.attention_fwd(torch.zeros(2 * 8, 3 * 2 * 48, device=DEV), 2, 8, 2, 48, 0.1)   # d = 48
+
+
+def test_masking_and_token_plumbing():
+    gen = torch.Generator().manual_seed(2)
+    B, L, D, Dd = 5, 196, 64, 32
+    noise = torch.rand(B, L, generator=gen)
+    noise[0, 3] = noise[0, 100]                                # a tie: lower index first (stable)
+    keep, mask, restore = M.random_masking_ids(noise, 0.75)
+    K = keep.shape[1]
+    ik, ir, mk = ops.mae_mask(noise.to(DEV), K)
+    # argsort is not stable for the tie: compare through the defining properties
+    assert torch.equal(ir.cpu().long()[1:], restore[1:]) and torch.equal(ik.cpu().long()[1:], keep[1:])
+    assert torch.equal(mk.cpu()[1:], mask[1:])
+    assert sorted(ir[0].cpu().tolist()) == list(range(L)) and int(ir[0, 3]) + 1 == int(ir[0, 100])
+    for dtype in DTYPES:
+        x = rnd(torch.randn(B, L, D, generator=gen), dtype)
+        cls = torch.randn(D, generator=gen)
+        pos = torch.randn(L + 1, D, generator=gen)
+        ref = torch.cat([(cls + pos[0]).expand(B, 1, D),
+                         torch.gather(x + pos[1:], 1, keep.unsqueeze(-1).expand(-1, -1, D))], 1)
+        got = ops.mae_gather(x.reshape(B * L, D).to(DEV).to(dtype), cls.to(DEV), pos.to(DEV), ik, B, L)
+        assert relmax(got.float().reshape(B, K + 1, D), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+        dout = rnd(torch.randn(B, K + 1, D, generator=gen), dtype)
+        dcls = torch.zeros(D, device=DEV)
+        dx = ops.mae_gather_bwd(dout.reshape(-1, D).to(DEV).to(dtype), ir, dcls, B, L, K)
+        dref = torch.zeros(B, L, D).scatter_(1, keep.unsqueeze(-1).expand(-1, -1, D), dout[:, 1:])
+        assert relmax(dx.float().reshape(B, L, D), dref) < 1e-6 and relmax(dcls, dout[:, 0].sum(0)) < 1e-5
+        # decoder side
+        xd = rnd(torch.randn(B, K + 1, Dd, generator=gen), dtype)
+        mt = torch.randn(Dd, generator=gen)
+        dpos = torch.randn(L + 1, Dd, generator=gen)
+        x_ = torch.cat([xd[:, 1:], mt.expand(B, L - K, Dd)], 1)
+        x_ = torch.gather(x_, 1, restore.unsqueeze(-1).expand(-1, -1, Dd))
+        refd = torch.cat([xd[:, :1], x_], 1) + dpos
+        gotd = ops.mae_unshuffle(xd.reshape(-1, Dd).to(DEV).to(dtype), mt.to(DEV), dpos.to(DEV), ir, B, K)
+        assert relmax(gotd.float().reshape(B, L + 1, Dd), refd) < (1e-6 if dtype == torch.float32 else 1e-2)
+        dd = rnd(torch.randn(B, L + 1, Dd, generator=gen), dtype)
+        dmt = torch.zeros(Dd, device=DEV)
+        dxd = ops.mae_unshuffle_bwd(dd.reshape(-1, Dd).to(DEV).to(dtype), ik, ir, dmt, B)
+        dref2 = torch.cat([dd[:, :1], torch.gather(dd[:, 1:], 1, keep.unsqueeze(-1).expand(-1, -1, Dd))], 1)
+        assert relmax(dxd.float().reshape(B, K + 1, Dd), dref2) < 1e-6
+        assert relmax(dmt, (dd[:, 1:] * mask.unsqueeze(-1)).sum((0, 1))) < 1e-4
+
+
+def test_patchify_and_masked_patch_loss():
+    gen = torch.Generator().manual_seed(3)
+    B, p, HW = 3, 16, 64
+    img = torch.randn(B, 3, HW, HW, generator=gen)
+    ref = M.patchify(img, p)
+    for dtype in DTYPES:
+        got = ops.patchify(img.to(DEV), p, dtype)
+        assert float((got.float().cpu().reshape(ref.shape) - rnd(ref, dtype)).abs().max()) == 0
+    L = (HW // p) ** 2
+    mask = (torch.rand(B, L, generator=gen) > 0.25).float()
+    for norm_pix in (False, True):
+        pred = torch.randn(B, L + 1, p * p * 3, generator=gen, dtype=torch.float64).requires_grad_(True)
+        tgt = ref.double()
+        if norm_pix:
+            tgt = (tgt - tgt.mean(-1, keepdim=True)) / (tgt.var(-1, keepdim=True) + 1e-6) ** .5
+        loss = ((((pred[:, 1:] - tgt) ** 2).mean(-1)) * mask).sum() / mask.sum()
+        (loss * 1.7).backward()
+        pd = pred.detach().float().to(DEV).reshape(-1, p * p * 3)
+        got = ops.mae_loss_fwd(img.to(DEV), pd, mask.to(DEV), p, norm_pix, float(mask.sum()))
+        assert abs(float(got) - float(loss)) < 2e-5 * max(1.0, float(loss))
+        dp = ops.mae_loss_bwd(img.to(DEV), pd, mask.to(DEV), torch.tensor([1.7], device=DEV), p, norm_pix,
+                              float(mask.sum()))
+        assert relmax(dp.reshape(B, L + 1, -1), pred.grad) < 1e-4
+        assert float(dp.reshape(B, L + 1, -1)[:, 0].abs().max()) == 0
+
+
+def test_adamw_kernel_vs_oracle_rule():
+    gen = torch.Generator().manual_seed(4)
+    n = 100003
+    p = torch.randn(n, generator=gen); g = torch.randn(n, generator=gen) * 0.1
+    m = torch.zeros(n); v = torch.zeros(n)
+    pd, gd, md, vd = p.to(DEV), g.to(DEV), m.to(DEV), v.to(DEV)
+    lr, b1, b2, eps, wd = 1e-2, 0.9, 0.95, 1e-8, 0.05
+    pr = p.double().clone(); mr = m.double().clone(); vr = v.double().clone()
+    for t in (1, 2, 3):
+        ops.adamw(pd, gd, md, vd, lr, b1, b2, eps, wd, b1 ** t, b2 ** t, 0.5)
+        gg = g.double() * 0.5
+        pr = pr * (1 - lr * wd)
+        mr = b1 * mr + (1 - b1) * gg
+        vr = b2 * vr + (1 - b2) * gg * gg
+        pr = pr - lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t) * mr / (vr.sqrt() + eps * math.sqrt(1 - b2 ** t))
+    assert float((pd.cpu().double() - pr).abs().max()) < 1e-5
+    assert float((md.cpu().double() - mr).abs().max()) < 1e-6 and float((vd.cpu().double() - vr).abs().max()) < 1e-6
+
+
+SMALL = dict(img_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=4, decoder_embed_dim=64,
+             decoder_depth=2, decoder_num_heads=2, mlp_ratio=4.0)
+WATCH = ['patch_embed.proj.weight', 'cls_token', 'mask_token', 'blocks.0.attn.qkv.weight',
+         'blocks.1.mlp.fc2.bias', 'blocks.1.norm2.weight', 'norm.bias', 'decoder_embed.weight',
+         'decoder_blocks.0.attn.proj.weight', 'decoder_blocks.1.mlp.fc1.weight', 'decoder_pred.bias']
+TOL_F32 = dict(loss=1e-3, pred=1e-3, grad=1e-3, param=1e-4)
+# bf16 storage of activations / Linear operands (fp32 accumulate, fp32 loss): stated bounds for the
+# benchmark dtype (the reference has no bf16 path)
+TOL_BF16 = dict(loss=3e-2, pred=1e-1, grad=1e-1, param=2e-2)
+
+
+def _run_against_golden(name, cfg, dtype, steps_cap, tol):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    N, steps, npl = [int(v) for v in z['meta']]
+    oracle0 = M.MAEOracle(dict(cfg, norm_pix_loss=bool(npl)), seed=0, **U.SOLVER)
+    model, opt = U.build_product(cfg, dtype, bool(npl))
+    U.load_oracle_state(model, oracle0)
+    model.train()
+    gen = torch.Generator().manual_seed(777)
+    L = (cfg['img_size'] // cfg['patch_size']) ** 2
+    report, bad = [], []
+
+    def check(what, got, ref, nominal, rel=False):
+        got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+        scale = max(float(np.max(np.abs(ref))), 1e-12) if rel else 1.0
+        err = float(np.max(np.abs(got - ref))) / scale
+        line = '%-50s err %.3e  bound %.1e' % (what, err, nominal)
+        report.append(line)
+        if not err <= nominal:
+            bad.append(line)
+
+    for s in range(min(steps, steps_cap)):
+        x = torch.randn(N, 3, cfg['img_size'], cfg['img_size'], generator=gen)
+        noise = torch.rand(N, L, generator=gen)
+        captured = {}
+        bb = model.backbone
+        orig = bb.forward_loss
+
+        def spy(imgs, pred_rows, mask):
+            captured.update(pred=pred_rows.detach(), mask=mask.detach())
+            return orig(imgs, pred_rows, mask)
+        bb.forward_loss = spy
+        out = U.product_step(model, opt, x.to(DEV), noise.to(DEV))
+        bb.forward_loss = orig
+        pre = 's%d_' % s
+        check(pre + 'loss', float(out['loss'].detach()), z[pre + 'loss'], tol['loss'])
+        assert np.array_equal(captured['mask'].cpu().numpy().astype(np.uint8), z[pre + 'mask'])
+        pred = captured['pred'].float().cpu().reshape(N, L + 1, -1)[:, 1:]
+        check(pre + 'pred[:, :4, :8]', pred[:, :4, :8].numpy(), z[pre + 'pred_head'], tol['pred'])
+        ps = dict(model.backbone.named_parameters())
+        for n in WATCH:
+            check(pre + 'gradnorm/' + n, ps[n].grad.double().norm().item(), z[pre + 'gradnorm/' + n],
+                  tol['grad'], rel=True)
+            check(pre + 'pnorm/' + n, ps[n].detach().double().norm().item(), z[pre + 'pnorm/' + n],
+                  tol['param'], rel=True)
+    print('\n'.join(report))
+    try:
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/parity_%s_%s.txt' % (name, str(dtype).split('.')[-1]), 'w') as f:
+            f.write('\n'.join(report) + '\n\nVIOLATIONS (%d)\n' % len(bad) + '\n'.join(bad) + '\n')
+    except OSError:
+        pass
+    assert not bad, 'parity violations:\n' + '\n'.join(bad)
+
+
+def test_golden_small_fp32():
+    _run_against_golden('mae_small', SMALL, torch.float32, 3, TOL_F32)
+
+
+def test_golden_small_rawpix_fp32():
+    _run_against_golden('mae_small_rawpix', SMALL, torch.float32, 1, TOL_F32)
+
+
+def test_golden_vit_b_fp32():
+    """BASELINE configs[3] architecture: ViT-B/16, 50 encoder / 197 decoder tokens."""
+    _run_against_golden('mae_vit_b', M.VIT_B, torch.float32, 2, TOL_F32)
+
+
+def test_golden_small_bf16():
+    _run_against_golden('mae_small', SMALL, torch.bfloat16, 3, TOL_BF16)
+
+
+def test_golden_vit_b_bf16():
+    _run_against_golden('mae_vit_b', M.VIT_B, torch.bfloat16, 2, TOL_BF16)
