@@ -34,9 +34,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None,
                     help='per-GPU batch (default: 256 = BASELINE configs[1]; simclr: 64)')
-    ap.add_argument('--workload', default='moco', choices=['moco', 'simclr'],
-                    help="moco = BASELINE.json's metric (default); simclr = the SimCLR row "
-                         '(no-maxpool R50, NT-Xent+CO2, LARS), an extra measurement')
+    ap.add_argument('--workload', default='moco', choices=['moco', 'simclr', 'mae'],
+                    help="moco = BASELINE.json's metric (default); simclr / mae = the SimCLR and MAE "
+                         'rows (extra measurements: no-maxpool R50 + NT-Xent+CO2 + LARS; ViT-B/16 MAE)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
@@ -68,11 +68,12 @@ def cpu_baseline():
 
 def main():
     args = parse()
-    simclr = args.workload == 'simclr'
+    simclr, mae = args.workload == 'simclr', args.workload == 'mae'
     if args.batch is None:
         args.batch = 64 if simclr else 256
-    # SimCLR: 2 views x (fwd + bwd = 3) x 15.99 GMAC x 2 FLOP per two-view sample
-    flop_per_sample = 2 * 3 * 15.99e9 * 2 if simclr else FLOP_PER_SAMPLE
+    # SimCLR: 2 views x (fwd + bwd = 3) x 15.99 GMAC x 2 FLOP per two-view sample;
+    # MAE ViT-B/16: 3 x 9.78 GMAC x 2 FLOP per image
+    flop_per_sample = 2 * 3 * 15.99e9 * 2 if simclr else (3 * 9.78e9 * 2 if mae else FLOP_PER_SAMPLE)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d' % args.gpus
@@ -83,8 +84,9 @@ def main():
     from passl_amd.hooks import OptimizerHook, LRSchedulerHook
     from passl_amd.utils.config import get_config
 
-    cfg = get_config(os.path.join(ROOT, 'configs/simclr/simclr_r50_synthetic.yaml' if simclr
-                                  else 'configs/moco/moco_v2_r50_synthetic.yaml'),
+    cfg = get_config(os.path.join(ROOT, 'configs/simclr/simclr_r50_synthetic.yaml' if simclr else
+                                  ('configs/mae/mae_vit_b_synthetic.yaml' if mae else
+                                   'configs/moco/moco_v2_r50_synthetic.yaml')),
                      ['dataloader.train.sampler.batch_size=%d' % args.batch,
                       'compute_dtype=%s' % args.dtype])
     cfg.timestamp = ''
@@ -148,13 +150,17 @@ def main():
         ips = args.batch * world * args.steps / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         out = {
-            'metric': 'images/sec/node (2-view), %s bs%d/GPU' % (
+            'metric': ('images/sec/node, MAE ViT-B/16 mask 0.75 bs%d/GPU' % args.batch) if mae else
+            'images/sec/node (2-view), %s bs%d/GPU' % (
                 'SimCLR R50 (no stem max-pool)' if simclr else 'MoCo-v2 R50', args.batch),
             'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': ('SimCLR ResNet-50 (no stem max-pool) %s, bs=%d/GPU, 2x224^2 '
+            'config': {'workload': ('MAE ViT-B/16 %s, bs=%d/GPU, 224^2 synthetic images, mask 0.75 (50 '
+                                    'encoder / 197 decoder tokens), norm_pix_loss, AdamW (MAE row; '
+                                    'BASELINE configs[3])' if mae else
+                                    'SimCLR ResNet-50 (no stem max-pool) %s, bs=%d/GPU, 2x224^2 '
                                     'synthetic views, NT-Xent+CO2 T=0.1, LARS (SimCLR row; '
                                     'BASELINE configs[2] shape at a smaller per-GPU batch)'
                                     if simclr else
@@ -182,7 +188,7 @@ def main():
             if wn:
                 out['roofline']['wgrad_kernel_ms_per_step'] = round(wms / args.steps, 3)
                 out['roofline']['igemm_kernel_ms_per_step'] = round(ms / args.steps, 3)
-        if world == 1 and not args.no_cpu_baseline and not simclr:
+        if world == 1 and not args.no_cpu_baseline and not simclr and not mae:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
