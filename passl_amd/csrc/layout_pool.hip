@@ -155,31 +155,38 @@ __global__ void __launch_bounds__(kThreads) avgpool_bwd_kernel(const T* __restri
   }
 }
 
-// out[c] = sum_m x[m][c]; block = 8-channel chunk group; threads split rows, LDS reduce.
+// out[c] += sum_m x[m][c] (out zeroed by the host wrapper).  A block covers 32 consecutive
+// 8-channel chunks (512 contiguous bytes per row in bf16) x one slab of rows: 32 chunk columns x
+// 8 row lanes, coalesced row reads, LDS reduce over the row lanes, one atomic per column per block.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) colsum_kernel(const T* __restrict__ x,
                                                           float* __restrict__ out, int64_t M,
-                                                          int C) {
-  __shared__ float red[kThreads][9];
-  const int c8 = blockIdx.x;
+                                                          int C, int rows_per_block) {
+  __shared__ float red[8][32 * 8 + 8];
+  const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cc) * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t m = threadIdx.x; m < M; m += kThreads) {
-    float v[8];
-    ElemTraits<T>::load8(x + m * C + c8 * 8, v);
+  if (c < C) {
+    for (int64_t m = r0 + rl; m < r1; m += 8) {
+      float v[8];
+      ElemTraits<T>::load8(x + m * C + c, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += v[e];
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
-  __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + s][e];
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
-    __syncthreads();
   }
-  if (threadIdx.x < 8) out[c8 * 8 + threadIdx.x] = red[0][threadIdx.x];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cc * 8 + e] = acc[e];
+  __syncthreads();
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) s += red[l][threadIdx.x];
+    atomicAdd(out + col, s);
+  }
 }
 
 // dx = dy * (y > 0)
@@ -286,9 +293,14 @@ extern "C" int passl_hip_avgpool_bwd(const void* dy, void* dx, int N, int HW, in
 extern "C" int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype,
                                 passl_stream_t stream) {
   if (!x || !out || M <= 0 || C <= 0 || (C & 7) || !aligned16(x)) return PASSL_EINVAL;
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3(C >> 3), dim3(kThreads), 0,
-                                           as_stream(stream), reinterpret_cast<const T*>(x), out,
-                                           M, C);)
+  if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess)
+    return PASSL_ELAUNCH;
+  int slabs = (int)((M + 255) / 256);
+  if (slabs > 512) slabs = 512;
+  const int rows = (int)((M + slabs - 1) / slabs);
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 255) / 256, slabs),
+                                           dim3(kThreads), 0, as_stream(stream),
+                                           reinterpret_cast<const T*>(x), out, M, C, rows);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

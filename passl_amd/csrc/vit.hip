@@ -263,30 +263,48 @@ __global__ void __launch_bounds__(kThreads) mae_unshuffle_kernel(
 }
 
 // backward: dx[b,0] = dout[b,0]; dx[b,1+r] = dout[b,1+l] where ids_restore[b,l] = r < K (the kept
-// token k sits at position l = ids_keep[b,k]); dmask_token += sum over masked positions
+// token k sits at position l = ids_keep[b,k]); dmask_token += sum over masked positions.
+// A thread keeps ONE column chunk for all the tokens it visits (block = 32 chunks x 8 token lanes,
+// grid.y = token slabs), so the mask-token gradient is accumulated in registers, reduced over the
+// token lanes in LDS and flushed with one atomic per column per block.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) mae_unshuffle_bwd_kernel(
     const T* __restrict__ dout, const int32_t* __restrict__ ids_keep,
     const int32_t* __restrict__ ids_restore, T* __restrict__ dx, float* __restrict__ dmask,
-    int B, int L, int K, int D) {
-  const int cpr = D >> 3;
-  const int64_t total = (int64_t)B * (L + 1) * cpr;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * kThreads) {
-    const int c = (int)(i % cpr) * 8;
-    const int64_t tok = i / cpr;
-    const int t = (int)(tok % (L + 1)), b = (int)(tok / (L + 1));
-    float v[8];
-    if (t <= K) {       // destination row t of dx: source position in dout
-      const int src = t == 0 ? 0 : 1 + ids_keep[(int64_t)b * K + t - 1];
-      ld8(dout + ((int64_t)b * (L + 1) + src) * D + c, v);
-      ElemTraits<T>::store8(dx + ((int64_t)b * (K + 1) + t) * D + c, v);
-    }
-    if (t > 0 && ids_restore[(int64_t)b * L + t - 1] >= K) {
-      ld8(dout + tok * D + c, v);
+    int B, int L, int K, int D, int toks_per_block) {
+  __shared__ float red[8][32 * 8 + 8];
+  const int cc = threadIdx.x & 31, tl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cc) * 8;
+  const int64_t ntok = (int64_t)B * (L + 1);
+  const int64_t t0 = (int64_t)blockIdx.y * toks_per_block;
+  int64_t t1 = t0 + toks_per_block;
+  if (t1 > ntok) t1 = ntok;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < D) {
+    for (int64_t tok = t0 + tl; tok < t1; tok += 8) {
+      const int t = (int)(tok % (L + 1)), b = (int)(tok / (L + 1));
+      float v[8];
+      if (t <= K) {       // destination row t of dx: source position in dout
+        const int src = t == 0 ? 0 : 1 + ids_keep[(int64_t)b * K + t - 1];
+        ld8(dout + ((int64_t)b * (L + 1) + src) * D + c, v);
+        ElemTraits<T>::store8(dx + ((int64_t)b * (K + 1) + t) * D + c, v);
+      }
+      if (t > 0 && ids_restore[(int64_t)b * L + t - 1] >= K) {
+        ld8(dout + tok * D + c, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(dmask + c + e, v[e]);
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
     }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tl][cc * 8 + e] = acc[e];
+  __syncthreads();
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col < D) {
+    float s = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) s += red[l][threadIdx.x];
+    atomicAdd(dmask + col, s);
   }
 }
 
@@ -525,10 +543,14 @@ extern "C" int passl_hip_mae_unshuffle_bwd(const void* dout, const int32_t* ids_
   if (!dout || !ids_keep || !ids_restore || !dx || !dmask_token || B <= 0 || L <= 0 || K <= 0 ||
       K > L || D <= 0 || (D & 7))
     return PASSL_EINVAL;
-  VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_unshuffle_bwd_kernel<T>,
-                                         dim3(grid_for((int64_t)B * (L + 1) * (D >> 3))), dim3(kThreads), 0,
-                                         as_stream(stream), reinterpret_cast<const T*>(dout), ids_keep,
-                                         ids_restore, reinterpret_cast<T*>(dx), dmask_token, B, L, K, D);)
+  const int64_t ntok = (int64_t)B * (L + 1);
+  int slabs = (int)((ntok + 127) / 128);
+  if (slabs > 1024) slabs = 1024;
+  const int tpb = (int)((ntok + slabs - 1) / slabs);
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_unshuffle_bwd_kernel<T>, dim3((D + 255) / 256, slabs),
+                                         dim3(kThreads), 0, as_stream(stream),
+                                         reinterpret_cast<const T*>(dout), ids_keep, ids_restore,
+                                         reinterpret_cast<T*>(dx), dmask_token, B, L, K, D, tpb);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
