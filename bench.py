@@ -33,10 +33,11 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None,
-                    help='per-GPU batch (default: 256 = BASELINE configs[1]; simclr: 64)')
-    ap.add_argument('--workload', default='moco', choices=['moco', 'simclr', 'mae'],
-                    help="moco = BASELINE.json's metric (default); simclr / mae = the SimCLR and MAE "
-                         'rows (extra measurements: no-maxpool R50 + NT-Xent+CO2 + LARS; ViT-B/16 MAE)')
+                    help='per-GPU batch (default: 256 = BASELINE configs[1]; simclr: 64; clip: 128)')
+    ap.add_argument('--workload', default='moco', choices=['moco', 'simclr', 'mae', 'clip'],
+                    help="moco = BASELINE.json's metric (default); simclr / mae / clip = the SimCLR, MAE and "
+                         'CLIP rows (extra measurements: no-maxpool R50 + NT-Xent+CO2 + LARS; ViT-B/16 MAE; '
+                         'CLIP ViT-B/32 image-text pairs)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
@@ -68,12 +69,15 @@ def cpu_baseline():
 
 def main():
     args = parse()
-    simclr, mae = args.workload == 'simclr', args.workload == 'mae'
+    simclr, mae, clip = args.workload == 'simclr', args.workload == 'mae', args.workload == 'clip'
     if args.batch is None:
-        args.batch = 64 if simclr else 256
+        args.batch = 64 if simclr else (128 if clip else 256)
     # SimCLR: 2 views x (fwd + bwd = 3) x 15.99 GMAC x 2 FLOP per two-view sample;
     # MAE ViT-B/16: 3 x 9.78 GMAC x 2 FLOP per image
+    # CLIP ViT-B/32: 4.41 GMAC (image, 50 tokens) + 2.98 GMAC (text, 77 tokens) per pair
     flop_per_sample = 2 * 3 * 15.99e9 * 2 if simclr else (3 * 9.78e9 * 2 if mae else FLOP_PER_SAMPLE)
+    if clip:
+        flop_per_sample = 3 * 7.39e9 * 2
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d' % args.gpus
@@ -86,7 +90,8 @@ def main():
 
     cfg = get_config(os.path.join(ROOT, 'configs/simclr/simclr_r50_synthetic.yaml' if simclr else
                                   ('configs/mae/mae_vit_b_synthetic.yaml' if mae else
-                                   'configs/moco/moco_v2_r50_synthetic.yaml')),
+                                   ('configs/clip/vit-b-32_synthetic.yaml' if clip else
+                                    'configs/moco/moco_v2_r50_synthetic.yaml'))),
                      ['dataloader.train.sampler.batch_size=%d' % args.batch,
                       'compute_dtype=%s' % args.dtype])
     cfg.timestamp = ''
@@ -150,14 +155,18 @@ def main():
         ips = args.batch * world * args.steps / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         out = {
-            'metric': ('images/sec/node, MAE ViT-B/16 mask 0.75 bs%d/GPU' % args.batch) if mae else
+            'metric': ('image-text pairs/sec/node, CLIP ViT-B/32 bs%d/GPU' % args.batch) if clip else
+            ('images/sec/node, MAE ViT-B/16 mask 0.75 bs%d/GPU' % args.batch) if mae else
             'images/sec/node (2-view), %s bs%d/GPU' % (
                 'SimCLR R50 (no stem max-pool)' if simclr else 'MoCo-v2 R50', args.batch),
             'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': ('MAE ViT-B/16 %s, bs=%d/GPU, 224^2 synthetic images, mask 0.75 (50 '
+            'config': {'workload': ('CLIP ViT-B/32 + 12-layer causal text transformer %s, bs=%d/GPU, 224^2 '
+                                    'synthetic images + 77-token synthetic captions, AdamW (CLIP row; '
+                                    'configs/clip/vit-b-32.yaml)' if clip else
+                                    'MAE ViT-B/16 %s, bs=%d/GPU, 224^2 synthetic images, mask 0.75 (50 '
                                     'encoder / 197 decoder tokens), norm_pix_loss, AdamW (MAE row; '
                                     'BASELINE configs[3])' if mae else
                                     'SimCLR ResNet-50 (no stem max-pool) %s, bs=%d/GPU, 2x224^2 '
@@ -188,7 +197,7 @@ def main():
             if wn:
                 out['roofline']['wgrad_kernel_ms_per_step'] = round(wms / args.steps, 3)
                 out['roofline']['igemm_kernel_ms_per_step'] = round(ms / args.steps, 3)
-        if world == 1 and not args.no_cpu_baseline and not simclr and not mae:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'moco':
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

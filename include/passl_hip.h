@@ -301,13 +301,15 @@ int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int d
                        passl_stream_t stream);
 /* Fused softmax(q k^T * scale) v per (image, head) on the fused projection qkv [B,T,3,H,DH];
  * out [B,T,H,DH]; lse [B,H,T] (row log-sum-exp, saved for the backward).  DH in {32, 64},
- * T <= 208 (PASSL_EUNSUPPORTED otherwise).  Replaces Attention.forward, mae.py:141-155. */
+ * T <= 208 (PASSL_EUNSUPPORTED otherwise).  Replaces Attention.forward, mae.py:141-155.
+ * causal != 0: key j visible to query i iff j <= i (the CLIP text tower's additive triu(-inf, 1)
+ * mask, passl_v110/modeling/backbones/clip.py:284-286 + vision_transformer.py:107-113). */
 int passl_hip_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int DH,
-                            float scale, int dtype, passl_stream_t stream);
+                            float scale, int causal, int dtype, passl_stream_t stream);
 /* dqkv [B,T,3,H,DH] (fully written) from dout [B,T,H,DH]. */
 int passl_hip_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
-                            void* dqkv, int B, int T, int H, int DH, float scale, int dtype,
-                            passl_stream_t stream);
+                            void* dqkv, int B, int T, int H, int DH, float scale, int causal,
+                            int dtype, passl_stream_t stream);
 /* random_masking (mae.py:461-488) without the sort: ids_restore[b,l] = rank of noise[b,l] in its row
  * (ties by index), ids_keep[b,rank] = l for rank < len_keep, mask[b,l] = rank >= len_keep. */
 int passl_hip_mae_mask(const float* noise, int B, int L, int len_keep, int32_t* ids_keep,
@@ -355,6 +357,50 @@ int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, flo
  * accumulated kernel time (ms) and launch count per kernel class (0 = igemm, 1 = wgrad). */
 int passl_hip_prof_enable(int on);
 int passl_hip_prof_collect(int kernel_class, double* total_ms, int64_t* launches);
+
+/* ---------------------------------------------------------------- CLIP
+ * Reference: class CLIP, passl_v110/modeling/backbones/clip.py:183-336; QuickGELU
+ * base_transformer.py:25-28; CLIPHead, passl_v110/modeling/heads/clip_head.py:24-36. */
+
+/* QuickGELU y = x * sigmoid(1.702 x) and dx = dy * d/dx; n % 8 == 0. */
+int passl_hip_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream);
+int passl_hip_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,
+                             passl_stream_t stream);
+/* encode_text input (clip.py:295-298): out[b,t] = table[text[b,t]] + pos[t]; text int64 [B,T],
+ * table fp32 [vocab,C], pos fp32 [T,C], out [B*T,C] in `dtype`.  Ids outside [0,vocab) read as 0. */
+int passl_hip_embed_fwd(const int64_t* text, const float* table, const float* pos, void* out, int B,
+                        int T, int C, int vocab, int dtype, passl_stream_t stream);
+/* its backward: dtable[text[b,t]] += dout[b,t] (scatter-add), dpos[t] += sum_b dout[b,t]; both fp32,
+ * ACCUMULATED into.  C <= 2048. */
+int passl_hip_embed_bwd(const int64_t* text, const void* dout, float* dtable, float* dpos, int B,
+                        int T, int C, int vocab, int dtype, passl_stream_t stream);
+/* out[r] = x[idx[r]] for r < n (class-token rows x[:, 0], EOT rows x[i][argmax text[i]]). */
+int passl_hip_gather_rows(const void* x, const int32_t* idx, void* out, int n, int C, int dtype,
+                          passl_stream_t stream);
+/* backward of gather_rows for distinct idx: dx [rows_total, C] = 0 except dx[idx[r]] = dout[r]. */
+int passl_hip_scatter_rows(const void* dout, const int32_t* idx, void* dx, int n, int64_t rows_total,
+                           int C, int dtype, passl_stream_t stream);
+/* idx[b] = b*T + argmax_t text[b,t] (first maximum) — clip.py:303-306. */
+int passl_hip_eot_index(const int64_t* text, int B, int T, int32_t* idx, passl_stream_t stream);
+/* CLIP.forward's logits (clip.py:317-336) from fp32 features img, txt [B,D] (D % 16 == 0):
+ * logits [B,B] = exp(logit_scale) * (img/|img|) (txt/|txt|)^T = image_logits; text_logits is its
+ * transpose.  logit_scale (device scalar, the parameter) is then clipped in place to
+ * [clip_lo, clip_hi].  ws: caller-owned fp32 workspace of passl_hip_clip_logits_ws_floats(B, D) floats
+ * that must survive until the backward call. */
+int64_t passl_hip_clip_logits_ws_floats(int B, int D);
+int passl_hip_clip_logits_fwd(const float* img, const float* txt, float* logit_scale, int B, int D,
+                              float clip_lo, float clip_hi, float* ws, float* logits,
+                              passl_stream_t stream);
+/* dimg, dtxt [B,D] fully written; dlogit_scale[0] += sum(dlogits .* logits). */
+int passl_hip_clip_logits_bwd(const float* dlogits, const float* logits, const float* ws, int B, int D,
+                              float* dimg, float* dtxt, float* dlogit_scale, passl_stream_t stream);
+/* CLIPHead (clip_head.py:24-36) with labels arange(B): out = {CE over the rows of logits (img_loss),
+ * CE over its columns (= rows of text_logits; text_loss), their sum (loss)}; lse [2B] = row and
+ * column log-sum-exp, saved for the backward. */
+int passl_hip_clip_ce_fwd(const float* logits, int B, float* lse, float* out, passl_stream_t stream);
+/* dlogits[i][j] = gloss/B * (softmax_row_i[j] + softmax_col_j[i] - 2 [i == j]); gloss: device scalar. */
+int passl_hip_clip_ce_bwd(const float* logits, const float* lse, const float* gloss, int B,
+                          float* dlogits, passl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,20 @@ def _install_tensor_patches():
         with torch.no_grad():
             self.copy_(torch.as_tensor(value, dtype=self.dtype))
 
+    _orig_norm, _orig_argmax = _T.norm, _T.argmax
+
+    def norm(self, p=2, axis=None, keepdim=False, dim=None):
+        return _orig_norm(self, p=p, dim=axis if dim is None else dim, keepdim=keepdim)
+
+    def argmax(self, axis=None, keepdim=False, dim=None):
+        return _orig_argmax(self, dim=axis if dim is None else dim, keepdim=keepdim)
+
+    def clip_(self, lo=None, hi=None):        # in dygraph an in-place clip of a parameter is allowed
+        with torch.no_grad():
+            return self.clamp_(lo, hi)
+
+    _T.norm, _T.argmax, _T.clip_ = norm, argmax, clip_
+    _T._share_buffer_to = lambda self, other: None
     _T.transpose = transpose
     _T.set_value = set_value
     _T.stop_gradient = property(lambda s: not s.requires_grad,
@@ -54,9 +68,14 @@ def _install_tensor_patches():
     _T._paddle_shim = True
 
 
+WIDEN_FLOAT32 = False      # golden generation in fp64: an explicit astype("float32") keeps the wide type
+
+
 def _dtype(dt):
     if isinstance(dt, torch.dtype):
         return dt
+    if dt == 'float32' and WIDEN_FLOAT32:
+        return torch.float64
     return {'float32': torch.float32, 'float64': torch.float64, 'int64': torch.int64,
             'int32': torch.int32, 'bool': torch.bool, None: torch.float32}[dt]
 
@@ -73,7 +92,14 @@ class Layer(torch.nn.Module):
 
     def create_parameter(self, shape, attr=None, dtype='float32', is_bias=False,
                          default_initializer=None):
-        return torch.nn.Parameter(torch.zeros(*shape, dtype=_dtype(dtype)))
+        p = torch.nn.Parameter(torch.zeros(*shape, dtype=_dtype(dtype)))
+        if default_initializer is not None:
+            default_initializer(p)
+        return p
+
+    def add_parameter(self, name, parameter):
+        self.register_parameter(name, parameter)
+        return parameter
 
     def set_state_dict(self, sd):
         return self.load_state_dict(sd)
@@ -219,6 +245,16 @@ class LayerList(torch.nn.ModuleList, Layer):
     pass
 
 
+class Embedding(Layer):
+    def __init__(self, num_embeddings, embedding_dim, padding_idx=None, sparse=False, weight_attr=None,
+                 name=None):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(num_embeddings, embedding_dim))
+
+    def forward(self, x):
+        return self.weight[x]
+
+
 class _Initializer(object):
     """Callable initialisers (paddle.nn.initializer.*): in dygraph `init(param)` fills in place.
     `reshape` returns a view sharing storage, so initialising a reshaped weight initialises it."""
@@ -243,6 +279,14 @@ class _TruncatedNormal(_Initializer):
 
     def sample(self, t):
         return torch.fmod(torch.randn_like(t), 2.0) * self.std + self.mean
+
+
+class _Normal(_Initializer):
+    def __init__(self, mean=0.0, std=1.0, name=None):
+        self.mean, self.std = mean, std
+
+    def sample(self, t):
+        return torch.randn_like(t) * self.std + self.mean
 
 
 class _XavierUniform(_Initializer):
@@ -352,7 +396,7 @@ def install():
     paddle.nn = nn
     for cls in (Layer, Sequential, ReLU, Conv2D, BatchNorm2D, BatchNorm1D, BatchNorm,
                 SyncBatchNorm, GroupNorm, MaxPool2D, AdaptiveAvgPool2D, Linear,
-                CrossEntropyLoss, LayerNorm, GELU, Dropout, LayerList):
+                CrossEntropyLoss, LayerNorm, GELU, Dropout, LayerList, Embedding):
         setattr(nn, cls.__name__, cls)
     F = mod('paddle.nn.functional')
     nn.functional = F
@@ -369,8 +413,9 @@ def install():
                                                                 reduction=reduction)
     init_mod = mod('paddle.nn.initializer')
     nn.initializer = init_mod
-    for nm in ('XavierNormal', 'Normal', 'KaimingNormal'):
+    for nm in ('XavierNormal', 'KaimingNormal', 'Uniform'):
         setattr(init_mod, nm, type(nm, (_Noop,), {}))
+    init_mod.Normal = _Normal
     init_mod.Constant = _Constant
     init_mod.TruncatedNormal = _TruncatedNormal
     init_mod.XavierUniform = _XavierUniform
@@ -379,6 +424,17 @@ def install():
     norm = mod('paddle.nn.layer.norm')
     layer.norm = norm
     norm._BatchNormBase = _BatchNormBase
+    # CLIP row: additive float masks pass through; bool masks become (m - 1) * 1e9
+    tr = mod('paddle.nn.layer.transformer')
+    layer.transformer = tr
+    tr._convert_attention_mask = lambda m, dtype: ((m.to(dtype) - 1.0) * 1e9 if m.dtype == torch.bool
+                                                   else m.to(dtype))
+    tensor_mod = mod('paddle.tensor')
+    paddle.tensor = tensor_mod
+    tensor_mod.triu = lambda x, diagonal=0: torch.triu(x, diagonal)
+    paddle.get_default_dtype = lambda: torch.get_default_dtype()
+    paddle.shape = lambda x: list(x.shape)
+    F.sigmoid = torch.sigmoid
 
     dist = mod('paddle.distributed')
     paddle.distributed = dist
@@ -412,6 +468,9 @@ def install():
         top = input.topk(k, dim=1).indices
         return (top == label.reshape(-1, 1)).any(dim=1).float().mean()
     fl.accuracy = fl_accuracy
+    df = mod('paddle.fluid.data_feeder')
+    fluid.data_feeder = df
+    df.convert_dtype = lambda d: str(d).replace('torch.', '')
 
     utils = mod('paddle.utils')
     paddle.utils = utils

@@ -87,6 +87,13 @@ def load():
     imp(PKG + '.modules.get_sincos_pe')
     imp(PKG + '.modeling.backbones.mae')
     imp(PKG + '.modeling.architectures.MAE')
+    # CLIP row: backbones/{base_transformer,vision_transformer,clip}.py, heads/clip_head.py,
+    # architectures/CLIPWrapper.py
+    imp(PKG + '.modeling.backbones.base_transformer')
+    imp(PKG + '.modeling.backbones.vision_transformer')
+    imp(PKG + '.modeling.backbones.clip')
+    imp(PKG + '.modeling.heads.clip_head')
+    imp(PKG + '.modeling.architectures.CLIPWrapper')
     return _namespace()
 
 
@@ -105,6 +112,8 @@ def _namespace():
     ns.mae = sys.modules[PKG + '.modeling.backbones.mae']
     ns.MAE = ns.mae.MAE
     ns.MAE_PRETRAIN = sys.modules[PKG + '.modeling.architectures.MAE'].MAE_PRETRAIN
+    ns.CLIP = sys.modules[PKG + '.modeling.backbones.clip'].CLIP
+    ns.CLIPWrapper = sys.modules[PKG + '.modeling.architectures.CLIPWrapper'].CLIPWrapper
     ns.SimCLR = sys.modules[PKG + '.modeling.architectures.simclr'].SimCLR
     ns.SimCLRContrastiveHead = sys.modules[
         PKG + '.modeling.heads.simclr_contrastive_head'].SimCLRContrastiveHead
@@ -192,6 +201,27 @@ def load_mae_state(model, oracle):
     import torch
     with torch.no_grad():
         sd = model.state_dict()
+        assert set(sd.keys()) == set(oracle.st.keys()), set(sd.keys()) ^ set(oracle.st.keys())
+        for n, t in oracle.st.items():
+            assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)
+            sd[n].copy_(t.detach())
+
+
+def build_reference_clip(cfg):
+    """The reference's CLIPWrapper (architectures/CLIPWrapper.py:27) built by its MODELS registry from
+    the `model:` block of configs/clip/vit-b-32.yaml with the sizes in `cfg`."""
+    ns = load()
+    arch = dict(name='CLIP', qkv_bias=True, pre_norm=True, proj=True, patch_bias=False)
+    arch.update({k: cfg[k] for k in ('embed_dim', 'image_resolution', 'vision_layers', 'vision_width',
+                                     'vision_patch_size', 'context_length', 'vocab_size',
+                                     'transformer_width', 'transformer_heads', 'transformer_layers')})
+    return ns.build_model(dict(name='CLIPWrapper', architecture=arch, head=dict(name='CLIPHead')))
+
+
+def load_clip_state(model, oracle):
+    import torch
+    with torch.no_grad():
+        sd = model.model.state_dict()
         assert set(sd.keys()) == set(oracle.st.keys()), set(sd.keys()) ^ set(oracle.st.keys())
         for n, t in oracle.st.items():
             assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)

@@ -12,6 +12,8 @@
 // in the A-operand layout of the second MFMA (P x V, dS x K, P^T x dO, dS^T x Q).
 // Backward = two sweeps: own query rows x swept keys -> dQ;  own key columns x swept queries ->
 // dK, dV (P is recomputed from the saved row log-sum-exp; delta_i = dO_i . O_i).
+// `causal` (CLIP text tower, passl_v110/modeling/backbones/clip.py:284-286: additive triu(-inf, 1)
+// mask): key j is visible to query i iff j <= i; fully masked tiles are skipped.
 // Limits: d in {32, 64}, T <= 208 (13 tiles) — the MAE pre-training shapes; larger T needs a
 // KV-tiled (flash-style) variant.  bf16 inputs are converted when staged; all arithmetic is fp32.
 #include "common.h"
@@ -100,7 +102,7 @@ template <typename T, int DH>
 __global__ void __launch_bounds__(kThreads) attn_fwd_kernel(const T* __restrict__ qkv,
                                                             T* __restrict__ out,
                                                             float* __restrict__ lse, int Tn, int H,
-                                                            float scale) {
+                                                            float scale, int causal) {
   constexpr int P = DH + 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -119,15 +121,17 @@ __global__ void __launch_bounds__(kThreads) attn_fwd_kernel(const T* __restrict_
     glb_row<T, DH>(qkv + qkv_off<DH>(b, row < Tn ? row : 0, 0, h, Tn, H), row < Tn, l4, q);
     float s[kMaxTiles][4];
     float m = kNeg;
+    const int ntc = causal ? rb + 1 : nt;        // causal: key tiles beyond the diagonal are all masked
+    const int lim = causal ? min(row, Tn - 1) : Tn - 1;   // last visible key of this query row
 #pragma unroll
     for (int ct = 0; ct < kMaxTiles; ++ct) {
-      if (ct < nt) {
+      if (ct < ntc) {
         float kr[DH / 4];
         lds_row<DH>(Ks, ct * 16 + l15, l4, kr);
         const f32x4 a = dot_tile<DH>(kr, q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[ct][r] = (ct * 16 + l4 * 4 + r < Tn) ? a[r] * scale : kNeg;
+          s[ct][r] = (ct * 16 + l4 * 4 + r <= lim) ? a[r] * scale : kNeg;
           m = fmaxf(m, s[ct][r]);
         }
       }
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(kThreads) attn_fwd_kernel(const T* __restrict_
     float z = 0.f;
 #pragma unroll
     for (int ct = 0; ct < kMaxTiles; ++ct)
-      if (ct < nt) {
+      if (ct < ntc) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s[ct][r] = __expf(s[ct][r] - m); z += s[ct][r]; }
       }
@@ -149,7 +153,7 @@ __global__ void __launch_bounds__(kThreads) attn_fwd_kernel(const T* __restrict_
     for (int jd = 0; jd < DH / 16; ++jd) o[jd] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < kMaxTiles; ++ct)
-      if (ct < nt) {
+      if (ct < ntc) {
         float p[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = s[ct][r] * inv;
@@ -172,7 +176,7 @@ __global__ void __launch_bounds__(kThreads) attn_fwd_kernel(const T* __restrict_
 template <typename T, int DH>
 __global__ void __launch_bounds__(kThreads) attn_bwd_q_kernel(
     const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
-    const float* __restrict__ lse, T* __restrict__ dqkv, int Tn, int H, float scale) {
+    const float* __restrict__ lse, T* __restrict__ dqkv, int Tn, int H, float scale, int causal) {
   constexpr int P = DH + 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -203,7 +207,9 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_q_kernel(
     f32x4 dq[DH / 16];
 #pragma unroll
     for (int jd = 0; jd < DH / 16; ++jd) dq[jd] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ct = 0; ct < nt; ++ct) {
+    const int ntc = causal ? rb + 1 : nt;
+    const int lim = causal ? min(row, Tn - 1) : Tn - 1;
+    for (int ct = 0; ct < ntc; ++ct) {
       float kr[DH / 4], vr[DH / 4];
       lds_row<DH>(Ks, ct * 16 + l15, l4, kr);
       lds_row<DH>(Vs, ct * 16 + l15, l4, vr);
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_q_kernel(
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool cv = rv && (ct * 16 + l4 * 4 + r < Tn);
+        const bool cv = rv && (ct * 16 + l4 * 4 + r <= lim);
         const float p = cv ? __expf(s[r] * scale - l) : 0.f;
         ds[r] = p * (dp[r] - delta) * scale;
       }
@@ -233,7 +239,7 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_q_kernel(
 template <typename T, int DH>
 __global__ void __launch_bounds__(kThreads) attn_bwd_kv_kernel(
     const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
-    const float* __restrict__ lse, T* __restrict__ dqkv, int Tn, int H, float scale) {
+    const float* __restrict__ lse, T* __restrict__ dqkv, int Tn, int H, float scale, int causal) {
   constexpr int P = DH + 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_kv_kernel(
     f32x4 dk[DH / 16], dv[DH / 16];
 #pragma unroll
     for (int jd = 0; jd < DH / 16; ++jd) { dk[jd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[jd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int rt = 0; rt < nt; ++rt) {
+    for (int rt = causal ? cb : 0; rt < nt; ++rt) {      // causal: query rows before the key see nothing
       float qr[DH / 4], dr[DH / 4];
       lds_row<DH>(Qs, rt * 16 + l15, l4, qr);
       lds_row<DH>(Ds, rt * 16 + l15, l4, dr);
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_kv_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rt * 16 + l4 * 4 + r;
-        const bool ok = cv && row < Tn;
+        const bool ok = cv && row < Tn && (!causal || row >= col);
         p[r] = ok ? __expf(s[r] * scale - Ls[row]) : 0.f;
         ds[r] = p[r] * (dp[r] - Dl[row]) * scale;
       }
@@ -297,7 +303,8 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_kv_kernel(
 }
 
 template <typename T, int DH>
-int launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, float scale, hipStream_t st) {
+int launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, float scale, int causal,
+               hipStream_t st) {
   const int Tpad = (Tn + 15) / 16 * 16;
   const int ldsb = 2 * Tpad * (DH + 4) * 4;
   static bool attr = false;
@@ -307,13 +314,13 @@ int launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, flo
     attr = true;
   }
   hipLaunchKernelGGL((attn_fwd_kernel<T, DH>), dim3(B * H), dim3(kThreads), ldsb, st,
-                     reinterpret_cast<const T*>(qkv), reinterpret_cast<T*>(out), lse, Tn, H, scale);
+                     reinterpret_cast<const T*>(qkv), reinterpret_cast<T*>(out), lse, Tn, H, scale, causal);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
 template <typename T, int DH>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
-               int Tn, int H, float scale, hipStream_t st) {
+               int Tn, int H, float scale, int causal, hipStream_t st) {
   const int Tpad = (Tn + 15) / 16 * 16;
   const int lds1 = 2 * Tpad * (DH + 4) * 4;
   const int lds2 = lds1 + 2 * Tpad * 4;
@@ -328,11 +335,11 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   }
   hipLaunchKernelGGL((attn_bwd_q_kernel<T, DH>), dim3(B * H), dim3(kThreads), lds1, st,
                      reinterpret_cast<const T*>(qkv), reinterpret_cast<const T*>(out),
-                     reinterpret_cast<const T*>(dout), lse, reinterpret_cast<T*>(dqkv), Tn, H, scale);
+                     reinterpret_cast<const T*>(dout), lse, reinterpret_cast<T*>(dqkv), Tn, H, scale, causal);
   if (hipGetLastError() != hipSuccess) return PASSL_ELAUNCH;
   hipLaunchKernelGGL((attn_bwd_kv_kernel<T, DH>), dim3(B * H), dim3(kThreads), lds2, st,
                      reinterpret_cast<const T*>(qkv), reinterpret_cast<const T*>(out),
-                     reinterpret_cast<const T*>(dout), lse, reinterpret_cast<T*>(dqkv), Tn, H, scale);
+                     reinterpret_cast<const T*>(dout), lse, reinterpret_cast<T*>(dqkv), Tn, H, scale, causal);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
@@ -343,30 +350,30 @@ bool shape_ok(int B, int Tn, int H, int DH) {
 }  // namespace
 
 extern "C" int passl_hip_attention_fwd(const void* qkv, void* out, float* lse, int B, int T_, int H,
-                                       int DH, float scale, int dtype, passl_stream_t stream) {
+                                       int DH, float scale, int causal, int dtype, passl_stream_t stream) {
   if (!qkv || !out || !lse) return PASSL_EINVAL;
   if (!shape_ok(B, T_, H, DH)) return PASSL_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
   if (dtype == PASSL_BF16)
-    return DH == 64 ? launch_fwd<bf16_t, 64>(qkv, out, lse, B, T_, H, scale, st)
-                    : launch_fwd<bf16_t, 32>(qkv, out, lse, B, T_, H, scale, st);
+    return DH == 64 ? launch_fwd<bf16_t, 64>(qkv, out, lse, B, T_, H, scale, causal, st)
+                    : launch_fwd<bf16_t, 32>(qkv, out, lse, B, T_, H, scale, causal, st);
   if (dtype == PASSL_F32)
-    return DH == 64 ? launch_fwd<float, 64>(qkv, out, lse, B, T_, H, scale, st)
-                    : launch_fwd<float, 32>(qkv, out, lse, B, T_, H, scale, st);
+    return DH == 64 ? launch_fwd<float, 64>(qkv, out, lse, B, T_, H, scale, causal, st)
+                    : launch_fwd<float, 32>(qkv, out, lse, B, T_, H, scale, causal, st);
   return PASSL_EUNSUPPORTED;
 }
 
 extern "C" int passl_hip_attention_bwd(const void* qkv, const void* out, const void* dout,
                                        const float* lse, void* dqkv, int B, int T_, int H, int DH,
-                                       float scale, int dtype, passl_stream_t stream) {
+                                       float scale, int causal, int dtype, passl_stream_t stream) {
   if (!qkv || !out || !dout || !lse || !dqkv) return PASSL_EINVAL;
   if (!shape_ok(B, T_, H, DH)) return PASSL_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
   if (dtype == PASSL_BF16)
-    return DH == 64 ? launch_bwd<bf16_t, 64>(qkv, out, dout, lse, dqkv, B, T_, H, scale, st)
-                    : launch_bwd<bf16_t, 32>(qkv, out, dout, lse, dqkv, B, T_, H, scale, st);
+    return DH == 64 ? launch_bwd<bf16_t, 64>(qkv, out, dout, lse, dqkv, B, T_, H, scale, causal, st)
+                    : launch_bwd<bf16_t, 32>(qkv, out, dout, lse, dqkv, B, T_, H, scale, causal, st);
   if (dtype == PASSL_F32)
-    return DH == 64 ? launch_bwd<float, 64>(qkv, out, dout, lse, dqkv, B, T_, H, scale, st)
-                    : launch_bwd<float, 32>(qkv, out, dout, lse, dqkv, B, T_, H, scale, st);
+    return DH == 64 ? launch_bwd<float, 64>(qkv, out, dout, lse, dqkv, B, T_, H, scale, causal, st)
+                    : launch_bwd<float, 32>(qkv, out, dout, lse, dqkv, B, T_, H, scale, causal, st);
   return PASSL_EUNSUPPORTED;
 }

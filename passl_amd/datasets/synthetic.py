@@ -23,6 +23,33 @@ class SyntheticTwoView(object):
 
 
 @DATASETS.register()
+class SyntheticImageText(object):
+    """(image, text) pairs shaped like the reference's TextImageDataset output
+    (passl_v110/datasets/text_image_dataset.py): image ~ N(0,1) fp32 [3,S,S]; text int64
+    [context_length] = random ids, the EOT (largest id = vocab_size-1) at a random position, zero
+    padding after it."""
+
+    def __init__(self, num_samples=75750, image_size=224, context_length=77, vocab_size=49408, seed=1234,
+                 num_batches_cached=1, **ignored):
+        self.num_samples, self.image_size = int(num_samples), int(image_size)
+        self.context_length, self.vocab_size = int(context_length), int(vocab_size)
+        self.seed, self.num_batches_cached = int(seed), int(num_batches_cached)
+
+    def __len__(self):
+        return self.num_samples
+
+    def make_batch(self, gen, batch_size):
+        s, T, V = self.image_size, self.context_length, self.vocab_size
+        image = torch.randn(batch_size, 3, s, s, generator=gen)
+        n = torch.randint(3, T + 1, (batch_size,), generator=gen)
+        text = torch.randint(1, V - 2, (batch_size, T), generator=gen)
+        pos = torch.arange(T).unsqueeze(0)
+        text = torch.where(pos < (n - 1).unsqueeze(1), text, torch.zeros_like(text))
+        text[torch.arange(batch_size), n - 1] = V - 1
+        return image, text
+
+
+@DATASETS.register()
 class ImageNet(object):
     def __init__(self, **kwargs):
         raise NotImplementedError(
@@ -44,6 +71,9 @@ class SyntheticLoader(object):
         s = dataset.image_size
         self._cache = []
         for _ in range(max(1, dataset.num_batches_cached)):
+            if hasattr(dataset, 'make_batch'):
+                self._cache.append(tuple(t.to(device) for t in dataset.make_batch(gen, self.batch_size)))
+                continue
             xq = torch.randn(self.batch_size, 3, s, s, generator=gen)
             xk = torch.randn(self.batch_size, 3, s, s, generator=gen)
             self._cache.append((xq.to(device), xk.to(device)))

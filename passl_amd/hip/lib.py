@@ -94,8 +94,20 @@ SIGNATURES = {
     'passl_hip_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p]),
     'passl_hip_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
-    'passl_hip_attention_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
-    'passl_hip_attention_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    'passl_hip_attention_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    'passl_hip_attention_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
+    'passl_hip_quick_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
+    'passl_hip_quick_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
+    'passl_hip_embed_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_embed_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_gather_rows': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    'passl_hip_scatter_rows': (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p]),
+    'passl_hip_eot_index': (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    'passl_hip_clip_logits_ws_floats': (c_l, [c_i, c_i]),
+    'passl_hip_clip_logits_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
+    'passl_hip_clip_logits_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'passl_hip_clip_ce_fwd': (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    'passl_hip_clip_ce_bwd': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p]),
     'passl_hip_mae_mask': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     'passl_hip_mae_gather': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_mae_gather_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

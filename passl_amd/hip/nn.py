@@ -486,22 +486,60 @@ class _AttentionFn(Function):
     """softmax(q k^T * scale) v per (image, head) on the fused qkv projection [B*T, 3*H*d]."""
 
     @staticmethod
-    def forward(ctx, qkv, B, T, H, DH, scale):
-        out, lse = ops.attention_fwd(qkv.contiguous(), B, T, H, DH, scale)
+    def forward(ctx, qkv, B, T, H, DH, scale, causal):
+        out, lse = ops.attention_fwd(qkv.contiguous(), B, T, H, DH, scale, causal)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.dims = (B, T, H, DH, scale)
+        ctx.dims = (B, T, H, DH, scale, causal)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        B, T, H, DH, scale = ctx.dims
-        return ops.attention_bwd(qkv, out, dout.contiguous(), lse, B, T, H, DH, scale), None, None, None, \
-            None, None
+        B, T, H, DH, scale, causal = ctx.dims
+        return ops.attention_bwd(qkv, out, dout.contiguous(), lse, B, T, H, DH, scale, causal), None, None, \
+            None, None, None, None
 
 
-def attention(qkv, B, T, H, DH, scale):
-    return _AttentionFn.apply(qkv, B, T, H, DH, float(scale))
+def attention(qkv, B, T, H, DH, scale, causal=False):
+    return _AttentionFn.apply(qkv, B, T, H, DH, float(scale), bool(causal))
+
+
+class _QuickGeluFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.quick_gelu_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.quick_gelu_bwd(dy.contiguous(), x)
+
+
+class QuickGELU(Layer):
+    """x * sigmoid(1.702 x) (passl_v110/modeling/backbones/base_transformer.py:25-28)."""
+
+    def forward(self, x):
+        return _QuickGeluFn.apply(x)
+
+
+class _GatherRowsFn(Function):
+    """out[r] = x[idx[r]] for distinct row indices (class token / EOT token selection)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = x.shape[0]
+        return ops.gather_rows(x.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        return ops.scatter_rows(dout.contiguous(), idx, ctx.rows), None
+
+
+def gather_rows(x, idx):
+    return _GatherRowsFn.apply(x, idx)
 
 
 # =============================================================================== head pieces

@@ -398,19 +398,20 @@ def gelu_bwd(dy, x):
     return dx
 
 
-def attention_fwd(qkv, B, T, H, DH, scale):
+def attention_fwd(qkv, B, T, H, DH, scale, causal=False):
     """qkv [B*T, 3*H*DH] -> out [B*T, H*DH], lse [B, H, T]."""
     out = torch.empty(B * T, H * DH, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
     L.check(_lib().passl_hip_attention_fwd(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, DH, scale,
-                                           L.dt(qkv), L.stream()), 'attention_fwd')
+                                           int(causal), L.dt(qkv), L.stream()), 'attention_fwd')
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, B, T, H, DH, scale):
+def attention_bwd(qkv, out, dout, lse, B, T, H, DH, scale, causal=False):
     dqkv = torch.empty_like(qkv)
     L.check(_lib().passl_hip_attention_bwd(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(dqkv),
-                                           B, T, H, DH, scale, L.dt(qkv), L.stream()), 'attention_bwd')
+                                           B, T, H, DH, scale, int(causal), L.dt(qkv), L.stream()),
+            'attention_bwd')
     return dqkv
 
 
@@ -486,3 +487,94 @@ def mae_loss_bwd(img, pred, mask, gscale, p, norm_pix, denom):
 def adamw(p, g, m, v, lr, b1, b2, eps, wd, b1pow, b2pow, grad_scale=1.0):
     L.check(_lib().passl_hip_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, wd,
                                    b1pow, b2pow, grad_scale, L.stream()), 'adamw')
+
+
+# ------------------------------------------------------------------ CLIP
+def quick_gelu_fwd(x):
+    y = torch.empty_like(x)
+    L.check(_lib().passl_hip_quick_gelu_fwd(L.ptr(x), L.ptr(y), x.numel(), L.dt(x), L.stream()),
+            'quick_gelu_fwd')
+    return y
+
+
+def quick_gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    L.check(_lib().passl_hip_quick_gelu_bwd(L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.dt(x), L.stream()),
+            'quick_gelu_bwd')
+    return dx
+
+
+def embed_fwd(text, table, pos, dtype):
+    """text int64 [B,T]; table fp32 [V,C]; pos fp32 [T,C] -> [B*T, C] in `dtype`."""
+    B, T = text.shape
+    V, Cc = table.shape
+    out = torch.empty(B * T, Cc, dtype=dtype, device=table.device)
+    L.check(_lib().passl_hip_embed_fwd(L.ptr(text), L.ptr(table), L.ptr(pos), L.ptr(out), B, T, Cc, V,
+                                       L.dt(out), L.stream()), 'embed_fwd')
+    return out
+
+
+def embed_bwd(text, dout, dtable, dpos):
+    B, T = text.shape
+    V, Cc = dtable.shape
+    L.check(_lib().passl_hip_embed_bwd(L.ptr(text), L.ptr(dout), L.ptr(dtable), L.ptr(dpos), B, T, Cc, V,
+                                       L.dt(dout), L.stream()), 'embed_bwd')
+
+
+def gather_rows(x, idx):
+    n, Cc = idx.numel(), x.shape[-1]
+    out = torch.empty(n, Cc, dtype=x.dtype, device=x.device)
+    L.check(_lib().passl_hip_gather_rows(L.ptr(x), L.ptr(idx), L.ptr(out), n, Cc, L.dt(x), L.stream()),
+            'gather_rows')
+    return out
+
+
+def scatter_rows(dout, idx, rows_total):
+    n, Cc = dout.shape
+    dx = torch.empty(rows_total, Cc, dtype=dout.dtype, device=dout.device)
+    L.check(_lib().passl_hip_scatter_rows(L.ptr(dout), L.ptr(idx), L.ptr(dx), n, rows_total, Cc, L.dt(dout),
+                                          L.stream()), 'scatter_rows')
+    return dx
+
+
+def eot_index(text):
+    B, T = text.shape
+    idx = torch.empty(B, dtype=torch.int32, device=text.device)
+    L.check(_lib().passl_hip_eot_index(L.ptr(text), B, T, L.ptr(idx), L.stream()), 'eot_index')
+    return idx
+
+
+def clip_logits_fwd(img, txt, logit_scale, clip_lo=-4.6, clip_hi=4.6):
+    """-> logits [B,B] (= image_logits; text_logits is its transpose), ws (workspace for the backward).
+    logit_scale (the fp32 parameter) is clipped in place after use."""
+    B, Dd = img.shape
+    ws = torch.empty(int(_lib().passl_hip_clip_logits_ws_floats(B, Dd)), dtype=torch.float32, device=img.device)
+    logits = torch.empty(B, B, dtype=torch.float32, device=img.device)
+    L.check(_lib().passl_hip_clip_logits_fwd(L.ptr(img), L.ptr(txt), L.ptr(logit_scale), B, Dd, clip_lo,
+                                             clip_hi, L.ptr(ws), L.ptr(logits), L.stream()), 'clip_logits_fwd')
+    return logits, ws
+
+
+def clip_logits_bwd(dlogits, logits, ws, Dd, dlogit_scale):
+    B = logits.shape[0]
+    dimg = torch.empty(B, Dd, dtype=torch.float32, device=ws.device)
+    dtxt = torch.empty(B, Dd, dtype=torch.float32, device=ws.device)
+    L.check(_lib().passl_hip_clip_logits_bwd(L.ptr(dlogits), L.ptr(logits), L.ptr(ws), B, Dd, L.ptr(dimg),
+                                             L.ptr(dtxt), L.ptr(dlogit_scale), L.stream()), 'clip_logits_bwd')
+    return dimg, dtxt
+
+
+def clip_ce_fwd(logits):
+    """-> out[3] = (img_loss, text_loss, loss), lse [2B]."""
+    B = logits.shape[0]
+    lse = torch.empty(2 * B, dtype=torch.float32, device=logits.device)
+    out = torch.empty(3, dtype=torch.float32, device=logits.device)
+    L.check(_lib().passl_hip_clip_ce_fwd(L.ptr(logits), B, L.ptr(lse), L.ptr(out), L.stream()), 'clip_ce_fwd')
+    return out, lse
+
+
+def clip_ce_bwd(logits, lse, gloss):
+    dlogits = torch.empty_like(logits)
+    L.check(_lib().passl_hip_clip_ce_bwd(L.ptr(logits), L.ptr(lse), L.ptr(gloss), logits.shape[0],
+                                         L.ptr(dlogits), L.stream()), 'clip_ce_bwd')
+    return dlogits

@@ -1,0 +1,45 @@
+"""CLIPWrapper — reference passl_v110/modeling/architectures/CLIPWrapper.py:26-60: ``train_iter(image,
+text)`` builds labels ``arange(B)``, calls ``self.model(image, text, is_train=True)`` and hands the
+two logits matrices to the head (CLIPHead).  Parameters live in one EncoderArena (flat fp32 master /
+gradient buffers for AdamW and the data-parallel reducer)."""
+import torch
+
+from ...hip import nn
+from ...hip.nn import EncoderArena
+from ..backbones import build_backbone
+from ..heads import build_head
+from .builder import MODELS
+
+
+@MODELS.register()
+class CLIPWrapper(nn.Layer):
+    def __init__(self, architecture=None, head=None):
+        super().__init__()
+        self.model = build_backbone(architecture)
+        self.automatic_optimization = False
+        self.head = build_head(head)
+        self.arena_q = EncoderArena(self.model, trainable=True)
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.arena_q.refresh()
+        return r
+
+    def train_iter(self, *inputs, **kwargs):
+        image, text = inputs
+        # the reference's labels are arange(len(image)); CLIPHead's kernel has them built in
+        img_labels = torch.arange(len(image), device=image.device)
+        text_labels = torch.arange(len(text), device=text.device)
+        self.arena_q.refresh()
+        img_logits, text_logits = self.model(image, text, is_train=True)
+        return self.head(img_logits, text_logits, img_labels, text_labels)
+
+    def forward(self, *inputs, mode='train', **kwargs):
+        if mode == 'train':
+            return self.train_iter(*inputs, **kwargs)
+        elif mode == 'extract':
+            with torch.no_grad():
+                self.arena_q.refresh()
+                return self.model.encode_image(inputs[0])
+        else:
+            raise Exception("No such mode: {}".format(mode))

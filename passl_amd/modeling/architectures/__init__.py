@@ -2,3 +2,4 @@ from .builder import MODELS, build_model
 from .moco import MoCo
 from .simclr import SimCLR
 from .MAE import MAE_PRETRAIN
+from .CLIPWrapper import CLIPWrapper

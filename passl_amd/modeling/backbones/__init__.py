@@ -2,3 +2,5 @@ from .builder import BACKBONES, build_backbone
 from .resnet import ResNet, BottleneckBlock
 from .resnetsimclr import ResNetsimclr
 from .mae import MAE
+from .vision_transformer import VisionTransformer
+from .clip import CLIP

@@ -60,14 +60,14 @@ class _PatchProj(nn.Layer):
     krsc_weight = True
     no_dgrad = True           # the image needs no gradient
 
-    def __init__(self, in_chans, embed_dim, patch):
+    def __init__(self, in_chans, embed_dim, patch, bias=True):
         super().__init__()
         dev = config.get_device()
         self.patch, self.in_chans, self.out_features = patch, in_chans, embed_dim
         self.in_features = in_chans * patch * patch
         self.geom = P.ConvGeom(self.in_features, embed_dim, 1, 1, 0)
         self.weight = tnn.Parameter(torch.empty(embed_dim, in_chans, patch, patch, device=dev))
-        self.bias = tnn.Parameter(torch.zeros(embed_dim, device=dev))
+        self.bias = tnn.Parameter(torch.zeros(embed_dim, device=dev)) if bias else None
         self._rt = None
         self._plans = {}
 

@@ -1,0 +1,47 @@
+"""CLIPHead — reference passl_v110/modeling/heads/clip_head.py:20-36: ``loss = CE(img_logits,
+img_labels) + CE(text_logits, text_labels)`` with outputs ``img_loss / text_loss / loss``.
+
+HIP execution: CLIP.forward returns ``text_logits`` as the transpose view of ``img_logits`` and
+CLIPWrapper's labels are ``arange(B)``, so both cross-entropies run over ONE matrix (rows and
+columns) in csrc/clip.hip; other inputs raise instead of silently computing something else."""
+import torch
+from torch.autograd import Function
+
+from ...hip import nn, ops
+from .builder import HEADS
+
+
+class _SymmetricCEFn(Function):
+    @staticmethod
+    def forward(ctx, logits):
+        out, lse = ops.clip_ce_fwd(logits.contiguous())
+        ctx.save_for_backward(logits, lse)
+        img_loss, text_loss, loss = out[0:1], out[1:2], out[2:3]
+        ctx.mark_non_differentiable(img_loss, text_loss)
+        return img_loss, text_loss, loss
+
+    @staticmethod
+    def backward(ctx, _gi, _gt, gloss):
+        logits, lse = ctx.saved_tensors
+        return ops.clip_ce_bwd(logits, lse, gloss.contiguous().float())
+
+
+@HEADS.register()
+class CLIPHead(nn.Layer):
+    def __init__(self):
+        super(CLIPHead, self).__init__()
+
+    def forward(self, img_logits, text_logits, img_labels, text_labels):
+        B = img_logits.shape[0]
+        same = (text_logits.data_ptr() == img_logits.data_ptr() and text_logits.shape == img_logits.shape and
+                text_logits.stride() == img_logits.stride()[::-1] and img_logits.is_contiguous())
+        if not same:
+            raise NotImplementedError('CLIPHead runs on the (logits, logits.t()) pair CLIP.forward returns')
+        if img_labels.numel() != B or text_labels.numel() != B:
+            raise ValueError('labels must have one entry per row')
+        img_loss, text_loss, loss = _SymmetricCEFn.apply(img_logits)
+        outputs = dict()
+        outputs['img_loss'] = img_loss
+        outputs['text_loss'] = text_loss
+        outputs['loss'] = loss
+        return outputs

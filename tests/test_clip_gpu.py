@@ -1,0 +1,274 @@
+"""CLIP path on a real MI355X through the registries and the C ABI: per-kernel parity against plain
+PyTorch fp32/fp64 references (causal attention, QuickGELU, token embedding gather / scatter-add, row
+gather / scatter, EOT index, logits + symmetric cross-entropy) and whole training steps against the
+golden vectors produced by the reference's own CLIP sources (tests/golden/clip_*.npz)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import clip_util as U                          # noqa: E402
+from oracle import clip as OC                  # noqa: E402
+from passl_amd.hip import ops                  # noqa: E402
+
+DEV = 'cuda'
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def relmax(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rnd(t, dtype):
+    return t.to(dtype).float()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,T,H,DH', [(3, 77, 8, 64), (2, 12, 2, 64), (2, 50, 4, 32), (1, 16, 1, 64), (2, 17, 2, 32)])
+def test_causal_attention_fwd_bwd(dtype, B, T, H, DH):
+    """softmax(q k^T d^-0.5 + triu(-inf, 1)) v — vision_transformer.py:107-117 with clip.py:284-286's mask."""
+    gen = torch.Generator().manual_seed(T * 7 + DH)
+    qkv = rnd(torch.randn(B, T, 3, H, DH, generator=gen), dtype).requires_grad_(True)
+    q, k, v = [qkv.double()[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    mask = torch.triu(torch.full((T, T), -math.inf, dtype=torch.float64), 1)
+    a = torch.softmax(q @ k.transpose(-1, -2) * DH ** -0.5 + mask, dim=-1)
+    out = (a @ v).permute(0, 2, 1, 3).reshape(B * T, H * DH)
+    dout = rnd(torch.randn(B * T, H * DH, generator=gen), dtype)
+    out.backward(dout.double())
+    qd = qkv.detach().reshape(B * T, 3 * H * DH).to(DEV).to(dtype)
+    od, lse = ops.attention_fwd(qd, B, T, H, DH, DH ** -0.5, causal=True)
+    tf, tb = (2e-5, 2e-4) if dtype == torch.float32 else (2e-2, 4e-2)
+    assert relmax(od.float(), out.detach()) < tf
+    dq = ops.attention_bwd(qd, od, dout.to(DEV).to(dtype), lse, B, T, H, DH, DH ** -0.5, causal=True)
+    assert relmax(dq.float().reshape(B, T, 3, H, DH), qkv.grad) < tb
+    # non-causal call unchanged by the flag plumbing
+    a2 = torch.softmax(q @ k.transpose(-1, -2) * DH ** -0.5, dim=-1)
+    o2 = (a2 @ v).permute(0, 2, 1, 3).reshape(B * T, H * DH)
+    od2, _ = ops.attention_fwd(qd, B, T, H, DH, DH ** -0.5)
+    assert relmax(od2.float(), o2.detach()) < tf
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_quick_gelu(dtype):
+    gen = torch.Generator().manual_seed(1)
+    x = rnd(torch.randn(64, 2048, generator=gen) * 2, dtype).requires_grad_(True)
+    y = x.double() * torch.sigmoid(1.702 * x.double())
+    dy = rnd(torch.randn(64, 2048, generator=gen), dtype)
+    y.backward(dy.double())
+    t = 1e-5 if dtype == torch.float32 else 1e-2
+    xd = x.detach().to(DEV).to(dtype)
+    assert relmax(ops.quick_gelu_fwd(xd).float(), y.detach()) < t
+    assert relmax(ops.quick_gelu_bwd(dy.to(DEV).to(dtype), xd).float(), x.grad) < t
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,T,C,V', [(5, 77, 512, 1000), (3, 12, 128, 300), (40, 9, 64, 50)])
+def test_token_embedding_fwd_bwd(dtype, B, T, C, V):
+    gen = torch.Generator().manual_seed(B)
+    table = torch.randn(V, C, generator=gen)
+    pos = torch.randn(T, C, generator=gen)
+    text = OC.make_text(gen, B, T, V)
+    ref = table[text] + pos
+    got = ops.embed_fwd(text.to(DEV), table.to(DEV), pos.to(DEV), dtype)
+    assert relmax(got.float().reshape(B, T, C), ref) < (1e-6 if dtype == torch.float32 else 8e-3)
+    dout = rnd(torch.randn(B * T, C, generator=gen), dtype)
+    dt = torch.zeros(V, C).index_add_(0, text.reshape(-1), dout)
+    dp = dout.reshape(B, T, C).sum(0)
+    gt = torch.full((V, C), 0.5, device=DEV)           # accumulated INTO
+    gp = torch.full((T, C), -1.0, device=DEV)
+    ops.embed_bwd(text.to(DEV), dout.to(DEV).to(dtype), gt, gp)
+    assert relmax(gt.cpu() - 0.5, dt) < 1e-5 and relmax(gp.cpu() + 1.0, dp) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_row_gather_scatter_and_eot_index(dtype):
+    gen = torch.Generator().manual_seed(3)
+    B, T, C = 9, 77, 512
+    text = OC.make_text(gen, B, T, 49408)
+    text[2, :] = 0
+    text[2, 5] = 7; text[2, 9] = 7                      # tie: first maximum wins
+    idx = ops.eot_index(text.to(DEV))
+    assert idx.cpu().tolist() == [b * T + int(text[b].argmax()) for b in range(B)] and int(idx[2]) == 2 * T + 5
+    x = rnd(torch.randn(B * T, C, generator=gen), dtype).to(DEV).to(dtype)
+    got = ops.gather_rows(x, idx)
+    assert torch.equal(got, x[idx.long()])
+    dx = ops.scatter_rows(got, idx, B * T)
+    ref = torch.zeros_like(x)
+    ref[idx.long()] = got
+    assert torch.equal(dx, ref)
+
+
+@pytest.mark.parametrize('B,D', [(8, 64), (128, 512), (37, 48), (300, 512)])
+def test_logits_and_symmetric_ce_fwd_bwd(B, D):
+    """clip.py:317-336 + clip_head.py:24-36 in fp64 autograd vs the HIP kernels."""
+    gen = torch.Generator().manual_seed(B + D)
+    fi = (torch.randn(B, D, generator=gen) * 3).requires_grad_(True)
+    ft = (torch.randn(B, D, generator=gen) * 0.5).requires_grad_(True)
+    s = torch.tensor([math.log(1 / 0.07)], dtype=torch.float64, requires_grad=True)
+    ni = fi.double() / fi.double().norm(dim=-1, keepdim=True)
+    nt = ft.double() / ft.double().norm(dim=-1, keepdim=True)
+    il = (s.exp() * ni) @ nt.t()
+    tl = (s.exp() * nt) @ ni.t()
+    lab = torch.arange(B)
+    li, lt = F.cross_entropy(il, lab), F.cross_entropy(tl, lab)
+    ((li + lt) * 1.3).backward()
+    sd = torch.tensor([math.log(1 / 0.07)], device=DEV)
+    logits, ws = ops.clip_logits_fwd(fi.detach().to(DEV), ft.detach().to(DEV), sd)
+    assert relmax(logits, il.detach()) < 2e-6
+    out, lse = ops.clip_ce_fwd(logits)
+    assert abs(float(out[0]) - float(li)) < 2e-5 and abs(float(out[1]) - float(lt)) < 2e-5
+    assert abs(float(out[2]) - float(li + lt)) < 4e-5
+    G = ops.clip_ce_bwd(logits, lse, torch.tensor([1.3], device=DEV))
+    ds = torch.full((1,), 2.0, device=DEV)
+    dimg, dtxt = ops.clip_logits_bwd(G, logits, ws, D, ds)
+    assert relmax(dimg, fi.grad) < 1e-4 and relmax(dtxt, ft.grad) < 1e-4
+    assert abs(float(ds) - 2.0 - float(s.grad)) < 1e-4 * max(1.0, abs(float(s.grad)))
+
+
+def test_logit_scale_is_clipped_in_place_after_use():
+    fi = torch.randn(8, 64, device=DEV)
+    ft = torch.randn(8, 64, device=DEV)
+    s = torch.tensor([5.0], device=DEV)
+    logits, _ = ops.clip_logits_fwd(fi, ft, s)
+    cos = F.normalize(fi, dim=-1) @ F.normalize(ft, dim=-1).t()
+    assert relmax(logits, math.exp(5.0) * cos) < 1e-5          # this step still uses exp(5.0)
+    assert abs(float(s) - 4.6) < 1e-6                          # clip.py:309-311
+
+
+WATCH = ['visual.class_embedding', 'visual.positional_embedding', 'visual.proj',
+         'visual.patch_embed.proj.weight', 'visual.norm_pre.weight', 'visual.blocks.0.attn.qkv.weight',
+         'visual.blocks.1.mlp.fc2.bias', 'visual.norm_post.bias', 'transformer.blocks.0.attn.qkv.bias',
+         'transformer.blocks.1.mlp.fc1.weight', 'transformer.blocks.1.attn.proj.weight',
+         'token_embedding.weight', 'positional_embedding', 'ln_final.weight', 'text_projection',
+         'logit_scale']
+# The key third of a qkv bias shifts every score of a query row by the same amount: its gradient is
+# mathematically zero, numerically rounding noise (|g| ~ 1e-9 < Adam's eps), and Adam turns that noise
+# into updates of up to lr * |g| / (|g| + eps) with the noise's sign.  The parameter norm after the step
+# is therefore implementation-noise-defined (the reference's own fp32 vs fp64 runs differ the same way);
+# its gradient norm is still checked.
+ADAM_NOISE_DEFINED = {'transformer.blocks.0.attn.qkv.bias'}
+TOL_F32 = dict(loss=1e-3, logits=2e-3, feat=1e-3, grad=2e-3, param=1e-4)
+# bf16 storage of activations / Linear operands (fp32 accumulate; fp32 features, logits, loss): stated
+# bounds for the benchmark dtype (the reference has no bf16 path).  exp(logit_scale) = 14.3 multiplies
+# every feature error into the logits, hence the wider logits / loss bounds.
+TOL_BF16 = dict(loss=3e-2, logits=2e-1, feat=6e-2, grad=8e-2, param=1e-2)
+
+
+def _run_against_golden(name, cfg, dtype, steps_cap, tol):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    N, steps = [int(v) for v in z['meta']]
+    oracle0 = OC.CLIPOracle(cfg, seed=0, text_std_cap=U.STD_CAP, **U.SOLVER)
+    model, opt = U.build_product(cfg, dtype)
+    U.load_oracle_state(model, oracle0)
+    model.train()
+    gen = torch.Generator().manual_seed(4242)
+    R = cfg['image_resolution']
+    report, bad = [], []
+
+    def check(what, got, ref, nominal, rel=False):
+        got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+        scale = max(float(np.max(np.abs(ref))), 1e-12) if rel else 1.0
+        err = float(np.max(np.abs(got - ref))) / scale
+        line = '%-58s err %.3e  bound %.1e' % (what, err, nominal)
+        report.append(line)
+        if not err <= nominal:
+            bad.append(line)
+
+    for s in range(min(steps, steps_cap)):
+        image = torch.randn(N, 3, R, R, generator=gen)
+        text = OC.make_text(gen, N, cfg['context_length'], cfg['vocab_size'])
+        captured = {}
+        orig = model.head.forward
+
+        def spy(il, tl, a, b):
+            captured['logits'] = il.detach().clone()
+            return orig(il, tl, a, b)
+        model.head.forward = spy
+        clip = model.model
+        oi, ot = clip.encode_image, clip.encode_text
+        clip.encode_image = lambda im: captured.setdefault('fi', oi(im))
+        clip.encode_text = lambda tx: captured.setdefault('ft', ot(tx))
+        out = U.product_step(model, opt, image.to(DEV), text.to(DEV))
+        model.head.forward, clip.encode_image, clip.encode_text = orig, oi, ot
+        pre, p64 = 's%d_' % s, 's%d_f64_' % s
+        for k in ('loss', 'img_loss', 'text_loss'):
+            check(pre + k, float(out[k].detach()), z[pre + k], tol['loss'])
+        check(pre + 'image_logits (vs fp64)', captured['logits'].cpu().numpy(), z[p64 + 'image_logits'], tol['logits'])
+        check(pre + 'image_features[:, :16]', captured['fi'].detach().float().cpu().numpy()[:, :16],
+              z[p64 + 'image_features'], tol['feat'], rel=True)
+        check(pre + 'text_features[:, :16]', captured['ft'].detach().float().cpu().numpy()[:, :16],
+              z[p64 + 'text_features'], tol['feat'], rel=True)
+        for n in WATCH:
+            check(pre + 'gradnorm/' + n, U.product_grad(model, n).double().norm().item(), z[pre + 'gradnorm/' + n],
+                  tol['grad'], rel=True)
+            if n not in ADAM_NOISE_DEFINED:
+                check(pre + 'pnorm/' + n, U.product_param(model, n).double().norm().item(), z[pre + 'pnorm/' + n],
+                      tol['param'], rel=True)
+    print('\n'.join(report))
+    try:
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/parity_%s_%s.txt' % (name, str(dtype).split('.')[-1]), 'w') as f:
+            f.write('\n'.join(report) + '\n\nVIOLATIONS (%d)\n' % len(bad) + '\n'.join(bad) + '\n')
+    except OSError:
+        pass
+    assert not bad, 'parity violations:\n' + '\n'.join(bad)
+
+
+def test_golden_small_fp32():
+    _run_against_golden('clip_small', OC.SMALL, torch.float32, 3, TOL_F32)
+
+
+def test_golden_vit_b32_fp32():
+    """configs/clip/vit-b-32.yaml architecture: ViT-B/32 (50 tokens), 12-layer causal text tower (77 tokens)."""
+    _run_against_golden('clip_vit_b32', OC.VIT_B_32, torch.float32, 2, TOL_F32)
+
+
+def test_golden_small_bf16():
+    _run_against_golden('clip_small', OC.SMALL, torch.bfloat16, 1, TOL_BF16)
+
+
+def test_golden_vit_b32_bf16():
+    _run_against_golden('clip_vit_b32', OC.VIT_B_32, torch.bfloat16, 1, TOL_BF16)
+
+
+def test_trainer_runs_clip_config_end_to_end(tmp_path):
+    """The v110 Trainer + hook bus drive the CLIP config (CLIPWrapper, CLIPHead, AdamW, LinearWarmup o
+    CosineAnnealingDecay) on synthetic image-text pairs; the loss goes down."""
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_config(os.path.join(root, 'configs/clip/vit-b-32_synthetic.yaml'),
+                     ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+                      'dataloader.train.dataset.num_samples=64', 'dataloader.train.dataset.context_length=16',
+                      'dataloader.train.dataset.vocab_size=400', 'epochs=3',
+                      'model.architecture.image_resolution=64', 'model.architecture.vision_layers=2',
+                      'model.architecture.vision_width=128', 'model.architecture.context_length=16',
+                      'model.architecture.vocab_size=400', 'model.architecture.transformer_width=128',
+                      'model.architecture.transformer_heads=2', 'model.architecture.transformer_layers=2',
+                      'model.architecture.embed_dim=64', 'lr_scheduler.warmup_steps=1',
+                      'lr_scheduler.learning_rate.learning_rate=1e-3', 'lr_scheduler.end_lr=1e-3',
+                      'output_dir=%s' % tmp_path, 'log_config.interval=4'])
+    cfg.timestamp = ''
+    tr = Trainer(cfg)
+    assert tr.optimizer.type == 'adamw' and tr.iters_per_epoch == 8
+    # the reference's initial proj std of the text blocks (width^-0.5 * 2 depth) is kept by the product;
+    # for this tiny fit it is tamed so that the loss curve is not dominated by the init
+    with torch.no_grad():
+        for blk in tr.model.model.transformer.blocks:
+            blk.attn.proj.weight.mul_(0.02)
+            blk.mlp.fc2.weight.mul_(0.02)
+    tr.model.arena_q.refresh()
+    data = next(iter(tr.train_dataloader))
+    tr.model.train()
+    l0 = float(tr.model(*data)['loss'].detach())
+    tr.train()
+    assert tr.current_iter == 24
+    l1 = float(tr.outputs['loss'].detach())
+    assert np.isfinite(l1) and l1 < l0, (l0, l1)           # one cached batch: it must be fitted

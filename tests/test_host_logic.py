@@ -364,3 +364,91 @@ def test_checkpoint_file_format_and_extract_weight(tmp_path):
     from passl_amd.utils.checkpoint import to_numpy, to_tensors
     opt2.set_state_dict(to_tensors(to_numpy(opt.state_dict())))
     assert torch.equal(opt2._velocity[0], opt._velocity[0]) and sched2.last_epoch == 5 and sched2() == sched()
+
+
+# ------------------------------------------------------------------ MAE / CLIP rows (host side)
+REF_MAE_CFG = '/root/reference/configs/mae/mae_vit_b_pretrain.yaml'
+REF_CLIP_CFG = '/root/reference/configs/clip/vit-b-32.yaml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAE_CFG), reason='reference tree not present')
+def test_reference_mae_config_loads_and_builds_unchanged():
+    hip_config.set_device('cpu')
+    from passl_amd.modeling import build_model
+    from passl_amd.solver import build_lr_scheduler, build_optimizer
+    from oracle.mae import init_state, VIT_B
+    cfg = get_config(REF_MAE_CFG, [])
+    model = build_model(cfg.model)
+    arch = {k: VIT_B[k] for k in ('img_size', 'patch_size', 'embed_dim', 'depth', 'decoder_embed_dim',
+                                  'decoder_depth', 'mlp_ratio')}
+    ost = init_state(torch.Generator().manual_seed(0), **arch)
+    sd = model.backbone.state_dict()
+    assert set(sd.keys()) == set(ost.keys())
+    assert all(tuple(sd[k].shape) == tuple(ost[k].shape) for k in ost)
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 111655680
+    sched = build_lr_scheduler(cfg.lr_scheduler, 10)
+    opt = build_optimizer(cfg.optimizer, sched, [model])
+    assert opt.type == 'adamw' and (opt._b1, opt._b2, opt._wd) == (0.9, 0.95, 0.05)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLIP_CFG), reason='reference tree not present')
+def test_reference_clip_config_loads_and_builds_unchanged():
+    hip_config.set_device('cpu')
+    from passl_amd.modeling import build_model
+    from passl_amd.solver import build_lr_scheduler, build_optimizer
+    from oracle.clip import init_state, VIT_B_32
+    cfg = get_config(REF_CLIP_CFG, [])
+    model = build_model(cfg.model)
+    ost = init_state(torch.Generator().manual_seed(0), VIT_B_32)
+    sd = model.model.state_dict()
+    # same keys as the reference's CLIP.state_dict() (pinned in oracle/ref_runner.load_clip_state),
+    # including the raw matrices `visual.proj` / `text_projection` that run as bias-free Linears here
+    assert set(sd.keys()) == set(ost.keys())
+    assert all(tuple(sd[k].shape) == tuple(ost[k].shape) for k in ost)
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for v in ost.values()) == 151277313
+    assert model.model.transformer.blocks[0].attn.causal and not model.model.visual.blocks[0].attn.causal
+    assert abs(float(model.model.logit_scale.detach()) - math.log(1 / 0.07)) < 1e-6
+    # reference init (clip.py:271-282): text proj std = width^-0.5 * (2 * depth)
+    w = model.model.transformer.blocks[3].attn.proj.weight
+    assert abs(float(w.std()) - 512 ** -0.5 * 24) < 0.02
+    sched = build_lr_scheduler(cfg.lr_scheduler, 591)
+    opt = build_optimizer(cfg.optimizer, sched, [model])
+    assert opt.type == 'adamw' and (opt._b1, opt._b2, opt._eps, opt._wd) == (0.9, 0.98, 1e-8, 0.0005)
+    # state_dict round trip through the alias hooks
+    sd2 = {k: v.clone() for k, v in model.state_dict().items()}
+    assert 'model.visual.proj' in sd2 and 'model.visual.proj.weight' not in sd2
+
+
+def test_clip_mask_and_registry_guards():
+    hip_config.set_device('cpu')
+    from passl_amd.modeling.backbones import BACKBONES
+    from passl_amd.modeling.backbones.vision_transformer import _is_causal
+    from passl_amd.modeling.heads import HEADS
+    assert 'CLIP' in BACKBONES and 'VisionTransformer' in BACKBONES and 'CLIPHead' in HEADS
+    T = 5
+    causal = torch.triu(torch.full((T, T), -math.inf), 1)
+    assert _is_causal(causal) and _is_causal('causal') and not _is_causal(None)
+    with pytest.raises(NotImplementedError):
+        _is_causal(torch.zeros(T, T))
+    with pytest.raises(NotImplementedError):          # ModifiedResNet tower is not built
+        BACKBONES.get('CLIP')(embed_dim=64, image_resolution=64, vision_layers=(1, 1, 1, 1), vision_width=64,
+                              vision_patch_size=None, pre_norm=True, proj=True, patch_bias=False,
+                              context_length=8, vocab_size=50, transformer_width=64, transformer_heads=1,
+                              transformer_layers=1, qkv_bias=True)
+    head = HEADS.get('CLIPHead')()
+    a = torch.zeros(4, 4)
+    with pytest.raises(NotImplementedError):          # not the (logits, logits.t()) pair
+        head(a, torch.zeros(4, 4), torch.arange(4), torch.arange(4))
+
+
+def test_synthetic_image_text_dataset():
+    from passl_amd.datasets.builder import build_dataloader
+    cfg = dict(dataset=dict(name='SyntheticImageText', num_samples=64, image_size=32, context_length=12,
+                            vocab_size=100), sampler=dict(batch_size=8))
+    loader, _ = build_dataloader(cfg, 'cpu')
+    image, text = next(iter(loader))
+    assert image.shape == (8, 3, 32, 32) and text.shape == (8, 12) and text.dtype == torch.int64
+    am = text.argmax(dim=-1)
+    assert bool((text[torch.arange(8), am] == 99).all()) and int(text.max()) == 99 and int(text.min()) == 0
+    assert all(int(text[b, am[b] + 1:].abs().sum()) == 0 for b in range(8))
+    assert len(loader) == 8
