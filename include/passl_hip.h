@@ -230,6 +230,8 @@ int passl_hip_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int d
                        passl_stream_t stream);
 /* out[c] = sum_m x[m][c] (fp32 out) — Linear bias gradient. */
 int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype, passl_stream_t stream);
+/* out[c] += sum_m x[m][c] — accumulates straight into the (zero-initialised) gradient buffer. */
+int passl_hip_colsum_acc(const void* x, float* out, int64_t M, int C, int dtype, passl_stream_t stream);
 
 /* ---------------------------------------------------------------- contrastive head */
 

@@ -103,6 +103,10 @@ __global__ void __launch_bounds__(kThreads) embed_bwd_kernel(const int64_t* __re
   const int t = blockIdx.x;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (rl < rows_par) {
+    // run-length accumulation: captions are zero-padded, so at most positions the ids of consecutive
+    // images repeat (the pad id) — their gradients are summed in registers and flushed once
+    float run[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int64_t run_tok = -1;
     for (int b = blockIdx.y * rows_par + rl; b < B; b += gridDim.y * rows_par) {
       const int64_t row = (int64_t)b * Tn + t;
       float v[8];
@@ -110,11 +114,24 @@ __global__ void __launch_bounds__(kThreads) embed_bwd_kernel(const int64_t* __re
       const int64_t tok = text[row];
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += v[k];
-      if (tok >= 0 && tok < vocab) {
-        float* dst = dE + tok * C + ch * 8;
+      if (tok != run_tok) {
+        if (run_tok >= 0 && run_tok < vocab) {
+          float* dst = dE + run_tok * C + ch * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(dst + k, v[k]);
+          for (int k = 0; k < 8; ++k) atomicAdd(dst + k, run[k]);
+        }
+        run_tok = tok;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) run[k] = v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) run[k] += v[k];
       }
+    }
+    if (run_tok >= 0 && run_tok < vocab) {
+      float* dst = dE + run_tok * C + ch * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(dst + k, run[k]);
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[rl * C + ch * 8 + k] = acc[k];
@@ -424,7 +441,7 @@ extern "C" int passl_hip_embed_bwd(const int64_t* text, const void* dout, float*
   const int chunks = C >> 3;
   if (chunks > kThreads) return PASSL_EUNSUPPORTED;       // C <= 2048
   const int rows_par = kThreads / chunks;
-  int slabs = (B + rows_par * 8 - 1) / (rows_par * 8);    // ~8 images per thread
+  int slabs = (B + rows_par * 32 - 1) / (rows_par * 32);  // ~32 images per thread (long pad runs)
   if (slabs < 1) slabs = 1;
   if (slabs > 64) slabs = 64;
   CLIP_DISPATCH(dtype, hipLaunchKernelGGL(embed_bwd_kernel<T>, dim3(T_, slabs), dim3(kThreads),

@@ -290,10 +290,11 @@ extern "C" int passl_hip_avgpool_bwd(const void* dy, void* dx, int N, int HW, in
   return PASSL_OK;
 }
 
-extern "C" int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype,
-                                passl_stream_t stream) {
+static int colsum_impl(const void* x, float* out, int64_t M, int C, int dtype, bool accumulate,
+                       passl_stream_t stream) {
   if (!x || !out || M <= 0 || C <= 0 || (C & 7) || !aligned16(x)) return PASSL_EINVAL;
-  if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess)
+  if (!accumulate &&
+      hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess)
     return PASSL_ELAUNCH;
   int slabs = (int)((M + 255) / 256);
   if (slabs > 512) slabs = 512;
@@ -303,6 +304,16 @@ extern "C" int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int
                                            reinterpret_cast<const T*>(x), out, M, C, rows);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
+}
+
+extern "C" int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype,
+                                passl_stream_t stream) {
+  return colsum_impl(x, out, M, C, dtype, false, stream);
+}
+
+extern "C" int passl_hip_colsum_acc(const void* x, float* out, int64_t M, int C, int dtype,
+                                    passl_stream_t stream) {
+  return colsum_impl(x, out, M, C, dtype, true, stream);
 }
 
 extern "C" int passl_hip_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype,

@@ -452,9 +452,11 @@ extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const floa
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0 || C <= 0 ||
       (C & 7) || C > 512 * kLnMaxChunks || !aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma))
     return PASSL_EINVAL;
-  int nb = (int)((M + 63) / 64);
-  if (nb > 1024) nb = 1024;
-  const int rows = (int)((M + nb - 1) / nb);
+  // 16..64 rows per block: >= 2 blocks per CU for the short-sequence shapes (CLIP: M = 6400 / 9856)
+  // while the dgamma/dbeta atomics (2 C per block) stay small next to the row traffic
+  int rows = (int)(M / 1024);
+  rows = rows < 16 ? 16 : (rows > 64 ? 64 : rows);
+  const int nb = (int)((M + rows - 1) / rows);
   VIT_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nb), dim3(kThreads),
                                          8 * C * sizeof(float), as_stream(stream),
                                          reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x),

@@ -79,6 +79,7 @@ SIGNATURES = {
     'passl_hip_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_relu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_colsum': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
+    'passl_hip_colsum_acc': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
     'passl_hip_l2norm_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
     'passl_hip_l2norm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'passl_hip_infonce_workspace_bytes': (c_l, [c_i, c_i]),

@@ -363,9 +363,7 @@ class _LinearFn(Function):
             ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
         ops.conv_wgrad(pl.wd, x, dy, rt.dw)
         if layer.bias is not None:
-            tmp = torch.empty(layer.out_features, dtype=torch.float32, device=dy.device)
-            ops.colsum_into(dy, tmp)
-            layer.bias.grad.add_(tmp)
+            ops.colsum_into(dy, layer.bias.grad, accumulate=True)     # straight into the arena's gradient
         rt.arena.grad_ready(rt.indices)
         # y = x W + b + residual: the residual branch's gradient is dy itself
         return dx, None, None, None, None, None, (dy if ctx.has_res else None)

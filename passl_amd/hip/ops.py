@@ -249,10 +249,11 @@ def relu_bwd(dy, y):
     return dx
 
 
-def colsum_into(x, out):
-    """out[C] (fp32) = column sums of x [M, C]."""
+def colsum_into(x, out, accumulate=False):
+    """out[C] (fp32) = (accumulate: +=) column sums of x [M, C]."""
     M, Cc = x.shape
-    L.check(_lib().passl_hip_colsum(L.ptr(x), L.ptr(out), M, Cc, L.dt(x), L.stream()), 'colsum')
+    fn = _lib().passl_hip_colsum_acc if accumulate else _lib().passl_hip_colsum
+    L.check(fn(L.ptr(x), L.ptr(out), M, Cc, L.dt(x), L.stream()), 'colsum')
     return out
 
 

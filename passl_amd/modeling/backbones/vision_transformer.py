@@ -185,9 +185,7 @@ class _ClsPosFn(Function):
                 p.grad = torch.zeros_like(p)
         dout = dout.contiguous()
         dx = ops.mae_gather_bwd(dout, ids, cls.grad, B, L, L)              # dx rows + dcls += sum_b dout[b, 0]
-        tmp = torch.empty(pos.numel(), dtype=torch.float32, device=dout.device)
-        ops.colsum_into(dout.view(B, -1), tmp)                             # dpos[t] = sum_b dout[b, t]
-        pos.grad.view(-1).add_(tmp)
+        ops.colsum_into(dout.view(B, -1), pos.grad.view(-1), accumulate=True)   # dpos[t] += sum_b dout[b, t]
         return dx, None, None, None, None, None
 
 
