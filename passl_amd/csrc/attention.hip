@@ -15,10 +15,28 @@
 // `causal` (CLIP text tower, passl_v110/modeling/backbones/clip.py:284-286: additive triu(-inf, 1)
 // mask): key j is visible to query i iff j <= i; fully masked tiles are skipped.
 // Limits: d in {32, 64}, T <= 208 (13 tiles) — the MAE pre-training shapes; larger T needs a
-// KV-tiled (flash-style) variant.  bf16 inputs are converted when staged; all arithmetic is fp32.
+// KV-tiled (flash-style) variant.  The kernels in THIS file use exact-fp32 MFMA (bf16 inputs are
+// converted when staged): they serve fp32 activations (the parity dtype); bf16 activations take
+// the bf16-MFMA kernels of attention_bf16.hip.
+#include <stdlib.h>
 #include "common.h"
 
+// attention_bf16.hip: bf16-MFMA kernels for bf16 activations
+int passl_attn_bf16_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, int DH, float scale,
+                        int causal, hipStream_t st);
+int passl_attn_bf16_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                        int B, int Tn, int H, int DH, float scale, int causal, hipStream_t st);
+
 namespace {
+
+// PASSL_ATTN_F32MFMA=1 routes bf16 activations through the exact-fp32-MFMA kernels (A/B runs)
+bool use_bf16_mfma() {
+  static const bool v = [] {
+    const char* e = getenv("PASSL_ATTN_F32MFMA");
+    return !(e && e[0] == '1');
+  }();
+  return v;
+}
 
 constexpr int kThreads = 256;
 constexpr int kMaxTiles = 13;
@@ -354,6 +372,8 @@ extern "C" int passl_hip_attention_fwd(const void* qkv, void* out, float* lse, i
   if (!qkv || !out || !lse) return PASSL_EINVAL;
   if (!shape_ok(B, T_, H, DH)) return PASSL_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
+  if (dtype == PASSL_BF16 && use_bf16_mfma() && aligned16(qkv) && aligned16(out))
+    return passl_attn_bf16_fwd(qkv, out, lse, B, T_, H, DH, scale, causal, st);
   if (dtype == PASSL_BF16)
     return DH == 64 ? launch_fwd<bf16_t, 64>(qkv, out, lse, B, T_, H, scale, causal, st)
                     : launch_fwd<bf16_t, 32>(qkv, out, lse, B, T_, H, scale, causal, st);
@@ -369,6 +389,9 @@ extern "C" int passl_hip_attention_bwd(const void* qkv, const void* out, const v
   if (!qkv || !out || !dout || !lse || !dqkv) return PASSL_EINVAL;
   if (!shape_ok(B, T_, H, DH)) return PASSL_EUNSUPPORTED;
   hipStream_t st = as_stream(stream);
+  if (dtype == PASSL_BF16 && use_bf16_mfma() && aligned16(qkv) && aligned16(out) && aligned16(dout) &&
+      aligned16(dqkv))
+    return passl_attn_bf16_bwd(qkv, out, dout, lse, dqkv, B, T_, H, DH, scale, causal, st);
   if (dtype == PASSL_BF16)
     return DH == 64 ? launch_bwd<bf16_t, 64>(qkv, out, dout, lse, dqkv, B, T_, H, scale, causal, st)
                     : launch_bwd<bf16_t, 32>(qkv, out, dout, lse, dqkv, B, T_, H, scale, causal, st);
