@@ -74,7 +74,9 @@ int passl_hip_momentum_sgd(float* p, const float* g, float* v, int64_t n, float 
  *   local_lr = lr*lars_coeff*|p_s| / (|g_s| + wd_s*|p_s| + epsilon)   if wd_s > 0, |p_s| > 0, |g_s| > 0
  *            = lr                                                     otherwise
  *   v = mu*v + local_lr*(g*grad_scale + wd_s*p);   p = p - v
- * norms: workspace [n_seg][2] (zeroed inside).  Two launches (norms, update).
+ * norms: workspace [n_seg][2] (fully written).  blk_seg must be ascending (the blocks of one parameter are
+ * consecutive).  Three launches (per-block partial sums, fixed-order per-parameter reduction — no atomics,
+ * so data-parallel replicas compute bit-identical local learning rates — and the update).
  * Replaces paddle.fluid.optimizer.LarsMomentumOptimizer.minimize called from
  * passl_v110/hooks/optimizer_hook.py:44-45 (registered at passl_v110/solver/optimizer.py:25). */
 int passl_hip_lars_momentum(float* p, const float* g, float* v, const int64_t* blk_off,

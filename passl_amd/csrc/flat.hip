@@ -99,11 +99,12 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// norms[seg][0] += sum p^2, norms[seg][1] += sum (g*gs)^2 over the block's chunk
+// partial[block] = (sum p^2, sum (g*gs)^2) over the block's chunk.  No atomics: the per-parameter
+// norms must be BIT-IDENTICAL on every data-parallel rank (identical inputs after the gradient
+// all-reduce), otherwise the replicas drift apart through the local learning rates.
 __global__ void __launch_bounds__(kThreads) lars_norm_kernel(
     const float* __restrict__ p, const float* __restrict__ g, const int64_t* __restrict__ blk_off,
-    const int32_t* __restrict__ blk_len, const int32_t* __restrict__ blk_seg, float gs,
-    float* __restrict__ norms) {
+    const int32_t* __restrict__ blk_len, float gs, float* __restrict__ partial) {
   __shared__ float red[4];
   const int64_t off = blk_off[blockIdx.x];
   const int len = blk_len[blockIdx.x];
@@ -121,8 +122,39 @@ __global__ void __launch_bounds__(kThreads) lars_norm_kernel(
   sp = block_sum(sp, red);
   sg = block_sum(sg, red);
   if (threadIdx.x == 0) {
-    atomicAdd(norms + 2 * blk_seg[blockIdx.x], sp);
-    atomicAdd(norms + 2 * blk_seg[blockIdx.x] + 1, sg);
+    partial[2 * blockIdx.x] = sp;
+    partial[2 * blockIdx.x + 1] = sg;
+  }
+}
+
+// norms[seg] = fixed-order sum of the partials of the segment's blocks (blk_seg is ascending: the
+// blocks of one parameter are consecutive).  One workgroup per segment.
+__global__ void __launch_bounds__(kThreads) lars_seg_reduce_kernel(
+    const float* __restrict__ partial, const int32_t* __restrict__ blk_seg, int n_blocks,
+    float* __restrict__ norms) {
+  __shared__ float red[4];
+  __shared__ int range[2];
+  const int seg = blockIdx.x;
+  if (threadIdx.x < 2) {                      // lower bound of seg (+ threadIdx.x)
+    const int key = seg + (int)threadIdx.x;
+    int lo = 0, hi = n_blocks;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (blk_seg[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    range[threadIdx.x] = lo;
+  }
+  __syncthreads();
+  float sp = 0.f, sg = 0.f;
+  for (int b = range[0] + threadIdx.x; b < range[1]; b += kThreads) {
+    sp += partial[2 * b];
+    sg += partial[2 * b + 1];
+  }
+  sp = block_sum(sp, red);
+  sg = block_sum(sg, red);
+  if (threadIdx.x == 0) {
+    norms[2 * seg] = sp;
+    norms[2 * seg + 1] = sg;
   }
 }
 
@@ -266,10 +298,23 @@ extern "C" int passl_hip_lars_momentum(float* p, const float* g, float* v, const
     return PASSL_EINVAL;
   if (n_blocks == 0) return PASSL_OK;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(norms, 0, 2 * sizeof(float) * (size_t)n_seg, st) != hipSuccess)
-    return PASSL_ELAUNCH;
+  // per-block partial sums: library-owned workspace, grown on demand (2 floats per 4096-element block)
+  static float* partial = nullptr;
+  static int64_t partial_cap = 0;
+  if (n_blocks > partial_cap) {
+    if (partial) (void)hipFree(partial);
+    partial_cap = ((int64_t)n_blocks + 1023) / 1024 * 1024;
+    if (hipMalloc(&partial, 2 * sizeof(float) * (size_t)partial_cap) != hipSuccess) {
+      partial = nullptr;
+      partial_cap = 0;
+      return PASSL_ELAUNCH;
+    }
+  }
   hipLaunchKernelGGL(lars_norm_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, blk_off, blk_len,
-                     blk_seg, grad_scale, norms);
+                     grad_scale, partial);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(lars_seg_reduce_kernel, dim3(n_seg), dim3(kThreads), 0, st, partial, blk_seg,
+                     (int)n_blocks, norms);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   hipLaunchKernelGGL(lars_update_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, v, blk_off,
                      blk_len, blk_seg, seg_wd, norms, lr, mu, lars_coeff, epsilon, grad_scale);

@@ -59,8 +59,10 @@ def _init_distributed(device):
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = 'nccl' if device.type == 'cuda' else 'gloo'
-        kw = {'device_id': device} if device.type == 'cuda' else {}
+        # "nccl" IS RCCL on ROCm.  PASSL_DIST_BACKEND=gloo lets several ranks share ONE GPU (together with
+        # PASSL_DEVICE_INDEX) to exercise the data-parallel path on a single-GPU box (tests/test_dp_gpu.py)
+        backend = os.environ.get('PASSL_DIST_BACKEND') or ('nccl' if device.type == 'cuda' else 'gloo')
+        kw = {'device_id': device} if (device.type == 'cuda' and backend == 'nccl') else {}
         dist.init_process_group(backend=backend, **kw)
     return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
 

@@ -19,7 +19,8 @@ def set_device(name):
     if isinstance(name, torch.device):
         _state['device'] = name
     elif name in ('gpu', 'cuda'):
-        _state['device'] = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+        _state['device'] = torch.device('cuda', int(os.environ.get('PASSL_DEVICE_INDEX',
+                                                                  os.environ.get('LOCAL_RANK', 0))))
         torch.cuda.set_device(_state['device'])
     elif name == 'cpu':
         _state['device'] = torch.device('cpu')

@@ -1,0 +1,97 @@
+"""Worker of tests/test_dp_gpu.py: one data-parallel rank of a short training run on the HIP path.
+Launched by torch.distributed.run; several ranks may share one GPU (PASSL_DEVICE_INDEX) with the
+gloo backend (PASSL_DIST_BACKEND) — the collectives then stage through the host, everything else
+(kernels, reducer bucketing, broadcast at start-up, gathered keys / embeddings) is the production
+path.  Prints `DP-OK <workload> <loss>` on rank 0 when every check passed."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+OVERRIDES = {
+    'moco': ('configs/moco/moco_v2_r50_synthetic.yaml',
+             ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+              'dataloader.train.dataset.num_samples=256']),
+    'simclr': ('configs/simclr/simclr_r50_synthetic.yaml',
+               ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+                'dataloader.train.dataset.num_samples=256']),
+    'mae': ('configs/mae/mae_vit_b_synthetic.yaml',
+            ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+             'dataloader.train.dataset.num_samples=256', 'model.architecture.depth=2',
+             'model.architecture.embed_dim=128', 'model.architecture.num_heads=4',
+             'model.architecture.decoder_embed_dim=64', 'model.architecture.decoder_depth=1',
+             'model.architecture.decoder_num_heads=2']),
+    'clip': ('configs/clip/vit-b-32_synthetic.yaml',
+             ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+              'dataloader.train.dataset.num_samples=256', 'dataloader.train.dataset.context_length=16',
+              'dataloader.train.dataset.vocab_size=400', 'model.architecture.image_resolution=64',
+              'model.architecture.vision_layers=2', 'model.architecture.vision_width=128',
+              'model.architecture.context_length=16', 'model.architecture.vocab_size=400',
+              'model.architecture.transformer_width=128', 'model.architecture.transformer_heads=2',
+              'model.architecture.transformer_layers=2', 'model.architecture.embed_dim=64']),
+}
+
+
+def main():
+    workload = sys.argv[1]
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.hooks import OptimizerHook, LRSchedulerHook
+    from passl_amd.utils.config import get_config
+    path, ov = OVERRIDES[workload]
+    cfg = get_config(os.path.join(ROOT, path), ov + ['compute_dtype=fp32'])
+    if workload == 'mae':
+        cfg.model.architecture.img_size = 64
+    if workload == 'moco':
+        cfg.model.K = 256
+    cfg.timestamp = ''
+    tr = Trainer(cfg)
+    assert tr.world_size == int(os.environ['WORLD_SIZE']) > 1 and tr.grad_reducer is not None
+    tr.mode = 'train'
+    tr.model.train()
+    opt_hook = next(h for h in tr.hooks if isinstance(h, OptimizerHook))
+    lr_hook = next(h for h in tr.hooks if isinstance(h, LRSchedulerHook))
+    data = next(iter(tr.train_dataloader))
+    # ranks draw different batches (seed + rank)
+    t0 = data[0].double().sum().reshape(1)
+    both = [torch.zeros_like(t0) for _ in range(tr.world_size)]
+    dist.all_gather(both, t0)
+    assert len({float(b) for b in both}) == tr.world_size, 'ranks must see different data'
+
+    def flat_params():
+        return torch.cat([p.detach().reshape(-1).double() for p in tr.model.parameters()])
+
+    def same_everywhere(t, what):
+        ref = t.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, t), '%s differs between ranks (max abs diff %.3e)' % (
+            what, float((ref - t).abs().max()))
+
+    same_everywhere(flat_params(), 'initial parameters')
+    p0 = flat_params()
+    for _ in range(3):
+        tr.current_iter += 1
+        tr.outputs = tr.model(*data, total_iters=tr.total_iters, current_iter=tr.current_iter, mixup_fn=None)
+        opt_hook.train_iter_end(tr)
+        lr_hook.train_iter_end(tr)
+    torch.cuda.synchronize()
+    loss = float(tr.outputs['loss'].detach())
+    assert loss == loss and abs(loss) < 1e4, loss
+    p1 = flat_params()
+    assert float((p1 - p0).abs().max()) > 0, 'parameters did not move'
+    # identical averaged gradients on every rank <=> replicas stay bit-identical
+    same_everywhere(p1, 'parameters after 3 steps')
+    if workload == 'moco':
+        same_everywhere(tr.model.queue.double(), 'queue (gathered keys)')
+        assert tr.model._ptr == 3 * 8 * tr.world_size
+    dist.barrier()
+    if tr.rank == 0:
+        print('DP-OK %s %.6f' % (workload, loss), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
