@@ -1,7 +1,8 @@
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; KB per dispatch),
 summed per training step.  FETCH_SIZE is doubled: on gfx950 rocprofv3 tallies the 128-byte
 requests of wide coalesced reads at 64 B (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is
-uncalibrated (reported as is).   python tools/pmc_summary.py <fetch.db> <write.db> <steps>"""
+uncalibrated (reported as is).   python tools/pmc_summary.py <fetch.db> <write.db> <steps> [out.json]
+With out.json: per-kernel bytes per launch (the figure bench.py reports as roofline.traffic)."""
 import re
 import sqlite3
 import sys
@@ -44,6 +45,26 @@ def main():
         tf += fgb
         tw += wgb
     print('# total per step: fetch %.2f GB, write %.2f GB' % (tf, tw))
+    if len(sys.argv) > 4:
+        import json
+        per = {}
+        for k in f:
+            calls, fkb, dur = f[k]
+            wkb = w.get(k, [0, 0.0, 0.0])[1]
+            per[k] = {'launches': calls, 'fetch_bytes_per_launch': round(2.0 * fkb * 1024 / calls),
+                      'write_bytes_per_launch': round(wkb * 1024 / calls),
+                      'avg_launch_us': round(dur / 1e3 / calls, 2)}
+        gemm = [k for k in per if 'igemm' in k]
+        n = sum(per[k]['launches'] for k in gemm)
+        agg = {'launches': n,
+               'hbm_bytes_per_launch': round(sum(per[k]['launches'] * (per[k]['fetch_bytes_per_launch'] +
+                                                                         per[k]['write_bytes_per_launch'])
+                                                 for k in gemm) / max(n, 1)),
+               'kernels': sorted(gemm)}
+        json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 '
+                             '(gfx950 128-byte requests are tallied at 64 B), per launch',
+                   'steps_profiled': steps, 'fetch_gb_per_step': round(tf, 2), 'write_gb_per_step': round(tw, 2),
+                   'igemm_all_variants': agg, 'per_kernel': per}, open(sys.argv[4], 'w'), indent=1)
 
 
 if __name__ == '__main__':
