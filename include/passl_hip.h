@@ -74,7 +74,8 @@ int passl_hip_momentum_sgd(float* p, const float* g, float* v, int64_t n, float 
  *   local_lr = lr*lars_coeff*|p_s| / (|g_s| + wd_s*|p_s| + epsilon)   if wd_s > 0, |p_s| > 0, |g_s| > 0
  *            = lr                                                     otherwise
  *   v = mu*v + local_lr*(g*grad_scale + wd_s*p);   p = p - v
- * norms: workspace [n_seg][2] (fully written).  blk_seg must be ascending (the blocks of one parameter are
+ * norms: caller-owned fp32 workspace of 2*(n_seg + n_blocks) floats ([n_seg][2] squared norms followed by
+ * the per-block partial sums; fully written).  blk_seg must be ascending (the blocks of one parameter are
  * consecutive).  Three launches (per-block partial sums, fixed-order per-parameter reduction — no atomics,
  * so data-parallel replicas compute bit-identical local learning rates — and the update).
  * Replaces paddle.fluid.optimizer.LarsMomentumOptimizer.minimize called from
@@ -99,7 +100,10 @@ typedef struct passl_pack_job {
   int32_t K, R, S, C;          /* source dims */
   int32_t TR, TS;              /* taps kept */
   int32_t r_base, r_step, s_base, s_step;
-  int32_t transpose;           /* 1: dst is [C][TR][TS][K]; 0: dst is [K][TR][TS][C] */
+  int32_t transpose;           /* 1: dst is [C][TR][TS][K]; 0: dst is [K][TR][TS][C];
+                                * fast paths chosen by the host for whole-tensor jobs: 2 = R=S=1 transpose
+                                * dst[c][k] = src[k][c] (block_start = index of a 32x32 tile, k fastest),
+                                * 3 = contiguous cast dst[e] = src[e] (block_start = first element) */
   int32_t c_pad;               /* dst innermost-dim padding: dst C (or K) dim is c_pad wide (>= C), zero filled; 0 = no pad */
 } passl_pack_job;
 int passl_hip_pack_weights(const float* src, void* dst, int dtype, const passl_pack_job* jobs,
@@ -295,10 +299,12 @@ int passl_hip_ntxent_bwd(const float* a, const float* b, const float* a_all, con
 int passl_hip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                             float* mean, float* rstd, int64_t M, int C, float eps, int dtype,
                             passl_stream_t stream);
-/* dx; dgamma/dbeta (fp32 [C]) are ACCUMULATED into (atomics).  C <= 2048. */
+/* dx (+ dres when non-NULL: the gradient arriving through the residual branch that forked off x, so
+ * that `x + f(LN(x))` needs no separate add); dgamma/dbeta (fp32 [C]) are ACCUMULATED into (atomics).
+ * C <= 2048. */
 int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                            const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t M,
-                            int C, int dtype, passl_stream_t stream);
+                            const float* rstd, const void* dres, void* dx, float* dgamma,
+                            float* dbeta, int64_t M, int C, int dtype, passl_stream_t stream);
 /* exact (erf) GELU and its backward dx = dy * gelu'(x); n % 8 == 0. */
 int passl_hip_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream);
 int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,

@@ -202,6 +202,43 @@ __global__ void __launch_bounds__(kThreads) pack_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ block_job,
                                                         const int32_t* __restrict__ block_start) {
   const passl_pack_job j = jobs[block_job[blockIdx.x]];
+  if (j.transpose == 2) {
+    // 2-D transpose of a Linear / 1x1 weight: dst[c][k] = src[k][c]; block_start = tile index over
+    // 32 x 32 tiles; coalesced rows on both sides through a padded LDS tile
+    __shared__ float tile[32][33];
+    const int tiles_k = (j.K + 31) >> 5;
+    const int tk = block_start[blockIdx.x] % tiles_k, tc = block_start[blockIdx.x] / tiles_k;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* s = src + j.src_off;
+    T* d = dst + j.dst_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = tk * 32 + ty + 8 * i, c = tc * 32 + tx;
+      tile[ty + 8 * i][tx] = (k < j.K && c < j.C) ? s[(int64_t)k * j.C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tc * 32 + ty + 8 * i, k = tk * 32 + tx;
+      if (c < j.C && k < j.K) ElemTraits<T>::st(d + (int64_t)c * j.K + k, tile[tx][ty + 8 * i]);
+    }
+    return;
+  }
+  if (j.transpose == 3) {
+    // straight cast of a contiguous weight (forward operand of a Linear / unpadded conv): 4 per thread
+    const int64_t total = (int64_t)j.K * j.R * j.S * j.C;
+    const int64_t e = (int64_t)block_start[blockIdx.x] + threadIdx.x * 4;
+    const float* s = src + j.src_off;
+    T* d = dst + j.dst_off;
+    if (e + 4 <= total) {
+      const float4 v = *reinterpret_cast<const float4*>(s + e);
+      ElemTraits<T>::st(d + e, v.x); ElemTraits<T>::st(d + e + 1, v.y);
+      ElemTraits<T>::st(d + e + 2, v.z); ElemTraits<T>::st(d + e + 3, v.w);
+    } else {
+      for (int64_t q = e; q < total; ++q) ElemTraits<T>::st(d + q, s[q]);
+    }
+    return;
+  }
   const int inner_src = j.transpose ? j.K : j.C;            // logical innermost dim of dst
   const int inner = j.c_pad > 0 ? j.c_pad : inner_src;      // padded width
   const int outer = j.transpose ? j.C : j.K;
@@ -298,18 +335,8 @@ extern "C" int passl_hip_lars_momentum(float* p, const float* g, float* v, const
     return PASSL_EINVAL;
   if (n_blocks == 0) return PASSL_OK;
   hipStream_t st = as_stream(stream);
-  // per-block partial sums: library-owned workspace, grown on demand (2 floats per 4096-element block)
-  static float* partial = nullptr;
-  static int64_t partial_cap = 0;
-  if (n_blocks > partial_cap) {
-    if (partial) (void)hipFree(partial);
-    partial_cap = ((int64_t)n_blocks + 1023) / 1024 * 1024;
-    if (hipMalloc(&partial, 2 * sizeof(float) * (size_t)partial_cap) != hipSuccess) {
-      partial = nullptr;
-      partial_cap = 0;
-      return PASSL_ELAUNCH;
-    }
-  }
+  // caller-provided workspace: norms[n_seg][2] followed by the per-block partial sums [n_blocks][2]
+  float* partial = norms + 2 * (size_t)n_seg;
   hipLaunchKernelGGL(lars_norm_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, blk_off, blk_len,
                      grad_scale, partial);
   PASSL_RETURN_IF_LAUNCH_FAILED();

@@ -59,8 +59,9 @@ constexpr int kLnMaxChunks = 4;            // C <= 2048
 template <typename T>
 __global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
-    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int rows_per_block) {
+    const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dres,
+    T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
+    int rows_per_block) {
   extern __shared__ float col[];            // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
@@ -108,6 +109,12 @@ __global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
         for (int e = 0; e < 8; ++e) {
           const float xh = (v[e] - mu) * rs;
           o[e] = rs * (d[e] * g[e] - s1 - xh * s2);
+        }
+        if (dres) {                       // gradient of the residual branch that forked off x
+          float rr[8];
+          ld8(dres + (int64_t)row * C + c, rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += rr[e];
         }
         ElemTraits<T>::store8(dr + c, o);
       }
@@ -446,11 +453,12 @@ extern "C" int passl_hip_layernorm_fwd(const void* x, const float* gamma, const 
 }
 
 extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma,
-                                       const float* mean, const float* rstd, void* dx,
-                                       float* dgamma, float* dbeta, int64_t M, int C, int dtype,
-                                       passl_stream_t stream) {
+                                       const float* mean, const float* rstd, const void* dres,
+                                       void* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                                       int dtype, passl_stream_t stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0 || C <= 0 ||
-      (C & 7) || C > 512 * kLnMaxChunks || !aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma))
+      (C & 7) || C > 512 * kLnMaxChunks || !aligned16(dy) || !aligned16(x) || !aligned16(dx) ||
+      !aligned16(gamma) || (dres && !aligned16(dres)))
     return PASSL_EINVAL;
   // 16..64 rows per block: >= 2 blocks per CU for the short-sequence shapes (CLIP: M = 6400 / 9856)
   // while the dgamma/dbeta atomics (2 C per block) stay small next to the row traffic
@@ -460,8 +468,8 @@ extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const floa
   VIT_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nb), dim3(kThreads),
                                          8 * C * sizeof(float), as_stream(stream),
                                          reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x),
-                                         gamma, mean, rstd, reinterpret_cast<T*>(dx), dgamma, dbeta,
-                                         (int)M, C, rows);)
+                                         gamma, mean, rstd, reinterpret_cast<const T*>(dres),
+                                         reinterpret_cast<T*>(dx), dgamma, dbeta, (int)M, C, rows);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

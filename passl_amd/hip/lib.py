@@ -92,7 +92,7 @@ SIGNATURES = {
     'passl_hip_ntxent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p,
                                    c_p, c_p, c_p, c_p]),
     'passl_hip_layernorm_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p]),
-    'passl_hip_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p]),
+    'passl_hip_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p]),
     'passl_hip_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_attention_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),

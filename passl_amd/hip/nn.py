@@ -443,8 +443,44 @@ class _LayerNormFn(Function):
         return dx, None, None, None
 
 
+class _LayerNormForkFn(Function):
+    """(LN(x), x): the pre-norm residual fork `x + f(LN(x))`.  The second output is x itself, handed to
+    the residual consumer (the GEMM epilogue of f's last Linear); in backward the gradient that comes
+    back through it is added to the LayerNorm gradient INSIDE the LayerNorm backward kernel, so the fork
+    costs no separate elementwise add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, layer):
+        x = x.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x, gamma.detach(), beta.detach(), layer._epsilon)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.layer = layer
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, mean, rstd = ctx.saved_tensors
+        layer = ctx.layer
+        for p in (layer.weight, layer.bias):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        if dres is not None:
+            dres = dres.contiguous()
+            if dres.dtype != x.dtype:
+                dres = dres.to(x.dtype)
+        dx = ops.layernorm_bwd(dy.contiguous(), x, layer.weight.detach(), mean, rstd, layer.weight.grad,
+                               layer.bias.grad, dres=dres)
+        if layer._rt is not None:
+            layer._rt.arena.grad_ready(layer._rt.indices)
+        return dx, None, None, None
+
+
 class LayerNorm(Layer):
     """paddle.nn.LayerNorm over the last axis (biased variance), rows [M, C] in the compute dtype."""
+
+    def fork(self, x):
+        """-> (LN(x), x_for_the_residual_add); see _LayerNormForkFn."""
+        return _LayerNormForkFn.apply(x, self.weight, self.bias, self)
 
     def __init__(self, normalized_shape, epsilon=1e-05, weight_attr=None, bias_attr=None, name=None):
         super().__init__()

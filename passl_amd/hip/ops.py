@@ -356,7 +356,9 @@ def ntxent_bwd(a, b, a_all, b_all, rowstats, gscale, row_offset, T, co2_weight=3
 
 def lars_momentum(p, g, v, table, lr, mu, coeff, eps, grad_scale=1.0):
     """`table` = dict(blk_off int64[nb], blk_len int32[nb], blk_seg int32[nb], seg_wd float[ns],
-    norms float[ns,2]) on the device (built once by the optimizer)."""
+    norms float[ns + nb, 2] = workspace: squared norms + per-block partial sums) on the device (built
+    once by the optimizer)."""
+    assert table['norms'].numel() >= 2 * (table['seg_wd'].numel() + table['blk_off'].numel())
     L.check(_lib().passl_hip_lars_momentum(L.ptr(p), L.ptr(g), L.ptr(v), L.ptr(table['blk_off']),
                                            L.ptr(table['blk_len']), L.ptr(table['blk_seg']),
                                            table['blk_off'].numel(), L.ptr(table['seg_wd']),
@@ -376,13 +378,15 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
+    """dres: gradient of the residual branch that forked off x (added to dx inside the kernel)."""
     Cc = x.shape[-1]
     M = x.numel() // Cc
     dx = torch.empty_like(x)
     L.check(_lib().passl_hip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
-                                           L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), M, Cc, L.dt(x),
-                                           L.stream()), 'layernorm_bwd')
+                                           L.ptr(dres) if dres is not None else None, L.ptr(dx),
+                                           L.ptr(dgamma), L.ptr(dbeta), M, Cc, L.dt(x), L.stream()),
+            'layernorm_bwd')
     return dx
 
 

@@ -43,6 +43,16 @@ class WeightPacker:
             j.TR, j.TS = p.TR, p.TS
             j.r_base, j.r_step, j.s_base, j.s_step = p.r_base, p.r_step, p.s_base, p.s_step
             j.transpose, j.c_pad = p.transpose, p.c_pad
+            full = (p.TR == R and p.TS == S and p.r_base == 0 and p.r_step == 1 and p.s_base == 0 and
+                    p.s_step == 1)
+            if p.transpose and R == 1 and S == 1 and full and p.c_pad in (0, K) and p.size == K * Cc:
+                j.transpose = 2            # tiled 2-D transpose: blocks enumerate 32 x 32 tiles
+                for t in range(((K + 31) // 32) * ((Cc + 31) // 32)):
+                    bj.append(i)
+                    bs.append(t)
+                continue
+            if not p.transpose and full and p.c_pad in (0, Cc) and p.size == K * R * S * Cc and src_off % 4 == 0:
+                j.transpose = 3            # contiguous cast
             for start in range(0, p.size, _BLOCK_ELEMS):
                 bj.append(i)
                 bs.append(start)

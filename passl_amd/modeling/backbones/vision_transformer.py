@@ -123,8 +123,12 @@ class Block(nn.Layer):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def forward(self, x, B, T):
-        x = self.attn(self.norm1(x), B, T, residual=x)       # x + attn(norm1(x)): add in proj's epilogue
-        return self.mlp(self.norm2(x), residual=x)           # x + mlp(norm2(x)): add in fc2's epilogue
+        # x + attn(norm1(x)) and x + mlp(norm2(x)): the add runs in the epilogue of proj / fc2, the
+        # fork's gradient add inside the LayerNorm backward kernel (nn.LayerNorm.fork)
+        h, xr = self.norm1.fork(x)
+        x = self.attn(h, B, T, residual=xr)
+        h, xr = self.norm2.fork(x)
+        return self.mlp(h, residual=xr)
 
 
 class Transformer(nn.Layer):

@@ -168,7 +168,7 @@ class LarsMomentumOptimizer(object):
                     blk_len=torch.tensor(blk_len, dtype=torch.int32, device=dev),
                     blk_seg=torch.tensor(blk_seg, dtype=torch.int32, device=dev),
                     seg_wd=torch.tensor(seg_wd, dtype=torch.float32, device=dev),
-                    norms=torch.zeros(len(seg_wd), 2, dtype=torch.float32, device=dev))
+                    norms=torch.zeros(len(seg_wd) + len(blk_len), 2, dtype=torch.float32, device=dev))
 
     def get_lr(self):
         lr = self._learning_rate

@@ -47,6 +47,13 @@ def test_layernorm_fwd_bwd(dtype, M_, C):
     dx = ops.layernorm_bwd(dy.to(DEV).to(dtype), x.detach().to(DEV).to(dtype), g.detach().to(DEV), mean, rstd, dg, db)
     assert relmax(dx.float(), x.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
     assert relmax(dg, g.grad) < 1e-4 and relmax(db, b.grad) < 1e-4
+    # residual-fork variant: the gradient of the skip branch is added inside the kernel
+    dres = rnd(torch.randn(M_, C, generator=gen), dtype)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx2 = ops.layernorm_bwd(dy.to(DEV).to(dtype), x.detach().to(DEV).to(dtype), g.detach().to(DEV), mean, rstd,
+                            dg2, db2, dres=dres.to(DEV).to(dtype))
+    assert relmax(dx2.float(), x.grad + dres) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert torch.allclose(dg2, dg, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -113,7 +113,7 @@ def test_lars_kernel_vs_oracle_rule():
                  blk_len=torch.tensor(blk_len, dtype=torch.int32, device=DEV),
                  blk_seg=torch.tensor(blk_seg, dtype=torch.int32, device=DEV),
                  seg_wd=torch.tensor(wd, dtype=torch.float32, device=DEV),
-                 norms=torch.zeros(len(sizes), 2, device=DEV))
+                 norms=torch.zeros(len(sizes) + len(blk_len), 2, device=DEV))
     pd, gd, vd = p.to(DEV), g.to(DEV), v.to(DEV)
     ops.lars_momentum(pd, gd, vd, table, lr, mu, coeff, 0.0, gs)
     pr, vr = p.clone(), v.clone()
