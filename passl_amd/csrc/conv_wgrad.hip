@@ -14,6 +14,7 @@
 // global atomics (dW is zeroed by the caller).  Per-row gather info (image base, ih0, iw0) for
 // the next reduction tile is computed by 64 threads into a double-buffered LDS table.
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 #include "prof.h"
 
@@ -517,7 +518,13 @@ int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
+int g_wgrad_tile = 0;     // 0 = by shape; 1 = 64x64, 2 = 64x128, 3 = 128x64, 4 = 128x128 (experiments)
+
 int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
+  if (g_wgrad_tile == 1) return launch_dma<64, 64>(p, splits, a_bytes, dy_bytes, st);
+  if (g_wgrad_tile == 2) return launch_dma<64, 128>(p, splits, a_bytes, dy_bytes, st);
+  if (g_wgrad_tile == 3) return launch_dma<128, 64>(p, splits, a_bytes, dy_bytes, st);
+  if (g_wgrad_tile == 4) return launch_dma<128, 128>(p, splits, a_bytes, dy_bytes, st);
   const bool m64 = p.NCOLS <= 64, n64 = p.KDIM <= 64;
   if (m64 && n64) return launch_dma<64, 64>(p, splits, a_bytes, dy_bytes, st);
   if (m64) return launch_dma<64, 128>(p, splits, a_bytes, dy_bytes, st);
@@ -526,6 +533,11 @@ int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_byt
 }
 
 }  // namespace
+
+int passl_wgrad_option(const char* name, int value) {
+  if (strcmp(name, "wgrad_tile") == 0) { g_wgrad_tile = value; return PASSL_OK; }
+  return PASSL_EINVAL;
+}
 
 extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t stream) {
   if (!d || !d->a || !d->dy || !d->dw) return PASSL_EINVAL;

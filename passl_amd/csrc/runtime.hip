@@ -60,9 +60,11 @@ extern "C" int passl_hip_prof_collect(int cls, double* total_ms, int64_t* launch
 }
 
 int passl_igemm_ring_option(const char* name, int value);    // conv_igemm_ring.hip
+int passl_wgrad_option(const char* name, int value);         // conv_wgrad.hip
 
 extern "C" int passl_hip_set_option(const char* name, int value) {
   if (!name) return PASSL_EINVAL;
+  if (passl_wgrad_option(name, value) == PASSL_OK) return PASSL_OK;
   return passl_igemm_ring_option(name, value);
 }
 

@@ -43,8 +43,9 @@ class WeightPacker:
             j.TR, j.TS = p.TR, p.TS
             j.r_base, j.r_step, j.s_base, j.s_step = p.r_base, p.r_step, p.s_base, p.s_step
             j.transpose, j.c_pad = p.transpose, p.c_pad
-            full = (p.TR == R and p.TS == S and p.r_base == 0 and p.r_step == 1 and p.s_base == 0 and
-                    p.s_step == 1)
+            # every tap kept, in order (the step is irrelevant for a single tap)
+            full = (p.TR == R and p.TS == S and p.r_base == 0 and (R == 1 or p.r_step == 1) and
+                    p.s_base == 0 and (S == 1 or p.s_step == 1))
             if p.transpose and R == 1 and S == 1 and full and p.c_pad in (0, K) and p.size == K * Cc:
                 j.transpose = 2            # tiled 2-D transpose: blocks enumerate 32 x 32 tiles
                 for t in range(((K + 31) // 32) * ((Cc + 31) // 32)):
