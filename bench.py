@@ -34,7 +34,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None,
                     help='per-GPU batch (default: 256 = BASELINE configs[1]; simclr: 64; clip: 128)')
-    ap.add_argument('--workload', default='moco', choices=['moco', 'simclr', 'mae', 'clip'],
+    ap.add_argument('--workload', default='moco', choices=['moco', 'simclr', 'mae', 'clip', 'linprobe'],
                     help="moco = BASELINE.json's metric (default); simclr / mae / clip = the SimCLR, MAE and "
                          'CLIP rows (extra measurements: no-maxpool R50 + NT-Xent+CO2 + LARS; ViT-B/16 MAE; '
                          'CLIP ViT-B/32 image-text pairs)')
@@ -82,6 +82,7 @@ def pmc_traffic(args):
 def main():
     args = parse()
     simclr, mae, clip = args.workload == 'simclr', args.workload == 'mae', args.workload == 'clip'
+    linprobe = args.workload == 'linprobe'
     if args.batch is None:
         args.batch = 64 if simclr else (128 if clip else 256)
     # SimCLR: 2 views x (fwd + bwd = 3) x 15.99 GMAC x 2 FLOP per two-view sample;
@@ -90,6 +91,8 @@ def main():
     flop_per_sample = 2 * 3 * 15.99e9 * 2 if simclr else (3 * 9.78e9 * 2 if mae else FLOP_PER_SAMPLE)
     if clip:
         flop_per_sample = 3 * 7.39e9 * 2
+    if linprobe:                        # frozen trunk forward only (4.087 GMAC) + the fc
+        flop_per_sample = 4.09e9 * 2
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert world == args.gpus, 'launch with torchrun --nproc-per-node %d' % args.gpus
@@ -103,7 +106,8 @@ def main():
     cfg = get_config(os.path.join(ROOT, 'configs/simclr/simclr_r50_synthetic.yaml' if simclr else
                                   ('configs/mae/mae_vit_b_synthetic.yaml' if mae else
                                    ('configs/clip/vit-b-32_synthetic.yaml' if clip else
-                                    'configs/moco/moco_v2_r50_synthetic.yaml'))),
+                                    ('configs/moco/moco_clas_r50_synthetic.yaml' if linprobe else
+                                     'configs/moco/moco_v2_r50_synthetic.yaml')))),
                      ['dataloader.train.sampler.batch_size=%d' % args.batch,
                       'compute_dtype=%s' % args.dtype])
     cfg.timestamp = ''
@@ -167,7 +171,8 @@ def main():
         ips = args.batch * world * args.steps / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         out = {
-            'metric': ('image-text pairs/sec/node, CLIP ViT-B/32 bs%d/GPU' % args.batch) if clip else
+            'metric': ('images/sec/node, linear probe on frozen R50 bs%d/GPU' % args.batch) if linprobe else
+            ('image-text pairs/sec/node, CLIP ViT-B/32 bs%d/GPU' % args.batch) if clip else
             ('images/sec/node, MAE ViT-B/16 mask 0.75 bs%d/GPU' % args.batch) if mae else
             'images/sec/node (2-view), %s bs%d/GPU' % (
                 'SimCLR R50 (no stem max-pool)' if simclr else 'MoCo-v2 R50', args.batch),
@@ -175,7 +180,10 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': ('CLIP ViT-B/32 + 12-layer causal text transformer %s, bs=%d/GPU, 224^2 '
+            'config': {'workload': ('linear probe: frozen ResNet-50 (fused inference BN) + fc 2048->1000 %s, '
+                                    'bs=%d/GPU, 224^2 synthetic labelled images, momentum-SGD on the fc '
+                                    '(configs/moco/moco_clas_r50.yaml)' if linprobe else
+                                    'CLIP ViT-B/32 + 12-layer causal text transformer %s, bs=%d/GPU, 224^2 '
                                     'synthetic images + 77-token synthetic captions, AdamW (CLIP row; '
                                     'configs/clip/vit-b-32.yaml)' if clip else
                                     'MAE ViT-B/16 %s, bs=%d/GPU, 224^2 synthetic images, mask 0.75 (50 '

@@ -412,6 +412,18 @@ int passl_hip_clip_ce_fwd(const float* logits, int B, float* lse, float* out, pa
 int passl_hip_clip_ce_bwd(const float* logits, const float* lse, const float* gloss, int B,
                           float* dlogits, passl_stream_t stream);
 
+/* ---------------------------------------------------------------- linear probe
+ * Reference: ClasHead.loss + accuracy, passl_v110/modeling/heads/clas_head.py:47-72. */
+
+/* scores fp32 [N,C], labels int64 [N] -> lse [N] (row log-sum-exp, saved for the backward),
+ * out = {mean cross-entropy, acc1 (%), acc5 (%)}.  Top-k membership by rank counting (ties resolve to
+ * the lower index).  A label outside [0,C) makes the loss NaN. */
+int passl_hip_softmax_ce_fwd(const float* scores, const int64_t* labels, int N, int C, float* lse,
+                             float* out, passl_stream_t stream);
+/* dscores[i][j] = gloss/N * (softmax(scores_i)[j] - [j == labels[i]]); gloss: device scalar. */
+int passl_hip_softmax_ce_bwd(const float* scores, const float* lse, const int64_t* labels,
+                             const float* gloss, int N, int C, float* dscores, passl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,9 @@ def _install_tensor_patches():
     _T.set_value = set_value
     _T.stop_gradient = property(lambda s: not s.requires_grad,
                                 lambda s, v: s.requires_grad_(not v) if s.is_leaf else None)
+    # Parameter.trainable = False  <=>  stop_gradient = True  [Paddle-semantics]
+    _T.trainable = property(lambda s: s.requires_grad,
+                            lambda s, v: s.requires_grad_(bool(v)) if s.is_leaf else None)
     _T.cuda = lambda self, *a, **k: self
     _T.astype = lambda self, dt: self.to(_dtype(dt))
     _T._paddle_shim = True

@@ -94,6 +94,9 @@ def load():
     imp(PKG + '.modeling.backbones.clip')
     imp(PKG + '.modeling.heads.clip_head')
     imp(PKG + '.modeling.architectures.CLIPWrapper')
+    # linear-probe row: heads/clas_head.py, architectures/clas.py
+    imp(PKG + '.modeling.heads.clas_head')
+    imp(PKG + '.modeling.architectures.clas')
     return _namespace()
 
 
@@ -222,6 +225,25 @@ def load_clip_state(model, oracle):
     import torch
     with torch.no_grad():
         sd = model.model.state_dict()
+        assert set(sd.keys()) == set(oracle.st.keys()), set(sd.keys()) ^ set(oracle.st.keys())
+        for n, t in oracle.st.items():
+            assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)
+            sd[n].copy_(t.detach())
+
+
+def build_reference_clas(num_classes=1000):
+    """The reference's Classification model built by its MODELS registry from the `model:` block of
+    configs/moco/moco_clas_r50.yaml (frozen_stages = 4)."""
+    ns = load()
+    return ns.build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50, frozen_stages=4),
+                               head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048,
+                                         num_classes=num_classes)))
+
+
+def load_clas_state(model, oracle):
+    import torch
+    with torch.no_grad():
+        sd = model.state_dict()
         assert set(sd.keys()) == set(oracle.st.keys()), set(sd.keys()) ^ set(oracle.st.keys())
         for n, t in oracle.st.items():
             assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)

@@ -50,6 +50,36 @@ class SyntheticImageText(object):
 
 
 @DATASETS.register()
+class SyntheticLabeled(object):
+    """(image, label) pairs shaped like the reference's ImageNet dataset with ``return_label: True``
+    (passl_v110/datasets/imagenet.py): image ~ N(0,1) fp32 [3,S,S] plus a class-dependent offset (so a
+    linear probe has something to fit), label int64; ``evaluate`` = imagenet.py:75-80."""
+
+    def __init__(self, num_samples=1281167, image_size=224, num_classes=1000, seed=1234,
+                 num_batches_cached=1, **ignored):
+        self.num_samples, self.image_size = int(num_samples), int(image_size)
+        self.num_classes, self.seed = int(num_classes), int(seed)
+        self.num_batches_cached = int(num_batches_cached)
+
+    def __len__(self):
+        return self.num_samples
+
+    def make_batch(self, gen, batch_size):
+        s = self.image_size
+        label = torch.randint(0, self.num_classes, (batch_size,), generator=gen)
+        image = torch.randn(batch_size, 3, s, s, generator=gen)
+        # a per-class colour cast: channel c shifted by cos(label * (c + 1))
+        shift = torch.cos(label.double().unsqueeze(1) * torch.arange(1, 4).double()).float()
+        return image + shift.view(batch_size, 3, 1, 1), label
+
+    def evaluate(self, preds, labels, topk=(1, 5)):
+        from ..modeling.heads.clas_head import accuracy
+        eval_res = {}
+        eval_res['acc1'], eval_res['acc5'] = accuracy(preds, labels, topk)
+        return eval_res
+
+
+@DATASETS.register()
 class ImageNet(object):
     def __init__(self, **kwargs):
         raise NotImplementedError(

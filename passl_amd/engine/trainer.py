@@ -27,6 +27,7 @@ import torch.distributed as dist
 from ..core.sync_utils import GradReducer, param_sync
 from ..datasets import build_dataloader
 from ..hip import config as hip_config
+from ..utils.misc import AverageMeter
 from ..hooks import Hook, build_hook
 from ..modeling.architectures import build_model
 from ..solver import build_lr_scheduler, build_lr_scheduler_simclr, build_optimizer
@@ -187,6 +188,47 @@ class Trainer:
                 self.call_hook('train_epoch_end')
                 self.current_epoch += 1
         self.call_hook('run_end')
+
+    # ---- evaluation loop — reference trainer.py:339-417
+    def val(self, **kargs):
+        if not hasattr(self, 'val_dataloader'):
+            self.val_dataloader, _mixup = build_dataloader(self.cfg.dataloader.val, self.device)
+        self.logger.info('start evaluate on epoch {} ..'.format(self.current_epoch + 1))
+        rank, world_size = self.rank, self.world_size
+        model = self.model
+        total_samples = len(self.val_dataloader.dataset)
+        self.logger.info('Evaluate total samples {}'.format(total_samples))
+        accum_samples = 0
+        self.model.eval()
+        outs = OrderedDict()
+        for data in self.val_dataloader:
+            batch_size = data.shape[0] if torch.is_tensor(data) else data[0].shape[0]
+            labels = data[-1]
+            pred = model(*data, mode='test')
+            current_samples = batch_size * world_size
+            accum_samples += current_samples
+            if world_size > 1:
+                pred_all = torch.empty((world_size * pred.shape[0],) + tuple(pred.shape[1:]), dtype=pred.dtype,
+                                       device=pred.device)
+                dist.all_gather_into_tensor(pred_all, pred.contiguous())
+                lab_all = torch.empty(world_size * labels.shape[0], dtype=labels.dtype, device=labels.device)
+                dist.all_gather_into_tensor(lab_all, labels.contiguous().view(-1))
+                pred, labels = pred_all, lab_all
+                if accum_samples > total_samples:
+                    keep = total_samples + current_samples - accum_samples
+                    self.logger.info('total samples {} {} {}'.format(total_samples, accum_samples, keep))
+                    pred, labels = pred[:keep], labels[:keep]
+                    current_samples = keep
+            res = self.val_dataloader.dataset.evaluate(pred, labels, **kargs)
+            for k, v in res.items():
+                if k not in outs:
+                    outs[k] = AverageMeter(k, ':6.3f')
+                outs[k].update(float(v), current_samples)
+        log_items = ['{} ({:6.3f})'.format(m.name, m.avg) for m in outs.values()]
+        self.logger.info(f'Validate Epoch [{self.current_epoch + 1}] ' + ', '.join(log_items))
+        self.val_results = OrderedDict((k, m.avg) for k, m in outs.items())
+        self.model.train()
+        return self.val_results
 
     # ---- checkpoint plumbing (scope row §8f-3) — reference trainer.py:419-444
     def resume(self, checkpoint_path):

@@ -118,6 +118,8 @@ SIGNATURES = {
     'passl_hip_mae_loss_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'passl_hip_mae_loss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'passl_hip_adamw': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
+    'passl_hip_softmax_ce_fwd': (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    'passl_hip_softmax_ce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),
     'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),
 }

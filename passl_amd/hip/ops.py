@@ -583,3 +583,22 @@ def clip_ce_bwd(logits, lse, gloss):
     L.check(_lib().passl_hip_clip_ce_bwd(L.ptr(logits), L.ptr(lse), L.ptr(gloss), logits.shape[0],
                                          L.ptr(dlogits), L.stream()), 'clip_ce_bwd')
     return dlogits
+
+
+# ------------------------------------------------------------------ linear probe
+def softmax_ce_fwd(scores, labels):
+    """scores fp32 [N,C], labels int64 [N] -> out[3] = (loss, acc1 %, acc5 %), lse [N]."""
+    N, Cc = scores.shape
+    lse = torch.empty(N, dtype=torch.float32, device=scores.device)
+    out = torch.empty(3, dtype=torch.float32, device=scores.device)
+    L.check(_lib().passl_hip_softmax_ce_fwd(L.ptr(scores), L.ptr(labels), N, Cc, L.ptr(lse), L.ptr(out),
+                                            L.stream()), 'softmax_ce_fwd')
+    return out, lse
+
+
+def softmax_ce_bwd(scores, lse, labels, gloss):
+    N, Cc = scores.shape
+    ds = torch.empty_like(scores)
+    L.check(_lib().passl_hip_softmax_ce_bwd(L.ptr(scores), L.ptr(lse), L.ptr(labels), L.ptr(gloss), N, Cc,
+                                            L.ptr(ds), L.stream()), 'softmax_ce_bwd')
+    return ds

@@ -5,3 +5,4 @@ from .timer_hook import IterTimerHook
 from .log_hook import LogHook
 from .lr_scheduler_hook import LRSchedulerHook
 from .checkpoint_hook import CheckpointHook
+from .evaluate_hook import EvaluateHook

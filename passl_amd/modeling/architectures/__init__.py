@@ -3,3 +3,4 @@ from .moco import MoCo
 from .simclr import SimCLR
 from .MAE import MAE_PRETRAIN
 from .CLIPWrapper import CLIPWrapper
+from .clas import Classification

@@ -18,6 +18,7 @@ import torch
 from ...hip import config, nn, ops, plan as P
 from ...modules import init, freeze
 from ...utils.logger import get_logger
+from ...modules.freeze import freeze_batchnorm_statictis
 from .builder import BACKBONES
 
 
@@ -102,10 +103,12 @@ class ResNet(nn.Layer):
         self.frozen_stages = frozen_stages
         self.init_parameters()
         if pretrained is not None:
-            state_dict = torch.load(pretrained, map_location='cpu')
+            # paddle.load of a paddle.save'd dict = the reference's pickle-of-numpy checkpoint layout
+            from ...utils.checkpoint import load_pickle, to_tensors
+            state_dict = load_pickle(pretrained)
             if 'state_dict' in state_dict:
                 state_dict = state_dict['state_dict']
-            self.set_state_dict(state_dict)
+            self.set_state_dict(to_tensors(state_dict))
             get_logger().info('Load pretrained backbone weight from {} success!'.format(pretrained))
         self._freeze_stages()
 
@@ -134,9 +137,20 @@ class ResNet(nn.Layer):
                     init.constant_init(m.bn3, 0)
 
     def _freeze_stages(self):
-        if self.frozen_stages >= 0:
-            raise NotImplementedError('frozen_stages>=0 (linear-probe configs) is outside the '
-                                      'MoCo pre-training hot path')
+        """resnet.py:90-106.  Built: -1 (nothing frozen: pre-training) and 4 (everything frozen: the
+        linear-probe configs, e.g. configs/moco/moco_clas_r50.yaml) — then every BatchNorm uses its
+        running statistics, no parameter is trainable and forward() runs the fused inference path."""
+        self.fully_frozen = False
+        if self.frozen_stages < 0:
+            return
+        if self.frozen_stages < 4:
+            raise NotImplementedError('partially frozen trunks (frozen_stages 0..3) are not built; '
+                                      'supported: -1 (pre-training) and 4 (linear probe)')
+        freeze_batchnorm_statictis(self)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.fully_frozen = True
+        get_logger().info('Frozen layer before stage {}'.format(self.frozen_stages + 1))
 
     def _all_bn_frozen(self):
         return all(m.uses_global_stats() for m in self.modules() if isinstance(m, nn._BatchNormBase))
@@ -149,13 +163,14 @@ class ResNet(nn.Layer):
         _Hp, Wp = P.stem_padded_hw(H, W)
         xp = ops.nchw_to_nhwc_pad(x.contiguous().float(), P.STEM_PAD, Wp, P.STEM_CP, dtype)
         frozen = self._all_bn_frozen()
-        if frozen and not torch.is_grad_enabled():
-            y = self.conv1.infer(xp, self.bn1, relu=True, hw=(H, W))
-            if self.stem_pool:
-                y = self.maxpool(y)
-            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
-                for blk in stage:
-                    y = blk.forward_frozen(y)
+        if frozen and (self.fully_frozen or not torch.is_grad_enabled()):
+            with torch.no_grad():
+                y = self.conv1.infer(xp, self.bn1, relu=True, hw=(H, W))
+                if self.stem_pool:
+                    y = self.maxpool(y)
+                for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                    for blk in stage:
+                        y = blk.forward_frozen(y)
         else:
             ops.stats_pool.reset()        # one fill for all fused-BN accumulators of this pass
             y, st = self.conv1(xp, hw=(H, W), want_stats=True)

@@ -25,6 +25,10 @@ OVERRIDES = {
              'model.architecture.embed_dim=128', 'model.architecture.num_heads=4',
              'model.architecture.decoder_embed_dim=64', 'model.architecture.decoder_depth=1',
              'model.architecture.decoder_num_heads=2']),
+    'linprobe': ('configs/moco/moco_clas_r50_synthetic.yaml',
+                 ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
+                  'dataloader.train.dataset.num_samples=256', 'dataloader.train.dataset.num_classes=16',
+                  'lr_scheduler.learning_rate=0.00002']),
     'clip': ('configs/clip/vit-b-32_synthetic.yaml',
              ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.image_size=64',
               'dataloader.train.dataset.num_samples=256', 'dataloader.train.dataset.context_length=16',
@@ -47,6 +51,9 @@ def main():
         cfg.model.architecture.img_size = 64
     if workload == 'moco':
         cfg.model.K = 256
+    if workload == 'linprobe':
+        cfg.model.head.num_classes = 16
+        cfg.custom_config = []                        # no EvaluateHook in the 3-step run
     cfg.timestamp = ''
     tr = Trainer(cfg)
     assert tr.world_size == int(os.environ['WORLD_SIZE']) > 1 and tr.grad_reducer is not None

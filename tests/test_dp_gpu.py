@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize('workload', ['moco', 'simclr', 'mae', 'clip'])
+@pytest.mark.parametrize('workload', ['moco', 'simclr', 'mae', 'clip', 'linprobe'])
 def test_two_ranks_one_gpu(workload):
     env = dict(os.environ, PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',

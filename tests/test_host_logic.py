@@ -452,3 +452,51 @@ def test_synthetic_image_text_dataset():
     assert bool((text[torch.arange(8), am] == 99).all()) and int(text.max()) == 99 and int(text.min()) == 0
     assert all(int(text[b, am[b] + 1:].abs().sum()) == 0 for b in range(8))
     assert len(loader) == 8
+
+
+# ------------------------------------------------------------------ linear-probe row (host side)
+REF_CLAS_CFG = '/root/reference/configs/moco/moco_clas_r50.yaml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLAS_CFG), reason='reference tree not present')
+def test_reference_linear_probe_config_loads_and_builds_unchanged():
+    hip_config.set_device('cpu')
+    from passl_amd.hooks import build_hook, EvaluateHook
+    from passl_amd.modeling import build_model
+    from passl_amd.solver import build_lr_scheduler, build_optimizer
+    from oracle.clas import init_state
+    cfg = get_config(REF_CLAS_CFG, [])
+    model = build_model(cfg.model)
+    ost = init_state(torch.Generator().manual_seed(0))
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(ost.keys())
+    assert all(tuple(sd[k].shape) == tuple(ost[k].shape) for k in ost)
+    # frozen_stages = 4: only the fc is trainable, every BatchNorm uses its running statistics
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == ['head.fc_cls.bias',
+                                                                                 'head.fc_cls.weight']
+    assert model.backbone.fully_frozen and model.backbone._all_bn_frozen()
+    sched = build_lr_scheduler(cfg.lr_scheduler, 100)          # milestones are epochs -> iterations
+    assert sched() == 30.0
+    for _ in range(6000):
+        sched.step()
+    assert abs(sched() - 3.0) < 1e-9
+    opt = build_optimizer(cfg.optimizer, sched, [model])
+    assert opt.type == 'momentum' and opt._wd == 0.0 and opt._momentum == 0.9 and len(opt._parameter_list) == 2
+    assert isinstance(build_hook(dict(cfg.custom_config[0])), EvaluateHook)
+    with pytest.raises(NotImplementedError):
+        build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50, frozen_stages=2),
+                         head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048)))
+    with pytest.raises(NotImplementedError):
+        build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50),
+                         head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048)))
+
+
+def test_synthetic_labeled_dataset_and_evaluate_contract():
+    from passl_amd.datasets.builder import build_dataloader
+    cfg = dict(dataset=dict(name='SyntheticLabeled', num_samples=64, image_size=32, num_classes=10),
+               sampler=dict(batch_size=8, drop_last=False))
+    loader, _ = build_dataloader(cfg, 'cpu')
+    image, label = next(iter(loader))
+    assert image.shape == (8, 3, 32, 32) and label.shape == (8,) and label.dtype == torch.int64
+    assert int(label.min()) >= 0 and int(label.max()) < 10 and len(loader) == 8 and len(loader.dataset) == 64
+    assert hasattr(loader.dataset, 'evaluate')
