@@ -1,8 +1,6 @@
 """WeightPacker: one-launch repacking of the fp32 master weights (flat buffer, each conv weight
 physically [K][R][S][C]) into the compute-dtype operand buffers the implicit-GEMM kernels read
 (forward [K][R][S][C], data-gradient [C][TR][TS][K] per residue class, stem padding)."""
-import ctypes as C
-
 import numpy as np
 import torch
 

@@ -8,7 +8,7 @@ Reference call sites being planned: nn.Conv2D uses at
 passl_v110/modeling/backbones/resnetimagenet.py:114-131 (bottleneck), :190-195 (stem),
 :216-224 (downsample); nn.Linear at passl_v110/modeling/necks/base_neck.py:80-85.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional
 
 

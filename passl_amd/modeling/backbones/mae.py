@@ -13,7 +13,6 @@ tests inject the reference's draw); the argsort pair is replaced by a rank kerne
 import math
 from functools import partial
 
-import numpy as np
 import torch
 import torch.nn as tnn
 from torch.autograd import Function

@@ -16,7 +16,7 @@ epilogue, i.e. one kernel per conv and no extra pass over the activations.
 import torch
 
 from ...hip import config, nn, ops, plan as P
-from ...modules import init, freeze
+from ...modules import init
 from ...utils.logger import get_logger
 from ...modules.freeze import freeze_batchnorm_statictis
 from .builder import BACKBONES

@@ -10,7 +10,6 @@ out); BN gamma=1, beta=0.
 """
 import math
 
-import torch
 
 from ...hip import nn
 from ...modules import init

@@ -4,7 +4,6 @@ img_labels) + CE(text_logits, text_labels)`` with outputs ``img_loss / text_loss
 HIP execution: CLIP.forward returns ``text_logits`` as the transpose view of ``img_logits`` and
 CLIPWrapper's labels are ``arange(B)``, so both cross-entropies run over ONE matrix (rows and
 columns) in csrc/clip.hip; other inputs raise instead of silently computing something else."""
-import torch
 from torch.autograd import Function
 
 from ...hip import nn, ops
