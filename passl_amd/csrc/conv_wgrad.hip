@@ -15,6 +15,7 @@
 // the next reduction tile is computed by 64 threads into a double-buffered LDS table.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "common.h"
 #include "prof.h"
 
@@ -501,6 +502,222 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_dma_kernel(const WParams p,
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dense variant (1x1 stride-1 unpadded convolutions over a contiguous NHWC tensor and every Linear
+// layer: x row m = bytes [m*C*2, (m+1)*C*2)): a 4-stage ring of 32-row tiles with register
+// double-buffering of the MFMA fragments.  Compared with wgrad_dma_kernel: no row-info table
+// (offsets are linear in m), three tiles in flight per workgroup instead of one (the 64 KB ring is
+// cut into 4 x 16 KB), the DMA of tile t+4 is issued as soon as the barrier of iteration t proves
+// stage t % 4 free, and the fragments of tile t+1 are fetched while tile t is multiplied.  The
+// transposing LDS reads are inline asm: hipcc orders any compiler-visible LDS read behind a full
+// `s_waitcnt vmcnt(0)` whenever an LDS-DMA is outstanding, which would drain the ring every iteration.
+template <int OFF>
+__device__ __forceinline__ uint2 lds_read_tr64(uint32_t addr) {
+  uint2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <int BMo, int BNo>
+__global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p, uint32_t a_bytes,
+                                                                 uint32_t dy_bytes) {
+  constexpr int BKM = 32, NST = 4;
+  constexpr int WM = BMo / 2, WN = BNo / 2;
+  constexpr int FM = WM / 16, FN = WN / 16;
+  constexpr int CPA = BMo / 8, CPB = BNo / 8;          // 16-byte chunks per row
+  constexpr int PA = BMo * 2, PB = BNo * 2;            // row pitch (bytes)
+  constexpr int A_BYTES = BKM * PA, B_BYTES = BKM * PB;
+  constexpr int NIA = A_BYTES / 1024 / 4, NIB = B_BYTES / 1024 / 4;   // DMA instructions per wave
+  constexpr int RPA = 1024 / PA, RPB = 1024 / PB;      // rows per DMA instruction
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int IPT = NIA + NIB;
+  static_assert(NIA >= 1 && NIB >= 1, "tile too narrow for one DMA instruction per wave");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int vb;
+  {
+    const int bid = blockIdx.x, nb = gridDim.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int bx = vb % p.grid_j, by = (vb / p.grid_j) % p.grid_oc, bz = vb / (p.grid_j * p.grid_oc);
+  const int oc0 = by * BMo;
+  const int j0 = bx * BNo;
+  const int kt_begin = bz * p.tiles_per_split;
+  int kt_end = kt_begin + p.tiles_per_split;
+  if (kt_end > p.nk_total) kt_end = p.nk_total;
+  if (kt_begin >= kt_end) return;
+  const int nk = kt_end - kt_begin;
+
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, dy_bytes, 0x00020000);
+
+  // ---- static per-thread DMA geometry (rows advance by 32 per tile: the swizzle term is invariant)
+  int a_row[NIA]; uint32_t a_col[NIA];                 // dy tile
+#pragma unroll
+  for (int i = 0; i < NIA; ++i) {
+    const int q = i * 4 + wave;
+    const int row = q * RPA + lane / CPA;
+    const int chunk = (lane % CPA) ^ (hswz<CPA>(row) << 1);
+    const int oc = oc0 + chunk * 8;
+    a_row[i] = row;
+    a_col[i] = oc < p.NCOLS ? (uint32_t)oc * 2u : kOOB;
+  }
+  int b_row[NIB]; uint32_t b_col[NIB];                 // x tile
+#pragma unroll
+  for (int i = 0; i < NIB; ++i) {
+    const int q = i * 4 + wave;
+    const int row = q * RPB + lane / CPB;
+    const int chunk = (lane % CPB) ^ (hswz<CPB>(row) << 1);
+    const int j = j0 + chunk * 8;
+    b_row[i] = row;
+    b_col[i] = j < p.KDIM ? (uint32_t)j * 2u : kOOB;
+  }
+  const uint32_t dy_pitch = (uint32_t)(p.dy_ld * 2), x_pitch = (uint32_t)(p.C * 2);
+
+  int issued = 0;                                      // tiles issued so far (relative to kt_begin)
+  auto issue_tile = [&]() {
+    char* Ab = smem + (issued % NST) * STAGE;
+    char* Bb = Ab + A_BYTES;
+    const int mbase = (kt_begin + issued) * BKM;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int m = mbase + a_row[i];
+      const uint32_t off = (m < p.M && a_col[i] != kOOB) ? (uint32_t)m * dy_pitch + a_col[i] : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_dy, (__attribute__((address_space(3))) void*)(Ab + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int m = mbase + b_row[i];
+      const uint32_t off = (m < p.M && b_col[i] != kOOB) ? (uint32_t)m * x_pitch + b_col[i] : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_a, (__attribute__((address_space(3))) void*)(Bb + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+    ++issued;
+  };
+
+  // ---- transposing fragment reads: 16-lane group g = l4 reads rows 8g + 4*half + (lane>>2)&3, the
+  // lane's own 8 bytes sit at channel 4*(lane&3) of the fragment's 16-channel block
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int r4 = (lane >> 2) & 3, c4 = lane & 3;
+  uint32_t a_rd[2][FM], b_rd[2][FN];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * l4 + 4 * h + r4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int pair = (wm * WM) / 16 + i;
+      a_rd[h][i] = (uint32_t)(row * PA + ((pair ^ hswz<CPA>(row)) << 5) + c4 * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int pair = (wn * WN) / 16 + j;
+      b_rd[h][j] = (uint32_t)(A_BYTES + row * PB + ((pair ^ hswz<CPB>(row)) << 5) + c4 * 8);
+    }
+  }
+  uint4 af[2][FM], bfr[2][FN];
+  auto read_frags = [&](auto SET, int t) {
+    constexpr int S_ = decltype(SET)::value;
+    const uint32_t sb = lds0 + (uint32_t)((t % NST) * STAGE);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const uint2 lo = lds_read_tr64<0>(sb + a_rd[0][i]), hi = lds_read_tr64<0>(sb + a_rd[1][i]);
+      af[S_][i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const uint2 lo = lds_read_tr64<0>(sb + b_rd[0][j]), hi = lds_read_tr64<0>(sb + b_rd[1][j]);
+      bfr[S_][j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Ring protocol (cf. conv_igemm_ring.hip).  Before iteration t: tiles <= t+3 issued, tile t in the
+  // register set t & 1.  Iteration t: wait for the own DMAs of tile t+1 (up to two newer tiles stay
+  // in flight) -> barrier (everybody's tile t+1 landed; everybody finished reading stage t % 4 during
+  // iteration t-1) -> issue tile t+4 into stage t % 4 -> fetch tile t+1 into the other register set
+  // -> MFMAs of tile t -> lgkmcnt(0).
+  auto iteration = [&](auto SET, int t) {
+    constexpr int S_ = decltype(SET)::value;
+    if (t + 1 < nk) {
+      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
+      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + NST < nk) issue_tile();
+      read_frags(std::integral_constant<int, 1 - S_>{}, t + 1);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[S_][i]),
+                                                            __builtin_bit_cast(bf16x8_t, bfr[S_][j]),
+                                                            acc[i][j], 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int t = 0; t < NST && t < nk; ++t) issue_tile();
+  if (nk >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPT) : "memory");
+  else if (nk == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
+  else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(std::integral_constant<int, 0>{}, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    iteration(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) iteration(std::integral_constant<int, 1>{}, kt + 1);
+  }
+
+  // ---- epilogue: fp32 atomics into dW[oc][j]
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int oc = oc0 + wm * WM + i * 16 + l4 * 4 + r;
+        const int jj = j0 + wn * WN + j * 16 + l15;
+        if (oc < p.NCOLS && jj < p.KDIM && !(p.dbg & 1)) atomicAdd(p.dw + (int64_t)oc * p.KDIM + jj, acc[i][j][r]);
+      }
+}
+
+template <int BMo, int BNo>
+int launch_pipe(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
+  constexpr int LDS = 4 * 32 * (BMo + BNo) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pipe_kernel<BMo, BNo>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  WParams q = p;
+  q.nk_total = (p.M + 31) / 32;                         // 32-row tiles
+  if (splits > q.nk_total) splits = q.nk_total;
+  q.tiles_per_split = (q.nk_total + splits - 1) / splits;
+  splits = (q.nk_total + q.tiles_per_split - 1) / q.tiles_per_split;
+  q.grid_j = (p.KDIM + BNo - 1) / BNo;
+  q.grid_oc = (p.NCOLS + BMo - 1) / BMo;
+  hipLaunchKernelGGL((wgrad_pipe_kernel<BMo, BNo>), dim3(q.grid_j * q.grid_oc * splits), dim3(kThreads),
+                     LDS, st, q, a_bytes, dy_bytes);
+  return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
 template <int BMo, int BNo>
 int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
   constexpr int LDS = 2 * 64 * (BMo + BNo) * 2 + 2 * 64 * (int)sizeof(RowInfo2);
@@ -520,7 +737,18 @@ int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes
 
 int g_wgrad_tile = 0;     // 0 = by shape; 1 = 64x64, 2 = 64x128, 3 = 128x64, 4 = 128x128 (experiments)
 
+int g_wgrad_pipe = 1;     // dense 4-stage ring kernel for 1x1/Linear shapes (0: wgrad_dma_kernel everywhere)
+
+// x is a contiguous [M][C] matrix: 1x1, stride 1, no padding over a dense NHWC tensor (or a Linear)
+bool dense_rows(const WParams& p) {
+  return p.R == 1 && p.S == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && p.OP == p.IH &&
+         p.OQ == p.IW && p.a_sw == p.C && p.a_sh == (int64_t)p.IW * p.C &&
+         p.a_sn == (int64_t)p.IH * p.IW * p.C;
+}
+
 int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
+  if (g_wgrad_pipe && g_wgrad_tile == 0 && dense_rows(p) && p.NCOLS > 64 && p.KDIM > 64)
+    return launch_pipe<128, 128>(p, splits, a_bytes, dy_bytes, st);
   if (g_wgrad_tile == 1) return launch_dma<64, 64>(p, splits, a_bytes, dy_bytes, st);
   if (g_wgrad_tile == 2) return launch_dma<64, 128>(p, splits, a_bytes, dy_bytes, st);
   if (g_wgrad_tile == 3) return launch_dma<128, 64>(p, splits, a_bytes, dy_bytes, st);
@@ -536,6 +764,7 @@ int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_byt
 
 int passl_wgrad_option(const char* name, int value) {
   if (strcmp(name, "wgrad_tile") == 0) { g_wgrad_tile = value; return PASSL_OK; }
+  if (strcmp(name, "wgrad_pipe") == 0) { g_wgrad_pipe = value; return PASSL_OK; }
   return PASSL_EINVAL;
 }
 
