@@ -78,8 +78,21 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
   return v;
 }
 
-template <int BM, int BN, int STAGES>
+// BK = K-elements per ring stage.  64: LDS rows of 128 B, 8 chunks, slot ^= (row >> 1) & 7.
+// 32: LDS rows of 64 B, 4 chunks, slot ^= g((row >> 2) & 3) with g = {0, 3, 2, 1}: for every one of
+// the four 16-lane groups that ds_read_b128 services together ({0-3,12-15,20-27}, {4-11,16-19,28-31}
+// and the same in the upper half-wave) the 16 lanes then fall on 16 different 16-byte bank quads —
+// the 4 rows that share a 64-byte bank range carry 4 different physical chunks.  BK = 32 with 4
+// stages keeps the 64 KB ring (2 workgroups per CU) but has up to 3 half-tiles in flight.
+__device__ __forceinline__ int swz32(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+template <int BM, int BN, int STAGES, int BK = 64>
 __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
+  constexpr int RB = BK * 2;                // LDS row bytes
+  constexpr int KS = BK / 32;               // 16x16x32 MFMA k-steps per stage
+  constexpr int RPI = 1024 / RB;            // tile rows per DMA instruction (8 or 16)
+  constexpr int CPRW = RB / 16;             // 16-byte chunks per row (8 or 4)
+  static_assert(BK == 64 || BK == 32, "ring stage depth");
   constexpr int kThreads = BM * 2;          // 4 waves for 128-row tiles, 8 for 256-row tiles
   constexpr int WAVES = kThreads / 64;
   constexpr int WAVES_N = BN == 128 ? 2 : 1;
@@ -88,7 +101,7 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
   constexpr int WN = BN / WAVES_N;          // 64 columns per wave
   constexpr int FM = WM / 16, FN = WN / 16;
   static_assert(FN == 4 && (FM == 4 || FM == 2), "wave tile is 64 or 32 rows x 64 columns");
-  constexpr int A_BYTES = BM * kRowBytes, B_BYTES = BN * kRowBytes;
+  constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB;
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int NIA = A_BYTES / 1024 / WAVES;   // A DMA instructions per wave per tile (4)
   constexpr int NIB = B_BYTES / 1024 / WAVES;   // 1, 2 or 4
@@ -133,9 +146,9 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
   int ih0[NIA], iw0[NIA];
 #pragma unroll
   for (int i = 0; i < NIA; ++i) {
-    const int row = (i * WAVES + wave) * 8 + (lane >> 3);
+    const int row = (i * WAVES + wave) * RPI + lane / CPRW;
     const int m = m0 + row;
-    const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    const uint32_t chunk = (uint32_t)(((lane % CPRW) ^ (BK == 64 ? ((row >> 1) & 7) : swz32(row))) * 16);
     if (m < p.M) {
       if (p.dense) {
         a_base[i] = (uint32_t)m * (uint32_t)(p.C * 2) + chunk;
@@ -157,9 +170,9 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
   uint32_t b_off[NIB];
 #pragma unroll
   for (int i = 0; i < NIB; ++i) {
-    const int row = (i * WAVES + wave) * 8 + (lane >> 3);
+    const int row = (i * WAVES + wave) * RPI + lane / CPRW;
     const int col = n0 + row;
-    const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) * 16);
+    const uint32_t chunk = (uint32_t)(((lane % CPRW) ^ (BK == 64 ? ((row >> 1) & 7) : swz32(row))) * 16);
     b_off[i] = col < p.NCOLS ? (uint32_t)col * (uint32_t)(p.KDIM * 2) + chunk : kOOB;
   }
   // output row offsets (elements) for the epilogue; -1 = row out of range
@@ -180,14 +193,14 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
     rowoff[tid] = off;
   }
 
-  const int nk = p.KDIM / 64;
+  const int nk = p.KDIM / BK;
   // (r, s, c0) of the NEXT tile to issue, advanced incrementally (wave-uniform scalars)
   int ir = 0, is = 0, ic = 0;
   int issued = 0;
   auto issue_tile = [&]() {
     char* Ab = smem + (issued % STAGES) * STAGE;
     char* Bb = Ab + A_BYTES;
-    const uint32_t koff = (uint32_t)issued * 128u;        // byte offset of the K-tile in a B row
+    const uint32_t koff = (uint32_t)issued * (uint32_t)RB;   // byte offset of the K-tile in a B row
     const uint32_t tap = (uint32_t)(ir * p.a_sh2 + is * p.a_sw2 + ic * 2);   // wave-uniform
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
@@ -203,7 +216,7 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
           rs_b, (__attribute__((address_space(3))) void*)(Bb + (i * WAVES + wave) * 1024), 16, off, 0, 0, 0);
     }
     ++issued;
-    ic += 64;
+    ic += BK;
     if (ic == p.C) { ic = 0; if (++is == p.S) { is = 0; ++ir; } }
   };
 
@@ -215,34 +228,36 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
 
   // fragment read addresses (bytes from the stage base): row r, slot (ks*4 + l4) ^ ((r >> 1) & 7);
   // rows of the other fragments differ by multiples of 16 -> same swizzle term, immediate offsets
-  uint32_t a_rd[2], b_rd[2];
+  uint32_t a_rd[KS], b_rd[KS];
   {
     const int ra = wm * WM + l15, rb = wn * WN + l15;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      a_rd[ks] = (uint32_t)(ra * kRowBytes + (((ks * 4 + l4) ^ ((ra >> 1) & 7)) << 4));
-      b_rd[ks] = (uint32_t)(A_BYTES + rb * kRowBytes + (((ks * 4 + l4) ^ ((rb >> 1) & 7)) << 4));
+    for (int ks = 0; ks < KS; ++ks) {
+      const int sa = BK == 64 ? ((ks * 4 + l4) ^ ((ra >> 1) & 7)) : (l4 ^ swz32(ra));
+      const int sbb = BK == 64 ? ((ks * 4 + l4) ^ ((rb >> 1) & 7)) : (l4 ^ swz32(rb));
+      a_rd[ks] = (uint32_t)(ra * RB + (sa << 4));
+      b_rd[ks] = (uint32_t)(A_BYTES + rb * RB + (sbb << 4));
     }
   }
 
   // two register sets of fragments: tile t is multiplied from one set while tile t+1 is read
   // from LDS into the other (the reads overlap the MFMAs; waited at the end of the iteration)
-  u32x4 af[2][2][FM], bfr[2][2][FN];
+  u32x4 af[2][KS][FM], bfr[2][KS][FN];
   auto read_frags = [&](auto SET, int t) {
     constexpr int S_ = decltype(SET)::value;
     const uint32_t sb = lds0 + (uint32_t)((t % STAGES) * STAGE);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {           // fragment f sits 16 rows = 16 * RB bytes further
       af[S_][ks][0] = lds_read_b128<0>(sb + a_rd[ks]);
-      af[S_][ks][1] = lds_read_b128<2048>(sb + a_rd[ks]);
+      af[S_][ks][1] = lds_read_b128<16 * RB>(sb + a_rd[ks]);
       if constexpr (FM == 4) {
-        af[S_][ks][2] = lds_read_b128<4096>(sb + a_rd[ks]);
-        af[S_][ks][3] = lds_read_b128<6144>(sb + a_rd[ks]);
+        af[S_][ks][2] = lds_read_b128<32 * RB>(sb + a_rd[ks]);
+        af[S_][ks][3] = lds_read_b128<48 * RB>(sb + a_rd[ks]);
       }
       bfr[S_][ks][0] = lds_read_b128<0>(sb + b_rd[ks]);
-      bfr[S_][ks][1] = lds_read_b128<2048>(sb + b_rd[ks]);
-      bfr[S_][ks][2] = lds_read_b128<4096>(sb + b_rd[ks]);
-      bfr[S_][ks][3] = lds_read_b128<6144>(sb + b_rd[ks]);
+      bfr[S_][ks][1] = lds_read_b128<16 * RB>(sb + b_rd[ks]);
+      bfr[S_][ks][2] = lds_read_b128<32 * RB>(sb + b_rd[ks]);
+      bfr[S_][ks][3] = lds_read_b128<48 * RB>(sb + b_rd[ks]);
     }
   };
   // Ring protocol.  Before iteration t: tiles <= t+STAGES-1 are issued, tile t sits in
@@ -253,14 +268,16 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
   auto iteration = [&](auto SET, int t) {
     constexpr int S_ = decltype(SET)::value;
     if (t + 1 < nk) {
-      if (t + 2 < nk && STAGES > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * IPT + 0) : "memory");
+      // tiles issued after t+1 so far: min(STAGES - 2, nk - 2 - t)
+      if (STAGES >= 4 && t + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
+      else if (STAGES >= 3 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (t + STAGES < nk) issue_tile();
       read_frags(std::integral_constant<int, 1 - S_>{}, t + 1);
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -273,10 +290,11 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  static_assert(STAGES == 2 || STAGES == 3, "vmcnt bookkeeping below covers 2 or 3 stages");
+  static_assert(STAGES >= 2 && STAGES <= 4, "vmcnt bookkeeping covers 2 to 4 stages");
   for (int t = 0; t < STAGES && t < nk; ++t) issue_tile();
   // tile 0 landed: at most min(STAGES, nk) - 1 newer tiles may stay in flight
   if (nk >= STAGES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 1) * IPT) : "memory");
+  else if (nk == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
   else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -396,16 +414,16 @@ __global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
   }
 }
 
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, int BK = 64>
 int launch(const Params& p, hipStream_t st) {
-  constexpr int LDS = STAGES * (BM + BN) * kRowBytes + BM * 8;
+  constexpr int LDS = STAGES * (BM + BN) * BK * 2 + BM * 8;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, STAGES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, STAGES, BK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, STAGES>), dim3(p.ntiles), dim3(BM * 2), LDS, st, p);
+  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, STAGES, BK>), dim3(p.ntiles), dim3(BM * 2), LDS, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
@@ -413,13 +431,18 @@ int launch(const Params& p, hipStream_t st) {
 
 // Returns PASSL_EUNSUPPORTED when the descriptor is outside this kernel's envelope (the caller
 // then uses igemm_kernel); the descriptor has already been validated by passl_hip_conv_igemm.
-static int g_ring_enabled = -1, g_ring_min_tiles = 1, g_ring_bm = 128, g_ring_min_nk = 8;
+static int g_ring_enabled = -1, g_ring_min_tiles = 1, g_ring_bm = 128, g_ring_min_nk = 8, g_ring_bk = 64;
 
 // passl_hip_set_option("igemm_ring", 0/1) / ("igemm_ring_min_tiles", n)   (runtime.hip dispatches)
 int passl_igemm_ring_option(const char* name, int value) {
   if (!strcmp(name, "igemm_ring")) { g_ring_enabled = value != 0; return PASSL_OK; }
   if (!strcmp(name, "igemm_ring_min_tiles")) { g_ring_min_tiles = value; return PASSL_OK; }
   if (!strcmp(name, "igemm_ring_min_nk")) { g_ring_min_nk = value; return PASSL_OK; }
+  if (!strcmp(name, "igemm_ring_bk")) {
+    if (value != 64 && value != 32) return PASSL_EINVAL;
+    g_ring_bk = value;
+    return PASSL_OK;
+  }
   if (!strcmp(name, "igemm_ring_bm")) {
     if (value != 128 && value != 256) return PASSL_EINVAL;
     g_ring_bm = value;
@@ -478,5 +501,6 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
   p.d_oq = ring::make_fastdiv((uint32_t)d->OQ);
   p.d_tn = ring::make_fastdiv((uint32_t)tiles_n);
   if (bm == 256) return bn == 64 ? ring::launch<256, 64, 3>(p, st) : ring::launch<256, 128, 3>(p, st);
+  if (g_ring_bk == 32) return bn == 64 ? ring::launch<128, 64, 4, 32>(p, st) : ring::launch<128, 128, 4, 32>(p, st);
   return bn == 64 ? ring::launch<128, 64, 2>(p, st) : ring::launch<128, 128, 2>(p, st);
 }
