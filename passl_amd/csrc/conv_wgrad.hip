@@ -518,10 +518,11 @@ __device__ __forceinline__ uint2 lds_read_tr64(uint32_t addr) {
   return v;
 }
 
-template <int BMo, int BNo>
+template <int BMo, int BNo, int BKM, int NST, bool DENSE>
 __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p, uint32_t a_bytes,
                                                                  uint32_t dy_bytes) {
-  constexpr int BKM = 32, NST = 4;
+  constexpr int KS = BKM / 32;                         // 16x16x32 MFMA k-steps per stage
+  static_assert((BKM == 32 || BKM == 64) && NST >= 2 && NST <= 4, "ring shape");
   constexpr int WM = BMo / 2, WN = BNo / 2;
   constexpr int FM = WM / 16, FN = WN / 16;
   constexpr int CPA = BMo / 8, CPB = BNo / 8;          // 16-byte chunks per row
@@ -535,6 +536,8 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  // general (gathered) x rows: per-row image base / input origin, 4 slots of BKM rows, slot = tile % 4
+  RowInfo2* rinfo = reinterpret_cast<RowInfo2*>(smem + NST * STAGE);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -549,6 +552,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
   const int bx = vb % p.grid_j, by = (vb / p.grid_j) % p.grid_oc, bz = vb / (p.grid_j * p.grid_oc);
   const int oc0 = by * BMo;
   const int j0 = bx * BNo;
+  const int opq = p.OP * p.OQ;
   const int kt_begin = bz * p.tiles_per_split;
   int kt_end = kt_begin + p.tiles_per_split;
   if (kt_end > p.nk_total) kt_end = p.nk_total;
@@ -569,7 +573,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
     a_row[i] = row;
     a_col[i] = oc < p.NCOLS ? (uint32_t)oc * 2u : kOOB;
   }
-  int b_row[NIB]; uint32_t b_col[NIB];                 // x tile
+  int b_row[NIB], b_r[NIB], b_s[NIB]; uint32_t b_col[NIB];   // x tile
 #pragma unroll
   for (int i = 0; i < NIB; ++i) {
     const int q = i * 4 + wave;
@@ -577,9 +581,37 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
     const int chunk = (lane % CPB) ^ (hswz<CPB>(row) << 1);
     const int j = j0 + chunk * 8;
     b_row[i] = row;
-    b_col[i] = j < p.KDIM ? (uint32_t)j * 2u : kOOB;
+    if (DENSE) {
+      b_r[i] = 0; b_s[i] = 0;
+      b_col[i] = j < p.KDIM ? (uint32_t)j * 2u : kOOB;
+    } else {
+      const int rs = j / p.C;
+      b_r[i] = rs / p.S;
+      b_s[i] = rs - b_r[i] * p.S;
+      b_col[i] = j < p.KDIM ? (uint32_t)(j - rs * p.C) * 2u : kOOB;
+    }
   }
   const uint32_t dy_pitch = (uint32_t)(p.dy_ld * 2), x_pitch = (uint32_t)(p.C * 2);
+
+  auto fill_rowinfo = [&](int t) {                     // tile t (relative), slot t & 3
+    if (!DENSE && tid < BKM) {
+      const int m = (kt_begin + t) * BKM + tid;
+      RowInfo2 ri;
+      if (m < p.M) {
+        const int n = m / opq;
+        const int rem = m - n * opq;
+        const int op = rem / p.OQ;
+        const int oq = rem - op * p.OQ;
+        ri.base = (uint32_t)((int64_t)n * p.a_sn * 2);
+        ri.ih0 = op * p.sh - p.ph;
+        ri.iw0 = oq * p.sw - p.pw;
+        ri.valid = 1;
+      } else {
+        ri.base = 0; ri.ih0 = 0; ri.iw0 = 0; ri.valid = 0;
+      }
+      rinfo[(t & 3) * 64 + tid] = ri;
+    }
+  };
 
   int issued = 0;                                      // tiles issued so far (relative to kt_begin)
   auto issue_tile = [&]() {
@@ -595,8 +627,18 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
     }
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
-      const int m = mbase + b_row[i];
-      const uint32_t off = (m < p.M && b_col[i] != kOOB) ? (uint32_t)m * x_pitch + b_col[i] : kOOB;
+      uint32_t off = kOOB;
+      if (DENSE) {
+        const int m = mbase + b_row[i];
+        if (m < p.M && b_col[i] != kOOB) off = (uint32_t)m * x_pitch + b_col[i];
+      } else {
+        // read right after the iteration's `vmcnt(0)` + barrier: no DMA is outstanding, so the
+        // compiler's conservative wait in front of this LDS read costs nothing
+        const RowInfo2 ri = rinfo[(issued & 3) * 64 + b_row[i]];
+        const int ih = ri.ih0 + b_r[i], iw = ri.iw0 + b_s[i];
+        if (ri.valid && b_col[i] != kOOB && ih >= 0 && ih < p.IH && iw >= 0 && iw < p.IW)
+          off = ri.base + (uint32_t)(ih * (int)(p.a_sh * 2) + iw * (int)(p.a_sw * 2)) + b_col[i];
+      }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rs_a, (__attribute__((address_space(3))) void*)(Bb + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
     }
@@ -607,6 +649,8 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
   // lane's own 8 bytes sit at channel 4*(lane&3) of the fragment's 16-channel block
   const int l15 = lane & 15, l4 = lane >> 4;
   const int r4 = (lane >> 2) & 3, c4 = lane & 3;
+  // rows 32 further down (second k-step of a 64-row stage) keep the swizzle term (hswz uses row bits
+  // 0, 1 and 3 only): they are reached with the immediate offset 32 * pitch
   uint32_t a_rd[2][FM], b_rd[2][FN];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -622,19 +666,27 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
       b_rd[h][j] = (uint32_t)(A_BYTES + row * PB + ((pair ^ hswz<CPB>(row)) << 5) + c4 * 8);
     }
   }
-  uint4 af[2][FM], bfr[2][FN];
+  uint4 af[2][KS][FM], bfr[2][KS][FN];
   auto read_frags = [&](auto SET, int t) {
     constexpr int S_ = decltype(SET)::value;
     const uint32_t sb = lds0 + (uint32_t)((t % NST) * STAGE);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const uint2 lo = lds_read_tr64<0>(sb + a_rd[0][i]), hi = lds_read_tr64<0>(sb + a_rd[1][i]);
-      af[S_][i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      af[S_][0][i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      if constexpr (KS == 2) {
+        const uint2 lo2 = lds_read_tr64<32 * PA>(sb + a_rd[0][i]), hi2 = lds_read_tr64<32 * PA>(sb + a_rd[1][i]);
+        af[S_][1][i] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+      }
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const uint2 lo = lds_read_tr64<0>(sb + b_rd[0][j]), hi = lds_read_tr64<0>(sb + b_rd[1][j]);
-      bfr[S_][j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      bfr[S_][0][j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      if constexpr (KS == 2) {
+        const uint2 lo2 = lds_read_tr64<32 * PB>(sb + b_rd[0][j]), hi2 = lds_read_tr64<32 * PB>(sb + b_rd[1][j]);
+        bfr[S_][1][j] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+      }
     }
   };
 
@@ -652,28 +704,39 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
   auto iteration = [&](auto SET, int t) {
     constexpr int S_ = decltype(SET)::value;
     if (t + 1 < nk) {
-      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
-      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+      // tiles issued after t+1 so far: min(NST - 2, nk - 2 - t)
+      if (NST >= 4 && t + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
+      else if (NST >= 3 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (t + NST < nk) issue_tile();
       read_frags(std::integral_constant<int, 1 - S_>{}, t + 1);
     }
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[S_][i]),
-                                                            __builtin_bit_cast(bf16x8_t, bfr[S_][j]),
-                                                            acc[i][j], 0, 0, 0);
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[S_][ks][i]),
+                                                              __builtin_bit_cast(bf16x8_t, bfr[S_][ks][j]),
+                                                              acc[i][j], 0, 0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    // row info of tile t+NST+1: its slot held tile t+NST-3's, consumed when that tile was issued
+    if (!DENSE && t + NST + 1 < nk) fill_rowinfo(t + NST + 1);
   };
 
+  if (!DENSE) {
+    static_assert(DENSE || NST == 2, "the gathered variant's row-info ring (4 slots) is sized for 2 stages");
+    for (int t = 0; t < NST + 1 && t < nk; ++t) fill_rowinfo(t);
+    __syncthreads();
+  }
   for (int t = 0; t < NST && t < nk; ++t) issue_tile();
-  if (nk >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPT) : "memory");
-  else if (nk == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
-  else if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
+  // tile 0 landed: min(NST, nk) - 1 newer tiles may stay in flight
+  if (NST >= 4 && nk >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPT) : "memory");
+  else if (NST >= 3 && nk >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPT) : "memory");
+  else if (nk >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPT) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(std::integral_constant<int, 0>{}, 0);
@@ -697,24 +760,24 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
       }
 }
 
-template <int BMo, int BNo>
+template <int BMo, int BNo, int BKM, int NST, bool DENSE>
 int launch_pipe(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
-  constexpr int LDS = 4 * 32 * (BMo + BNo) * 2;
+  constexpr int LDS = NST * BKM * (BMo + BNo) * 2 + (DENSE ? 0 : 4 * 64 * (int)sizeof(RowInfo2));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pipe_kernel<BMo, BNo>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pipe_kernel<BMo, BNo, BKM, NST, DENSE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   WParams q = p;
-  q.nk_total = (p.M + 31) / 32;                         // 32-row tiles
+  q.nk_total = (p.M + BKM - 1) / BKM;
   if (splits > q.nk_total) splits = q.nk_total;
   q.tiles_per_split = (q.nk_total + splits - 1) / splits;
   splits = (q.nk_total + q.tiles_per_split - 1) / q.tiles_per_split;
   q.grid_j = (p.KDIM + BNo - 1) / BNo;
   q.grid_oc = (p.NCOLS + BMo - 1) / BMo;
-  hipLaunchKernelGGL((wgrad_pipe_kernel<BMo, BNo>), dim3(q.grid_j * q.grid_oc * splits), dim3(kThreads),
-                     LDS, st, q, a_bytes, dy_bytes);
+  hipLaunchKernelGGL((wgrad_pipe_kernel<BMo, BNo, BKM, NST, DENSE>), dim3(q.grid_j * q.grid_oc * splits),
+                     dim3(kThreads), LDS, st, q, a_bytes, dy_bytes);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
@@ -737,7 +800,9 @@ int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes
 
 int g_wgrad_tile = 0;     // 0 = by shape; 1 = 64x64, 2 = 64x128, 3 = 128x64, 4 = 128x128 (experiments)
 
-int g_wgrad_pipe = 1;     // dense 4-stage ring kernel for 1x1/Linear shapes (0: wgrad_dma_kernel everywhere)
+// wgrad_pipe_kernel (register double-buffered fragments): 2 = 2 x 64-row stages for every shape (default),
+// 3 = same, 1 = 4 x 32-row stages for dense 128x128 shapes only, 0 = wgrad_dma_kernel everywhere
+int g_wgrad_pipe = 2;
 
 // x is a contiguous [M][C] matrix: 1x1, stride 1, no padding over a dense NHWC tensor (or a Linear)
 bool dense_rows(const WParams& p) {
@@ -747,8 +812,23 @@ bool dense_rows(const WParams& p) {
 }
 
 int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
-  if (g_wgrad_pipe && g_wgrad_tile == 0 && dense_rows(p) && p.NCOLS > 64 && p.KDIM > 64)
-    return launch_pipe<128, 128>(p, splits, a_bytes, dy_bytes, st);
+  if (g_wgrad_pipe && g_wgrad_tile == 0) {
+    const bool m64 = p.NCOLS <= 64, n64 = p.KDIM <= 64;
+    if (g_wgrad_pipe == 1 && dense_rows(p) && !m64 && !n64)
+      return launch_pipe<128, 128, 32, 4, true>(p, splits, a_bytes, dy_bytes, st);
+    if (dense_rows(p)) {
+      if (m64 && n64) return launch_pipe<64, 64, 64, 2, true>(p, splits, a_bytes, dy_bytes, st);
+      if (m64) return launch_pipe<64, 128, 64, 2, true>(p, splits, a_bytes, dy_bytes, st);
+      if (n64) return launch_pipe<128, 64, 64, 2, true>(p, splits, a_bytes, dy_bytes, st);
+      return launch_pipe<128, 128, 64, 2, true>(p, splits, a_bytes, dy_bytes, st);
+    }
+    if (g_wgrad_pipe >= 2) {
+      if (m64 && n64) return launch_pipe<64, 64, 64, 2, false>(p, splits, a_bytes, dy_bytes, st);
+      if (m64) return launch_pipe<64, 128, 64, 2, false>(p, splits, a_bytes, dy_bytes, st);
+      if (n64) return launch_pipe<128, 64, 64, 2, false>(p, splits, a_bytes, dy_bytes, st);
+      return launch_pipe<128, 128, 64, 2, false>(p, splits, a_bytes, dy_bytes, st);
+    }
+  }
   if (g_wgrad_tile == 1) return launch_dma<64, 64>(p, splits, a_bytes, dy_bytes, st);
   if (g_wgrad_tile == 2) return launch_dma<64, 128>(p, splits, a_bytes, dy_bytes, st);
   if (g_wgrad_tile == 3) return launch_dma<128, 64>(p, splits, a_bytes, dy_bytes, st);

@@ -298,7 +298,10 @@ static int colsum_impl(const void* x, float* out, int64_t M, int C, int dtype, b
     return PASSL_ELAUNCH;
   // ~64 rows per block: enough blocks in flight for the short-sequence ViT shapes (M = 6400 ... 50432),
   // the per-block atomics (256 columns) stay negligible
-  int slabs = (int)((M + 63) / 64);
+  // (measured: 64-row slabs help M <= 12800, 256-row slabs are better at M = 50432 where the extra
+  // blocks only add same-address atomics)
+  const int per = M >= 32768 ? 256 : 64;
+  int slabs = (int)((M + per - 1) / per);
   if (slabs > 1024) slabs = 1024;
   const int rows = (int)((M + slabs - 1) / slabs);
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 255) / 256, slabs),
