@@ -721,10 +721,12 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[S_][ks][i]),
                                                               __builtin_bit_cast(bf16x8_t, bfr[S_][ks][j]),
                                                               acc[i][j], 0, 0, 0);
+    // row info of tile t+NST+1: its slot held tile t+NST-3's, consumed when that tile was issued.
+    // Written BEFORE the lgkmcnt(0) below so that the store has completed when this wave reaches the
+    // next iteration's barrier (raw s_barrier carries no LDS wait of its own).
+    if (!DENSE && t + NST + 1 < nk) fill_rowinfo(t + NST + 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // row info of tile t+NST+1: its slot held tile t+NST-3's, consumed when that tile was issued
-    if (!DENSE && t + NST + 1 < nk) fill_rowinfo(t + NST + 1);
   };
 
   if (!DENSE) {
