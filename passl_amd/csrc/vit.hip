@@ -56,7 +56,11 @@ __global__ void __launch_bounds__(kThreads) layernorm_fwd_kernel(
 // combined across the 4 waves through LDS and flushed with one atomic per column per block.
 constexpr int kLnMaxChunks = 4;            // C <= 2048
 
-template <typename T>
+// NCH = number of 512-column chunks a lane owns (C <= 512 * NCH).  A wave handles RPI rows per
+// iteration (row, row + 4, ...): all rows' x / dy chunks are fetched back to back and kept in registers
+// for the second pass — the kernel is latency- not bandwidth-bound on the short ViT rows, a single
+// row per wave-iteration with a re-read left it at a third of the streaming rate.
+template <typename T, int NCH>
 __global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -66,62 +70,88 @@ __global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  float ag[kLnMaxChunks][8], ab[kLnMaxChunks][8];
+  float ag[NCH][8], ab[NCH][8], gm[NCH][8];
 #pragma unroll
-  for (int k = 0; k < kLnMaxChunks; ++k)
+  for (int k = 0; k < NCH; ++k) {
+    const int c = lane * 8 + k * 512;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; }
-  for (int row = r0 + wave; row < r1; row += 4) {
-    const T* xr = x + (int64_t)row * C;
-    const T* gr = dy + (int64_t)row * C;
-    const float mu = mean[row], rs = rstd[row];
-    float s1 = 0.f, s2 = 0.f;
+    for (int e = 0; e < 8; ++e) { ag[k][e] = 0.f; ab[k][e] = 0.f; gm[k][e] = 0.f; }
+    if (c < C) ElemTraits<float>::load8(gamma + c, gm[k]);
+  }
+  constexpr int RPI = NCH == 1 ? 4 : 2;
+  for (int row = r0 + wave; row < r1; row += 4 * RPI) {
+    int rows[RPI];
+    bool ok[RPI];
 #pragma unroll
-    for (int k = 0; k < kLnMaxChunks; ++k) {
-      const int c = lane * 8 + k * 512;
-      if (c < C) {
-        float v[8], d[8], g[8];
-        ld8(xr + c, v);
-        ld8(gr + c, d);
-        ElemTraits<float>::load8(gamma + c, g);
+    for (int u = 0; u < RPI; ++u) { rows[u] = row + 4 * u; ok[u] = rows[u] < r1; }
+    float xv[RPI][NCH][8], dv[RPI][NCH][8], rv[RPI][NCH][8];    // rv: residual-branch gradient
+    float mu[RPI], rs[RPI];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (v[e] - mu) * rs, gg = d[e] * g[e];
-          s1 += gg;
-          s2 += gg * xh;
-          ag[k][e] += d[e] * xh;
-          ab[k][e] += d[e];
+    for (int u = 0; u < RPI; ++u) {
+      mu[u] = ok[u] ? mean[rows[u]] : 0.f;
+      rs[u] = ok[u] ? rstd[rows[u]] : 0.f;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c = lane * 8 + k * 512;
+        if (ok[u] && c < C) {
+          ld8(x + (int64_t)rows[u] * C + c, xv[u][k]);
+          ld8(dy + (int64_t)rows[u] * C + c, dv[u][k]);
+          // fetched with the other operands: a load issued after the row reductions would put a
+          // second full memory round trip on the critical path of every iteration
+          if (dres) ld8(dres + (int64_t)rows[u] * C + c, rv[u][k]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xv[u][k][e] = 0.f; dv[u][k][e] = 0.f; }
         }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
-    T* dr = dx + (int64_t)row * C;
+    float s1[RPI], s2[RPI];
 #pragma unroll
-    for (int k = 0; k < kLnMaxChunks; ++k) {
-      const int c = lane * 8 + k * 512;
-      if (c < C) {
-        float v[8], d[8], g[8], o[8];
-        ld8(xr + c, v);
-        ld8(gr + c, d);
-        ElemTraits<float>::load8(gamma + c, g);
+    for (int u = 0; u < RPI; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (v[e] - mu) * rs;
-          o[e] = rs * (d[e] * g[e] - s1 - xh * s2);
+    for (int u = 0; u < RPI; ++u)
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c = lane * 8 + k * 512;
+        if (c < C) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (xv[u][k][e] - mu[u]) * rs[u], gg = dv[u][k][e] * gm[k][e];
+            xv[u][k][e] = xh;                 // rows beyond r1 carry rs = 0, dv = 0: no contribution
+            s1[u] += gg;
+            s2[u] += gg * xh;
+            ag[k][e] += dv[u][k][e] * xh;
+            ab[k][e] += dv[u][k][e];
+          }
         }
-        if (dres) {                       // gradient of the residual branch that forked off x
-          float rr[8];
-          ld8(dres + (int64_t)row * C + c, rr);
+      }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += rr[e];
+    for (int u = 0; u < RPI; ++u) {
+      s1[u] = wave_sum(s1[u]) / (float)C;
+      s2[u] = wave_sum(s2[u]) / (float)C;
+    }
+#pragma unroll
+    for (int u = 0; u < RPI; ++u) {
+      if (!ok[u]) continue;
+      T* dr = dx + (int64_t)rows[u] * C;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c = lane * 8 + k * 512;
+        if (c < C) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rs[u] * (dv[u][k][e] * gm[k][e] - s1[u] - xv[u][k][e] * s2[u]);
+          if (dres) {                       // gradient of the residual branch that forked off x
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += rv[u][k][e];
+          }
+          ElemTraits<T>::store8(dr + c, o);
         }
-        ElemTraits<T>::store8(dr + c, o);
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < kLnMaxChunks; ++k) {
+  for (int k = 0; k < NCH; ++k) {
     const int c = lane * 8 + k * 512;
     if (c < C) {
 #pragma unroll
@@ -460,16 +490,21 @@ extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const floa
       (C & 7) || C > 512 * kLnMaxChunks || !aligned16(dy) || !aligned16(x) || !aligned16(dx) ||
       !aligned16(gamma) || (dres && !aligned16(dres)))
     return PASSL_EINVAL;
-  // 16..64 rows per block: >= 2 blocks per CU for the short-sequence shapes (CLIP: M = 6400 / 9856)
-  // while the dgamma/dbeta atomics (2 C per block) stay small next to the row traffic
+  // 16..64 rows per block: >= 2 blocks per CU for the short-sequence shapes (CLIP: M = 6400 / 9856);
+  // the per-block dgamma/dbeta atomics (2 C) were measured not to matter at these block counts
   int rows = (int)(M / 1024);
   rows = rows < 16 ? 16 : (rows > 64 ? 64 : rows);
   const int nb = (int)((M + rows - 1) / rows);
-  VIT_DISPATCH(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3(nb), dim3(kThreads),
-                                         8 * C * sizeof(float), as_stream(stream),
-                                         reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x),
-                                         gamma, mean, rstd, reinterpret_cast<const T*>(dres),
+#define LN_BWD_LAUNCH(NCH)                                                                          \
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(nb), dim3(kThreads),  \
+                                         8 * C * sizeof(float), as_stream(stream),                  \
+                                         reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x), \
+                                         gamma, mean, rstd, reinterpret_cast<const T*>(dres),       \
                                          reinterpret_cast<T*>(dx), dgamma, dbeta, (int)M, C, rows);)
+  if (C <= 512) { LN_BWD_LAUNCH(1) }
+  else if (C <= 1024) { LN_BWD_LAUNCH(2) }
+  else { LN_BWD_LAUNCH(4) }
+#undef LN_BWD_LAUNCH
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
