@@ -73,3 +73,34 @@ def test_host_tensors_are_refused():
     from passl_amd.hip import ops
     with pytest.raises(L.PasslHipError):
         ops.ema_update(torch.zeros(16), torch.zeros(16), 0.9)
+
+
+def test_every_entry_point_rejects_null_arguments(lib):
+    """Every compute entry point validates its arguments before touching the device: all-NULL / zero
+    arguments yield an error status (never a crash, never a launch) — checked without a GPU."""
+    import ctypes as C
+    skip = {'passl_hip_abi_version', 'passl_hip_strerror', 'passl_hip_set_option', 'passl_hip_prof_enable',
+            'passl_hip_infonce_workspace_bytes', 'passl_hip_clip_logits_ws_floats'}
+    checked = 0
+    for name, (res, args) in sorted(L.SIGNATURES.items()):
+        if name in skip:
+            continue
+        zeros = []
+        for a in args:
+            if a is L.c_f:
+                zeros.append(0.0)
+            elif a in (L.c_i, L.c_l):
+                zeros.append(0)
+            else:
+                zeros.append(None)
+        rc = getattr(lib, name)(*zeros)
+        assert rc in (-1, -3), '%s(all null) returned %r' % (name, rc)
+        checked += 1
+    assert checked >= 50
+    # shapes outside a kernel's envelope are PASSL_EUNSUPPORTED, not a silent wrong answer
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    assert lib.passl_hip_attention_fwd(p, p, p, 1, 300, 1, 64, 0.125, 0, L.F32, None) == -3     # T > 208
+    assert lib.passl_hip_attention_fwd(p, p, p, 1, 16, 1, 48, 0.125, 0, L.F32, None) == -3      # head dim
+    assert lib.passl_hip_layernorm_bwd(p, p, p, p, p, None, p, p, p, 4, 4096, L.F32, None) == -1  # C > 2048
+    assert lib.passl_hip_set_option(b'no_such_option', 1) == -1
