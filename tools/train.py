@@ -19,10 +19,17 @@ def main(args, cfg):
     if args.dtype:
         cfg.compute_dtype = args.dtype
     trainer = Trainer(cfg)
+    # continue training or evaluate: the checkpoint holds epoch and optimizer state
     if args.resume:
         trainer.resume(args.resume)
-    if args.load:
+    # evaluate or fine-tune: only the model weights
+    elif args.load:
         trainer.load(args.load)
+    if args.evaluate_only:
+        trainer.val()
+        return
+    if args.export:
+        raise NotImplementedError('--export (paddle.jit inference model) is outside the hot path')
     trainer.train()
 
 
