@@ -87,7 +87,8 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
 __device__ __forceinline__ int swz32(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
 template <int BM, int BN, int STAGES, int BK = 64>
-__global__ void __launch_bounds__(BM * 2, 2) igemm_ring_kernel(const Params p) {
+__global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 <= 53 * 1024) ? 3 : 2)
+    igemm_ring_kernel(const Params p) {
   constexpr int RB = BK * 2;                // LDS row bytes
   constexpr int KS = BK / 32;               // 16x16x32 MFMA k-steps per stage
   constexpr int RPI = 1024 / RB;            // tile rows per DMA instruction (8 or 16)
@@ -431,13 +432,19 @@ int launch(const Params& p, hipStream_t st) {
 
 // Returns PASSL_EUNSUPPORTED when the descriptor is outside this kernel's envelope (the caller
 // then uses igemm_kernel); the descriptor has already been validated by passl_hip_conv_igemm.
-static int g_ring_enabled = -1, g_ring_min_tiles = 1, g_ring_bm = 128, g_ring_min_nk = 8, g_ring_bk = 64;
+static int g_ring_enabled = -1, g_ring_min_tiles = 1, g_ring_bm = 128, g_ring_min_nk = 8, g_ring_bk = 64,
+           g_ring_stages32 = 4;
 
 // passl_hip_set_option("igemm_ring", 0/1) / ("igemm_ring_min_tiles", n)   (runtime.hip dispatches)
 int passl_igemm_ring_option(const char* name, int value) {
   if (!strcmp(name, "igemm_ring")) { g_ring_enabled = value != 0; return PASSL_OK; }
   if (!strcmp(name, "igemm_ring_min_tiles")) { g_ring_min_tiles = value; return PASSL_OK; }
   if (!strcmp(name, "igemm_ring_min_nk")) { g_ring_min_nk = value; return PASSL_OK; }
+  if (!strcmp(name, "igemm_ring_stages32")) {       // ring depth of the BK = 32 variant: 3 (3 WG/CU) or 4
+    if (value != 3 && value != 4) return PASSL_EINVAL;
+    g_ring_stages32 = value;
+    return PASSL_OK;
+  }
   if (!strcmp(name, "igemm_ring_bk")) {
     if (value != 64 && value != 32) return PASSL_EINVAL;
     g_ring_bk = value;
@@ -501,6 +508,8 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
   p.d_oq = ring::make_fastdiv((uint32_t)d->OQ);
   p.d_tn = ring::make_fastdiv((uint32_t)tiles_n);
   if (bm == 256) return bn == 64 ? ring::launch<256, 64, 3>(p, st) : ring::launch<256, 128, 3>(p, st);
+  if (g_ring_bk == 32 && g_ring_stages32 == 3)
+    return bn == 64 ? ring::launch<128, 64, 3, 32>(p, st) : ring::launch<128, 128, 3, 32>(p, st);
   if (g_ring_bk == 32) return bn == 64 ? ring::launch<128, 64, 4, 32>(p, st) : ring::launch<128, 128, 4, 32>(p, st);
   return bn == 64 ? ring::launch<128, 64, 2>(p, st) : ring::launch<128, 128, 2>(p, st);
 }

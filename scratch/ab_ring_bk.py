@@ -17,6 +17,8 @@ rows += [(768, 2304, 1, 1, 0, 1, 12, 12800), (768, 768, 1, 1, 0, 1, 12, 12800), 
          (512, 1536, 1, 1, 0, 1, 8, 50432), (512, 2048, 1, 1, 0, 1, 8, 50432), (2048, 512, 1, 1, 0, 1, 8, 50432),
          (768, 2304, 1, 1, 0, 1, 12, 6400), (512, 2048, 1, 1, 0, 1, 12, 9856), (576, 72, 1, 1, 0, 1, 1, 1000), (512, 200, 3, 2, 1, 9, 1, 5)]
 tot = {64: [0.0, 0.0], 32: [0.0, 0.0]}
+STAGES32 = int(os.environ.get('STAGES32', 4))
+lib.passl_hip_set_option(b'igemm_ring_stages32', STAGES32)
 lib.passl_hip_set_option(b'igemm_ring', 1); lib.passl_hip_set_option(b'igemm_ring_min_nk', 1)
 for cin, cout, k, st, pad, H, cnt, n in rows:
     g = P.ConvGeom(cin, cout, k, st, pad); fd = P.fwd_desc(g, n, H, H); dds, _ = P.dgrad_plan(g, n, H, H)
