@@ -534,6 +534,14 @@ class _AttentionFn(Function):
             None, None, None, None
 
 
+def param_grad_ready(*params):
+    """Report raw arena parameters as reduced-ready from a custom backward (no-op outside an arena)."""
+    for p in params:
+        a = getattr(p, '_passl_arena', None)
+        if a is not None:
+            a.param_grad_ready(p)
+
+
 def attention(qkv, B, T, H, DH, scale, causal=False):
     return _AttentionFn.apply(qkv, B, T, H, DH, float(scale), bool(causal))
 
@@ -690,6 +698,7 @@ class EncoderArena:
                 gview = self.grads[o:o + n].view(old.shape) if trainable else None
             p = tnn.Parameter(view, requires_grad=trainable)
             p._passl_arena = self
+            p._passl_index = index          # position in param_slices (for param_grad_ready)
             if trainable:
                 p.grad = gview
             mod._parameters[name] = p
@@ -803,6 +812,14 @@ class EncoderArena:
     def clear_grad(self):
         if self.grads is not None:
             self.grads.zero_()
+
+    def param_grad_ready(self, *params):
+        """grad_ready for raw parameters (class / position embeddings, tokens, logit_scale ...) whose
+        gradient is produced by one dedicated backward kernel: without the mark their bucket (and, since
+        buckets launch in order, every later one) would only be reduced after the whole backward."""
+        if self.reducer is not None:
+            for p in params:
+                self.reducer.mark_ready(p._passl_index)
 
     def grad_ready(self, indices):
         """Called from the backward kernels' host code once the gradients of parameters

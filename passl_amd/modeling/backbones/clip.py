@@ -54,6 +54,7 @@ class _EmbedFn(Function):
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         ops.embed_bwd(text, dout.contiguous(), table.grad, pos.grad)
+        nn.param_grad_ready(table, pos)
         return None, None, None, None
 
 
@@ -72,6 +73,7 @@ class _LogitsFn(Function):
         if s.grad is None:
             s.grad = torch.zeros_like(s)
         dimg, dtxt = ops.clip_logits_bwd(dlogits.contiguous(), logits, ws, ctx.D, s.grad)
+        nn.param_grad_ready(s)
         return dimg, dtxt, None
 
 

@@ -144,6 +144,7 @@ class _GatherFn(Function):
         if cls.grad is None:
             cls.grad = torch.zeros_like(cls)
         dx = ops.mae_gather_bwd(dout.contiguous(), ids_restore, cls.grad, B, L, K)
+        nn.param_grad_ready(cls)
         return dx, None, None, None, None, None, None
 
 
@@ -162,6 +163,7 @@ class _UnshuffleFn(Function):
         if tok.grad is None:
             tok.grad = torch.zeros_like(tok)
         dx = ops.mae_unshuffle_bwd(dout.contiguous(), ids_keep, ids_restore, tok.grad, ctx.B)
+        nn.param_grad_ready(tok)
         return dx, None, None, None, None, None
 
 

@@ -190,6 +190,7 @@ class _ClsPosFn(Function):
         dout = dout.contiguous()
         dx = ops.mae_gather_bwd(dout, ids, cls.grad, B, L, L)              # dx rows + dcls += sum_b dout[b, 0]
         ops.colsum_into(dout.view(B, -1), pos.grad.view(-1), accumulate=True)   # dpos[t] += sum_b dout[b, t]
+        nn.param_grad_ready(cls, pos)
         return dx, None, None, None, None, None
 
 
