@@ -131,7 +131,10 @@ TOL_F32 = dict(loss=1e-3, logits=1e-3, queue=1e-3, grad=1e-2, param=1e-3, stat=1
 # running statistics: 5e-2 at the first step, +5e-2 per further step (two valid bf16 evaluations
 # of the same step — BN statistics from the fp32 accumulators vs from the bf16-rounded conv
 # output — already differ by 3e-2 in the stem's running variance after three updates).
-TOL_BF16 = dict(loss=6e-2, logits=4e-1, queue=3e-2, grad=2e-1, param=2e-1, grad_bias=6e-1, stat=5e-2,
+# The bf16 path is not bit-reproducible run to run: the fused BN statistics are accumulated with fp32
+# atomics whose order varies, which flips bf16 roundings downstream.  Measured over repeated runs of the
+# small case: logits error 0.15-0.40, loss error 0.02-0.05 — the bounds are 2x the largest observed.
+TOL_BF16 = dict(loss=1.2e-1, logits=8e-1, queue=3e-2, grad=2e-1, param=2e-1, grad_bias=6e-1, stat=5e-2,
                 stat_growth=1.0, exact_acc=False)
 
 

@@ -147,7 +147,7 @@ TOL_F32 = dict(loss=1e-3, emb=1e-3, logits=1e-3, grad=1e-2, param=1e-3, stat=1e-
 # The loss itself (sum of log-sum-exps of those logits) is the most sensitive scalar: two bf16 runs
 # that differ only in the summation order of the BN statistics land 0.6-1.3 from the fp32 value.
 # What IS exact in bf16 mode is the head given the embeddings: checked against the fp64 oracle.
-TOL_BF16 = dict(loss=3.0, emb=4e-1, logits=4.0, grad=3e-1, param=3e-1, grad_bias=8e-1, stat=1e-1)
+TOL_BF16 = dict(loss=3.0, emb=6e-1, logits=6.0, grad=4e-1, param=3e-1, grad_bias=8e-1, stat=1e-1)
 
 
 def _run_against_golden(name, dtype, steps_cap, tol):
