@@ -71,12 +71,15 @@ class MoCoOracle:
     """State + step of MoCo (moco.py) with Momentum-SGD (optimizer_hook.py)."""
 
     def __init__(self, dim=128, K=65536, m=0.999, T=0.2, lr=0.015, t_max=200 * 5004,
-                 weight_decay=1e-4, momentum=0.9, seed=0, width_div=1):
+                 weight_decay=1e-4, momentum=0.9, seed=0, width_div=1, neck='NonLinearNeckV1',
+                 milestones=None):
+        # neck='LinearNeck', T=0.07, lr=0.03, milestones=[120, 160] epochs = configs/moco/moco_v1_r50.yaml
+        self.milestones = milestones
         gen = torch.Generator().manual_seed(seed)
         self.K, self.m, self.T = K, m, T
         self.base_lr, self.t_max = lr, t_max
         self.wd, self.mu = weight_decay, momentum
-        self.q = R.init_encoder_state(gen, out_channels=dim, width_div=width_div)
+        self.q = R.init_encoder_state(gen, out_channels=dim, width_div=width_div, neck=neck)
         # moco.py:69-72  param_k.set_value(param_q) for every parameter (incl. BN stats)
         self.k = OrderedDict((n, t.clone()) for n, t in self.q.items())
         # moco.py:77-80
@@ -101,6 +104,8 @@ class MoCoOracle:
         self.queue_ptr = (ptr + bs) % self.K
 
     def lr(self):
+        if self.milestones is not None:       # MultiStepDecay (milestones already in iterations), gamma 0.1
+            return self.base_lr * 0.1 ** sum(1 for m in self.milestones if self.step_count >= m)
         return cosine_lr(self.base_lr, self.step_count, self.t_max)
 
     # -- moco.py:154-185 + optimizer_hook.py:25-50 ---------------------------

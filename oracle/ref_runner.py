@@ -132,7 +132,10 @@ MOCO_V2_CFG = dict(
 )
 
 
-def build_reference_moco(K=65536, dim=128, m=0.999, T=0.2):
+MOCO_V1_NECK = dict(name='LinearNeck', in_channels=2048, out_channels=128, with_avg_pool=True)
+
+
+def build_reference_moco(K=65536, dim=128, m=0.999, T=0.2, neck='NonLinearNeckV1'):
     """MoCo built by the reference's registries from the configs/moco/moco_v2_r50.yaml
     `model:` block (restated in MOCO_V2_CFG; T=0.2 there is the head temperature,
     the architecture's own T default is unused by train_iter)."""
@@ -141,6 +144,8 @@ def build_reference_moco(K=65536, dim=128, m=0.999, T=0.2):
     cfg = copy.deepcopy(MOCO_V2_CFG)
     cfg.update(K=K, dim=dim, m=m)
     cfg['head']['temperature'] = T
+    if neck == 'LinearNeck':              # configs/moco/moco_v1_r50.yaml `model:` block
+        cfg['neck'] = copy.deepcopy(MOCO_V1_NECK)
     return ns.build_model(cfg)
 
 

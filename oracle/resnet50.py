@@ -60,7 +60,7 @@ def conv_specs():
 
 
 def init_encoder_state(gen, in_channels=2048, hid_channels=2048, out_channels=128,
-                       width_div=1):
+                       width_div=1, neck='NonLinearNeckV1'):
     """Returns OrderedDict with keys '0.<backbone key>' and '1.<neck key>'
     (the nn.Sequential(backbone, neck) naming of moco.py:60-61).
 
@@ -77,6 +77,10 @@ def init_encoder_state(gen, in_channels=2048, hid_channels=2048, out_channels=12
         st['0.' + bn + '._mean'] = torch.zeros(cout)
         st['0.' + bn + '._variance'] = torch.ones(cout)
     cin_n = in_channels // width_div
+    if neck == 'LinearNeck':          # base_neck.py:44-65 (MoCo v1): avgpool + ONE fc, key `1.fc.*`
+        st['1.fc.weight'] = torch.randn(cin_n, out_channels, generator=gen) * math.sqrt(2.0 / cin_n)
+        st['1.fc.bias'] = torch.zeros(out_channels)
+        return st
     hid = hid_channels // width_div
     # Linear [in,out]; kaiming fan_in: Paddle's fan_in for a [in,out] weight is `in`.
     st['1.mlp.0.weight'] = torch.randn(cin_n, hid, generator=gen) * math.sqrt(2.0 / cin_n)
@@ -149,6 +153,8 @@ def encoder_forward(st, x, use_global_stats, new_stats=None, taps=None):
     x = trunk_forward(st, x, use_global_stats, new_stats, taps, maxpool=True)
     # NonLinearNeckV1.forward (base_neck.py:93-97)
     x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)
+    if '1.fc.weight' in st:           # LinearNeck.forward (base_neck.py:61-65)
+        return x @ st['1.fc.weight'] + st['1.fc.bias']
     x = F.relu(x @ st['1.mlp.0.weight'] + st['1.mlp.0.bias'])
     x = x @ st['1.mlp.2.weight'] + st['1.mlp.2.bias']
     return x

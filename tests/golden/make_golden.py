@@ -32,7 +32,10 @@ CASES = {
     'moco_v2_r50_cfg1': dict(N=32, hw=224, K=65536, steps=2),
     # fast case for every-commit runs
     'moco_v2_r50_small': dict(N=8, hw=64, K=1024, steps=3),
+    # configs/moco/moco_v1_r50.yaml: LinearNeck, T = 0.07, lr 0.03 MultiStepDecay
+    'moco_v1_r50_small': dict(N=8, hw=64, K=1024, steps=3, v1=True),
 }
+V1 = dict(neck='LinearNeck', T=0.07, lr=0.03, milestones=[120 * 5004, 160 * 5004])
 WATCH = ['0.conv1.weight', '0.layer1.0.conv2.weight', '0.layer2.0.downsample.0.weight',
          '0.layer4.2.conv3.weight', '0.layer3.5.bn2.weight', '0.bn1.bias',
          '1.mlp.0.weight', '1.mlp.2.weight', '1.mlp.2.bias']
@@ -46,10 +49,13 @@ def views(gen, N, hw):
     return xq, xk
 
 
-def run_case(name, N, hw, K, steps):
+def run_case(name, N, hw, K, steps, v1=False):
     torch.manual_seed(0)
-    oracle = MoCoOracle(K=K, seed=0, t_max=200 * 5004)
-    model = ref_runner.build_reference_moco(K=K)
+    okw = dict(V1) if v1 else {}
+    watch = [n for n in WATCH if not n.startswith('1.')] + (['1.fc.weight', '1.fc.bias'] if v1 else
+                                                            [n for n in WATCH if n.startswith('1.')])
+    oracle = MoCoOracle(K=K, seed=0, t_max=200 * 5004, **okw)
+    model = ref_runner.build_reference_moco(K=K, T=okw.get('T', 0.2), neck=okw.get('neck', 'NonLinearNeckV1'))
     ref_runner.load_oracle_state(model, oracle)
     model.train()
     captured = {}
@@ -85,7 +91,7 @@ def run_case(name, N, hw, K, steps):
         out[pre + 'queue_ptr'] = np.int64(int(model.queue_ptr[0]))
         out[pre + 'queue_new'] = model.queue[:, ptr0:ptr0 + N].detach().numpy().copy()
         out[pre + 'queue_sum64'] = np.float64(model.queue.double().sum().item())
-        for n in WATCH:
+        for n in watch:
             out[pre + 'gradnorm/' + n] = np.float64(grads[n].double().norm().item())
             out[pre + 'qnorm/' + n] = np.float64(oracle.q[n].double().norm().item())
             out[pre + 'knorm/' + n] = np.float64(ksd[n].double().norm().item())
@@ -100,7 +106,7 @@ def run_case(name, N, hw, K, steps):
     # R50 with batch-stat BN is ill-conditioned: fp32 and fp64 evaluations of the SAME algorithm
     # drift apart after the first update, so the tests bound |HIP - ref32| by a small multiple
     # of |ref32 - ref64| where that exceeds the nominal 1e-3.
-    o64 = MoCoOracle(K=K, seed=0, t_max=200 * 5004)
+    o64 = MoCoOracle(K=K, seed=0, t_max=200 * 5004, **okw)
     for d in (o64.q, o64.k):
         for n in d:
             d[n] = d[n].double()
@@ -114,7 +120,7 @@ def run_case(name, N, hw, K, steps):
         out[pre + 'loss'] = np.float64(float(r['loss']))
         out[pre + 'logits_head'] = r['logits'][:, :8].numpy().copy()
         out[pre + 'queue_new'] = o64.queue[:, ptr0:ptr0 + N].numpy().copy()
-        for n in WATCH:
+        for n in watch:
             out[pre + 'gradnorm/' + n] = np.float64(r['grads'][n].norm().item())
             out[pre + 'qnorm/' + n] = np.float64(o64.q[n].norm().item())
             out[pre + 'knorm/' + n] = np.float64(o64.k[n].norm().item())

@@ -13,6 +13,24 @@ WATCH_STATS = ['0.bn1._mean', '0.bn1._variance', '0.layer4.2.bn3._mean',
                '0.layer4.2.bn3._variance']
 
 
+# configs/moco/moco_v1_r50.yaml: LinearNeck, T = 0.07, lr 0.03 MultiStepDecay([120, 160] epochs)
+V1 = dict(neck='LinearNeck', T=0.07, lr=0.03, milestones=[120 * 5004, 160 * 5004])
+
+
+def is_v1(name):
+    return name.startswith('moco_v1')
+
+
+def oracle_kwargs(name):
+    return dict(V1) if is_v1(name) else {}
+
+
+def watch(name):
+    if not is_v1(name):
+        return WATCH
+    return [n for n in WATCH if not n.startswith('1.')] + ['1.fc.weight', '1.fc.bias']
+
+
 def load(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
     N, hw, K, steps = [int(v) for v in z['meta']]

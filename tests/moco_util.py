@@ -1,5 +1,7 @@
 """Shared helpers for the whole-step tests: build the product MoCo, load oracle state into it,
 run the reference's hook sequence (OptimizerHook + LRSchedulerHook) by hand."""
+import copy
+
 import torch
 
 from passl_amd.hip import config as hip_config
@@ -16,13 +18,23 @@ MODEL_CFG = dict(
 )
 
 
-def build_product(K, dtype, device='gpu'):
+def build_product(K, dtype, device='gpu', v1=False):
+    """v1: the `model:` / solver blocks of configs/moco/moco_v1_r50.yaml (LinearNeck, T = 0.07, lr 0.03
+    MultiStepDecay [120, 160] epochs x 5004 iterations)."""
     hip_config.set_device(device)
     hip_config.set_compute_dtype(dtype)
-    cfg = dict(MODEL_CFG)
+    cfg = copy.deepcopy(MODEL_CFG)
     cfg.update(K=K)
+    if v1:
+        cfg['neck'] = dict(name='LinearNeck', in_channels=2048, out_channels=128, with_avg_pool=True)
+        cfg['head']['temperature'] = 0.07
     torch.manual_seed(0)
     model = build_model(cfg)
+    if v1:
+        from passl_amd.solver.lr_scheduler import MultiStepDecay
+        sched = MultiStepDecay(0.03, milestones=[120 * 5004, 160 * 5004])
+        opt = Momentum(sched, parameters=list(model.parameters()), weight_decay=1e-4)
+        return model, opt, sched
     sched = CosineAnnealingDecay(0.015, T_max=200 * 5004)
     opt = Momentum(sched, parameters=list(model.parameters()), weight_decay=1e-4)
     return model, opt, sched

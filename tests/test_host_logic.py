@@ -500,3 +500,29 @@ def test_synthetic_labeled_dataset_and_evaluate_contract():
     assert image.shape == (8, 3, 32, 32) and label.shape == (8,) and label.dtype == torch.int64
     assert int(label.min()) >= 0 and int(label.max()) < 10 and len(loader) == 8 and len(loader.dataset) == 64
     assert hasattr(loader.dataset, 'evaluate')
+
+
+REF_MOCO_V1_CFG = '/root/reference/configs/moco/moco_v1_r50.yaml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MOCO_V1_CFG), reason='reference tree not present')
+def test_reference_moco_v1_config_loads_and_builds_unchanged():
+    """configs/moco/moco_v1_r50.yaml: LinearNeck projector, T = 0.07, MultiStepDecay(0.03, [120, 160])."""
+    hip_config.set_device('cpu')
+    from passl_amd.modeling import build_model
+    from passl_amd.solver import build_lr_scheduler, build_optimizer
+    from oracle.resnet50 import init_encoder_state
+    cfg = get_config(REF_MOCO_V1_CFG, [])
+    model = build_model(cfg.model)
+    assert type(model.encoder_q[1]).__name__ == 'LinearNeck' and model.head.temperature == 0.07
+    ost = init_encoder_state(torch.Generator().manual_seed(0), neck='LinearNeck')
+    sd = model.encoder_q.state_dict()
+    assert list(sd.keys()) == list(ost.keys())
+    assert all(tuple(sd[k].shape) == tuple(ost[k].shape) for k in ost)
+    sched = build_lr_scheduler(cfg.lr_scheduler, 5004)
+    assert sched() == 0.03
+    for _ in range(120 * 5004):
+        sched.last_epoch += 1
+    assert abs(sched.get_lr() - 0.003) < 1e-12
+    opt = build_optimizer(cfg.optimizer, sched, [model])
+    assert opt.type == 'momentum' and opt._wd == 1e-4

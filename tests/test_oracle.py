@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run_oracle_against(name, max_steps):
     z, N, hw, K, steps = G.load(name)
-    o = M.MoCoOracle(K=K, seed=0, t_max=200 * 5004)
+    o = M.MoCoOracle(K=K, seed=0, t_max=200 * 5004, **G.oracle_kwargs(name))
     gen = torch.Generator().manual_seed(1234)
     for s in range(min(steps, max_steps)):
         xq, xk = G.views(gen, N, hw)
@@ -34,7 +34,7 @@ def _run_oracle_against(name, max_steps):
                                    rtol=0, atol=1e-5)
         np.testing.assert_allclose(o.queue[:, ptr0:ptr0 + N].numpy(), z[pre + 'queue_new'],
                                    rtol=0, atol=1e-6)
-        for n in G.WATCH:
+        for n in G.watch(name):
             g = out['grads'][n].double().norm().item()
             assert abs(g - float(z[pre + 'gradnorm/' + n])) <= 1e-4 * max(g, 1e-6), n
             assert abs(o.q[n].double().norm().item() - float(z[pre + 'qnorm/' + n])) < 1e-4
@@ -46,6 +46,17 @@ def _run_oracle_against(name, max_steps):
 
 def test_oracle_matches_golden_small():
     _run_oracle_against('moco_v2_r50_small', 3)
+
+
+def test_oracle_matches_golden_v1_small():
+    """configs/moco/moco_v1_r50.yaml: LinearNeck projector, T = 0.07, MultiStepDecay."""
+    _run_oracle_against('moco_v1_r50_small', 3)
+    o = M.MoCoOracle(K=256, seed=0, **G.V1)
+    assert o.lr() == 0.03
+    o.step_count = 120 * 5004
+    assert abs(o.lr() - 0.003) < 1e-12
+    o.step_count = 160 * 5004
+    assert abs(o.lr() - 0.0003) < 1e-12
 
 
 def test_oracle_matches_golden_cfg1_first_step():
