@@ -68,15 +68,14 @@ def cpu_baseline():
 
 
 def pmc_traffic(args):
-    """HBM bytes per igemm launch from the committed PMC passes of this same command
+    """HBM bytes per igemm launch (a number) from the committed PMC passes of this same command
     (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py); null for any other workload/shape."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
     if args.workload != 'moco' or args.batch != 256 or args.dtype != 'bf16' or not os.path.exists(path):
         return None
     with open(path) as f:
         z = json.load(f)
-    return {'hbm_bytes_per_launch': z['igemm_all_variants']['hbm_bytes_per_launch'], 'unit': 'bytes',
-            'source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)'}
+    return z['igemm_all_variants']['hbm_bytes_per_launch']
 
 
 def main():
@@ -210,6 +209,8 @@ def main():
                 'kernel': 'igemm_kernel (implicit-GEMM conv fwd + dgrad + linear)', 'bound': 'mfma',
                 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(ach / peak, 5), 'traffic': pmc_traffic(args),
+                'traffic_unit': 'HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, '
+                                'profiles/r01_pmc_traffic.json)',
                 'launches': int(n), 'avg_launch_us': round(1000 * ms / n, 2),
                 'algorithmic_gflop_per_launch': round(flops['igemm'] / n / 1e9, 3),
                 'share_of_step_time': round(ms / (1000 * elapsed), 4)}
