@@ -1,0 +1,1 @@
+"""passl_amd — MI355X-native (gfx950) hot paths of PaddlePaddle/PASSL behind the reference's Python interface."""

@@ -1,57 +1,50 @@
-"""Hook interface of the Trainer — reference passl_v110/hooks/hook.py:16-69."""
+"""Hook interface of the Trainer (the event names and the train_/val_ -> generic forwarding are the
+contract of passl_v110/hooks/hook.py:16-69; hooks in this package and user hooks written for the
+reference override the same methods).
+
+The event table is data: ``STAGES`` lists the generic events, every ``train_<event>`` / ``val_<event>``
+forwards to ``<event>`` unless a subclass overrides it."""
+
+STAGES = ('epoch_begin', 'epoch_end', 'iter_begin', 'iter_end')
+
+
+def _forward_to(event):
+    def handler(self, trainer):
+        return getattr(self, event)(trainer)
+    handler.__name__ = event
+    handler.__doc__ = 'forwards to %s()' % event
+    return handler
 
 
 class Hook:
+    """Base class: every event is a no-op."""
+
     def run_begin(self, trainer):
-        pass
+        """once, before the first epoch"""
 
     def run_end(self, trainer):
-        pass
+        """once, after the last iteration"""
 
-    def epoch_begin(self, trainer):
-        pass
-
-    def epoch_end(self, trainer):
-        pass
-
-    def iter_begin(self, trainer):
-        pass
-
-    def iter_end(self, trainer):
-        pass
-
-    def train_epoch_begin(self, trainer):
-        self.epoch_begin(trainer)
-
-    def val_epoch_begin(self, trainer):
-        self.epoch_begin(trainer)
-
-    def train_epoch_end(self, trainer):
-        self.epoch_end(trainer)
-
-    def val_epoch_end(self, trainer):
-        self.epoch_end(trainer)
-
-    def train_iter_begin(self, trainer):
-        self.iter_begin(trainer)
-
-    def val_iter_begin(self, trainer):
-        self.iter_begin(trainer)
-
-    def train_iter_end(self, trainer):
-        self.iter_end(trainer)
-
-    def val_iter_end(self, trainer):
-        self.iter_end(trainer)
+    # ---- periodic predicates used by the hooks (1-based counters, n <= 0 never fires)
+    @staticmethod
+    def _hits(count, n):
+        return n > 0 and count % n == 0
 
     def every_n_epochs(self, trainer, n):
-        return (trainer.current_epoch + 1) % n == 0 if n > 0 else False
-
-    def every_n_inner_iters(self, trainer, n):
-        return trainer.inner_iter % n == 0 if n > 0 else False
+        return self._hits(trainer.current_epoch + 1, n)
 
     def every_n_iters(self, trainer, n):
-        return (trainer.current_iter + 1) % n == 0 if n > 0 else False
+        return self._hits(trainer.current_iter + 1, n)
+
+    def every_n_inner_iters(self, trainer, n):
+        return self._hits(trainer.inner_iter, n)
 
     def end_of_epoch(self, trainer):
-        return trainer.inner_iter + 1 == trainer.iters_per_epoch
+        return trainer.iters_per_epoch == trainer.inner_iter + 1
+
+
+for _event in STAGES:
+    setattr(Hook, _event, (lambda self, trainer: None))
+    for _phase in ('train', 'val'):
+        setattr(Hook, '%s_%s' % (_phase, _event), _forward_to(_event))
+del _event, _phase

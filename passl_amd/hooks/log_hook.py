@@ -45,42 +45,32 @@ class LogHook(Hook):
             i += n
         self._pending.clear()
 
-    def _log_info(self, log_dict, trainer):
-        if trainer.mode == 'train':
-            lr_str = 'lr: {:.3e}'.format(log_dict['lr'])
-            if self.by_epoch:
-                log_str = 'Epoch [{}/{}][{}/{}]\t'.format(log_dict['epoch'], trainer.epochs,
-                                                          log_dict['iter'], trainer.iters_per_epoch)
-            else:
-                log_str = 'Iter [{}/{}]\t'.format(log_dict['iter'], trainer.total_iters)
-            log_str += '{}, '.format(lr_str)
-            if 'time' in log_dict.keys():
-                self.time_sec_tot += log_dict['time'].sum
-                time_sec_avg = log_dict['time'].avg
-                eta_sec = time_sec_avg * (trainer.total_iters - trainer.current_iter - 1)
-                log_str += 'eta: {}, '.format(str(datetime.timedelta(seconds=int(eta_sec))))
-                log_str += 'time: {:.3f}, data_time: {:.3f}, '.format(time_sec_avg,
-                                                                      log_dict['data_time'].avg)
-        else:
-            log_str = 'Epoch({}) [{}][{}]\t'.format(log_dict['mode'], log_dict['epoch'] - 1,
-                                                    log_dict['iter'])
-        items = []
-        for name, val in log_dict.items():
-            if name in ['mode', 'Epoch', 'iter', 'lr', 'time', 'data_time', 'memory', 'epoch']:
-                continue
-            items.append(str(val) if isinstance(val, AverageMeter) else val)
-        trainer.logger.info(log_str + ', '.join(str(i) for i in items))
+    _META_KEYS = frozenset(('mode', 'Epoch', 'epoch', 'iter', 'lr', 'time', 'data_time', 'memory'))
+
+    def _prefix(self, logs, trainer):
+        """The part of the line before the meters (same text as the reference's log lines)."""
+        if trainer.mode != 'train':
+            return 'Epoch({}) [{}][{}]\t'.format(logs['mode'], logs['epoch'] - 1, logs['iter'])
+        where = ('Epoch [{}/{}][{}/{}]\t'.format(logs['epoch'], trainer.epochs, logs['iter'], trainer.iters_per_epoch)
+                 if self.by_epoch else 'Iter [{}/{}]\t'.format(logs['iter'], trainer.total_iters))
+        parts = [where + 'lr: {:.3e}'.format(logs['lr'])]
+        timer = logs.get('time')
+        if timer is not None:
+            self.time_sec_tot += timer.sum
+            remaining = trainer.total_iters - trainer.current_iter - 1
+            parts.append('eta: {}'.format(datetime.timedelta(seconds=int(timer.avg * remaining))))
+            parts.append('time: {:.3f}, data_time: {:.3f}'.format(timer.avg, logs['data_time'].avg))
+        return ', '.join(parts) + ', '
 
     def print_log(self, trainer):
         self._flush(trainer)
-        log_dict = trainer.logs
-        mode = 'train' if 'time' in trainer.logs else 'val'
-        log_dict['mode'] = mode
-        log_dict['epoch'] = trainer.current_epoch + 1
-        log_dict['iter'] = trainer.inner_iter if self.by_epoch else trainer.current_iter
-        cur_lr = trainer.lr_scheduler.get_lr()
-        log_dict['lr'] = cur_lr[0] if isinstance(cur_lr, list) else cur_lr
-        self._log_info(log_dict, trainer)
+        logs = trainer.logs
+        lr = trainer.lr_scheduler.get_lr()
+        logs.update(mode='train' if 'time' in logs else 'val', epoch=trainer.current_epoch + 1,
+                    iter=trainer.inner_iter if self.by_epoch else trainer.current_iter,
+                    lr=lr[0] if isinstance(lr, list) else lr)
+        meters = [str(v) for k, v in logs.items() if k not in self._META_KEYS]
+        trainer.logger.info(self._prefix(logs, trainer) + ', '.join(meters))
 
     def epoch_begin(self, trainer):
         self._pending.clear()

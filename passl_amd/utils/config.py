@@ -1,10 +1,15 @@
-"""YAML -> nested AttrDict with ``-o a.b.0.c=v`` overrides.
+"""YAML config -> nested ``AttrDict`` with ``-o a.b.0.c=v`` overrides.
 
-Same behaviour as the reference's passl_v110/utils/config.py:25-128: string leaves go through
-``literal_eval`` (so ``1.0/255.0`` stays a string but ``[0.2, 1.]`` becomes a list), overrides
-are ``eval``-ed when possible, must address an existing key / index, and ``get_config`` asserts
-that the file exists.
+Behavioural contract (what the reference's configs and launch lines rely on,
+passl_v110/utils/config.py:25-128):
+  * every mapping becomes an ``AttrDict`` (attribute access), at any depth, also inside lists;
+  * string leaves are passed through ``ast.literal_eval`` when they parse (``"[0.2, 1.]"`` -> list,
+    ``"1.0/255.0"`` stays a string because it is an expression, not a literal);
+  * an override addresses an EXISTING key (dict) or index (list) by a dotted path; its value is
+    evaluated as a Python expression when possible, kept as a string otherwise;
+  * a missing file, a malformed option or an unknown key is an ``AssertionError``.
 """
+import copy
 import os
 from ast import literal_eval
 
@@ -14,95 +19,89 @@ __all__ = ['AttrDict', 'get_config', 'parse_config', 'override_config', 'create_
 
 
 class AttrDict(dict):
-    def __getattr__(self, key):
-        try:
-            return self[key]
-        except KeyError:
-            raise AttributeError(key)
+    """dict whose items are also attributes."""
 
-    def __setattr__(self, key, value):
-        if key in self.__dict__:
-            self.__dict__[key] = value
+    def __getattr__(self, name):
+        if name in self:
+            return self[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in self.__dict__:
+            object.__setattr__(self, name, value)
         else:
-            self[key] = value
+            self[name] = value
 
     def __deepcopy__(self, memo):
-        import copy
-        return AttrDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
+        return AttrDict((k, copy.deepcopy(v, memo)) for k, v in self.items())
+
+
+def _literal(value):
+    """str -> Python literal when it is one."""
+    if not isinstance(value, str):
+        return value
+    try:
+        return literal_eval(value)
+    except (ValueError, SyntaxError, TypeError, MemoryError, RecursionError):
+        return value
+
+
+def _convert(node):
+    """Recursively wrap mappings and evaluate string literals (lists are converted in place)."""
+    if isinstance(node, dict):
+        wrapped = node if isinstance(node, AttrDict) else AttrDict(node)
+        for key in list(wrapped):
+            wrapped[key] = _convert(wrapped[key])
+        return wrapped
+    if isinstance(node, list):
+        for i, item in enumerate(node):
+            node[i] = _convert(item) if isinstance(item, (dict, list)) else item
+        return node
+    return _literal(node)
 
 
 def create_attr_dict(cfg):
-    for key, value in list(cfg.items()):
-        if type(value) is dict:
-            cfg[key] = value = AttrDict(value)
-        if isinstance(value, str):
-            try:
-                value = literal_eval(value)
-            except BaseException:
-                pass
-        if isinstance(value, AttrDict):
-            create_attr_dict(cfg[key])
-        elif isinstance(value, list):
-            _recurse_list(value)
-        else:
-            cfg[key] = value
-    return None
-
-
-def _recurse_list(lst):
-    for i, v in enumerate(lst):
-        if type(v) is dict or isinstance(v, AttrDict):
-            lst[i] = v if isinstance(v, AttrDict) else AttrDict(v)
-            create_attr_dict(lst[i])
-        elif isinstance(v, list):
-            _recurse_list(v)
+    """In-place conversion of a (possibly plain) mapping tree."""
+    for key in list(cfg):
+        cfg[key] = _convert(cfg[key])
 
 
 def parse_config(cfg_file):
     with open(cfg_file, 'r') as f:
-        cfg = AttrDict(yaml.load(f, Loader=yaml.SafeLoader))
-    create_attr_dict(cfg)
-    return cfg
+        return _convert(yaml.load(f, Loader=yaml.SafeLoader))
 
 
-def override(dl, ks, v):
-    def str2num(s):
-        try:
-            return eval(s)
-        except Exception:
-            return s
+def _evaluate(text):
+    try:
+        return eval(text)            # the reference evaluates override values the same way
+    except Exception:
+        return text
 
-    assert isinstance(dl, (list, dict)), '{} should be a list or a dict'.format(dl)
-    assert len(ks) > 0, 'lenght of keys should larger than 0'
-    if isinstance(dl, list):
-        k = str2num(ks[0])
-        if len(ks) == 1:
-            assert k < len(dl), 'index({}) out of range({})'.format(k, dl)
-            dl[k] = str2num(v)
-        else:
-            override(dl[k], ks[1:], v)
+
+def _assign(node, path, text):
+    """Walk ``path`` (list of keys / indices) and replace the addressed leaf."""
+    assert isinstance(node, (list, dict)), '{} should be a list or a dict'.format(node)
+    assert path, 'empty override key'
+    head = _evaluate(path[0]) if isinstance(node, list) else path[0]
+    if isinstance(node, list):
+        assert isinstance(head, int) and head < len(node), 'index({}) out of range({})'.format(head, node)
     else:
-        if len(ks) == 1:
-            assert ks[0] in dl, '{} is not exist in {}'.format(ks[0], dl)
-            dl[ks[0]] = str2num(v)
-        else:
-            override(dl[ks[0]], ks[1:], v)
+        assert head in node, '{} is not exist in {}'.format(head, node)
+    if len(path) == 1:
+        node[head] = _evaluate(text)
+    else:
+        _assign(node[head], path[1:], text)
 
 
 def override_config(config, options=None):
-    if options is not None:
-        for opt in options:
-            assert isinstance(opt, str), 'option({}) should be a str'.format(opt)
-            assert '=' in opt, 'option({}) should contain a = to distinguish between key and value'.format(opt)
-            pair = opt.split('=')
-            assert len(pair) == 2, 'there can be only a = in the option'
-            key, value = pair
-            override(config, key.split('.'), value)
+    for opt in options or ():
+        assert isinstance(opt, str), 'option({}) should be a str'.format(opt)
+        assert opt.count('=') == 1, 'option({}) must be key=value with a single ='.format(opt)
+        dotted, text = opt.split('=')
+        _assign(config, dotted.split('.'), text)
     return config
 
 
 def get_config(fname, overrides=None):
     assert os.path.exists(fname), 'config file({}) is not exist'.format(fname)
-    config = parse_config(fname)
-    override_config(config, overrides)
-    return config
+    return override_config(parse_config(fname), overrides)

@@ -1,10 +1,12 @@
-"""Process logger: INFO to stdout on rank 0 (+ optional file), WARNING elsewhere
-(reference: passl_v110/utils/logger.py)."""
+"""Process logger (role of passl_v110/utils/logger.py): rank 0 logs INFO to stdout, other ranks only
+WARNING and above; with ``output`` every rank also appends to a file (``<output>/log.txt`` or the given
+.txt/.log path, suffixed ``.rank<r>`` off rank 0).  Handlers are installed once per logger name."""
 import logging
 import os
 import sys
 
 logger_initialized = []
+_FORMAT = logging.Formatter('[%(asctime)s] %(name)s %(levelname)s: %(message)s', datefmt='%m/%d %H:%M:%S')
 
 
 def _rank():
@@ -17,36 +19,35 @@ def _rank():
     return int(os.environ.get('RANK', 0))
 
 
+def _log_path(output, rank):
+    path = output if output.endswith(('.txt', '.log')) else os.path.join(output, 'log.txt')
+    return path if rank == 0 else '%s.rank%d' % (path, rank)
+
+
+def _attach(logger, handler):
+    handler.setLevel(logging.DEBUG)
+    handler.setFormatter(_FORMAT)
+    logger.addHandler(handler)
+
+
 def setup_logger(output=None, name='passl'):
     logger = logging.getLogger(name)
     if name in logger_initialized:
         return logger
-    logger.setLevel(logging.INFO)
-    logger.propagate = False
-    fmt = logging.Formatter('[%(asctime)s] %(name)s %(levelname)s: %(message)s', datefmt='%m/%d %H:%M:%S')
     rank = _rank()
+    logger.propagate = False
+    logger.setLevel(logging.INFO if rank == 0 else logging.WARNING)
     if rank == 0:
-        ch = logging.StreamHandler(stream=sys.stdout)
-        ch.setLevel(logging.DEBUG)
-        ch.setFormatter(fmt)
-        logger.addHandler(ch)
-    else:
-        logger.setLevel(logging.WARNING)
+        _attach(logger, logging.StreamHandler(stream=sys.stdout))
     if output is not None:
-        filename = output if output.endswith(('.txt', '.log')) else os.path.join(output, 'log.txt')
-        if rank > 0:
-            filename = filename + '.rank{}'.format(rank)
-        os.makedirs(os.path.dirname(filename) or '.', exist_ok=True)
-        fh = logging.FileHandler(filename, mode='a')
-        fh.setLevel(logging.DEBUG)
-        fh.setFormatter(fmt)
-        logger.addHandler(fh)
+        path = _log_path(output, rank)
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        _attach(logger, logging.FileHandler(path, mode='a'))
     logger_initialized.append(name)
     return logger
 
 
 def get_logger(name='passl', output=None):
-    logger = logging.getLogger(name)
     if name in logger_initialized:
-        return logger
-    return setup_logger(name=name, output=output)
+        return logging.getLogger(name)
+    return setup_logger(output=output, name=name)

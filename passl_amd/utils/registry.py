@@ -1,9 +1,11 @@
 """Name -> class registries and ``build_from_config``.
 
-Mirrors the contract of the reference's passl_v110/utils/registry.py:25-133: ``register()`` as
-decorator or call (keyed on ``__name__`` unless ``name=`` is given, duplicate names rejected),
-``get()`` raising KeyError, and ``build_from_config(cfg, registry, default_args)`` which pops
-``name`` and instantiates ``cls(**rest)``, printing and re-raising constructor errors.
+Contract (the one the reference's builders and YAML files rely on, passl_v110/utils/registry.py:25-133):
+``register`` works as ``@R.register()``, ``@R.register(name=...)`` or ``R.register(obj, name=...)`` and keys
+on ``__name__`` by default (a duplicate key is an ``AssertionError``); ``get`` raises ``KeyError``;
+``build_from_config(cfg, registry, default_args)`` merges the defaults under ``cfg``, pops ``name`` (a
+registered key or a class) and instantiates it with the remaining items, printing the traceback of a
+failing constructor before re-raising.
 """
 import inspect
 import traceback
@@ -14,53 +16,55 @@ class Registry(object):
         self._name = name
         self._obj_map = {}
 
-    def _do_register(self, name, obj):
-        assert name not in self._obj_map, \
-            "An object named '{}' was already registered in '{}' registry!".format(name, self._name)
-        self._obj_map[name] = obj
+    def __contains__(self, key):
+        return key in self._obj_map
+
+    def __len__(self):
+        return len(self._obj_map)
+
+    def _add(self, obj, key=None):
+        key = key or obj.__name__
+        assert key not in self._obj_map, \
+            "An object named '{}' was already registered in '{}' registry!".format(key, self._name)
+        self._obj_map[key] = obj
+        return obj
 
     def register(self, obj=None, name=None):
-        if obj is None:
-            def deco(func_or_class, name=name):
-                self._do_register(name or func_or_class.__name__, func_or_class)
-                return func_or_class
-            return deco
-        self._do_register(name or obj.__name__, obj)
+        if obj is not None:                       # plain call: R.register(cls) / R.register(cls, name='x')
+            self._add(obj, name)
+            return None
+        return lambda target: self._add(target, name)     # decorator form
 
     def get(self, name):
-        ret = self._obj_map.get(name)
-        if ret is None:
-            raise KeyError("No object named '{}' found in '{}' registry!".format(name, self._name))
-        return ret
+        try:
+            return self._obj_map[name]
+        except KeyError:
+            raise KeyError("No object named '{}' found in '{}' registry!".format(name, self._name)) from None
 
-    def __contains__(self, name):
-        return name in self._obj_map
+
+def _resolve(target, registry):
+    if isinstance(target, str):
+        return registry.get(target)
+    if inspect.isclass(target):
+        return target
+    raise TypeError('name must be a str or valid name, but got {}'.format(type(target)))
 
 
 def build_from_config(cfg, registry, default_args=None):
-    if not isinstance(cfg, dict):
-        raise TypeError('cfg must be a dict, but got {}'.format(type(cfg)))
-    if 'name' not in cfg and (default_args is None or 'name' not in default_args):
+    for what, value, ok in (('cfg', cfg, isinstance(cfg, dict)),
+                            ('registry', registry, isinstance(registry, Registry)),
+                            ('default_args', default_args, default_args is None or isinstance(default_args, dict))):
+        if not ok:
+            raise TypeError('{} has the wrong type: {}'.format(what, type(value)))
+    kwargs = dict(default_args or {})
+    kwargs.update(cfg)
+    if 'name' not in kwargs:
         raise KeyError('`cfg` or `default_args` must contain the key "name", but got {}\n{}'.format(
             cfg, default_args))
-    if not isinstance(registry, Registry):
-        raise TypeError('registry must be an Registry object, but got {}'.format(type(registry)))
-    if not (isinstance(default_args, dict) or default_args is None):
-        raise TypeError('default_args must be a dict or None, but got {}'.format(type(default_args)))
-    args = dict(cfg)
-    if default_args is not None:
-        for k, v in default_args.items():
-            args.setdefault(k, v)
-    cls_name = args.pop('name')
-    if isinstance(cls_name, str):
-        obj_cls = registry.get(cls_name)
-    elif inspect.isclass(cls_name):
-        obj_cls = cls_name
-    else:
-        raise TypeError('name must be a str or valid name, but got {}'.format(type(cls_name)))
+    target = kwargs.pop('name')
+    obj_cls = _resolve(target, registry)
     try:
-        return obj_cls(**args)
-    except Exception as e:
-        print('Fail to initial class [{}] with error: {} and stack:\n{}'.format(
-            cls_name, e, traceback.format_exc()))
-        raise e
+        return obj_cls(**kwargs)
+    except Exception as err:
+        print('Fail to initial class [{}] with error: {} and stack:\n{}'.format(target, err, traceback.format_exc()))
+        raise
