@@ -1,52 +1,115 @@
 """bench.py — MoCo-v2 ResNet-50 two-view training step on N MI355X GPUs (one process per GPU).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                   # N=1, 50 timed steps after 5 warm-up steps
+    python bench.py --gpus 8                          # spawns 8 ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
+        --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 5       # the driver's form
 
 One "step" = the full hot path of BASELINE.json configs[1] on one resident synthetic batch:
 q forward (train BN), key-encoder EMA, k forward, fused InfoNCE, enqueue, backward, gradient
-all-reduce (N>1), momentum-SGD, lr step — driven through the Trainer's hooks (OptimizerHook,
-LRSchedulerHook).  Prints ONE JSON line (rank 0).  `value` = images/s over all ranks, where one
-image = one two-view sample (PASSL's own `ips`, passl/engine/loops/loop.py:102-104).
+all-reduce (N>1), momentum-SGD, lr step — driven through the Trainer's whole hook bus
+(train_iter_begin / train_iter_end of OptimizerHook, IterTimerHook, LogHook, LRSchedulerHook, ...).
+
+Two loops:
+  1. the TIMED loop: exactly --steps steps, nothing but the product path between a barrier +
+     torch.cuda.synchronize() on both sides -> `value`, `ms_per_step`;
+  2. an INSTRUMENTED loop afterwards (HIP events around every launch of the dominant kernel class on
+     its launch stream + a FLOP counter on the descriptors) -> `roofline`.  It never contributes to
+     `value`.
+Prints ONE JSON line (rank 0).  `value` = images/s over all ranks, where one image = one two-view
+sample (PASSL's own `ips`, passl/engine/loops/loop.py:102-104).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch                                   # noqa: E402
-import torch.distributed as dist               # noqa: E402
-
 FLOP_PER_SAMPLE = 32.77e9      # 2*[(3+1)*(4.0871+0.00446) + 2*0.00839] GMAC
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PMC_TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')
+
+# workload -> (config, default per-GPU batch, algorithmic FLOP per sample, metric text, workload text)
+WORKLOADS = {
+    'moco': ('configs/moco/moco_v2_r50_synthetic.yaml', 256, FLOP_PER_SAMPLE,
+             'images/sec/node (2-view), MoCo-v2 R50 bs%d/GPU',
+             'MoCo-v2 ResNet-50 %s, bs=%d/GPU, 2x224^2 synthetic views, queue=65536, dim=128, T=0.2, '
+             'm=0.999, momentum-SGD (BASELINE configs[1])'),
+    # SimCLR: 2 views x (fwd + bwd = 3) x 15.99 GMAC x 2 FLOP per two-view sample
+    'simclr': ('configs/simclr/simclr_r50_synthetic.yaml', 64, 2 * 3 * 15.99e9 * 2,
+               'images/sec/node (2-view), SimCLR R50 (no stem max-pool) bs%d/GPU',
+               'SimCLR ResNet-50 (no stem max-pool) %s, bs=%d/GPU, 2x224^2 synthetic views, '
+               'NT-Xent+CO2 T=0.1, LARS (SimCLR row; BASELINE configs[2] shape)'),
+    # MAE ViT-B/16: 3 x 9.78 GMAC x 2 FLOP per image
+    'mae': ('configs/mae/mae_vit_b_synthetic.yaml', 256, 3 * 9.78e9 * 2,
+            'images/sec/node, MAE ViT-B/16 mask 0.75 bs%d/GPU',
+            'MAE ViT-B/16 %s, bs=%d/GPU, 224^2 synthetic images, mask 0.75 (50 encoder / 197 decoder '
+            'tokens), norm_pix_loss, AdamW (MAE row; BASELINE configs[3])'),
+    # CLIP ViT-B/32: 4.41 GMAC (image, 50 tokens) + 2.98 GMAC (text, 77 tokens) per pair
+    'clip': ('configs/clip/vit-b-32_synthetic.yaml', 128, 3 * 7.39e9 * 2,
+             'image-text pairs/sec/node, CLIP ViT-B/32 bs%d/GPU',
+             'CLIP ViT-B/32 + 12-layer causal text transformer %s, bs=%d/GPU, 224^2 synthetic images + '
+             '77-token synthetic captions, AdamW (CLIP row; configs/clip/vit-b-32.yaml)'),
+    # CLIP ViT-B/16 (BASELINE configs[4]): 17.56 GMAC image (197 tokens) + 2.98 GMAC text per pair
+    'clip16': ('configs/clip/vit-b-16_synthetic.yaml', 256, 3 * (17.56e9 + 2.98e9) * 2,
+               'image-text pairs/sec/node, CLIP ViT-B/16 bs%d/GPU',
+               'CLIP ViT-B/16 + 12-layer causal text transformer %s, bs=%d/GPU, 224^2 synthetic images '
+               '+ 77-token synthetic captions, cross-rank InfoNCE, AdamW (BASELINE configs[4] shape)'),
+    # frozen trunk forward only (4.087 GMAC) + the fc
+    'linprobe': ('configs/moco/moco_clas_r50_synthetic.yaml', 256, 4.09e9 * 2,
+                 'images/sec/node, linear probe on frozen R50 bs%d/GPU',
+                 'linear probe: frozen ResNet-50 (fused inference BN) + fc 2048->1000 %s, bs=%d/GPU, '
+                 '224^2 synthetic labelled images, momentum-SGD on the fc (configs/moco/moco_clas_r50.yaml)'),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None,
                     help='per-GPU batch (default: 256 = BASELINE configs[1]; simclr: 64; clip: 128)')
-    ap.add_argument('--workload', default='moco', choices=['moco', 'simclr', 'mae', 'clip', 'linprobe'],
-                    help="moco = BASELINE.json's metric (default); simclr / mae / clip = the SimCLR, MAE and "
-                         'CLIP rows (extra measurements: no-maxpool R50 + NT-Xent+CO2 + LARS; ViT-B/16 MAE; '
-                         'CLIP ViT-B/32 image-text pairs)')
+    ap.add_argument('--workload', default='moco', choices=sorted(WORKLOADS),
+                    help="moco = BASELINE.json's metric (default); the others are the SimCLR / MAE / CLIP / "
+                         'linear-probe rows (extra measurements)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true',
-                    help='do not bracket the MFMA kernels with HIP events (use under rocprofv3)')
+                    help='skip the instrumented loop (use under rocprofv3)')
+    ap.add_argument('--roofline-steps', type=int, default=10,
+                    help='steps of the instrumented loop that follows the timed loop')
     return ap.parse_args()
 
 
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) under
+    torch.distributed.run on this node and pass rank 0's JSON line through."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline():
-    """The oracle (CPU restatement of the reference step) on the host cores, cfg-1 shape."""
+    """The oracle (CPU restatement of the reference step) on the host cores, cfg-1 shape:
+    median of 5 steps after 2 warm-ups."""
+    import torch
     from oracle.moco import MoCoOracle
     n = 32
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
@@ -54,75 +117,87 @@ def cpu_baseline():
     gen = torch.Generator().manual_seed(1234)
     xq = torch.randn(n, 3, 224, 224, generator=gen)
     xk = torch.randn(n, 3, 224, 224, generator=gen)
-    o.train_step(xq, xk)                              # warm-up
-    times = []
     for _ in range(2):
+        o.train_step(xq, xk)
+    times = []
+    for _ in range(5):
         t = time.perf_counter()
         o.train_step(xq, xk)
         times.append(time.perf_counter() - t)
-    sec = sorted(times)[0]
+    sec = sorted(times)[len(times) // 2]
     return {'value': round(n / sec, 3), 'unit': 'images/sec', 'cores': torch.get_num_threads(),
             'kind': 'port',
             'sample': 'oracle (torch-CPU fp32 restatement; Paddle is not installable) full step, '
-                      'N=32 two-view 224^2, K=65536, best of 2 after 1 warm-up, %.2f s/step' % sec}
+                      'N=32 two-view 224^2, K=65536, median of 5 after 2 warm-ups, %.2f s/step '
+                      '(min %.2f, max %.2f)' % (sec, min(times), max(times))}
 
 
 def pmc_traffic(args):
-    """HBM bytes per igemm launch (a number) from the committed PMC passes of this same command
-    (profiles/r01_pmc_traffic.json, made by tools/pmc_summary.py); null for any other workload/shape."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    """(bytes per igemm-class launch, source) from the committed rocprofv3 --pmc passes of this same
+    command (tools/pmc_summary.py).  PMC counters need the profiler, so this number is NOT measured
+    by this run — the source says so; (None, None) for any other workload / shape."""
+    path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
     if args.workload != 'moco' or args.batch != 256 or args.dtype != 'bf16' or not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as f:
         z = json.load(f)
-    return z['igemm_all_variants']['hbm_bytes_per_launch']
+    return (z['igemm_all_variants']['hbm_bytes_per_launch'],
+            '%s (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + WRITE_SIZE; '
+            'not measured by this run)' % PMC_TRAFFIC_FILE)
 
 
 def main():
     args = parse()
-    simclr, mae, clip = args.workload == 'simclr', args.workload == 'mae', args.workload == 'clip'
-    linprobe = args.workload == 'linprobe'
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
+
+    cfg_path, default_batch, flop_per_sample, metric_fmt, workload_fmt = WORKLOADS[args.workload]
     if args.batch is None:
-        args.batch = 64 if simclr else (128 if clip else 256)
-    # SimCLR: 2 views x (fwd + bwd = 3) x 15.99 GMAC x 2 FLOP per two-view sample;
-    # MAE ViT-B/16: 3 x 9.78 GMAC x 2 FLOP per image (SURVEY §8d)
-    # CLIP ViT-B/32: 4.41 GMAC (image, 50 tokens) + 2.98 GMAC (text, 77 tokens) per pair
-    flop_per_sample = 2 * 3 * 15.99e9 * 2 if simclr else (3 * 9.78e9 * 2 if mae else FLOP_PER_SAMPLE)
-    if clip:
-        flop_per_sample = 3 * 7.39e9 * 2
-    if linprobe:                        # frozen trunk forward only (4.087 GMAC) + the fc
-        flop_per_sample = 4.09e9 * 2
+        args.batch = default_batch
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, 'launch with torchrun --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks'
+                         % (args.gpus, world))
     assert torch.cuda.is_available(), 'bench.py runs the HIP path: an MI355X is required'
 
     from passl_amd.engine.trainer import Trainer
     from passl_amd.hip import lib as L, ops
-    from passl_amd.hooks import OptimizerHook, LRSchedulerHook
+    from passl_amd.utils import logger as plog
     from passl_amd.utils.config import get_config
 
-    cfg = get_config(os.path.join(ROOT, 'configs/simclr/simclr_r50_synthetic.yaml' if simclr else
-                                  ('configs/mae/mae_vit_b_synthetic.yaml' if mae else
-                                   ('configs/clip/vit-b-32_synthetic.yaml' if clip else
-                                    ('configs/moco/moco_clas_r50_synthetic.yaml' if linprobe else
-                                     'configs/moco/moco_v2_r50_synthetic.yaml')))),
+    # stdout carries exactly one JSON line: LogHook's lines (rank 0, every log_config.interval
+    # iterations, one device->host transfer each) go to stderr
+    import logging
+    lg = logging.getLogger('passl')
+    lg.propagate = False
+    lg.setLevel(logging.INFO if rank == 0 else logging.WARNING)
+    if 'passl' not in plog.logger_initialized:
+        lg.addHandler(logging.StreamHandler(stream=sys.stderr))
+        plog.logger_initialized.append('passl')
+
+    cfg = get_config(os.path.join(ROOT, cfg_path),
                      ['dataloader.train.sampler.batch_size=%d' % args.batch,
                       'compute_dtype=%s' % args.dtype])
     cfg.timestamp = ''
     trainer = Trainer(cfg)
     trainer.mode = 'train'
     trainer.model.train()
-    opt_hook = next(h for h in trainer.hooks if isinstance(h, OptimizerHook))
-    lr_hook = next(h for h in trainer.hooks if isinstance(h, LRSchedulerHook))
     data = next(iter(trainer.train_dataloader))
+    trainer.call_hook('run_begin')
+    trainer.call_hook('train_epoch_begin')
 
     def step():
+        # the body of Trainer.train's loop (engine/trainer.py) on the resident batch
+        trainer.inner_iter = trainer.current_iter % trainer.iters_per_epoch
         trainer.current_iter += 1
+        trainer.call_hook('train_iter_begin')
         trainer.outputs = trainer.model(*data, total_iters=trainer.total_iters,
-                                        current_iter=trainer.current_iter, mixup_fn=None)
-        opt_hook.train_iter_end(trainer)
-        lr_hook.train_iter_end(trainer)
+                                        current_iter=trainer.current_iter, mixup_fn=trainer.mixup_fn)
+        trainer.call_hook('train_iter_end')
 
     def barrier():
         if world > 1:
@@ -131,18 +206,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    lib = L.load()
-    timing = not args.no_kernel_timing
-    flops = {'igemm': 0.0}
-    if timing:
-        lib.passl_hip_prof_enable(1)
-        real_igemm = ops.conv_igemm
 
-        def counting_igemm(d, *a, **k):
-            kdim = 147 if (d.R, d.S, d.C) == (7, 1, 32) else d.R * d.S * d.C   # stem: real taps
-            flops['igemm'] += 2.0 * d.N * d.OP * d.OQ * d.NCOLS * kdim
-            return real_igemm(d, *a, **k)
-        ops.conv_igemm = counting_igemm
+    # ---- 1. timed loop: product path only
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -151,9 +216,31 @@ def main():
     elapsed = time.perf_counter() - t0
     loss = float(trainer.outputs['loss'].detach())
 
-    kern = {}
-    if timing:
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- 2. instrumented loop (rank 0's kernels; every rank runs the steps so collectives match)
+    kern, flops, rsteps = {}, {'igemm': 0.0}, 0
+    if not args.no_kernel_timing and args.roofline_steps > 0:
         import ctypes
+        lib = L.load()
+        rsteps = args.roofline_steps
+        lib.passl_hip_prof_enable(1)
+        real_igemm = ops.conv_igemm
+
+        def counting_igemm(d, *a, **k):
+            kdim = 147 if (d.R, d.S, d.C) == (7, 1, 32) else d.R * d.S * d.C   # stem: real taps
+            flops['igemm'] += 2.0 * d.N * d.OP * d.OQ * d.NCOLS * kdim
+            return real_igemm(d, *a, **k)
+        ops.conv_igemm = counting_igemm
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(rsteps):
+            step()
+        barrier()
+        instr_elapsed = time.perf_counter() - t1
         ops.conv_igemm = real_igemm
         for cls, name in ((0, 'igemm'), (1, 'wgrad')):
             ms, n = ctypes.c_double(), ctypes.c_int64()
@@ -161,63 +248,42 @@ def main():
             kern[name] = (ms.value, n.value)
         lib.passl_hip_prof_enable(0)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
     if rank == 0:
         ips = args.batch * world * args.steps / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         out = {
-            'metric': ('images/sec/node, linear probe on frozen R50 bs%d/GPU' % args.batch) if linprobe else
-            ('image-text pairs/sec/node, CLIP ViT-B/32 bs%d/GPU' % args.batch) if clip else
-            ('images/sec/node, MAE ViT-B/16 mask 0.75 bs%d/GPU' % args.batch) if mae else
-            'images/sec/node (2-view), %s bs%d/GPU' % (
-                'SimCLR R50 (no stem max-pool)' if simclr else 'MoCo-v2 R50', args.batch),
+            'metric': metric_fmt % args.batch,
             'value': round(ips, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1000 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': ('linear probe: frozen ResNet-50 (fused inference BN) + fc 2048->1000 %s, '
-                                    'bs=%d/GPU, 224^2 synthetic labelled images, momentum-SGD on the fc '
-                                    '(configs/moco/moco_clas_r50.yaml)' if linprobe else
-                                    'CLIP ViT-B/32 + 12-layer causal text transformer %s, bs=%d/GPU, 224^2 '
-                                    'synthetic images + 77-token synthetic captions, AdamW (CLIP row; '
-                                    'configs/clip/vit-b-32.yaml)' if clip else
-                                    'MAE ViT-B/16 %s, bs=%d/GPU, 224^2 synthetic images, mask 0.75 (50 '
-                                    'encoder / 197 decoder tokens), norm_pix_loss, AdamW (MAE row; '
-                                    'BASELINE configs[3])' if mae else
-                                    'SimCLR ResNet-50 (no stem max-pool) %s, bs=%d/GPU, 2x224^2 '
-                                    'synthetic views, NT-Xent+CO2 T=0.1, LARS (SimCLR row; '
-                                    'BASELINE configs[2] shape at a smaller per-GPU batch)'
-                                    if simclr else
-                                    'MoCo-v2 ResNet-50 %s, bs=%d/GPU, 2x224^2 synthetic views, '
-                                    'queue=65536, dim=128, T=0.2, m=0.999, momentum-SGD (BASELINE '
-                                    'configs[1])') % (args.dtype, args.batch),
+            'config': {'workload': workload_fmt % (args.dtype, args.batch),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                       'views_per_sec': round(2 * ips, 2), 'final_loss': round(loss, 4)},
+                       'views_per_sec': round(2 * ips, 2), 'final_loss': round(loss, 4),
+                       'timed_region': 'product path only (full hook bus); kernel instrumentation runs '
+                                       'in a separate loop afterwards'},
             'step_flop_roofline': {
                 'algorithmic_gflop_per_sample': flop_per_sample / 1e9,
                 'achieved_tflops_per_gpu': round(ips / world * flop_per_sample / 1e12, 2),
                 'frac_of_peak': round(ips / world * flop_per_sample / 1e12 / peak, 5)},
         }
-        if timing and kern.get('igemm', (0, 0))[1] > 0:
+        if kern.get('igemm', (0, 0))[1] > 0:
             ms, n = kern['igemm']
             ach = flops['igemm'] / (ms * 1e-3) / 1e12
+            traffic, source = pmc_traffic(args)
             out['roofline'] = {
-                'kernel': 'igemm_kernel (implicit-GEMM conv fwd + dgrad + linear)', 'bound': 'mfma',
-                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 5), 'traffic': pmc_traffic(args),
-                'traffic_unit': 'HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, '
-                                'profiles/r01_pmc_traffic.json)',
+                'kernel': 'igemm class (implicit-GEMM conv fwd + dgrad + linear; all tile variants)',
+                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(ach / peak, 5), 'traffic': traffic,
+                'traffic_unit': 'HBM bytes per launch', 'traffic_source': source,
+                'measured_over': '%d instrumented steps after the timed loop (%.3f ms/step with the HIP '
+                                 'events in place)' % (rsteps, 1000 * instr_elapsed / rsteps),
                 'launches': int(n), 'avg_launch_us': round(1000 * ms / n, 2),
                 'algorithmic_gflop_per_launch': round(flops['igemm'] / n / 1e9, 3),
-                'share_of_step_time': round(ms / (1000 * elapsed), 4)}
+                'igemm_kernel_ms_per_step': round(ms / rsteps, 3)}
             wms, wn = kern.get('wgrad', (0, 0))
             if wn:
-                out['roofline']['wgrad_kernel_ms_per_step'] = round(wms / args.steps, 3)
-                out['roofline']['igemm_kernel_ms_per_step'] = round(ms / args.steps, 3)
+                out['roofline']['wgrad_kernel_ms_per_step'] = round(wms / rsteps, 3)
         if world == 1 and not args.no_cpu_baseline and args.workload == 'moco':
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

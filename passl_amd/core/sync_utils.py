@@ -17,12 +17,29 @@ into the optimizer kernel (no extra pass).  xGMI is point-to-point (7 links/GPU)
 gradients in 4 x 28 MB buckets keeps every collective large enough to be bandwidth- rather than
 latency-bound while leaving 3/4 of the traffic overlappable with backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def _ws(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def dp_forced():
+    """PASSL_DP_FORCE=1: issue every data-parallel collective even in a 1-rank job.  A world-size-1
+    RCCL communicator still creates the transport, launches the collective kernels on its stream and
+    orders them against the compute stream — this is how the single-GPU test box loads and runs RCCL
+    (tests/test_dp_gpu.py::test_rccl_world1); results must equal the collective-free run bit for bit."""
+    return os.environ.get('PASSL_DP_FORCE') == '1'
+
+
+def collectives_active(group=None):
+    """True when the DP collectives of this process must be issued."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or dp_forced()
 
 
 class GradReducer(object):
@@ -32,6 +49,7 @@ class GradReducer(object):
         self.arena = arena
         self.group = group
         self.world = _ws(group)
+        self._forced = collectives_active(group)
         self.grads = arena.grads
         slices = arena.param_slices
         # buckets = runs of consecutive parameters, built from the end of the buffer
@@ -70,7 +88,7 @@ class GradReducer(object):
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
-        if self.world > 1:
+        if self.world > 1 or self._forced:
             self._handles.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))
 
@@ -106,7 +124,7 @@ def grad_sync(param_groups, comm_group=None, grad_avg=True):
     """v2 spelling (passl/core/sync_utils.py:18-43): blocking all_reduce of every parameter's
     gradient (+ average).  Arena-backed parameters are reduced as ONE flat call per arena."""
     nranks = _ws(comm_group)
-    if nranks < 2:
+    if not collectives_active(comm_group):
         return
     seen = []
     for group in param_groups:
@@ -130,7 +148,7 @@ def grad_sync(param_groups, comm_group=None, grad_avg=True):
 def param_sync(model, src_rank=0, comm_group=None):
     """Broadcast parameters and buffers from ``src_rank`` (passl/core/sync_utils.py:46-69).
     Arena-backed state is one broadcast per flat buffer."""
-    if _ws(comm_group) < 2:
+    if not collectives_active(comm_group):
         return
     arenas = [getattr(model, n) for n in ('arena_q', 'arena_k') if hasattr(model, n)]
     flat_ptrs = set()

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..core.sync_utils import GradReducer, param_sync
+from ..core.sync_utils import GradReducer, collectives_active, dp_forced, param_sync
 from ..datasets import build_dataloader
 from ..hip import config as hip_config
 from ..utils.misc import AverageMeter
@@ -58,7 +58,7 @@ class IterLoader:
 
 def _init_distributed(device):
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or (dp_forced() and 'RANK' in os.environ)) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # "nccl" IS RCCL on ROCm.  PASSL_DIST_BACKEND=gloo lets several ranks share ONE GPU (together with
         # PASSL_DEVICE_INDEX) to exercise the data-parallel path on a single-GPU box (tests/test_dp_gpu.py)
@@ -125,7 +125,7 @@ class Trainer:
                                       'the HIP path (cfg.compute_dtype); loss scaling is not needed')
 
         self.grad_reducer = None
-        if self.world_size > 1:
+        if self.world_size > 1 or collectives_active():
             param_sync(self.model, src_rank=0)
             self.grad_reducer = GradReducer(self.model.arena_q, self.optimizer)
 
@@ -254,5 +254,5 @@ class Trainer:
         self.load_numpy_state(state_dict)
 
     def load_numpy_state(self, sd):
-        from ..utils.checkpoint import to_tensors
-        self.model.load_state_dict(to_tensors(sd), strict=False)
+        from ..utils.checkpoint import load_lenient
+        load_lenient(self.model, sd, self.logger, what='checkpoint')

@@ -79,13 +79,18 @@ class LogHook(Hook):
     def train_iter_end(self, trainer):
         for k, v in trainer.outputs.items():
             if torch.is_tensor(v):
-                self._pending.setdefault(k, []).append(v)
+                # detach: a queued loss must not keep its autograd graph alive until the next print
+                self._pending.setdefault(k, []).append(v.detach())
             else:
                 if k not in trainer.logs:
                     trainer.logs[k] = AverageMeter(k, ':.4e' if 'loss' in k else ':6.3f')
                 trainer.logs[k].update(float(v))
         if self.by_epoch and self.every_n_inner_iters(trainer, self.interval):
             self.print_log(trainer)
+        elif self._hits(trainer.current_iter, self.interval):
+            # iteration-based runs print nothing here (as the reference), but the queue is still
+            # drained every `interval` iterations so it cannot grow for a whole epoch
+            self._flush(trainer)
 
     def train_epoch_end(self, trainer):
         self._flush(trainer)

@@ -20,6 +20,7 @@ buffer instead of 269 ``paddle.assign`` calls.  (3) encoders keep their state in
 import torch
 import torch.distributed as dist
 
+from ...core.sync_utils import collectives_active
 from ...hip import nn, ops
 from ...hip.nn import EncoderArena
 from ...modules import freeze_batchnorm_statictis
@@ -37,7 +38,7 @@ def _world_size():
 def concat_all_gather(tensor):
     """all_gather + concat along dim 0 (identity for a single process) — moco.py:198-210."""
     ws = _world_size()
-    if ws < 2:
+    if not collectives_active():
         return tensor
     out = torch.empty((ws * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
                       device=tensor.device)
@@ -104,7 +105,7 @@ class MoCo(nn.Layer):
         x_gather = concat_all_gather(x)
         n_all = x_gather.shape[0]
         idx_shuffle = torch.randperm(n_all, device=x.device)
-        if _world_size() > 1:
+        if collectives_active():
             dist.broadcast(idx_shuffle, src=0)
         idx_unshuffle = torch.argsort(idx_shuffle)
         rank = dist.get_rank() if _world_size() > 1 else 0

@@ -30,7 +30,10 @@ def xavier_uniform_(w, fan_in, fan_out):
 
 @torch.no_grad()
 def trunc_normal_(w, std=0.02):
-    w.copy_(torch.fmod(torch.randn(w.shape), 2.0) * std)
+    # paddle TruncatedNormal(std): N(0, std) re-sampled (not wrapped) into [-2 std, 2 std]
+    t = torch.empty(w.shape)
+    torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0 * std, b=2.0 * std)
+    w.copy_(t)
 
 
 class Identity(nn.Layer):

@@ -104,11 +104,13 @@ class ResNet(nn.Layer):
         self.init_parameters()
         if pretrained is not None:
             # paddle.load of a paddle.save'd dict = the reference's pickle-of-numpy checkpoint layout
-            from ...utils.checkpoint import load_pickle, to_tensors
+            from ...utils.checkpoint import load_pickle, load_lenient
             state_dict = load_pickle(pretrained)
             if 'state_dict' in state_dict:
                 state_dict = state_dict['state_dict']
-            self.set_state_dict(to_tensors(state_dict))
+            # lenient with warnings, like Layer.set_state_dict in the reference: published .pdparams
+            # carry fc.* keys this trunk (num_classes=0) does not have
+            load_lenient(self, state_dict, get_logger(), what='pretrained backbone')
             get_logger().info('Load pretrained backbone weight from {} success!'.format(pretrained))
         self._freeze_stages()
 

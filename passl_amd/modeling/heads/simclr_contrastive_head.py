@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 from torch.autograd import Function
 
+from ...core.sync_utils import collectives_active
 from ...hip import nn, ops
 from .builder import HEADS
 
@@ -24,8 +25,9 @@ class _NTXentFn(Function):
     def forward(ctx, h1, h2, T, co2_weight, gather):
         h1, h2 = h1.contiguous(), h2.contiguous()
         B = h1.shape[0]
-        ws = _world() if gather else 1
-        if ws > 1:
+        coll = bool(gather) and collectives_active()
+        ws = _world() if coll else 1
+        if coll:
             a_all = torch.empty(ws * B, h1.shape[1], dtype=h1.dtype, device=h1.device)
             b_all = torch.empty_like(a_all)
             dist.all_gather_into_tensor(a_all, h1)
@@ -35,7 +37,7 @@ class _NTXentFn(Function):
             a_all, b_all, roff = h1, h2, 0
         out, rowstats = ops.ntxent_fwd(h1, h2, a_all, b_all, roff, T, co2_weight)
         ctx.save_for_backward(h1, h2, a_all, b_all, rowstats)
-        ctx.T, ctx.w, ctx.roff, ctx.ws = T, co2_weight, roff, ws
+        ctx.T, ctx.w, ctx.roff, ctx.ws, ctx.coll = T, co2_weight, roff, ws, coll
         loss, acc1 = out[0:1], out[1:2]
         ctx.mark_non_differentiable(acc1)
         return loss, acc1
@@ -46,7 +48,7 @@ class _NTXentFn(Function):
         da, db, dA, dB = ops.ntxent_bwd(h1, h2, a_all, b_all, rowstats, gloss.contiguous().float(),
                                         ctx.roff, ctx.T, ctx.w)
         B = h1.shape[0]
-        if ctx.ws > 1:
+        if ctx.coll:
             ra, rb = torch.empty_like(da), torch.empty_like(db)
             dist.reduce_scatter_tensor(ra, dA)
             dist.reduce_scatter_tensor(rb, dB)

@@ -14,6 +14,21 @@ from .builder import OPTIMIZERS
 from .lr_scheduler import LRScheduler
 
 
+def _load_flat_state(dst, sd, key):
+    """Copy one flat optimizer-state vector from a checkpoint dict.  Values may be torch tensors or the
+    numpy arrays the checkpoint pickle stores (hooks/checkpoint_hook.py); the arena layout is this
+    code base's own (one vector per EncoderArena), so a size mismatch — e.g. a Paddle optimizer
+    state with per-parameter accumulators — is reported instead of broadcasting garbage."""
+    if key not in sd:
+        raise KeyError('optimizer state has no %r (flat-arena layout expected; Paddle per-parameter '
+                       'accumulator files are not interchangeable)' % key)
+    src = torch.as_tensor(sd[key])
+    if src.numel() != dst.numel():
+        raise ValueError('optimizer state %r has %d elements, the arena holds %d'
+                         % (key, src.numel(), dst.numel()))
+    dst.copy_(src.reshape(dst.shape).to(dst.dtype))
+
+
 @OPTIMIZERS.register()
 class Momentum(object):
     type = 'momentum'
@@ -74,7 +89,7 @@ class Momentum(object):
 
     def set_state_dict(self, sd):
         for i, v in enumerate(self._velocity):
-            v.copy_(sd['velocity_%d' % i])
+            _load_flat_state(v, sd, 'velocity_%d' % i)
         if 'LR_Scheduler' in sd and isinstance(self._learning_rate, LRScheduler):
             self._learning_rate.set_state_dict(sd['LR_Scheduler'])
 
@@ -201,7 +216,7 @@ class LarsMomentumOptimizer(object):
 
     def set_state_dict(self, sd):
         for i, v in enumerate(self._velocity):
-            v.copy_(sd['velocity_%d' % i])
+            _load_flat_state(v, sd, 'velocity_%d' % i)
         if 'LR_Scheduler' in sd and isinstance(self._learning_rate, LRScheduler):
             self._learning_rate.set_state_dict(sd['LR_Scheduler'])
 
@@ -276,7 +291,7 @@ class AdamW(object):
     def set_state_dict(self, sd):
         self._t = int(sd['t'])
         for i, (m, v) in enumerate(zip(self._m, self._v)):
-            m.copy_(torch.as_tensor(sd['moment1_%d' % i]))
-            v.copy_(torch.as_tensor(sd['moment2_%d' % i]))
+            _load_flat_state(m, sd, 'moment1_%d' % i)
+            _load_flat_state(v, sd, 'moment2_%d' % i)
         if 'LR_Scheduler' in sd and isinstance(self._learning_rate, LRScheduler):
             self._learning_rate.set_state_dict(sd['LR_Scheduler'])

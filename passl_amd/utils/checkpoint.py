@@ -41,3 +41,24 @@ def load_state_into(model, state_dict, strict=False):
     tools/extract_weight.py --remove_prefix) can be loaded into ``model.backbone``."""
     sd = to_tensors(state_dict)
     return model.load_state_dict(sd, strict=strict)
+
+
+def load_lenient(module, state_dict, logger=None, what='weights'):
+    """Paddle's ``set_state_dict`` policy: load what matches, WARN per missing / unexpected key, and
+    refuse a file in which nothing matched (a wrong key prefix would otherwise "load" successfully and
+    leave the model on its random init)."""
+    import logging
+    logger = logger or logging.getLogger('passl')
+    sd = to_tensors(state_dict)
+    own = module.state_dict()
+    matched = [k for k in sd if k in own]
+    if own and not matched:
+        raise ValueError('%s: none of the %d keys matches the model (first file key %r, first model '
+                         'key %r) - wrong prefix?' % (what, len(sd), next(iter(sd), None),
+                                                      next(iter(own), None)))
+    res = module.load_state_dict(sd, strict=False)
+    for k in res.missing_keys:
+        logger.warning('%s: %s is not found in the provided dict.' % (what, k))
+    for k in res.unexpected_keys:
+        logger.warning('%s: skip loading for %s (not in the model).' % (what, k))
+    return res

@@ -56,7 +56,11 @@ def main():
         cfg.custom_config = []                        # no EvaluateHook in the 3-step run
     cfg.timestamp = ''
     tr = Trainer(cfg)
-    assert tr.world_size == int(os.environ['WORLD_SIZE']) > 1 and tr.grad_reducer is not None
+    forced = os.environ.get('PASSL_DP_FORCE') == '1'
+    assert tr.world_size == int(os.environ['WORLD_SIZE']) and tr.grad_reducer is not None
+    assert tr.world_size > 1 or forced
+    if os.environ.get('PASSL_EXPECT_BACKEND'):
+        assert dist.get_backend() == os.environ['PASSL_EXPECT_BACKEND'], dist.get_backend()
     tr.mode = 'train'
     tr.model.train()
     opt_hook = next(h for h in tr.hooks if isinstance(h, OptimizerHook))
@@ -96,7 +100,8 @@ def main():
         assert tr.model._ptr == 3 * 8 * tr.world_size
     dist.barrier()
     if tr.rank == 0:
-        print('DP-OK %s %.6f' % (workload, loss), flush=True)
+        # digest of the final parameters: the world-1 RCCL run must equal the collective-free run
+        print('DP-OK %s %.6f digest=%.17g' % (workload, loss, float(p1.sum())), flush=True)
     dist.destroy_process_group()
 
 

@@ -26,9 +26,50 @@ def _free_port():
 
 @pytest.mark.parametrize('workload', ['moco', 'simclr', 'mae', 'clip', 'linprobe'])
 def test_two_ranks_one_gpu(workload):
-    env = dict(os.environ, PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'tests', 'dp_worker.py'), workload]
+    _run_worker(workload, 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0'))
+
+
+def _run_worker(workload, nproc, env_extra, launcher=True):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **env_extra)
+    worker = os.path.join(ROOT, 'tests', 'dp_worker.py')
+    if launcher:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), worker, workload]
+    else:
+        cmd = [sys.executable, worker, workload]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and ('DP-OK %s' % workload) in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith('DP-OK')][-1]
+    return line
+
+
+@pytest.mark.parametrize('workload', ['moco', 'simclr'])
+def test_rccl_world1(workload):
+    """RCCL itself (backend "nccl") on the hardware: ONE rank on the one GPU, every data-parallel
+    collective forced on (PASSL_DP_FORCE=1): communicator creation, flat start-up broadcast, the
+    bucketed asynchronous gradient all-reduce launched from backward on RCCL's stream, the key /
+    embedding all-gather (+ reduce-scatter for SimCLR).  A 1-rank all-reduce is the identity and the
+    1/world scale is 1, so the run must end bit-identical to the same run with gloo as transport."""
+    rccl = _run_worker(workload, 1, dict(PASSL_DP_FORCE='1', PASSL_EXPECT_BACKEND='nccl'))
+    gloo = _run_worker(workload, 1, dict(PASSL_DP_FORCE='1', PASSL_DIST_BACKEND='gloo',
+                                         PASSL_EXPECT_BACKEND='gloo'))
+    assert rccl.split('digest=')[1] == gloo.split('digest=')[1], (rccl, gloo)
+
+
+def test_bench_self_launch_gpus1_and_world1_launcher():
+    """bench.py under the driver's launcher form with one rank (RCCL world 1 is NOT forced here:
+    the production gate is world > 1) and the plain form; both print exactly one JSON line."""
+    import json
+    for cmd in ([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                 '--batch', '32', '--no-cpu-baseline', '--roofline-steps', '1'],
+                [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1',
+                 '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+                 os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '32',
+                 '--no-cpu-baseline', '--roofline-steps', '1']):
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, lines
+        out = json.loads(lines[0])
+        assert out['n_gpus'] == 1 and out['steps'] == 2 and out['value'] > 0 and 'roofline' in out
