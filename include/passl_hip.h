@@ -138,11 +138,29 @@ typedef struct passl_conv_desc {
   const float* scale;      /* [NCOLS] or NULL (=1) */
   const float* shift;      /* [NCOLS] or NULL (=0) */
   const void* residual;    /* addressed like y, dtype = out dtype; or NULL */
-  float* stats;            /* NULL, or fused BatchNorm statistics of the STORED output values:
-                              stats[rep][col][0..1] += (sum, sum of squares) over the rows of each
-                              output tile, rep = tile_row % stats_replicas; fp32 atomics, caller
-                              zeroes; bf16 output without residual only.  Feed it to
-                              passl_hip_bn_finalize as `partial` with nblocks = replicas. */
+  float* stats;            /* NULL, or the slab of fused BatchNorm statistics of the STORED output values
+                              (bf16 output without residual only): stats_tiles = ceil(M/128) row tiles,
+                                stats[t][col][0..1] = sum (v - s), sum (v - s)^2 over the rows of tile t,
+                                s = shifts[t][col] = the tile's first-row value, stored behind the sums at
+                                stats + stats_tiles*NCOLS*2 (shifted sums: no cancellation).
+                              stats_tiles*NCOLS*3 floats, fully written by plain stores (no atomics, no
+                              zeroing): feed it to passl_hip_bn_finalize with nblocks = stats_tiles,
+                              rows_per_block = 128. */
+  /* BatchNorm-backward statistics fused into a data-gradient launch (all NULL/0 when unused).  The
+   * launch's output is the gradient w.r.t. the OUTPUT of a BatchNorm(+ReLU) layer whose input was
+   * bnb_y (addressed like y).  The epilogue masks the gradient with that layer's ReLU mask
+   * (bnb_relu: 0 none, 2 recomputed as bnb_y*bnb_scale + bnb_shift > 0, 3 bit mask bnb_mask as written
+   * by passl_hip_bn_apply), STORES the masked gradient g, and writes per 128-row tile t
+   *   bnb_partial[bnb_tile_off + t][col][0..1] = sum g, sum g * (bnb_y - bnb_mean[col]) * bnb_invstd[col]
+   * (plain stores; passl_hip_bn_bwd_finalize consumes the slab, passl_hip_bn_bwd_reduce never runs).
+   * bf16 only; relu must be 0. */
+  const void* bnb_y;
+  const uint8_t* bnb_mask;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_scale;
+  const float* bnb_shift;
+  float* bnb_partial;
   int32_t N, OP, OQ;       /* M = N*OP*OQ */
   int32_t NCOLS;
   int32_t R, S, C;
@@ -153,13 +171,19 @@ typedef struct passl_conv_desc {
   int32_t relu;
   int32_t dtype;           /* passl_dtype of A, B */
   int32_t out_f32;         /* 1: y (and residual) are fp32 regardless of dtype */
-  int32_t stats_replicas;  /* number of accumulator replicas behind `stats` (spreads the atomics) */
+  int32_t stats_tiles;     /* must equal ceil(N*OP*OQ / 128) when stats != NULL */
+  int32_t bnb_relu;
+  int32_t bnb_tile_off;    /* first slab row of this launch (residue-class launches share one slab) */
 } passl_conv_desc;
 int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream);
 
 /* Weight gradient:  dw[col][r][s][c] += sum_{n,op,oq} dy[n,op,oq,col] * A[n, op*sh+r-ph, oq*sw+s-pw, c]
- * dw is fp32 [NCOLS][R*S*C] and is ACCUMULATED into (atomics; caller zeroes it).
- * dy is [M][NCOLS] dense (row stride dy_ld elements).  `splits` = number of M-slices (>=1).
+ * dw is fp32 [NCOLS][R*S*C] and is ACCUMULATED into (caller zeroes it).
+ * dy is [M][NCOLS] dense (row stride dy_ld elements).  `splits` = number of M-slices (>=1): every
+ * slice is one partial tile set.  With a workspace `ws` of at least splits*NCOLS*R*S*C floats
+ * (`ws_floats`) each slice writes its tiles into its own slab and a second launch adds the slabs to dw
+ * in slice order — bit-reproducible.  ws == NULL: slices > 1 accumulate with fp32 atomics (order-
+ * dependent rounding).  The workspace may be shared by all layers (stream-ordered use).
  * Replaces Conv2D/Linear backward-filter (autograd of the call sites above). */
 typedef struct passl_wgrad_desc {
   const void* a;
@@ -172,24 +196,37 @@ typedef struct passl_wgrad_desc {
   int32_t sh, sw, ph, pw;
   int64_t a_sn, a_sh, a_sw;
   int64_t dy_ld;
+  float* ws;               /* NULL or the split workspace (16-byte aligned) */
+  int64_t ws_floats;
   int32_t dtype;
   int32_t splits;
 } passl_wgrad_desc;
+
+/* out[i] (+)= sum_{z < slabs} ws[z*n + i], slabs added in ascending order (fixed-order replacement of
+ * atomic accumulation); n % 4 == 0, 16-byte aligned pointers. */
+int passl_hip_slab_reduce(const float* ws, float* out, int64_t n, int slabs, int accumulate,
+                          passl_stream_t stream);
 int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t stream);
 
 /* ---------------------------------------------------------------- BatchNorm (+ReLU, +residual) */
 
 /* Training-mode BN over NHWC rows x[M][C].  Three launches:
- *  stats:     partial[b][c][0..1] = sum, sum of squares over the b-th row slab   (nblocks slabs)
- *  finalize:  mean/invstd (biased var, eps), scale=gamma*invstd, shift=beta-mean*scale,
+ *  stats:     slab b = rows [b*rpb, (b+1)*rpb), rpb = ceil(M/nblocks):
+ *             partial[b][c][0..1] = sum (x - s), sum (x - s)^2 with s = shifts[b][c] = the slab's first row,
+ *             shifts stored behind the sums at partial + nblocks*C*2  (nblocks*C*3 floats in total;
+ *             shifted sums: the variance never comes from E[x^2] - mean^2 of large numbers).
+ *             The conv epilogue writes the same layout with rpb = 128 (passl_conv_desc.stats).
+ *  finalize:  fixed-order fp64 combine of the slabs (re-centred on slab 0's shift) -> mean/invstd
+ *             (biased var, eps), scale=gamma*invstd, shift=beta-mean*scale,
  *             running = momentum*running + (1-momentum)*batch   [Paddle: momentum 0.9, biased var]
  *  apply:     z = relu?( x*scale + shift + residual )
+ * No atomics anywhere: results are bit-reproducible run to run.
  * Replaces paddle.nn.BatchNorm2D + ReLU (+ `out += identity`) at
  * resnetimagenet.py:133-153,196-197,236-238. */
 int passl_hip_bn_stats(const void* x, float* partial, int64_t M, int C, int nblocks, int dtype,
                        passl_stream_t stream);
-int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t M, int C, const float* gamma,
-                          const float* beta, float* running_mean, float* running_var,
+int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t M, int C, int rows_per_block,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                           float momentum, float eps, float* mean, float* invstd, float* scale,
                           float* shift, passl_stream_t stream);
 /* relu_mask (optional, needs relu): one bit per element of z (bit e of byte i <-> element 8*i+e,
@@ -234,10 +271,14 @@ int passl_hip_avgpool_bwd(const void* dy, void* dx, int N, int HW, int C, int dt
  * (necks/base_neck.py:83). */
 int passl_hip_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype,
                        passl_stream_t stream);
-/* out[c] = sum_m x[m][c] (fp32 out) — Linear bias gradient. */
-int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype, passl_stream_t stream);
+/* out[c] = sum_m x[m][c] (fp32 out) — Linear bias gradient.  Rows are cut into at most 1024 slabs;
+ * with a workspace `ws` (>= 1024*C floats, `ws_floats` = its size) the slab partials are added in
+ * slab order (bit-reproducible); ws == NULL falls back to fp32 atomics when there is more than one slab. */
+int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype, float* ws,
+                     int64_t ws_floats, passl_stream_t stream);
 /* out[c] += sum_m x[m][c] — accumulates straight into the (zero-initialised) gradient buffer. */
-int passl_hip_colsum_acc(const void* x, float* out, int64_t M, int C, int dtype, passl_stream_t stream);
+int passl_hip_colsum_acc(const void* x, float* out, int64_t M, int C, int dtype, float* ws,
+                         int64_t ws_floats, passl_stream_t stream);
 
 /* ---------------------------------------------------------------- contrastive head */
 
@@ -254,18 +295,22 @@ int passl_hip_l2norm_bwd(const float* dy, const float* y, const float* norm, voi
  *   loss = mean_i( logsumexp(logits[i]) - logits[i][0] ),  acc1/acc5 = % rows whose column 0
  *   has rank < 1 / < 5 among strictly greater logits.
  * q,k: [N][D] fp32, queue: [D][K] fp32 (dim-major, as the reference stores it).
- * Outputs: out[0..2] = loss, acc1, acc5; row_lse[N]; optional logits [N][K+1] (may be NULL).
+ * Outputs: out[0..2] = loss, acc1, acc5 (fixed-order mean, fully written); row_lse[N]; optional
+ * logits [N][K+1] (may be NULL).
  * workspace: >= passl_hip_infonce_workspace_bytes(N,K) bytes. D must be 128, K % 128 == 0. */
 int64_t passl_hip_infonce_workspace_bytes(int N, int K);
 int passl_hip_infonce_fwd(const float* q, const float* k, const float* queue, int N, int D, int K,
                           float T, float* out, float* row_lse, float* logits, void* workspace,
                           passl_stream_t stream);
 /* dq[i] = gscale/(N*T) * ( (p_i0 - 1)*k[i] + sum_j p_ij * queue[:,j] ),  p = softmax(logits).
- * dq must be zeroed by the caller (accumulated with atomics). `gscale` device pointer to the
- * upstream scalar gradient (or NULL = 1). */
+ * dq is fully written (no zeroing): every 128-column queue slice writes its own [N][D] slab of
+ * `workspace` (>= passl_hip_infonce_bwd_workspace_bytes(N,K) bytes) and the slabs are added in slice
+ * order — no atomics, bit-reproducible.  `gscale` device pointer to the upstream scalar gradient
+ * (or NULL = 1). */
+int64_t passl_hip_infonce_bwd_workspace_bytes(int N, int K);
 int passl_hip_infonce_bwd(const float* q, const float* k, const float* queue,
                           const float* row_lse, const float* gscale, int N, int D, int K, float T,
-                          float* dq, passl_stream_t stream);
+                          float* dq, void* workspace, passl_stream_t stream);
 /* queue[:, ptr:ptr+B] = keys^T  (keys [B][D]).  Replaces the slice-assign of
  * MoCo._dequeue_and_enqueue, moco.py:101-102 (the pointer arithmetic stays on the host). */
 int passl_hip_enqueue(float* queue, const float* keys, int D, int K, int ptr, int B,

@@ -72,9 +72,12 @@ class MoCoOracle:
 
     def __init__(self, dim=128, K=65536, m=0.999, T=0.2, lr=0.015, t_max=200 * 5004,
                  weight_decay=1e-4, momentum=0.9, seed=0, width_div=1, neck='NonLinearNeckV1',
-                 milestones=None):
+                 milestones=None, bf16=False):
         # neck='LinearNeck', T=0.07, lr=0.03, milestones=[120, 160] epochs = configs/moco/moco_v1_r50.yaml
+        # bf16=True: bf16-emulating encoders (oracle/bf16.py); head, EMA and optimizer stay fp32 as
+        # in the product path
         self.milestones = milestones
+        self.bf16 = bf16
         gen = torch.Generator().manual_seed(seed)
         self.K, self.m, self.T = K, m, T
         self.base_lr, self.t_max = lr, t_max
@@ -111,13 +114,43 @@ class MoCoOracle:
     # -- moco.py:154-185 + optimizer_hook.py:25-50 ---------------------------
     def train_step(self, img_q, img_k, keys_all_ranks=None, taps=None):
         """One full step.  Returns dict(loss, acc1, acc5, logits, q, k, grads)."""
+        out = self.forward_backward(img_q, img_k, keys_all_ranks=keys_all_ranks, taps=taps)
+        self.apply_momentum(out['grads'])
+        return out
+
+    def train_step_accum(self, img_q, img_k, accum_steps):
+        """passl/engine/loops/contrastive_learning_loop.py:31-88: the batch is cut into ``accum_steps``
+        micro-batches; the MODEL is called once per micro-batch (so the key-encoder EMA, the
+        micro-batch BatchNorm statistics and the enqueue all happen per micro-batch, the second
+        micro-batch already sees the first one's keys in the queue), every loss is divided by
+        accum_steps before backward, gradients add up, then ONE optimizer step and lr step.
+        Returns dict(loss = sum of the scaled losses, grads = accumulated)."""
+        N = img_q.shape[0]
+        assert N % accum_steps == 0
+        step = N // accum_steps
+        total, loss = None, 0.0
+        for i in range(accum_steps):
+            sl = slice(i * step, (i + 1) * step)
+            out = self.forward_backward(img_q[sl], img_k[sl], loss_scale=1.0 / accum_steps)
+            loss = loss + out['loss'] / accum_steps
+            if total is None:
+                total = out['grads']
+            else:
+                for n in total:
+                    total[n] = total[n] + out['grads'][n]
+        self.apply_momentum(total)
+        return dict(loss=loss, grads=total)
+
+    def forward_backward(self, img_q, img_k, keys_all_ranks=None, taps=None, loss_scale=1.0):
+        """Forward, EMA, enqueue and backward of (loss * loss_scale); no optimizer step."""
         tkeys = R.trainable_keys(self.q)
         for n in tkeys:
+            self.q[n] = self.q[n].detach()
             self.q[n].requires_grad_(True)
             self.q[n].grad = None
         new_stats = {}
         q = R.encoder_forward(self.q, img_q, use_global_stats=False,
-                              new_stats=new_stats, taps=taps)
+                              new_stats=new_stats, taps=taps, bf16=self.bf16)
         q = l2_normalize(q, axis=1)
         with torch.no_grad():
             # BN running stats are written by the q forward *before* the EMA
@@ -125,15 +158,14 @@ class MoCoOracle:
             for n, v in new_stats.items():
                 self.q[n] = v
             self.momentum_update_key_encoder()
-            k = R.encoder_forward(self.k, img_k, use_global_stats=True)
+            k = R.encoder_forward(self.k, img_k, use_global_stats=True, bf16=self.bf16)
             k = l2_normalize(k, axis=1)
         l_pos = (q * k).sum(dim=1, keepdim=True)
         l_neg = q @ self.queue.clone().detach()
         loss, acc1, acc5, logits = contrastive_head(l_pos, l_neg, self.T)
         self.dequeue_and_enqueue(k if keys_all_ranks is None else keys_all_ranks)
-        loss.backward()
+        (loss * loss_scale).backward()
         grads = OrderedDict((n, self.q[n].grad.detach().clone()) for n in tkeys)
-        self.apply_momentum(grads)
         return dict(loss=loss.detach(), acc1=acc1, acc5=acc5, logits=logits.detach(),
                     q=q.detach(), k=k, grads=grads)
 

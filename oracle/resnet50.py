@@ -28,6 +28,8 @@ from collections import OrderedDict
 import torch
 import torch.nn.functional as F
 
+from .bf16 import round_act, round_weight, round_grad
+
 BN_MOMENTUM = 0.9
 BN_EPS = 1e-5
 LAYERS = (3, 4, 6, 3)          # resnetimagenet.py:178 (depth 50)
@@ -94,10 +96,13 @@ def trainable_keys(st):
     return [k for k in st if not (k.endswith('._mean') or k.endswith('._variance'))]
 
 
-def batch_norm(x, st, prefix, use_global_stats, new_stats=None):
+def batch_norm(x, st, prefix, use_global_stats, new_stats=None, affine_form=False):
     """paddle.nn.BatchNorm2D forward.  In training mode (use_global_stats False)
     normalises with biased batch statistics and records the running-stat update
-    in ``new_stats`` (applied by the caller after the forward, functionally)."""
+    in ``new_stats`` (applied by the caller after the forward, functionally).
+    ``affine_form`` evaluates the same function as  x*scale + shift  with
+    scale = w*rsqrt(var+eps), shift = b - mean*scale  (the arithmetic order of the
+    bf16 product path; used by the bf16-emulating mode only)."""
     w, b = st[prefix + '.weight'], st[prefix + '.bias']
     rm, rv = st[prefix + '._mean'], st[prefix + '._variance']
     dims = (0, 2, 3) if x.dim() == 4 else (0,)          # BatchNorm2D / BatchNorm1D on [N, C]
@@ -111,15 +116,31 @@ def batch_norm(x, st, prefix, use_global_stats, new_stats=None):
                 new_stats[prefix + '._mean'] = BN_MOMENTUM * rm + (1 - BN_MOMENTUM) * mean.detach()
                 new_stats[prefix + '._variance'] = BN_MOMENTUM * rv + (1 - BN_MOMENTUM) * var.detach()
     inv = torch.rsqrt(var + BN_EPS)
+    if affine_form:
+        scale = w * inv
+        shift = b - mean * scale
+        if x.dim() == 2:
+            return x * scale[None, :] + shift[None, :]
+        return x * scale[None, :, None, None] + shift[None, :, None, None]
     if x.dim() == 2:
         return (x - mean[None, :]) * (inv * w)[None, :] + b[None, :]
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=True):
+def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=True, bf16=False):
     """ResNet-50 trunk (keys '0.*'): [N,3,H,W] -> layer4 map.  ``maxpool=False`` is the
     SimCLR variant (passl_v110/modeling/backbones/resnetcifar.py:275 comments the stem pool
-    out, forward :321-333)."""
+    out, forward :321-333).
+
+    ``bf16=True`` is the bf16-EMULATING mode (oracle/bf16.py): the same fp32 arithmetic with values
+    rounded to bfloat16 exactly where the MI355X product path stores bf16 — image, operand copy of
+    the weights, every conv output in training mode (BatchNorm statistics are those of the stored
+    values), every BatchNorm(+residual)+ReLU output, and the same tensors' gradients on the way
+    back.  With frozen-statistics BatchNorm (key encoder) the affine is applied to the unrounded
+    accumulator and only the block output is rounded (conv epilogue fusion)."""
+    if bf16:
+        return _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool)
+
     def conv(name, x, stride, pad):
         return F.conv2d(x, st['0.' + name + '.weight'], None, stride, pad)
 
@@ -147,12 +168,82 @@ def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=Tr
     return x
 
 
-def encoder_forward(st, x, use_global_stats, new_stats=None, taps=None):
+# Second valid evaluation of the bf16 contract: products of bf16 operands accumulated in float64
+# instead of float32 (summation order / accumulator width are NOT part of the contract).  The golden
+# generator runs both; their difference is how far two correct bf16 implementations may be apart at a
+# given (ill-conditioned, random-init) point, and the GPU tests scale their bounds with it.
+ACCUM64 = False
+
+
+def _conv(x, w, stride, pad):
+    if ACCUM64:
+        return F.conv2d(x.double(), w.double(), None, stride, pad).float()
+    return F.conv2d(x, w, None, stride, pad)
+
+
+def _matmul(x, w):
+    if ACCUM64:
+        return (x.double() @ w.double()).float()
+    return x @ w
+
+
+def _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool):
+    """trunk_forward with the product path's bf16 storage points (see trunk_forward).
+
+    Training mode (query encoder): conv output rounded (stored, BatchNorm statistics are those of the
+    stored values); BatchNorm + residual + ReLU evaluated in fp32 and rounded once; the gradient
+    entering a block through conv1 / the downsample conv is rounded before the residual-fork sum
+    (the data-gradient kernel stores it in bf16 tiles before adding the other branch's gradient).
+    Frozen statistics (key encoder): one kernel per conv — affine on the accumulator, rounded, THEN
+    the residual add + ReLU, rounded again (conv epilogue order)."""
+    train = not use_global_stats
+
+    def conv(name, x, stride, pad):
+        y = _conv(x, round_weight(st['0.' + name + '.weight']), stride, pad)
+        return round_act(y) if train else y       # training: the conv output is stored (bf16)
+
+    def bn(name, x):
+        return batch_norm(x, st, '0.' + name, use_global_stats, new_stats, affine_form=True)
+
+    x = round_act(x)                              # bf16 NHWC image
+    x = round_act(F.relu(bn('bn1', conv('conv1', x, 2, 3))))
+    if maxpool:
+        x = F.max_pool2d(x, 3, 2, 1)
+    if taps is not None:
+        taps['stem'] = x
+    for li, blocks in enumerate(LAYERS, start=1):
+        for b in range(blocks):
+            p = 'layer%d.%d' % (li, b)
+            s = 2 if (li > 1 and b == 0) else 1
+            identity = x
+            xin = round_grad(x) if train else x    # dgrad tiles are bf16 before the fork gradients meet
+            out = round_act(F.relu(bn(p + '.bn1', conv(p + '.conv1', xin, 1, 0))))
+            out = round_act(F.relu(bn(p + '.bn2', conv(p + '.conv2', out, s, 1))))
+            out = bn(p + '.bn3', conv(p + '.conv3', out, 1, 0))
+            if not train:
+                out = round_act(out)               # epilogue: affine -> bf16 tile -> + residual -> ReLU -> bf16
+            if b == 0:
+                identity = round_act(bn(p + '.downsample.1', conv(p + '.downsample.0', xin, s, 0)))
+            x = round_act(F.relu(out + identity))
+        if taps is not None:
+            taps['layer%d' % li] = x
+    return x
+
+
+def encoder_forward(st, x, use_global_stats, new_stats=None, taps=None, bf16=False):
     """nn.Sequential(ResNet(depth=50,num_classes=0,with_pool=False),
-    NonLinearNeckV1(...)) forward; ``st`` keys as in init_encoder_state."""
-    x = trunk_forward(st, x, use_global_stats, new_stats, taps, maxpool=True)
+    NonLinearNeckV1(...)) forward; ``st`` keys as in init_encoder_state.
+    ``bf16``: bf16-emulating mode (trunk_forward): pooled features and the hidden layer are stored
+    in bf16, the projector output is fp32 but its gradient enters the Linear backward rounded."""
+    x = trunk_forward(st, x, use_global_stats, new_stats, taps, maxpool=True, bf16=bf16)
     # NonLinearNeckV1.forward (base_neck.py:93-97)
     x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)
+    if bf16:
+        x = round_act(x)
+        if '1.fc.weight' in st:
+            return round_grad(_matmul(x, round_weight(st['1.fc.weight'])) + st['1.fc.bias'])
+        x = round_act(F.relu(_matmul(x, round_weight(st['1.mlp.0.weight'])) + st['1.mlp.0.bias']))
+        return round_grad(_matmul(x, round_weight(st['1.mlp.2.weight'])) + st['1.mlp.2.bias'])
     if '1.fc.weight' in st:           # LinearNeck.forward (base_neck.py:61-65)
         return x @ st['1.fc.weight'] + st['1.fc.bias']
     x = F.relu(x @ st['1.mlp.0.weight'] + st['1.mlp.0.bias'])

@@ -1,7 +1,13 @@
 // Training-mode BatchNorm (+ReLU, +residual add) over NHWC rows x[M][C], forward and backward.
 // HBM-bound streaming kernels.  Per-channel reductions are two-level: each block reduces a row
 // slab in registers + LDS and writes a partial (no atomics, deterministic); a small finalize
-// kernel combines the partials in fp64.
+// kernel combines the partials in fp64 in a fixed order.  The partials may also come from the
+// epilogue of the convolution that produced x (forward) or dz (backward): csrc/igemm_epi.h.
+//
+// Forward statistics are SHIFTED sums: partial[b][c] = (sum (x - s), sum (x - s)^2) with
+// s = shifts[b][c] = the first row of slab b (stored behind the sums), so the variance never
+// comes from E[x^2] - mean^2 of large numbers; the finalize kernel re-centres every slab on
+// slab 0's shift in fp64.
 //
 // Algorithmic bytes per activation (bf16): stats 2, apply 4 (+2 with residual),
 // bwd_reduce 6, bwd_apply 8 (+2 with residual).
@@ -58,6 +64,14 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
     float mu[8], is[8], sc[8], sh[8];
+    if (MODE == 0) {
+      // shift = the slab's first row (mu doubles as the shift)
+      if (row0 < M) ElemTraits<T>::load8(x + row0 * C + col * 8, mu);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mu[e] = 0.f;
+      }
+    }
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { mu[e] = mean[col * 8 + e]; is[e] = invstd[col * 8 + e]; }
@@ -72,7 +86,7 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
         ElemTraits<T>::load8(x + r * C + col * 8, v);
         if (MODE == 0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { a0[e] += v[e]; a1[e] += v[e] * v[e]; }
+          for (int e = 0; e < 8; ++e) { const float d = v[e] - mu[e]; a0[e] += d; a1[e] += d * d; }
         } else {
           float g[8];
           ElemTraits<T>::load8(dz + r * C + col * 8, g);
@@ -102,36 +116,73 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
       float* o = partial + ((int64_t)blockIdx.x * C + col * 8) * 2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { o[e * 2] = s0[e]; o[e * 2 + 1] = s1[e]; }
+      if (MODE == 0) {
+        float* sp = partial + (int64_t)gridDim.x * C * 2 + (int64_t)blockIdx.x * C + col * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sp[e] = mu[e];
+      }
     }
   }
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
+// ---- fixed-order fp64 combine of a partial slab [nblocks][C][2].  A 1024-thread block owns 8
+// channels (64 contiguous bytes per slab row): lane = (row lane, channel), 128 row lanes stride over
+// the slab rows; the row lanes are folded with wave shuffles (xor 8, 16, 32), then the 16 waves
+// through LDS in wave order.  Returns the totals in threads 0..7 (channel = tid).
+constexpr int kFinThreads = 1024;
+
+template <bool SHIFTED>
+__device__ __forceinline__ void combine_slab(const float* __restrict__ partial, int nblocks, int C,
+                                             int64_t M, int rows_per_block, int c, bool c_ok,
+                                             double& t1, double& t2, float& g0) {
+  __shared__ double red[kFinThreads / 64][8][2];
+  const int rl = threadIdx.x >> 3;
+  const float* shifts = partial + (int64_t)nblocks * C * 2;
+  double a1 = 0.0, a2 = 0.0;
+  g0 = (SHIFTED && c_ok) ? shifts[c] : 0.f;            // slab 0 always holds rows
+  if (c_ok) {
+    for (int b = rl; b < nblocks; b += kFinThreads / 8) {
+      const float2 p = *reinterpret_cast<const float2*>(partial + ((int64_t)b * C + c) * 2);
+      if (SHIFTED) {
+        int64_t n = M - (int64_t)b * rows_per_block;
+        if (n > rows_per_block) n = rows_per_block;
+        if (n <= 0) continue;
+        const double d = (double)shifts[(int64_t)b * C + c] - (double)g0;
+        a1 += (double)p.x + (double)n * d;
+        a2 += (double)p.y + 2.0 * d * (double)p.x + (double)n * d * d;
+      } else {
+        a1 += (double)p.x;
+        a2 += (double)p.y;
+      }
+    }
+  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int o = 8; o < 64; o <<= 1) {
+    a1 += __shfl_xor(a1, o, 64);
+    a2 += __shfl_xor(a2, o, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane < 8) { red[wave][lane][0] = a1; red[wave][lane][1] = a2; }
+  __syncthreads();
+  t1 = 0.0; t2 = 0.0;
+  if (threadIdx.x < 8) {
+    for (int w = 0; w < kFinThreads / 64; ++w) { t1 += red[w][threadIdx.x][0]; t2 += red[w][threadIdx.x][1]; }
+  }
 }
 
-// one wave per channel (4 channels per 256-thread block); fp64 combine of the partials
-__global__ void __launch_bounds__(kThreads) bn_finalize_kernel(
-    const float* __restrict__ partial, int nblocks, int64_t M, int C,
+__global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = lane; b < nblocks; b += 64) {
-    const float2 p = *reinterpret_cast<const float2*>(partial + ((int64_t)b * C + c) * 2);
-    s += (double)p.x;
-    ss += (double)p.y;
-  }
-  s = wave_sum_f64(s);
-  ss = wave_sum_f64(ss);
-  if (lane != 0) return;
-  const double mu = s / (double)M;
-  double var = ss / (double)M - mu * mu;   // biased
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  double t1, t2;
+  float g0;
+  combine_slab<true>(partial, nblocks, C, M, rows_per_block, c, c < C, t1, t2, g0);
+  if (threadIdx.x >= 8 || c >= C) return;
+  const double dm = t1 / (double)M;                 // mean - g0
+  const double mu = (double)g0 + dm;
+  double var = t2 / (double)M - dm * dm;            // biased; centred on a sample value: no cancellation
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = (float)mu;
@@ -145,23 +196,16 @@ __global__ void __launch_bounds__(kThreads) bn_finalize_kernel(
   }
 }
 
-__global__ void __launch_bounds__(kThreads) bn_bwd_finalize_kernel(
+__global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int64_t M, int C,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ coef) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= C) return;
-  double sg = 0.0, sgx = 0.0;
-  for (int b = lane; b < nblocks; b += 64) {
-    const float2 p = *reinterpret_cast<const float2*>(partial + ((int64_t)b * C + c) * 2);
-    sg += (double)p.x;
-    sgx += (double)p.y;
-  }
-  sg = wave_sum_f64(sg);
-  sgx = wave_sum_f64(sgx);
-  if (lane != 0) return;
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  double sg, sgx;
+  float unused;
+  combine_slab<false>(partial, nblocks, C, M, 0, c, c < C, sg, sgx, unused);
+  if (threadIdx.x >= 8 || c >= C) return;
   dbeta[c] += (float)sg;      // accumulate: the flat gradient buffer is zeroed by clear_grad()
   dgamma[c] += (float)sgx;
   // dx = gamma*invstd*( g - sg/M - xhat*sgx/M ),  xhat = (x-mean)*invstd
@@ -276,16 +320,18 @@ extern "C" int passl_hip_bn_stats(const void* x, float* partial, int64_t M, int 
 }
 
 extern "C" int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t M, int C,
-                                     const float* gamma, const float* beta, float* running_mean,
+                                     int rows_per_block, const float* gamma, const float* beta,
+                                     float* running_mean,
                                      float* running_var, float momentum, float eps, float* mean,
                                      float* invstd, float* scale, float* shift,
                                      passl_stream_t stream) {
   if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || M <= 0 || C <= 0 ||
-      nblocks <= 0 || (running_mean && !running_var))
+      (C & 7) || nblocks <= 0 || rows_per_block <= 0 || (int64_t)nblocks * rows_per_block < M ||
+      (running_mean && !running_var) || (reinterpret_cast<uintptr_t>(partial) & 7))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(kThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, gamma, beta, running_mean, running_var, momentum, eps,
-                     mean, invstd, scale, shift);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 8), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, rows_per_block, gamma, beta, running_mean, running_var,
+                     momentum, eps, mean, invstd, scale, shift);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -339,9 +385,9 @@ extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int6
                                          const float* invstd, float* dgamma, float* dbeta,
                                          float* coef, passl_stream_t stream) {
   if (!partial || !gamma || !mean || !invstd || !dgamma || !dbeta || !coef || M <= 0 || C <= 0 ||
-      nblocks <= 0)
+      (C & 7) || nblocks <= 0 || (reinterpret_cast<uintptr_t>(partial) & 7))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(kThreads), 0, as_stream(stream),
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 8), dim3(kFinThreads), 0, as_stream(stream),
                      partial, nblocks, M, C, gamma, mean, invstd, dgamma, dbeta, coef);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;

@@ -26,6 +26,7 @@
 //   walks a contiguous range of tiles: the N-tiles that share an A row-panel hit the same L2.
 #include <stdlib.h>
 #include "common.h"
+#include "igemm_epi.h"
 #include "prof.h"
 
 namespace {
@@ -62,8 +63,17 @@ struct Params {
   const float* scale;
   const float* shift;
   const char* res;
-  float* stats;      // fused BatchNorm statistics: [stats_rep][NCOLS][2] (sum, sum of squares), atomics
-  int stats_rep;
+  float* stats;      // fused BatchNorm statistics slab (igemm_epi.h): [stats_tiles][NCOLS][2] + shifts
+  int stats_tiles;   // ceil(M / 128)
+  // BatchNorm-backward statistics fused into a data-gradient launch (igemm_epi.h)
+  const char* bnb_y;
+  const uint8_t* bnb_mask;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_scale;
+  const float* bnb_shift;
+  float* bnb_partial;
+  int bnb_relu, bnb_tile_off;
   int M, NCOLS, KDIM;
   int OP, OQ, R, S, C, IH, IW, sh, sw, ph, pw;
   int64_t a_sn, a_sh, a_sw;
@@ -358,118 +368,8 @@ __global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
       }
     }
   } else {
-    // ---- bf16 epilogue.  phase 1: affine (+ReLU when there is no residual) on the fp32
-    // accumulators; each lane packs its 4 consecutive channels and writes 8 bytes (ds_write_b64)
-    // into out[BM][LDOB].
-    char* outc = smem;
-    const bool relu_now = p.relu && !p.res;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = wn * WN + j * 16 + l4 * 4;
-      const int gcol = n0 + col;
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gcol < p.NCOLS) {
-        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + gcol);
-        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + gcol);
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        f32x4 a = acc[i][j];
-        a[0] = a[0] * sc.x + sh.x; a[1] = a[1] * sc.y + sh.y;
-        a[2] = a[2] * sc.z + sh.z; a[3] = a[3] * sc.w + sh.w;
-        if (relu_now) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
-        }
-        const int row = wm * WM + i * 16 + l15;
-        *reinterpret_cast<uint2*>(outc + row * (LDOB * 2) + col * 2) =
-            make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
-      }
-    }
-    // residual rows of this thread's phase-2 chunks: issued before the barrier (the accumulators are dead by now), consumed after it
-    constexpr int NT = BM * CPR / kThreads;
-    uint4 rres[NT];
-    if (p.res) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int chunk = tid + t * kThreads;
-        const int row = chunk / CPR, cc = chunk - row * CPR;
-        const int gcol = n0 + cc * 8;
-        const int64_t roff = rowoff[row];
-        rres[t] = make_uint4(0, 0, 0, 0);
-        if (roff >= 0 && gcol < p.NCOLS)
-          rres[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.res) + roff + gcol);
-      }
-    }
-    __syncthreads();
-    const bf16_t* outb = reinterpret_cast<const bf16_t*>(smem);
-    float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    static_assert(kThreads % CPR == 0, "a thread must keep its column chunk across iterations");
-#pragma unroll
-    for (int t = 0; t < BM * CPR / kThreads; ++t) {
-      const int chunk = tid + t * kThreads;
-      const int row = chunk / CPR, cc = chunk - row * CPR;
-      const int gcol = n0 + cc * 8;
-      const int64_t roff = rowoff[row];
-      if (roff < 0 || gcol >= p.NCOLS) continue;
-      const int64_t o = roff + gcol;
-      uint4 v = *reinterpret_cast<const uint4*>(outb + row * LDOB + cc * 8);
-      if (p.res) {
-        float a[8], rr[8];
-        a[0] = __uint_as_float(v.x << 16); a[1] = __uint_as_float(v.x & 0xffff0000u);
-        a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
-        a[4] = __uint_as_float(v.z << 16); a[5] = __uint_as_float(v.z & 0xffff0000u);
-        a[6] = __uint_as_float(v.w << 16); a[7] = __uint_as_float(v.w & 0xffff0000u);
-        rr[0] = __uint_as_float(rres[t].x << 16); rr[1] = __uint_as_float(rres[t].x & 0xffff0000u);
-        rr[2] = __uint_as_float(rres[t].y << 16); rr[3] = __uint_as_float(rres[t].y & 0xffff0000u);
-        rr[4] = __uint_as_float(rres[t].z << 16); rr[5] = __uint_as_float(rres[t].z & 0xffff0000u);
-        rr[6] = __uint_as_float(rres[t].w << 16); rr[7] = __uint_as_float(rres[t].w & 0xffff0000u);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          a[e] += rr[e];
-          if (p.relu) a[e] = fmaxf(a[e], 0.f);
-        }
-        ElemTraits<bf16_t>::store8(reinterpret_cast<bf16_t*>(p.y) + o, a);
-      } else {
-        if (!(p.dbg & 1)) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
-        if (p.stats) {
-          // fused BatchNorm statistics of the STORED (bf16) values: this thread owns the same 8
-          // columns in every iteration t, so it accumulates them in registers
-          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
-            ssum[2 * e] += lo; ssq[2 * e] += lo * lo;
-            ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * hi;
-          }
-        }
-      }
-    }
-    if (p.stats) {
-      // threads tid, tid+CPR, ... share a column chunk: each writes its 16 partial values to
-      // red[tid / CPR][BN][2] (the epilogue tile is dead by now), 2*BN threads add the
-      // kThreads/CPR partials and issue ONE global atomic per (column, statistic) of the tile.
-      constexpr int J = kThreads / CPR;
-      static_assert(J * BN * 2 * 4 <= MAIN_BYTES, "reduction scratch must fit the tile buffers");
-      __syncthreads();                       // every thread is done reading the output tile
-      float* red = reinterpret_cast<float*>(smem);
-      {
-        float* dst = red + (tid / CPR) * (BN * 2) + (tid % CPR) * 16;
-#pragma unroll
-        for (int e = 0; e < 8; e += 2)
-          *reinterpret_cast<float4*>(dst + e * 2) = make_float4(ssum[e], ssq[e], ssum[e + 1], ssq[e + 1]);
-      }
-      __syncthreads();
-      if (tid < 2 * BN && n0 + (tid >> 1) < p.NCOLS) {
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < J; ++j) a += red[j * (BN * 2) + tid];
-        const int rep = mt % p.stats_rep;
-        if (!(p.dbg & 16))
-          atomicAdd(p.stats + ((int64_t)rep * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1), a);
-      }
-    }
+    // ---- bf16 epilogue (shared with the ring kernel): igemm_epi.h
+    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
   }
 }
 
@@ -524,10 +424,15 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st);   // conv_ig
 
 extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream) {
   if (!d || !d->a || !d->b || !d->y) return PASSL_EINVAL;
-  // fused BN statistics live in the bf16-output epilogue only
-  if (d->stats && (d->dtype != PASSL_BF16 || d->out_f32 || d->residual || d->stats_replicas <= 0 ||
-                   (reinterpret_cast<uintptr_t>(d->stats) & 3)))
+  // fused BN statistics (forward or backward) live in the bf16-output epilogue only
+  if (d->stats && (d->dtype != PASSL_BF16 || d->out_f32 || d->residual || d->bnb_partial ||
+                   !aligned16(d->stats)))
     return PASSL_EUNSUPPORTED;
+  if (d->bnb_partial &&
+      (d->dtype != PASSL_BF16 || d->out_f32 || d->relu || !d->bnb_y || !d->bnb_mean || !d->bnb_invstd ||
+       !aligned16(d->bnb_y) || d->bnb_tile_off < 0 || (d->bnb_relu != 0 && d->bnb_relu != 2 && d->bnb_relu != 3) ||
+       (d->bnb_relu == 2 && (!d->bnb_scale || !d->bnb_shift)) || (d->bnb_relu == 3 && !d->bnb_mask)))
+    return PASSL_EINVAL;
   if (d->N <= 0 || d->OP <= 0 || d->OQ <= 0 || d->NCOLS <= 0 || d->R <= 0 || d->S <= 0 ||
       d->C <= 0 || d->IH <= 0 || d->IW <= 0)
     return PASSL_EINVAL;
@@ -551,7 +456,11 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   p.y = reinterpret_cast<char*>(d->y);
   p.scale = d->scale; p.shift = d->shift;
   p.res = reinterpret_cast<const char*>(d->residual);
-  p.stats = d->stats; p.stats_rep = d->stats ? d->stats_replicas : 1;
+  p.stats = d->stats;
+  p.bnb_y = reinterpret_cast<const char*>(d->bnb_y); p.bnb_mask = d->bnb_mask;
+  p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
+  p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
+  p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.R = d->R; p.S = d->S; p.C = d->C;
   p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
@@ -570,6 +479,8 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   const int bn = narrow ? 64 : 128;
   p.tiles_n = (d->NCOLS + bn - 1) / bn;
   const int tiles_m = (p.M + 127) / 128;
+  p.stats_tiles = tiles_m;
+  if (d->stats && d->stats_tiles != tiles_m) return PASSL_EINVAL;
   p.ntiles = tiles_m * p.tiles_n;
   p.d_opq = make_fastdiv((uint32_t)(d->OP * d->OQ));
   p.d_oq = make_fastdiv((uint32_t)d->OQ);

@@ -26,6 +26,7 @@
 #include <string.h>
 #include <type_traits>
 #include "common.h"
+#include "igemm_epi.h"
 
 namespace ring {
 
@@ -59,8 +60,16 @@ struct Params {
   const float* scale;
   const float* shift;
   const char* res;
-  float* stats;
-  int stats_rep;
+  float* stats;      // fused BatchNorm statistics slab (igemm_epi.h)
+  int stats_tiles;
+  const char* bnb_y;
+  const uint8_t* bnb_mask;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_scale;
+  const float* bnb_shift;
+  float* bnb_partial;
+  int bnb_relu, bnb_tile_off;
   uint32_t a_bytes, b_bytes;
   int M, NCOLS, KDIM;
   int OP, OQ, S, C, IH, IW, sh, sw, ph, pw;
@@ -308,109 +317,61 @@ __global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 
   }
   __syncthreads();      // all fragment reads done before the ring is reused as the output tile
 
-  // ---- epilogue (same as igemm_kernel's bf16 path).  phase 1: affine (+ReLU when there is no
-  // residual), packed bf16 pairs into out[BM][LDOB]
-  char* outc = smem;
-  const bool relu_now = p.relu && !p.res;
+  // ---- epilogue (shared with igemm_kernel's bf16 path): igemm_epi.h
+  if constexpr (BM == 128) {
+    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
+  } else {
+    // 256-row tiles (experimental igemm_ring_bm = 256): plain epilogue, no fused statistics
+    // (passl_igemm_ring_try refuses stats / bnb launches for this tile shape)
+    char* outc = smem;
+    const bool relu_now = p.relu && !p.res;
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int col = wn * WN + j * 16 + l4 * 4;
-    const int gcol = n0 + col;
-    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (gcol < p.NCOLS) {
-      if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + gcol);
-      if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + gcol);
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      f32x4 a = acc[i][j];
-      a[0] = a[0] * sc.x + sh.x; a[1] = a[1] * sc.y + sh.y;
-      a[2] = a[2] * sc.z + sh.z; a[3] = a[3] * sc.w + sh.w;
-      if (relu_now) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+    for (int j = 0; j < FN; ++j) {
+      const int col = wn * WN + j * 16 + l4 * 4;
+      const int gcol = n0 + col;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gcol < p.NCOLS) {
+        if (p.scale) sc = *reinterpret_cast<const float4*>(p.scale + gcol);
+        if (p.shift) sh = *reinterpret_cast<const float4*>(p.shift + gcol);
       }
-      const int row = wm * WM + i * 16 + l15;
-      *reinterpret_cast<uint2*>(outc + row * (LDOB * 2) + col * 2) =
-          make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        f32x4 a = acc[i][j];
+        a[0] = a[0] * sc.x + sh.x; a[1] = a[1] * sc.y + sh.y;
+        a[2] = a[2] * sc.z + sh.z; a[3] = a[3] * sc.w + sh.w;
+        if (relu_now) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+        }
+        const int row = wm * WM + i * 16 + l15;
+        *reinterpret_cast<uint2*>(outc + row * (LDOB * 2) + col * 2) =
+            make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+      }
     }
-  }
-  constexpr int NT = BM * CPR / kThreads;
-  uint4 rres[NT];
-  if (p.res) {
+    __syncthreads();
+    const bf16_t* outb = reinterpret_cast<const bf16_t*>(smem);
+    constexpr int NT = BM * CPR / kThreads;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int chunk = tid + t * kThreads;
       const int row = chunk / CPR, cc = chunk - row * CPR;
       const int gcol = n0 + cc * 8;
       const int64_t roff = rowoff[row];
-      rres[t] = make_uint4(0, 0, 0, 0);
-      if (roff >= 0 && gcol < p.NCOLS)
-        rres[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.res) + roff + gcol);
-    }
-  }
-  __syncthreads();
-  const bf16_t* outb = reinterpret_cast<const bf16_t*>(smem);
-  float ssum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float ssq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  static_assert(kThreads % CPR == 0, "a thread must keep its column chunk across iterations");
+      if (roff < 0 || gcol >= p.NCOLS) continue;
+      const int64_t o = roff + gcol;
+      uint4 v = *reinterpret_cast<const uint4*>(outb + row * LDOB + cc * 8);
+      if (p.res) {
+        float a[8], rr[8];
+        epi::unpack8(v, a);
+        epi::unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.res) + o), rr);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int chunk = tid + t * kThreads;
-    const int row = chunk / CPR, cc = chunk - row * CPR;
-    const int gcol = n0 + cc * 8;
-    const int64_t roff = rowoff[row];
-    if (roff < 0 || gcol >= p.NCOLS) continue;
-    const int64_t o = roff + gcol;
-    uint4 v = *reinterpret_cast<const uint4*>(outb + row * LDOB + cc * 8);
-    if (p.res) {
-      float a[8], rr[8];
-      a[0] = __uint_as_float(v.x << 16); a[1] = __uint_as_float(v.x & 0xffff0000u);
-      a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
-      a[4] = __uint_as_float(v.z << 16); a[5] = __uint_as_float(v.z & 0xffff0000u);
-      a[6] = __uint_as_float(v.w << 16); a[7] = __uint_as_float(v.w & 0xffff0000u);
-      rr[0] = __uint_as_float(rres[t].x << 16); rr[1] = __uint_as_float(rres[t].x & 0xffff0000u);
-      rr[2] = __uint_as_float(rres[t].y << 16); rr[3] = __uint_as_float(rres[t].y & 0xffff0000u);
-      rr[4] = __uint_as_float(rres[t].z << 16); rr[5] = __uint_as_float(rres[t].z & 0xffff0000u);
-      rr[6] = __uint_as_float(rres[t].w << 16); rr[7] = __uint_as_float(rres[t].w & 0xffff0000u);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        a[e] += rr[e];
-        if (p.relu) a[e] = fmaxf(a[e], 0.f);
-      }
-      ElemTraits<bf16_t>::store8(reinterpret_cast<bf16_t*>(p.y) + o, a);
-    } else {
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
-      if (p.stats) {
-        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float lo = __uint_as_float(w4[e] << 16), hi = __uint_as_float(w4[e] & 0xffff0000u);
-          ssum[2 * e] += lo; ssq[2 * e] += lo * lo;
-          ssum[2 * e + 1] += hi; ssq[2 * e + 1] += hi * hi;
+        for (int e = 0; e < 8; ++e) {
+          a[e] += rr[e];
+          if (p.relu) a[e] = fmaxf(a[e], 0.f);
         }
+        v = epi::pack8(a);
       }
-    }
-  }
-  if (p.stats) {
-    constexpr int J = kThreads / CPR;
-    static_assert(J * BN * 2 * 4 <= STAGES * STAGE, "reduction scratch must fit the ring");
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    {
-      float* dst = red + (tid / CPR) * (BN * 2) + (tid % CPR) * 16;
-#pragma unroll
-      for (int e = 0; e < 8; e += 2)
-        *reinterpret_cast<float4*>(dst + e * 2) = make_float4(ssum[e], ssq[e], ssum[e + 1], ssq[e + 1]);
-    }
-    __syncthreads();
-    if (tid < 2 * BN && n0 + (tid >> 1) < p.NCOLS) {
-      float a = 0.f;
-#pragma unroll
-      for (int j = 0; j < J; ++j) a += red[j * (BN * 2) + tid];
-      // 256-row tiles: two consecutive tiles share the replica slot of igemm_kernel's 128-row tiles
-      const int rep = mt % p.stats_rep;
-      atomicAdd(p.stats + ((int64_t)rep * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1), a);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
     }
   }
 }
@@ -480,6 +441,7 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
   const int bn = d->NCOLS <= 64 ? 64 : 128;
   const int tiles_n = (d->NCOLS + bn - 1) / bn;
   const int bm = g_ring_bm;
+  if (bm != 128 && (d->stats || d->bnb_partial)) return PASSL_EUNSUPPORTED;   // slabs are per 128-row tile
   const int64_t tiles_m = (M64 + bm - 1) / bm;
   if (tiles_m * tiles_n < min_tiles) return PASSL_EUNSUPPORTED;
 
@@ -489,7 +451,11 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
   p.y = reinterpret_cast<char*>(d->y);
   p.scale = d->scale; p.shift = d->shift;
   p.res = reinterpret_cast<const char*>(d->residual);
-  p.stats = d->stats; p.stats_rep = d->stats ? d->stats_replicas : 1;
+  p.stats = d->stats; p.stats_tiles = (int)((M64 + 127) / 128);
+  p.bnb_y = reinterpret_cast<const char*>(d->bnb_y); p.bnb_mask = d->bnb_mask;
+  p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
+  p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
+  p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
   p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.S = d->S; p.C = d->C;

@@ -32,7 +32,9 @@ struct WParams {
   int OP, OQ, R, S, C, IH, IW, sh, sw, ph, pw;
   int64_t a_sn, a_sh, a_sw, dy_ld;
   int tiles_per_split, nk_total;
-  int dbg;   // tuning switches (PASSL_WGRAD_DBG): 1 = skip the atomic epilogue
+  float* ws;        // split-M partial tiles [splits][NCOLS][KDIM] (fixed-order reduction afterwards) or null
+  int nsplits;      // number of M-slices of this launch
+  int dbg;   // tuning switches (PASSL_WGRAD_DBG): 1 = skip the epilogue stores
   int grid_j, grid_oc;   // tile counts of the 1-D launch of wgrad_dma_kernel
 };
 
@@ -43,6 +45,17 @@ struct RowInfo {
 
 __device__ __forceinline__ int swz(int row, int slot) {
   return slot ^ (((row >> 1) ^ (row >> 3)) & 7);
+}
+
+// One element of a partial tile.  Deterministic forms: a single M-slice owns dW (plain
+// read-modify-write), several slices write their tile into slab `bz` of the workspace (summed in slice
+// order by slab_reduce_kernel afterwards).  Without a workspace the slices fall back to fp32 atomics
+// (order-dependent rounding; kept for callers of the bare C ABI that pass no workspace).
+__device__ __forceinline__ void wg_store(const WParams& p, int bz, int oc, int jj, float v) {
+  const int64_t o = (int64_t)oc * p.KDIM + jj;
+  if (p.ws) p.ws[(int64_t)bz * p.NCOLS * p.KDIM + o] = v;
+  else if (p.nsplits == 1) p.dw[o] += v;
+  else atomicAdd(p.dw + o, v);
 }
 
 template <typename T, int BMo, int BNo>
@@ -252,7 +265,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(const WParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: fp32 atomics into dW[oc][j]
+  // ---- epilogue: partial tile -> dW[oc][j] / workspace slab (wg_store)
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -261,12 +274,19 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_kernel(const WParams p) {
       for (int r = 0; r < 4; ++r) {
         const int oc = oc0 + wm * WM + i * 16 + l4 * 4 + r;
         const int jj = j0 + wn * WN + j * 16 + l15;
-        if (oc < p.NCOLS && jj < p.KDIM) atomicAdd(p.dw + (int64_t)oc * p.KDIM + jj, acc[i][j][r]);
+        if (oc < p.NCOLS && jj < p.KDIM) wg_store(p, blockIdx.z, oc, jj, acc[i][j][r]);
       }
 }
 
+// number of M-slices the launch functions actually used (they may shrink the request); read by
+// passl_hip_conv_wgrad right after the dispatch to size the fixed-order reduction
+thread_local int t_eff_splits = 1;
+
 template <typename T, int BMo, int BNo>
-int launch(const WParams& p, int splits, hipStream_t st) {
+int launch(const WParams& p0, int splits, hipStream_t st) {
+  WParams p = p0;
+  p.nsplits = splits;
+  t_eff_splits = splits;
   constexpr bool BF = sizeof(T) == 2;
   constexpr int BKM = BF ? 64 : 32;
   constexpr int A_BYTES = BF ? BMo * 128 : BKM * (BMo * 4 + 64);
@@ -489,7 +509,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_dma_kernel(const WParams p,
     if (kt + 2 < kt_end) fill_rowinfo(kt + 2, buf);
   }
 
-  // ---- epilogue: fp32 atomics into dW[oc][j]
+  // ---- epilogue: partial tile -> dW[oc][j] / workspace slab (wg_store)
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -498,7 +518,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_dma_kernel(const WParams p,
       for (int r = 0; r < 4; ++r) {
         const int oc = oc0 + wm * WM + i * 16 + l4 * 4 + r;
         const int jj = j0 + wn * WN + j * 16 + l15;
-        if (oc < p.NCOLS && jj < p.KDIM && !(p.dbg & 1)) atomicAdd(p.dw + (int64_t)oc * p.KDIM + jj, acc[i][j][r]);
+        if (oc < p.NCOLS && jj < p.KDIM && !(p.dbg & 1)) wg_store(p, bz, oc, jj, acc[i][j][r]);
       }
 }
 
@@ -749,7 +769,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
     if (kt + 1 < nk) iteration(std::integral_constant<int, 1>{}, kt + 1);
   }
 
-  // ---- epilogue: fp32 atomics into dW[oc][j]
+  // ---- epilogue: partial tile -> dW[oc][j] / workspace slab (wg_store)
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -758,7 +778,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
       for (int r = 0; r < 4; ++r) {
         const int oc = oc0 + wm * WM + i * 16 + l4 * 4 + r;
         const int jj = j0 + wn * WN + j * 16 + l15;
-        if (oc < p.NCOLS && jj < p.KDIM && !(p.dbg & 1)) atomicAdd(p.dw + (int64_t)oc * p.KDIM + jj, acc[i][j][r]);
+        if (oc < p.NCOLS && jj < p.KDIM && !(p.dbg & 1)) wg_store(p, bz, oc, jj, acc[i][j][r]);
       }
 }
 
@@ -778,6 +798,8 @@ int launch_pipe(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_byte
   splits = (q.nk_total + q.tiles_per_split - 1) / q.tiles_per_split;
   q.grid_j = (p.KDIM + BNo - 1) / BNo;
   q.grid_oc = (p.NCOLS + BMo - 1) / BMo;
+  q.nsplits = splits;
+  t_eff_splits = splits;
   hipLaunchKernelGGL((wgrad_pipe_kernel<BMo, BNo, BKM, NST, DENSE>), dim3(q.grid_j * q.grid_oc * splits),
                      dim3(kThreads), LDS, st, q, a_bytes, dy_bytes);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
@@ -795,6 +817,8 @@ int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes
   WParams q = p;
   q.grid_j = (p.KDIM + BNo - 1) / BNo;
   q.grid_oc = (p.NCOLS + BMo - 1) / BMo;
+  q.nsplits = splits;
+  t_eff_splits = splits;
   hipLaunchKernelGGL((wgrad_dma_kernel<BMo, BNo>), dim3(q.grid_j * q.grid_oc * splits), dim3(kThreads),
                      LDS, st, q, a_bytes, dy_bytes);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
@@ -844,6 +868,9 @@ int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_byt
 
 }  // namespace
 
+int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, int accumulate,
+                             hipStream_t st);   // flat.hip
+
 int passl_wgrad_option(const char* name, int value) {
   if (strcmp(name, "wgrad_tile") == 0) { g_wgrad_tile = value; return PASSL_OK; }
   if (strcmp(name, "wgrad_pipe") == 0) { g_wgrad_pipe = value; return PASSL_OK; }
@@ -873,6 +900,7 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
   p.OP = d->OP; p.OQ = d->OQ; p.R = d->R; p.S = d->S; p.C = d->C;
   p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
   p.a_sn = d->a_sn; p.a_sh = d->a_sh; p.a_sw = d->a_sw; p.dy_ld = d->dy_ld;
+  p.ws = nullptr; p.nsplits = 1;
   const int bkm = d->dtype == PASSL_BF16 ? 64 : 32;
   p.nk_total = (p.M + bkm - 1) / bkm;
   int splits = d->splits;
@@ -885,6 +913,11 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
     if (dyn < 0) dyn = getenv("PASSL_WGRAD_DBG_DYNAMIC") ? 1 : 0;
     if (dyn || dbg == 0) { const char* e = getenv("PASSL_WGRAD_DBG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;
+  }
+  const int64_t n_out = (int64_t)d->NCOLS * K64;
+  if (splits > 1 && d->ws) {
+    if (!aligned16(d->ws) || !aligned16(d->dw) || d->ws_floats < (int64_t)splits * n_out) return PASSL_EINVAL;
+    p.ws = d->ws;
   }
   hipStream_t st = as_stream(stream);
   passl_prof_begin(1, st);
@@ -900,6 +933,11 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
     rc = dispatch_dma(p, splits, (uint32_t)a_bytes, (uint32_t)dy_bytes, st);
   else
     rc = d->dtype == PASSL_BF16 ? dispatch<bf16_t>(p, splits, st) : dispatch<float>(p, splits, st);
+  // several slices wrote slabs: dw += slab 0 + slab 1 + ... in slice order (one slice wrote dw itself)
+  if (rc == PASSL_OK && p.ws && t_eff_splits > 1)
+    rc = passl_slab_reduce_launch(p.ws, p.dw, n_out, t_eff_splits, 1, st);
+  else if (rc == PASSL_OK && p.ws && t_eff_splits == 1)
+    rc = passl_slab_reduce_launch(p.ws, p.dw, n_out, 1, 1, st);
   passl_prof_end(1, st);
   return rc;
 }

@@ -41,6 +41,45 @@ __global__ void __launch_bounds__(kThreads) ema_kernel(float* __restrict__ k,
   }
 }
 
+// out[i] (+)= sum_{z < slabs} ws[z*n + i], summed in a FIXED order: the deterministic replacement of
+// "every producer atomically adds its partial tile".  A block covers 64 consecutive float4 columns
+// (1 KB per slab row) x ZL slab lanes; lane zl adds slabs zl, zl+ZL, ... in ascending order, the
+// ZL partial sums are combined through LDS in lane order.  n % 4 == 0.
+template <int ZL>
+__global__ void __launch_bounds__(kThreads) slab_reduce_kernel(const float* __restrict__ ws,
+                                                               float* __restrict__ out, int64_t n4,
+                                                               int slabs, int accumulate) {
+  constexpr int COLS = kThreads / ZL;
+  __shared__ float4 red[ZL][COLS];
+  const int col = threadIdx.x % COLS, zl = threadIdx.x / COLS;
+  const int64_t i = (int64_t)blockIdx.x * COLS + col;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    for (int z = zl; z < slabs; z += ZL) {
+      const float4 v = reinterpret_cast<const float4*>(ws)[(int64_t)z * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if (ZL > 1) {
+    red[zl][col] = a;
+    __syncthreads();
+    if (zl != 0) return;
+#pragma unroll
+    for (int l = 1; l < ZL; ++l) {
+      const float4 v = red[l][col];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if (i < n4) {
+    float4* o = reinterpret_cast<float4*>(out) + i;
+    if (accumulate) {
+      const float4 v = *o;
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *o = a;
+  }
+}
+
 // g' = g*gs + wd*p; v = mu*v + g'; p -= lr*v.   20 bytes per element.
 __global__ void __launch_bounds__(kThreads) sgd_kernel(float* __restrict__ p,
                                                        const float* __restrict__ g,
@@ -268,6 +307,30 @@ __global__ void __launch_bounds__(kThreads) pack_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+// shared with conv_wgrad.hip / head.hip / layout_pool.hip (same library)
+int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, int accumulate,
+                             hipStream_t st) {
+  const int64_t n4 = n >> 2;
+  if (slabs <= 4) {
+    hipLaunchKernelGGL(slab_reduce_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(kThreads), 0, st,
+                       ws, out, n4, slabs, accumulate);
+  } else if (slabs <= 32) {
+    hipLaunchKernelGGL(slab_reduce_kernel<4>, dim3((unsigned)((n4 + 63) / 64)), dim3(kThreads), 0, st,
+                       ws, out, n4, slabs, accumulate);
+  } else {
+    hipLaunchKernelGGL(slab_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(kThreads), 0, st,
+                       ws, out, n4, slabs, accumulate);
+  }
+  return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+extern "C" int passl_hip_slab_reduce(const float* ws, float* out, int64_t n, int slabs,
+                                     int accumulate, passl_stream_t stream) {
+  if (!ws || !out || n <= 0 || (n & 3) || slabs <= 0 || !aligned16(ws) || !aligned16(out))
+    return PASSL_EINVAL;
+  return passl_slab_reduce_launch(ws, out, n, slabs, accumulate, as_stream(stream));
+}
 
 extern "C" int passl_hip_ema_update(float* k, const float* q, void* k_lp, int64_t n, float m,
                                     passl_stream_t stream) {

@@ -131,10 +131,11 @@ __global__ void __launch_bounds__(kThreads, 2) infonce_fwd_kernel(
   }
 }
 
-// one wave per row: combine partials + positive; block-level mean via atomics into out[0..2]
+// one wave per row: combine partials + positive; per-row (loss, top-1, top-5) go to rowvals[N][4],
+// infonce_mean_kernel folds them in a fixed order (no atomics: the loss is bit-reproducible)
 __global__ void __launch_bounds__(kThreads) infonce_finalize_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ part,
-    int nblk, int N, int K, float invT, float* __restrict__ out, float* __restrict__ row_lse,
+    int nblk, int N, int K, float invT, float* __restrict__ rowvals, float* __restrict__ row_lse,
     float* __restrict__ logits) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -159,18 +160,41 @@ __global__ void __launch_bounds__(kThreads) infonce_finalize_kernel(
   if (lane == 0) {
     row_lse[row] = lse;
     if (logits) logits[(int64_t)row * (K + 1)] = lp;
-    const float invN = 1.0f / (float)N;
-    atomicAdd(out + 0, (lse - lp) * invN);
-    atomicAdd(out + 1, (cnt < 0.5f ? 100.f : 0.f) * invN);
-    atomicAdd(out + 2, (cnt < 4.5f ? 100.f : 0.f) * invN);
+    *reinterpret_cast<float4*>(rowvals + (int64_t)row * 4) =
+        make_float4(lse - lp, cnt < 0.5f ? 100.f : 0.f, cnt < 4.5f ? 100.f : 0.f, 0.f);
   }
 }
 
-// dq += coef * ( sum_j p_ij queue[:,j]  [+ (p_i0 - 1) k_i  from block 0] )
+// out[0..2] = mean over rows of rowvals[:, 0..2]; one block, thread t adds rows t, t+256, ... in order,
+// then the 256 partial sums are folded pairwise through LDS (fixed tree)
+__global__ void __launch_bounds__(kThreads) infonce_mean_kernel(const float* __restrict__ rowvals, int N,
+                                                                float* __restrict__ out) {
+  __shared__ float red[kThreads][3];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int r = threadIdx.x; r < N; r += kThreads) {
+    const float4 v = *reinterpret_cast<const float4*>(rowvals + (int64_t)r * 4);
+    a0 += v.x; a1 += v.y; a2 += v.z;
+  }
+  red[threadIdx.x][0] = a0; red[threadIdx.x][1] = a1; red[threadIdx.x][2] = a2;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[threadIdx.x][0] += red[threadIdx.x + s][0];
+      red[threadIdx.x][1] += red[threadIdx.x + s][1];
+      red[threadIdx.x][2] += red[threadIdx.x + s][2];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out[threadIdx.x] = red[0][threadIdx.x] / (float)N;
+}
+
+// slab[blockIdx.x][N][D] = coef * sum_{j in this block's queue slice} p_ij queue[:,j];  block 0 also writes
+// slab[gridDim.x] = coef * (p_i0 - 1) k_i.   dq = sum of the slabs in slab order (slab_reduce_kernel): every
+// element is written by exactly one lane — no atomics, bit-reproducible gradients.
 __global__ void __launch_bounds__(kThreads, 2) infonce_bwd_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ queue,
     const float* __restrict__ row_lse, const float* __restrict__ gscale, int N, int K, float invT,
-    float* __restrict__ dq) {
+    float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float qs[];
   const int c0 = blockIdx.x * BC;
   stage_queue(queue, K, c0, qs);
@@ -178,6 +202,8 @@ __global__ void __launch_bounds__(kThreads, 2) infonce_bwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const float coef = (gscale ? *gscale : 1.0f) * invT / (float)N;
+  float* dq = slabs + (int64_t)blockIdx.x * N * D;
+  float* dpos = slabs + (int64_t)gridDim.x * N * D;
   for (int r0 = 0; r0 < N; r0 += 64) {
     const int row = r0 + wave * 16 + l15;
     float qreg[32];
@@ -211,7 +237,7 @@ __global__ void __launch_bounds__(kThreads, 2) infonce_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int orow = r0 + wave * 16 + l4 * 4 + r;
-        if (orow < N) atomicAdd(dq + (int64_t)orow * D + jd * 16 + l15, g[jd][r]);
+        if (orow < N) dq[(int64_t)orow * D + jd * 16 + l15] = g[jd][r];
       }
     if (blockIdx.x == 0 && row < N) {
       // positive term: (p_i0 - 1) * k_i ; lane (l15,l4) covers d in [l4*32, l4*32+32)
@@ -227,7 +253,9 @@ __global__ void __launch_bounds__(kThreads, 2) infonce_bwd_kernel(
       pos = row_sum4(pos);
       const float w = (__expf(pos * invT - lse) - 1.0f) * coef;
 #pragma unroll
-      for (int v = 0; v < 32; ++v) atomicAdd(dq + (int64_t)row * D + l4 * 32 + v, w * kreg[v]);
+      for (int v = 0; v < 32; v += 4)
+        *reinterpret_cast<float4*>(dpos + (int64_t)row * D + l4 * 32 + v) =
+            make_float4(w * kreg[v], w * kreg[v + 1], w * kreg[v + 2], w * kreg[v + 3]);
     }
   }
 }
@@ -280,9 +308,17 @@ __global__ void __launch_bounds__(kThreads) l2norm_bwd_kernel(const float* __res
 
 }  // namespace
 
+int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, int accumulate,
+                             hipStream_t st);   // flat.hip
+
 extern "C" int64_t passl_hip_infonce_workspace_bytes(int N, int K) {
   if (N <= 0 || K <= 0) return 0;
-  return (int64_t)(K / BC) * N * 4 * (int64_t)sizeof(float);
+  return (int64_t)(K / BC + 1) * N * 4 * (int64_t)sizeof(float);     // slice partials + per-row values
+}
+
+extern "C" int64_t passl_hip_infonce_bwd_workspace_bytes(int N, int K) {
+  if (N <= 0 || K <= 0) return 0;
+  return (int64_t)(K / BC + 1) * N * D * (int64_t)sizeof(float);     // one dq slab per slice + positives
 }
 
 extern "C" int passl_hip_infonce_fwd(const float* q, const float* k, const float* queue, int N,
@@ -301,23 +337,27 @@ extern "C" int passl_hip_infonce_fwd(const float* q, const float* k, const float
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr = true;
   }
-  if (hipMemsetAsync(out, 0, 3 * sizeof(float), st) != hipSuccess) return PASSL_ELAUNCH;
   const int nblk = K / BC;
+  float* rowvals = reinterpret_cast<float*>(workspace) + (int64_t)nblk * N * 4;
   hipLaunchKernelGGL(infonce_fwd_kernel, dim3(nblk), dim3(kThreads), kLds, st, q, k, queue, N, K,
                      1.0f / T, reinterpret_cast<float*>(workspace), logits);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   hipLaunchKernelGGL(infonce_finalize_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, st, q, k,
-                     reinterpret_cast<const float*>(workspace), nblk, N, K, 1.0f / T, out, row_lse,
+                     reinterpret_cast<const float*>(workspace), nblk, N, K, 1.0f / T, rowvals, row_lse,
                      logits);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(infonce_mean_kernel, dim3(1), dim3(kThreads), 0, st, rowvals, N, out);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
 
 extern "C" int passl_hip_infonce_bwd(const float* q, const float* k, const float* queue,
                                      const float* row_lse, const float* gscale, int N, int Dd,
-                                     int K, float T, float* dq, passl_stream_t stream) {
-  if (!q || !k || !queue || !row_lse || !dq || N <= 0 || Dd != D || K <= 0 || (K % BC) ||
-      !(T > 0.f) || !aligned16(q) || !aligned16(k) || !aligned16(queue))
+                                     int K, float T, float* dq, void* workspace,
+                                     passl_stream_t stream) {
+  if (!q || !k || !queue || !row_lse || !dq || !workspace || N <= 0 || Dd != D || K <= 0 || (K % BC) ||
+      !(T > 0.f) || !aligned16(q) || !aligned16(k) || !aligned16(queue) || !aligned16(dq) ||
+      !aligned16(workspace))
     return PASSL_EINVAL;
   hipStream_t st = as_stream(stream);
   static bool attr = false;
@@ -327,9 +367,10 @@ extern "C" int passl_hip_infonce_bwd(const float* q, const float* k, const float
     attr = true;
   }
   hipLaunchKernelGGL(infonce_bwd_kernel, dim3(K / BC), dim3(kThreads), kLds, st, q, k, queue,
-                     row_lse, gscale, N, K, 1.0f / T, dq);
+                     row_lse, gscale, N, K, 1.0f / T, reinterpret_cast<float*>(workspace));
   PASSL_RETURN_IF_LAUNCH_FAILED();
-  return PASSL_OK;
+  return passl_slab_reduce_launch(reinterpret_cast<const float*>(workspace), dq, (int64_t)N * D,
+                                  K / BC + 1, 0, st);
 }
 
 extern "C" int passl_hip_enqueue(float* queue, const float* keys, int Dd, int K, int ptr, int B,

@@ -155,13 +155,16 @@ __global__ void __launch_bounds__(kThreads) avgpool_bwd_kernel(const T* __restri
   }
 }
 
-// out[c] += sum_m x[m][c] (out zeroed by the host wrapper).  A block covers 32 consecutive
-// 8-channel chunks (512 contiguous bytes per row in bf16) x one slab of rows: 32 chunk columns x
-// 8 row lanes, coalesced row reads, LDS reduce over the row lanes, one atomic per column per block.
+// column sums of x[M][C].  A block covers 32 consecutive 8-channel chunks (512 contiguous bytes per
+// row in bf16) x one slab of rows: 32 chunk columns x 8 row lanes, coalesced row reads, LDS reduce over
+// the row lanes.  mode 0: out[col] = s (single slab), 1: out[col] += s (single slab), 2: the slab's
+// partial goes to ws[slab][C] (summed in slab order by slab_reduce_kernel), 3: fp32 atomics into out
+// (no workspace given: order-dependent rounding).
 template <typename T>
 __global__ void __launch_bounds__(kThreads) colsum_kernel(const T* __restrict__ x,
                                                           float* __restrict__ out, int64_t M,
-                                                          int C, int rows_per_block) {
+                                                          int C, int rows_per_block, int mode,
+                                                          float* __restrict__ ws) {
   __shared__ float red[8][32 * 8 + 8];
   const int cc = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = (blockIdx.x * 32 + cc) * 8;
@@ -185,7 +188,10 @@ __global__ void __launch_bounds__(kThreads) colsum_kernel(const T* __restrict__ 
     float s = 0.f;
 #pragma unroll
     for (int l = 0; l < 8; ++l) s += red[l][threadIdx.x];
-    atomicAdd(out + col, s);
+    if (mode == 0) out[col] = s;
+    else if (mode == 1) out[col] += s;
+    else if (mode == 2) ws[(int64_t)blockIdx.y * C + col] = s;
+    else atomicAdd(out + col, s);
   }
 }
 
@@ -290,35 +296,46 @@ extern "C" int passl_hip_avgpool_bwd(const void* dy, void* dx, int N, int HW, in
   return PASSL_OK;
 }
 
+int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, int accumulate,
+                             hipStream_t st);   // flat.hip
+
 static int colsum_impl(const void* x, float* out, int64_t M, int C, int dtype, bool accumulate,
-                       passl_stream_t stream) {
+                       float* ws, int64_t ws_floats, passl_stream_t stream) {
   if (!x || !out || M <= 0 || C <= 0 || (C & 7) || !aligned16(x)) return PASSL_EINVAL;
-  if (!accumulate &&
-      hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess)
-    return PASSL_ELAUNCH;
-  // ~64 rows per block: enough blocks in flight for the short-sequence ViT shapes (M = 6400 ... 50432),
-  // the per-block atomics (256 columns) stay negligible
-  // (measured: 64-row slabs help M <= 12800, 256-row slabs are better at M = 50432 where the extra
-  // blocks only add same-address atomics)
+  // ~64 rows per block: enough blocks in flight for the short-sequence ViT shapes (M = 6400 ... 50432);
+  // 256-row slabs at M >= 32768
   const int per = M >= 32768 ? 256 : 64;
   int slabs = (int)((M + per - 1) / per);
   if (slabs > 1024) slabs = 1024;
   const int rows = (int)((M + slabs - 1) / slabs);
+  slabs = (int)((M + rows - 1) / rows);              // every slab holds rows
+  int mode;
+  if (slabs == 1) mode = accumulate ? 1 : 0;
+  else if (ws) {
+    if (!aligned16(ws) || !aligned16(out) || ws_floats < (int64_t)slabs * C) return PASSL_EINVAL;
+    mode = 2;
+  } else {
+    mode = 3;
+    if (!accumulate &&
+        hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess)
+      return PASSL_ELAUNCH;
+  }
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 255) / 256, slabs),
                                            dim3(kThreads), 0, as_stream(stream),
-                                           reinterpret_cast<const T*>(x), out, M, C, rows);)
+                                           reinterpret_cast<const T*>(x), out, M, C, rows, mode, ws);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
+  if (mode == 2) return passl_slab_reduce_launch(ws, out, C, slabs, accumulate ? 1 : 0, as_stream(stream));
   return PASSL_OK;
 }
 
-extern "C" int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype,
-                                passl_stream_t stream) {
-  return colsum_impl(x, out, M, C, dtype, false, stream);
+extern "C" int passl_hip_colsum(const void* x, float* out, int64_t M, int C, int dtype, float* ws,
+                                int64_t ws_floats, passl_stream_t stream) {
+  return colsum_impl(x, out, M, C, dtype, false, ws, ws_floats, stream);
 }
 
-extern "C" int passl_hip_colsum_acc(const void* x, float* out, int64_t M, int C, int dtype,
-                                    passl_stream_t stream) {
-  return colsum_impl(x, out, M, C, dtype, true, stream);
+extern "C" int passl_hip_colsum_acc(const void* x, float* out, int64_t M, int C, int dtype, float* ws,
+                                    int64_t ws_floats, passl_stream_t stream) {
+  return colsum_impl(x, out, M, C, dtype, true, ws, ws_floats, stream);
 }
 
 extern "C" int passl_hip_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype,

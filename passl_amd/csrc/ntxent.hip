@@ -172,11 +172,31 @@ __global__ void __launch_bounds__(kThreads) ntxent_fwd_kernel(
     const float lx = s.mx + __logf(s.zx), ly = s.my + __logf(s.zy);
     const float kl = s.wy / s.zy - s.wx / s.zx;          // sum (Pb - Pa)(y - x)
     float* o = rowstats + (int64_t)row * kStatsStride;
-    o[0] = lce_a; o[1] = lce_b; o[2] = lx; o[3] = ly; o[4] = kl; o[5] = pos; o[6] = s.cnt; o[7] = 0.f;
-    const float invB = 1.0f / (float)B;
-    atomicAdd(out + 0, ((lce_a - pos) + (lce_b - pos) + co2w * kl) * invB);
-    atomicAdd(out + 1, (s.cnt < 0.5f ? 1.f : 0.f) * invB);
+    // o[7] = this row's loss term: ntxent_mean_kernel folds the rows in a fixed order (no atomics)
+    o[0] = lce_a; o[1] = lce_b; o[2] = lx; o[3] = ly; o[4] = kl; o[5] = pos; o[6] = s.cnt;
+    o[7] = (lce_a - pos) + (lce_b - pos) + co2w * kl;
   }
+}
+
+// out[0] = mean_i rowstats[i][7] (loss), out[1] = share of rows whose positive ranks first
+__global__ void __launch_bounds__(kThreads) ntxent_mean_kernel(const float* __restrict__ rowstats, int B,
+                                                               float* __restrict__ out) {
+  __shared__ float red[kThreads][2];
+  float a0 = 0.f, a1 = 0.f;
+  for (int r = threadIdx.x; r < B; r += kThreads) {
+    a0 += rowstats[(int64_t)r * kStatsStride + 7];
+    a1 += rowstats[(int64_t)r * kStatsStride + 6] < 0.5f ? 1.f : 0.f;
+  }
+  red[threadIdx.x][0] = a0; red[threadIdx.x][1] = a1;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[threadIdx.x][0] += red[threadIdx.x + s][0];
+      red[threadIdx.x][1] += red[threadIdx.x + s][1];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) out[threadIdx.x] = red[0][threadIdx.x] / (float)B;
 }
 
 // stage 16 rows x 128 floats of x (rows r0.., zero beyond nrows) into a wave-private LDS tile
@@ -285,16 +305,31 @@ __global__ void __launch_bounds__(kThreads) ntxent_bwd_kernel(
       }
     }
   }
+  // the 4 waves swept disjoint column tiles of the SAME 16 own rows: fold their partials through LDS in
+  // wave order and store (no atomics: out1 / out2 are fully written, bit-reproducible)
+  __syncthreads();                         // every wave is done with its staging tiles
 #pragma unroll
   for (int jd = 0; jd < 8; ++jd)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int orow = blockIdx.x * 16 + l4 * 4 + r;
-      if (orow < n_own) {
-        atomicAdd(out1 + (int64_t)orow * D + jd * 16 + l15, g1[jd][r]);
-        atomicAdd(out2 + (int64_t)orow * D + jd * 16 + l15, g2[jd][r]);
-      }
+      tileP[(l4 * 4 + r) * PITCH + jd * 16 + l15] = g1[jd][r];
+      tileQ[(l4 * 4 + r) * PITCH + jd * 16 + l15] = g2[jd][r];
     }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * 16 * (D / 4); e += kThreads) {
+    const int which = e / (16 * (D / 4)), rem = e % (16 * (D / 4));
+    const int r = rem / (D / 4), c4 = rem % (D / 4);
+    const int orow = blockIdx.x * 16 + r;
+    if (orow >= n_own) continue;
+    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(lds + w * (2 * 16 * PITCH) + which * (16 * PITCH) +
+                                                         r * PITCH + c4 * 4);
+      acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w;
+    }
+    *reinterpret_cast<float4*>((which ? out2 : out1) + (int64_t)orow * D + c4 * 4) = acc4;
+  }
 }
 
 constexpr int kBwdLds = 4 * 2 * 16 * PITCH * (int)sizeof(float);
@@ -310,9 +345,10 @@ extern "C" int passl_hip_ntxent_fwd(const float* a, const float* b, const float*
       !aligned16(a_all) || !aligned16(b_all) || !aligned16(rowstats))
     return PASSL_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(out, 0, 2 * sizeof(float), st) != hipSuccess) return PASSL_ELAUNCH;
   hipLaunchKernelGGL(ntxent_fwd_kernel, dim3((B + 15) / 16), dim3(kThreads), 0, st, a, b, a_all,
                      b_all, B, BL, row_offset, 1.0f / T, co2_weight, rowstats, out);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(ntxent_mean_kernel, dim3(1), dim3(kThreads), 0, st, rowstats, B, out);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

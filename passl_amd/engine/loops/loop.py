@@ -1,0 +1,113 @@
+"""TrainingEpochLoop — the epoch/iteration driver of the v2 engine, reference
+passl/engine/loops/loop.py:141-311 (``run`` -> ``train_one_epoch`` -> ``train_one_step``; global step
+counter, ``max_train_step`` early stop, timers reset after 5 warm-up iterations, ``ips`` =
+batch_size * world_size / batch_cost in the log line, lr stepping per epoch when
+``lr_decay_unit == 'epoch'``, checkpoint every ``save_interval`` epochs).
+
+Differences by design: losses are kept as device tensors and only converted when a line is printed
+(the reference calls ``.item()`` every iteration = one device->host sync per step, loop.py:85);
+``max_train_step`` ends the loop by returning instead of ``exit(0)``."""
+import datetime
+import logging
+import os
+import time
+
+import torch
+
+from ...utils.misc import AverageMeter
+
+logger = logging.getLogger('passl')
+
+
+class TrainingEpochLoop(object):
+    def __init__(self, trainer, epochs, max_train_step=None, val_loop=None):
+        self.trainer = trainer
+        self.start_eopch = 0                      # (sic) the reference's attribute name
+        self.epochs = epochs
+        self.cur_epoch_id = 0
+        self.global_step = 0
+        self.max_train_step = max_train_step
+        self.val_loop = val_loop
+        self.time_info = {'reader_cost': AverageMeter('reader_cost'), 'batch_cost': AverageMeter('batch_cost')}
+        self.output_info = {}
+        self._pending = []
+
+    @property
+    def max_steps(self):
+        return self.epochs * len(self.trainer.train_dataloader)
+
+    # ---- loop.py:207-252
+    def run(self):
+        assert self.trainer.mode == 'train' and self.trainer.training is True
+        self.total_batch_idx = len(self.trainer.train_dataloader)
+        for epoch_id in range(self.start_eopch + 1, self.epochs + 1):
+            self.cur_epoch_id = epoch_id
+            stop = self.train_one_epoch()
+            if self.trainer.lr_decay_unit == 'epoch' and self.trainer.lr_scheduler is not None:
+                self.trainer.lr_scheduler.step(self.cur_epoch_id)
+            self._flush()
+            logger.info('[Train][Epoch {}/{}][Avg]{}'.format(epoch_id, self.epochs, ', '.join(
+                '{}: {:.5f}'.format(k, m.avg) for k, m in self.output_info.items())))
+            self.output_info.clear()
+            if stop:
+                break
+            if epoch_id % self.trainer.save_interval == 0 or epoch_id == self.epochs:
+                self.save_checkpoint()
+        self.trainer.training = False
+
+    # ---- loop.py:255-308
+    def train_one_epoch(self):
+        self.trainer.model.train()
+        tic = time.time()
+        for batch_idx, batch in enumerate(self.trainer.train_dataloader):
+            self.cur_batch_idx = batch_idx
+            if self.max_train_step is not None and self.global_step >= self.max_train_step:
+                logger.info('global_step({}) >= max_train_step({}), training stops early.'.format(
+                    self.global_step, self.max_train_step))
+                return True
+            if batch_idx >= self.total_batch_idx:
+                break
+            if batch_idx == 5:
+                for m in self.time_info.values():
+                    m.reset()
+            self.time_info['reader_cost'].update(time.time() - tic)
+            self.global_step += 1
+            _out, loss_dict = self.train_one_step(batch)
+            self.time_info['batch_cost'].update(time.time() - tic)
+            self._pending.append(loss_dict)
+            if batch_idx % self.trainer.print_batch_step == 0:
+                self.log_info()
+            tic = time.time()
+        return False
+
+    def train_one_step(self, batch):
+        raise NotImplementedError
+
+    def _flush(self):
+        """One device->host transfer for everything queued since the last print."""
+        if not self._pending:
+            return
+        keys = list(self._pending[0])
+        vals = torch.stack([torch.stack([torch.as_tensor(d[k]).detach().reshape(()).float() for k in keys])
+                            for d in self._pending]).cpu()
+        for j, k in enumerate(keys):
+            m = self.output_info.setdefault(k, AverageMeter(k))
+            for i in range(vals.shape[0]):
+                m.update(float(vals[i, j]), self.batch_size)
+        self._pending = []
+
+    def log_info(self):
+        self._flush()
+        world = self.trainer.config['Global'].get('world_size', 1)
+        cost = max(self.time_info['batch_cost'].avg, 1e-9)
+        eta = ((self.epochs - self.cur_epoch_id + 1) * self.total_batch_idx - self.cur_batch_idx) * cost
+        logger.info('[Train][Epoch {}/{}][Iter: {}/{}] lr: {:.6f}, {}, {}, ips: {:.5f} images/sec, eta: {}'.format(
+            self.cur_epoch_id, self.epochs, self.cur_batch_idx, self.total_batch_idx,
+            self.trainer.optimizer.get_lr(),
+            ', '.join('{}: {:.5f}'.format(k, m.avg) for k, m in self.output_info.items()),
+            ', '.join('{}: {:.5f}'.format(k, m.avg) for k, m in self.time_info.items()),
+            self.batch_size * world / cost, datetime.timedelta(seconds=int(eta))))
+
+    def save_checkpoint(self):
+        out = os.path.join(self.trainer.output_dir, self.trainer.model_name, 'epoch_{}'.format(self.cur_epoch_id))
+        self.trainer.model.save(out, rank=self.trainer.config['Global'].get('rank', 0))

@@ -12,7 +12,8 @@ import torch
 
 _state = {'device': None, 'dtype': torch.bfloat16,
           'fused_bn_stats': os.environ.get('PASSL_FUSED_BN_STATS', '1') != '0',
-          'fuse_residual_grad': os.environ.get('PASSL_FUSE_RESIDUAL_GRAD', '1') != '0'}
+          'fuse_residual_grad': os.environ.get('PASSL_FUSE_RESIDUAL_GRAD', '1') != '0',
+          'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0'}
 
 
 def set_device(name):
@@ -59,6 +60,12 @@ def fuse_residual_grad():
     return _state['fuse_residual_grad']
 
 
+def fused_bn_backward():
+    """BatchNorm backward statistics (sum g, sum g*xhat) written by the epilogue of the data-gradient
+    launch that produces the BatchNorm output's gradient (bf16 only) instead of a separate pass."""
+    return _state['fused_bn_backward']
+
+
 def set_flag(name, value):
-    assert name in ('fused_bn_stats', 'fuse_residual_grad')
+    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward')
     _state[name] = bool(value)

@@ -23,6 +23,8 @@ c_f = C.c_float
 class ConvDesc(C.Structure):
     _fields_ = [('a', c_p), ('b', c_p), ('y', c_p), ('scale', c_p), ('shift', c_p),
                 ('residual', c_p), ('stats', c_p),
+                ('bnb_y', c_p), ('bnb_mask', c_p), ('bnb_mean', c_p), ('bnb_invstd', c_p),
+                ('bnb_scale', c_p), ('bnb_shift', c_p), ('bnb_partial', c_p),
                 ('N', C.c_int32), ('OP', C.c_int32), ('OQ', C.c_int32), ('NCOLS', C.c_int32),
                 ('R', C.c_int32), ('S', C.c_int32), ('C', C.c_int32),
                 ('IH', C.c_int32), ('IW', C.c_int32),
@@ -30,7 +32,7 @@ class ConvDesc(C.Structure):
                 ('a_sn', c_l), ('a_sh', c_l), ('a_sw', c_l),
                 ('y_sn', c_l), ('y_sh', c_l), ('y_sw', c_l),
                 ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32),
-                ('stats_replicas', C.c_int32)]
+                ('stats_tiles', C.c_int32), ('bnb_relu', C.c_int32), ('bnb_tile_off', C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -40,6 +42,7 @@ class WgradDesc(C.Structure):
                 ('IH', C.c_int32), ('IW', C.c_int32),
                 ('sh', C.c_int32), ('sw', C.c_int32), ('ph', C.c_int32), ('pw', C.c_int32),
                 ('a_sn', c_l), ('a_sh', c_l), ('a_sw', c_l), ('dy_ld', c_l),
+                ('ws', c_p), ('ws_floats', c_l),
                 ('dtype', C.c_int32), ('splits', C.c_int32)]
 
 
@@ -64,8 +67,9 @@ SIGNATURES = {
     'passl_hip_nchw_to_nhwc_pad': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_conv_igemm': (c_i, [C.POINTER(ConvDesc), c_p]),
     'passl_hip_conv_wgrad': (c_i, [C.POINTER(WgradDesc), c_p]),
+    'passl_hip_slab_reduce': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
     'passl_hip_bn_stats': (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
-    'passl_hip_bn_finalize': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p,
+    'passl_hip_bn_finalize': (c_i, [c_p, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p,
                                     c_p, c_p, c_p]),
     'passl_hip_bn_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     'passl_hip_bn_bwd_reduce': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i,
@@ -78,13 +82,14 @@ SIGNATURES = {
     'passl_hip_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_relu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
-    'passl_hip_colsum': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
-    'passl_hip_colsum_acc': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
+    'passl_hip_colsum': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p]),
+    'passl_hip_colsum_acc': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p]),
     'passl_hip_l2norm_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_p]),
     'passl_hip_l2norm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'passl_hip_infonce_workspace_bytes': (c_l, [c_i, c_i]),
     'passl_hip_infonce_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
-    'passl_hip_infonce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p]),
+    'passl_hip_infonce_bwd_workspace_bytes': (c_l, [c_i, c_i]),
+    'passl_hip_infonce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     'passl_hip_enqueue': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_lars_momentum': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_f, c_f,
                                       c_f, c_f, c_f, c_p]),

@@ -81,18 +81,38 @@ class GradSlot:
         return g
 
 
+class BNLink:
+    """Hand-off between a training-mode BatchNorm(+ReLU) layer and the ONE convolution that consumes
+    its output.  The BatchNorm's forward records what its backward statistics need (its input y, the
+    batch statistics, the ReLU mask source); the consumer's data-gradient launch — which produces
+    exactly the gradient w.r.t. the BatchNorm output — masks that gradient and writes the per-tile
+    (sum g, sum g*xhat) slab in its epilogue (csrc/igemm_epi.h), and reports it here.  The BatchNorm's
+    backward then skips its reduce pass, and the gradient it receives is already g."""
+
+    __slots__ = ('y', 'st', 'mask', 'relu_mode', 'fused')
+
+    def __init__(self, y, st, mask, relu_mode):
+        self.y, self.st, self.mask, self.relu_mode = y, st, mask, relu_mode
+        self.fused = None            # (slab, tiles) once a data-gradient launch has done the work
+
+
+def bn_link(t):
+    """The BNLink riding on a BatchNorm output tensor (None for anything else)."""
+    return getattr(t, '_passl_bn_link', None)
+
+
 # =============================================================================== conv
 class _ConvFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, layer, hw, stats, add_slot, sink_slot):
+    def forward(ctx, x, weight, layer, hw, stats, add_slot, sink_slot, producer):
         rt = _need_rt(layer)
         N = x.shape[0]
         pl = layer._plan(N, hw[0], hw[1])
         y = torch.empty(N, pl.fd.OP, pl.fd.OQ, layer.geom.cout, dtype=x.dtype, device=x.device)
-        ops.conv_igemm(pl.fd, x, rt.w_fwd, y, stats=stats)
+        ops.conv_igemm(pl.fd, x, rt.w_fwd, y, stats=stats[0] if stats is not None else None)
         ctx.save_for_backward(x)
         ctx.layer, ctx.pl, ctx.hw = layer, pl, hw
-        ctx.add_slot, ctx.sink_slot = add_slot, sink_slot
+        ctx.add_slot, ctx.sink_slot, ctx.producer = add_slot, sink_slot, producer
         return y
 
     @staticmethod
@@ -110,8 +130,23 @@ class _ConvFn(Function):
             extra = ctx.add_slot.take() if ctx.add_slot is not None else None
             if extra is not None and (len(pl.dds) != 1 or pl.dgrad_zero):
                 raise RuntimeError('residual-gradient fusion needs a single dense data-gradient conv')
+            link = ctx.producer
+            fuse = (link is not None and dy.dtype == torch.bfloat16 and not pl.dgrad_zero and
+                    ctx.sink_slot is None and config.fused_bn_backward())
+            slab, off = None, 0
+            if fuse:
+                tiles = sum(ops.conv_tiles(d) for d in pl.dds)
+                slab = torch.empty(tiles * g.cin * 2, dtype=torch.float32, device=dy.device)
             for d in pl.dds:
-                ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx, residual=extra)
+                bnb = None
+                if fuse:
+                    bnb = dict(y=link.y, mask=link.mask, mean=link.st[0], invstd=link.st[1],
+                               scale=link.st[2], shift=link.st[3], relu=link.relu_mode, partial=slab,
+                               tile_off=off)
+                    off += ops.conv_tiles(d)
+                ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx, residual=extra, bnb=bnb)
+            if fuse:
+                link.fused = (slab, off)
             if ctx.sink_slot is not None:
                 ctx.sink_slot.put(dx)
                 dx = None
@@ -122,7 +157,7 @@ class _ConvFn(Function):
         else:
             ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
         rt.arena.grad_ready(rt.indices)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
 class Conv2D(Layer):
@@ -158,21 +193,22 @@ class Conv2D(Layer):
             self._plans[key] = pl
         return pl
 
-    def forward(self, x, hw=None, want_stats=False, add_slot=None, sink_slot=None):
+    def forward(self, x, hw=None, want_stats=False, add_slot=None, sink_slot=None, producer=None):
         """x: NHWC compute-dtype tensor (the stem takes the zero-padded image + hw=(H, W)).
-        want_stats: also return the fused BatchNorm statistics accumulated by the conv epilogue
-        (None when the dtype has no fused path) -> (y, stats).
+        want_stats: also return the fused BatchNorm statistics slab written by the conv epilogue
+        ((slab, tiles); None when the dtype has no fused path) -> (y, stats).
         add_slot / sink_slot: residual-fork gradient hand-off (GradSlot): this conv's backward adds
         the slot's tensor to dx in the kernel epilogue / deposits its dx there instead of
-        returning it."""
+        returning it.
+        producer: BNLink of the BatchNorm layer whose output is x, given ONLY when this conv's
+        data-gradient launch produces the complete gradient of x (sole consumer, or the residual fork
+        folded in through add_slot): the launch then also does that BatchNorm's backward reduction."""
         if hw is None:
             hw = (x.shape[1], x.shape[2])
         stats = None
         if want_stats and x.dtype == torch.bfloat16 and config.fused_bn_stats():
-            g = self.geom
-            P_, Q_ = ((hw[0] + 2 * g.pad - g.k) // g.stride + 1, (hw[1] + 2 * g.pad - g.k) // g.stride + 1)
-            stats = ops.conv_stats_buffer(x.shape[0] * P_ * Q_, g.cout, x.device, pooled=True)
-        y = _ConvFn.apply(x, self.weight, self, hw, stats, add_slot, sink_slot)
+            stats = ops.conv_stats_buffer(self._plan(x.shape[0], hw[0], hw[1]).fd, x.device)
+        y = _ConvFn.apply(x, self.weight, self, hw, stats, add_slot, sink_slot, producer)
         return (y, stats) if want_stats else y
 
     @torch.no_grad()
@@ -194,7 +230,7 @@ class Conv2D(Layer):
 # =============================================================================== batch norm
 class _BNActFn(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, layer, relu, partial, res_slot):
+    def forward(ctx, y, gamma, beta, residual, layer, relu, partial, res_slot, link_box):
         has_res = residual is not None
         z, st, mask = ops.bn_train_fwd(y, gamma.detach(), beta.detach(), layer._mean,
                                        layer._variance, residual, relu, layer._momentum,
@@ -205,6 +241,9 @@ class _BNActFn(Function):
         ctx.relu_mode = 0 if not relu else (3 if has_res else 2)
         ctx.save_for_backward(y, st, mask)
         ctx.layer, ctx.has_res, ctx.res_slot = layer, has_res, res_slot
+        ctx.link = None
+        if link_box is not None:
+            ctx.link = link_box[0] = BNLink(y, st, mask, ctx.relu_mode)
         return z
 
     @staticmethod
@@ -215,15 +254,19 @@ class _BNActFn(Function):
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         want_dres = ctx.has_res and (ctx.needs_input_grad[3] or ctx.res_slot is not None)
+        # the consumer conv's data-gradient launch may already have masked dz and reduced it
+        fused = ctx.link.fused if ctx.link is not None else None
+        if ctx.link is not None:
+            ctx.link.y = ctx.link.st = ctx.link.mask = ctx.link.fused = None     # drop the references
         dx, dres = ops.bn_bwd(dz.contiguous(), mask, y, layer.weight.detach(), st[0], st[1],
                               layer.weight.grad, layer.bias.grad, relu=ctx.relu_mode,
-                              want_dres=want_dres, scale=st[2], shift=st[3])
+                              want_dres=want_dres, scale=st[2], shift=st[3], fused=fused)
         if ctx.res_slot is not None:
             ctx.res_slot.put(dres)
             dres = None
         if layer._rt is not None:
             layer._rt.arena.grad_ready(layer._rt.indices)
-        return dx, None, None, dres, None, None, None, None
+        return dx, None, None, dres, None, None, None, None, None
 
 
 class _BatchNormBase(Layer):
@@ -266,7 +309,13 @@ class _BatchNormBase(Layer):
                                           'the MoCo hot path (key encoder runs under no_grad)')
             scale, shift = self.infer_affine()
             return ops.bn_apply(y, scale, shift, residual, relu)
-        return _BNActFn.apply(y, self.weight, self.bias, residual, self, relu, stats, res_slot)
+        # the output carries a BNLink so that a sole-consumer conv can take over the backward reduction
+        box = [None] if (torch.is_grad_enabled() and y.dtype == torch.bfloat16 and
+                         config.fused_bn_backward()) else None
+        z = _BNActFn.apply(y, self.weight, self.bias, residual, self, relu, stats, res_slot, box)
+        if box is not None and box[0] is not None:
+            z._passl_bn_link = box[0]
+        return z
 
 
 class BatchNorm2D(_BatchNormBase):
@@ -604,27 +653,10 @@ def normalize(x, axis=1, epsilon=1e-12):
     return _L2NormFn.apply(x, epsilon)
 
 
-class _InfoNCEFn(Function):
-    """loss = mean_i CE([q_i.k_i | q_i.queue] / T, label 0); returns (loss[1], acc1[1], acc5[1])."""
-
-    @staticmethod
-    def forward(ctx, q, k, queue, T):
-        out, lse, _ = ops.infonce_fwd(q.contiguous(), k.contiguous(), queue, T, want_logits=False)
-        ctx.save_for_backward(q, k, queue, lse)
-        ctx.T = T
-        loss, acc1, acc5 = out[0:1], out[1:2], out[2:3]
-        ctx.mark_non_differentiable(acc1, acc5)
-        return loss, acc1, acc5
-
-    @staticmethod
-    def backward(ctx, gloss, _g1, _g5):
-        q, k, queue, lse = ctx.saved_tensors
-        dq = ops.infonce_bwd(q, k, queue, lse, gloss.contiguous().float(), ctx.T)
-        return dq, None, None, None
-
-
 def infonce(q, k, queue, T):
-    return _InfoNCEFn.apply(q, k, queue, float(T))
+    """Fused InfoNCE — lives in passl_amd/loss/moco.py (``passl.loss.moco``)."""
+    from ..loss.moco import info_nce
+    return info_nce(q, k, queue, T)
 
 
 # =============================================================================== arena

@@ -15,6 +15,28 @@ def _lib():
     return L.load()
 
 
+# ------------------------------------------------------------------ shared fp32 workspace
+class _Workspace:
+    """ONE grow-only fp32 scratch buffer per device for the fixed-order (atomic-free) reductions:
+    split-M weight-gradient slabs, InfoNCE dq slabs, column-sum partials.  Every user launches its
+    producer and its reduce kernel back to back on the current stream, so stream order makes sharing
+    safe; the buffer is never read across ops."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, n_floats, device):
+        key = (device.type, device.index)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < n_floats:
+            buf = torch.empty(max(int(n_floats), 16 << 20), dtype=torch.float32, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+workspace = _Workspace()
+
+
 # ------------------------------------------------------------------ convolution
 _desc_cache = {}
 
@@ -29,17 +51,24 @@ def _conv_struct(d: P.Desc):
               'a_sn', 'a_sh', 'a_sw', 'y_sn', 'y_sh', 'y_sw'):
         setattr(s, f, getattr(d, f))
     s.stats = None
-    s.stats_replicas = 0
+    s.stats_tiles = 0
     _desc_cache[key] = (d, s)
     return s
 
 
+def conv_tiles(d: P.Desc):
+    """Number of 128-row output tiles of a launch = slab rows of its fused statistics."""
+    return (d.N * d.OP * d.OQ + 127) // 128
+
+
 def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=False,
-               out_f32=False, stats=None):
+               out_f32=False, stats=None, bnb=None):
     """Launch one implicit-GEMM conv described by `d` (plan.Desc).  `a` activation tensor,
     `b` packed weights [NCOLS, R*S*C] (same dtype as a), `y` output tensor (written in place at
-    d.y_off with d's strides).  `stats`: zeroed fp32 [R, NCOLS, 2] accumulator of the fused
-    BatchNorm statistics (sum, sum of squares of the raw conv output), bf16 only."""
+    d.y_off with d's strides).  `stats`: fp32 slab from conv_stats_buffer (fused forward BatchNorm
+    statistics of the stored output, bf16 only).  `bnb`: dict(y, mask, mean, invstd, scale, shift,
+    relu, partial, tile_off) — BatchNorm-backward statistics fused into this data-gradient launch
+    (include/passl_hip.h: passl_conv_desc.bnb_*)."""
     s = _conv_struct(d)
     esz = 4 if out_f32 else y.element_size()
     s.a = L.ptr(a)
@@ -52,7 +81,20 @@ def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=F
     s.dtype = L.dt(a)
     s.out_f32 = 1 if out_f32 else 0
     s.stats = L.ptr(stats)
-    s.stats_replicas = stats.shape[0] if stats is not None else 0
+    s.stats_tiles = conv_tiles(d) if stats is not None else 0
+    if bnb is not None:
+        s.bnb_y = L.ptr(bnb['y']) + d.y_off * esz
+        # the bit mask is indexed like the dense tensor: shift it with the sub-lattice origin (y_off % 8 == 0)
+        mask = bnb.get('mask')
+        s.bnb_mask = (L.ptr(mask) + (d.y_off >> 3)) if mask is not None else None
+        s.bnb_mean, s.bnb_invstd = L.ptr(bnb['mean']), L.ptr(bnb['invstd'])
+        s.bnb_scale, s.bnb_shift = L.ptr(bnb.get('scale')), L.ptr(bnb.get('shift'))
+        s.bnb_partial = L.ptr(bnb['partial'])
+        s.bnb_relu, s.bnb_tile_off = int(bnb['relu']), int(bnb['tile_off'])
+    else:
+        s.bnb_y = s.bnb_mask = s.bnb_mean = s.bnb_invstd = s.bnb_scale = s.bnb_shift = None
+        s.bnb_partial = None
+        s.bnb_relu = s.bnb_tile_off = 0
     L.check(_lib().passl_hip_conv_igemm(C.byref(s), L.stream()), 'conv_igemm')
     return y
 
@@ -80,6 +122,11 @@ def conv_wgrad(d: P.Desc, a, dy, dw, splits=None):
     M = d.N * d.OP * d.OQ
     bkm = 64 if a.dtype == torch.bfloat16 else 32
     s.splits = splits or P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm)
+    # split-M partial tiles go to slabs of the shared workspace and are added in slice order
+    need = s.splits * d.NCOLS * d.R * d.S * d.C
+    ws = workspace.get(need, dw.device) if s.splits > 1 else None
+    s.ws = L.ptr(ws)
+    s.ws_floats = ws.numel() if ws is not None else 0
     L.check(_lib().passl_hip_conv_wgrad(C.byref(s), L.stream()), 'conv_wgrad')
     return dw
 
@@ -90,52 +137,19 @@ def _bn_blocks(M, Cch):
     return int(max(1, min(1024, -(-M // (16 * lanes)))))
 
 
-class _StatsPool:
-    """Bump allocator over ONE fp32 workspace for the conv epilogues' fused BN statistics.
-    `reset()` zeroes the part handed out so far with a single fill and rewinds; buffers are only
-    valid until the next reset on the same stream (a backbone forward resets once at its start:
-    every statistic is consumed by bn_finalize inside that forward)."""
-
-    def __init__(self):
-        self.buf = None
-        self.used = 0
-        self.dirty = 0
-
-    def reset(self):
-        if self.buf is not None and self.dirty:
-            self.buf[:self.dirty].zero_()
-        self.used = 0
-        self.dirty = 0
-
-    def take(self, n, device):
-        n = (n + 63) // 64 * 64
-        if self.buf is None or self.buf.device != device or self.used + n > self.buf.numel():
-            # grow: earlier views stay alive through their own storage
-            self.buf = torch.zeros(max(4 << 20, 2 * n), dtype=torch.float32, device=device)
-            self.used = self.dirty = 0
-        v = self.buf[self.used:self.used + n]
-        self.used += n
-        self.dirty = self.used
-        return v
-
-
-stats_pool = _StatsPool()
-
-
-def conv_stats_buffer(M, Cch, device, pooled=False):
-    """Zeroed accumulator for the conv epilogue's fused BN statistics: [R, C, 2] fp32, the R
-    replicas spread the atomics of the M/128 row tiles.  pooled: carve it from `stats_pool`."""
-    R = max(1, min(64, (M + 127) // 128 // 8))
-    if pooled:
-        return stats_pool.take(R * Cch * 2, device)[:R * Cch * 2].view(R, Cch, 2)
-    return torch.zeros(R, Cch, 2, dtype=torch.float32, device=device)
+def conv_stats_buffer(d: P.Desc, device):
+    """Slab for the conv epilogue's fused BN statistics of launch `d`: [tiles][C][2] shifted sums
+    followed by [tiles][C] shifts (include/passl_hip.h: passl_conv_desc.stats).  Fully written by the
+    kernel: no zeroing, no atomics.  Returns (tensor, tiles)."""
+    t = conv_tiles(d)
+    return torch.empty(t * d.NCOLS * 3, dtype=torch.float32, device=device), t
 
 
 def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum=0.9, eps=1e-5,
                  partial=None, want_mask=False):
     """x: [..., C] NHWC rows.  Returns z, stats[4,C] (mean, invstd, scale, shift), relu bit mask
-    (or None); updates rmean/rvar in place.  `partial` = the fused statistics a conv epilogue
-    already accumulated ([R, C, 2]); without it a stats pass over x is launched."""
+    (or None); updates rmean/rvar in place.  `partial` = (slab, tiles) of fused statistics a conv
+    epilogue already wrote (conv_stats_buffer); without it a stats pass over x is launched."""
     Cch = x.shape[-1]
     M = x.numel() // Cch
     dev = x.device
@@ -143,11 +157,14 @@ def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum
     lib, st, dtc = _lib(), L.stream(), L.dt(x)
     if partial is None:
         nb = _bn_blocks(M, Cch)
-        partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
+        rpb = -(-M // nb)
+        nb = -(-M // rpb)                   # every slab holds rows
+        partial = torch.empty(nb * Cch * 3, dtype=torch.float32, device=dev)
         L.check(lib.passl_hip_bn_stats(L.ptr(x), L.ptr(partial), M, Cch, nb, dtc, st), 'bn_stats')
     else:
-        nb = partial.shape[0]
-    L.check(lib.passl_hip_bn_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(beta),
+        partial, nb = partial
+        rpb = 128
+    L.check(lib.passl_hip_bn_finalize(L.ptr(partial), nb, M, Cch, rpb, L.ptr(gamma), L.ptr(beta),
                                       L.ptr(rmean), L.ptr(rvar), momentum, eps,
                                       L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
                                       L.ptr(stats[3]), st), 'bn_finalize')
@@ -172,29 +189,39 @@ def bn_apply(x, scale, shift, residual=None, relu=False):
 
 
 def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=False,
-           scale=None, shift=None):
+           scale=None, shift=None, fused=None):
     """Returns dx (and dres).  dgamma/dbeta (fp32 [C]) are accumulated into.
     `relu`: False/0 none, True/1 mask = z > 0, 2 mask recomputed from x*scale+shift (z unused),
-    3 `z` is the bit mask written by the forward's bn_apply."""
+    3 `z` is the bit mask written by the forward's bn_apply.
+    `fused` = (slab, tiles): the data-gradient launch that produced `dz` already masked it and wrote
+    the (sum g, sum g*xhat) slab (conv_igemm(bnb=...)): no reduce pass, no mask in the apply pass,
+    and the residual-branch gradient IS dz (returned as dres without a copy)."""
     Cch = x.shape[-1]
     M = x.numel() // Cch
-    nb = _bn_blocks(M, Cch)
     dev = x.device
-    partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
     coef = torch.empty(3 * Cch, dtype=torch.float32, device=dev)
     lib, st, dtc = _lib(), L.stream(), L.dt(x)
     r = int(relu)
     zp = L.ptr(z) if r in (1, 3) else None
-    L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), zp, L.ptr(x), L.ptr(mean), L.ptr(invstd),
-                                        L.ptr(scale), L.ptr(shift), L.ptr(partial), M, Cch, nb, r,
-                                        dtc, st), 'bn_bwd_reduce')
+    if fused is not None:
+        partial, nb = fused
+        r, zp = 0, None
+    else:
+        nb = _bn_blocks(M, Cch)
+        partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
+        L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), zp, L.ptr(x), L.ptr(mean), L.ptr(invstd),
+                                            L.ptr(scale), L.ptr(shift), L.ptr(partial), M, Cch, nb, r,
+                                            dtc, st), 'bn_bwd_reduce')
     L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(mean),
                                           L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
                                           st), 'bn_bwd_finalize')
     dx = torch.empty_like(x)
-    dres = torch.empty_like(x) if want_dres else None
+    if fused is not None:
+        dres_out, dres = None, (dz if want_dres else None)
+    else:
+        dres_out = dres = torch.empty_like(x) if want_dres else None
     L.check(lib.passl_hip_bn_bwd_apply(L.ptr(dz), zp, L.ptr(x), L.ptr(coef), L.ptr(scale),
-                                       L.ptr(shift), L.ptr(dx), L.ptr(dres), M, Cch, r, dtc, st),
+                                       L.ptr(shift), L.ptr(dx), L.ptr(dres_out), M, Cch, r, dtc, st),
             'bn_bwd_apply')
     return dx, dres
 
@@ -253,7 +280,8 @@ def colsum_into(x, out, accumulate=False):
     """out[C] (fp32) = (accumulate: +=) column sums of x [M, C]."""
     M, Cc = x.shape
     fn = _lib().passl_hip_colsum_acc if accumulate else _lib().passl_hip_colsum
-    L.check(fn(L.ptr(x), L.ptr(out), M, Cc, L.dt(x), L.stream()), 'colsum')
+    ws = workspace.get(1024 * Cc, x.device)
+    L.check(fn(L.ptr(x), L.ptr(out), M, Cc, L.dt(x), L.ptr(ws), ws.numel(), L.stream()), 'colsum')
     return out
 
 
@@ -294,9 +322,11 @@ def infonce_fwd(q, k, queue, T, want_logits=False):
 def infonce_bwd(q, k, queue, lse, gscale, T):
     N, Dd = q.shape
     K = queue.shape[1]
-    dq = torch.zeros_like(q)
-    L.check(_lib().passl_hip_infonce_bwd(L.ptr(q), L.ptr(k), L.ptr(queue), L.ptr(lse),
-                                         L.ptr(gscale), N, Dd, K, T, L.ptr(dq), L.stream()),
+    dq = torch.empty_like(q)
+    lib = _lib()
+    ws = workspace.get(lib.passl_hip_infonce_bwd_workspace_bytes(N, K) // 4, q.device)
+    L.check(lib.passl_hip_infonce_bwd(L.ptr(q), L.ptr(k), L.ptr(queue), L.ptr(lse),
+                                      L.ptr(gscale), N, Dd, K, T, L.ptr(dq), L.ptr(ws), L.stream()),
             'infonce_bwd')
     return dq
 

@@ -170,19 +170,7 @@ class _UnshuffleFn(Function):
         return dx, None, None, None, None, None
 
 
-class _MAELossFn(Function):
-    @staticmethod
-    def forward(ctx, pred, imgs, mask, p, norm_pix, denom):
-        ctx.save_for_backward(pred, imgs, mask)
-        ctx.args = (p, norm_pix, denom)
-        return ops.mae_loss_fwd(imgs, pred, mask, p, norm_pix, denom)
-
-    @staticmethod
-    def backward(ctx, gloss):
-        pred, imgs, mask = ctx.saved_tensors
-        p, norm_pix, denom = ctx.args
-        return ops.mae_loss_bwd(imgs, pred, mask, gloss.contiguous().float(), p, norm_pix, denom), None, \
-            None, None, None, None
+from ...loss.mae import masked_patch_loss      # the fused loss lives in passl.loss.mae
 
 
 @BACKBONES.register()
@@ -273,8 +261,7 @@ class MAE(nn.Layer):
 
     def forward_loss(self, imgs, pred_rows, mask):
         denom = float(mask.shape[0] * (mask.shape[1] - int(self._len_keep)))
-        return _MAELossFn.apply(pred_rows, imgs.contiguous().float(), mask, self.patch_embed.patch_size[0],
-                                bool(self.norm_pix_loss), denom)
+        return masked_patch_loss(pred_rows, imgs, mask, self.patch_embed.patch_size[0], self.norm_pix_loss, denom)
 
     def forward(self, imgs, mask_ratio=0.75, noise=None):
         B = imgs.shape[0]

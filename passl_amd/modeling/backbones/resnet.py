@@ -49,11 +49,15 @@ class BottleneckBlock(nn.Layer):
         if config.fuse_residual_grad() and torch.is_grad_enabled() and x.requires_grad:
             slot = nn.GradSlot()
             slot.arm()
-        out, st = self.conv1(x, want_stats=True, add_slot=slot)
+        # conv1's data-gradient launch yields the COMPLETE gradient of x only when the identity /
+        # downsample branch is folded in through the slot: then it may also do the backward reduction
+        # of the BatchNorm that produced x (nn.BNLink); conv2 / conv3 are sole consumers of bn1 / bn2
+        out, st = self.conv1(x, want_stats=True, add_slot=slot,
+                             producer=nn.bn_link(x) if slot is not None else None)
         out = self.bn1(out, relu=True, stats=st)
-        out, st = self.conv2(out, want_stats=True)
+        out, st = self.conv2(out, want_stats=True, producer=nn.bn_link(out))
         out = self.bn2(out, relu=True, stats=st)
-        out, st3 = self.conv3(out, want_stats=True)
+        out, st3 = self.conv3(out, want_stats=True, producer=nn.bn_link(out))
         if self.downsample is not None:
             idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
             identity = self.downsample[1](idn, relu=False, stats=st)
@@ -174,7 +178,6 @@ class ResNet(nn.Layer):
                     for blk in stage:
                         y = blk.forward_frozen(y)
         else:
-            ops.stats_pool.reset()        # one fill for all fused-BN accumulators of this pass
             y, st = self.conv1(xp, hw=(H, W), want_stats=True)
             y = self.bn1(y, relu=True, stats=st)
             if self.stem_pool:

@@ -7,57 +7,11 @@ the default reproduces it exactly.  ``multi_rank=True`` here enables the cross-G
 BASELINE configs[2] (an extension, defined as in passl/models/mocov3.py:187-198: all-gather the
 embeddings, positives offset by rank*N; the gradient of the gathered copies is reduce-scattered
 back)."""
-import torch
-import torch.distributed as dist
-from torch.autograd import Function
-
-from ...core.sync_utils import collectives_active
-from ...hip import nn, ops
+from ...hip import nn
 from .builder import HEADS
 
 
-def _world():
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-
-
-class _NTXentFn(Function):
-    @staticmethod
-    def forward(ctx, h1, h2, T, co2_weight, gather):
-        h1, h2 = h1.contiguous(), h2.contiguous()
-        B = h1.shape[0]
-        coll = bool(gather) and collectives_active()
-        ws = _world() if coll else 1
-        if coll:
-            a_all = torch.empty(ws * B, h1.shape[1], dtype=h1.dtype, device=h1.device)
-            b_all = torch.empty_like(a_all)
-            dist.all_gather_into_tensor(a_all, h1)
-            dist.all_gather_into_tensor(b_all, h2)
-            roff = dist.get_rank() * B
-        else:
-            a_all, b_all, roff = h1, h2, 0
-        out, rowstats = ops.ntxent_fwd(h1, h2, a_all, b_all, roff, T, co2_weight)
-        ctx.save_for_backward(h1, h2, a_all, b_all, rowstats)
-        ctx.T, ctx.w, ctx.roff, ctx.ws, ctx.coll = T, co2_weight, roff, ws, coll
-        loss, acc1 = out[0:1], out[1:2]
-        ctx.mark_non_differentiable(acc1)
-        return loss, acc1
-
-    @staticmethod
-    def backward(ctx, gloss, _gacc):
-        h1, h2, a_all, b_all, rowstats = ctx.saved_tensors
-        da, db, dA, dB = ops.ntxent_bwd(h1, h2, a_all, b_all, rowstats, gloss.contiguous().float(),
-                                        ctx.roff, ctx.T, ctx.w)
-        B = h1.shape[0]
-        if ctx.coll:
-            ra, rb = torch.empty_like(da), torch.empty_like(db)
-            dist.reduce_scatter_tensor(ra, dA)
-            dist.reduce_scatter_tensor(rb, dB)
-            da += ra
-            db += rb
-        else:
-            da += dA[ctx.roff:ctx.roff + B]
-            db += dB[ctx.roff:ctx.roff + B]
-        return da, db, None, None, None
+from ...loss.nt_xent import _NTXentFn     # the fused loss lives in passl.loss.nt_xent
 
 
 @HEADS.register()

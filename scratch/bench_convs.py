@@ -47,7 +47,7 @@ for cin, cout, k, stv, pad, H, cnt in SHAPES:
     dw = torch.zeros(cout, k * k * cin, device=DEV)
     fl = 2.0 * N * fd.OP * fd.OQ * cout * k * k * cin
     t_f = timeit(lambda: ops.conv_igemm(fd, x, packer.view(fd.pack, cout), y))
-    st = ops.conv_stats_buffer(N * fd.OP * fd.OQ, cout, DEV)
+    st, _tiles = ops.conv_stats_buffer(fd, DEV)
     t_fs = timeit(lambda: ops.conv_igemm(fd, x, packer.view(fd.pack, cout), y, stats=st)) if dtype == torch.bfloat16 else 0
     def dg():
         for d in dds: ops.conv_igemm(d, dy, packer.view(d.pack, cin), dx)
@@ -56,7 +56,7 @@ for cin, cout, k, stv, pad, H, cnt in SHAPES:
     for nm, t in (('fwd', t_f), ('dgrad', t_d), ('wgrad', t_w)):
         tot[nm][0] += t * cnt; tot[nm][1] += fl * cnt
     tot.setdefault('fwd+stats', [0, 0]); tot['fwd+stats'][0] += t_fs * cnt; tot['fwd+stats'][1] += fl * cnt
-    print('%4d->%4d k%d s%d @%3d x%d       %8.2f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f | stats %8.1f R=%d' % (
-        cin, cout, k, stv, H, cnt, fl / 1e9, t_f * 1e3, fl / t_f / 1e9, t_d * 1e3, fl / t_d / 1e9, t_w * 1e3, fl / t_w / 1e9, t_fs * 1e3, st.shape[0]))
+    print('%4d->%4d k%d s%d @%3d x%d       %8.2f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f | stats %8.1f tiles=%d' % (
+        cin, cout, k, stv, H, cnt, fl / 1e9, t_f * 1e3, fl / t_f / 1e9, t_d * 1e3, fl / t_d / 1e9, t_w * 1e3, fl / t_w / 1e9, t_fs * 1e3, _tiles))
 for nm in tot:
     print('%s total: %.2f ms per pass, %.1f TF avg' % (nm, tot[nm][0], tot[nm][1] / tot[nm][0] / 1e9))

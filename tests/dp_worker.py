@@ -40,6 +40,31 @@ OVERRIDES = {
 }
 
 
+def three_steps(tr):
+    from passl_amd.hooks import OptimizerHook, LRSchedulerHook
+    opt_hook = next(h for h in tr.hooks if isinstance(h, OptimizerHook))
+    lr_hook = next(h for h in tr.hooks if isinstance(h, LRSchedulerHook))
+    data = next(iter(tr.train_dataloader))
+    losses = []
+    for _ in range(3):
+        tr.current_iter += 1
+        tr.outputs = tr.model(*data, total_iters=tr.total_iters, current_iter=tr.current_iter, mixup_fn=None)
+        opt_hook.train_iter_end(tr)
+        lr_hook.train_iter_end(tr)
+        losses.append(tr.outputs['loss'].detach().clone())
+    torch.cuda.synchronize()
+    return [float(l) for l in losses]
+
+
+def plain_run(tr, workload):
+    tr.mode = 'train'
+    tr.model.train()
+    losses = three_steps(tr)
+    p1 = torch.cat([p.detach().reshape(-1).double() for p in tr.model.parameters()])
+    print('DP-OK %s %.6f digest=%.17g losses=%s' % (workload, losses[-1], float(p1.sum()),
+                                                   ','.join('%.9g' % l for l in losses)), flush=True)
+
+
 def main():
     workload = sys.argv[1]
     from passl_amd.engine.trainer import Trainer
@@ -57,6 +82,10 @@ def main():
     cfg.timestamp = ''
     tr = Trainer(cfg)
     forced = os.environ.get('PASSL_DP_FORCE') == '1'
+    plain = 'WORLD_SIZE' not in os.environ          # reference arm: no process group, no collectives
+    if plain:
+        assert tr.world_size == 1 and tr.grad_reducer is None and not dist.is_initialized()
+        return plain_run(tr, workload)
     assert tr.world_size == int(os.environ['WORLD_SIZE']) and tr.grad_reducer is not None
     assert tr.world_size > 1 or forced
     if os.environ.get('PASSL_EXPECT_BACKEND'):
@@ -83,13 +112,8 @@ def main():
 
     same_everywhere(flat_params(), 'initial parameters')
     p0 = flat_params()
-    for _ in range(3):
-        tr.current_iter += 1
-        tr.outputs = tr.model(*data, total_iters=tr.total_iters, current_iter=tr.current_iter, mixup_fn=None)
-        opt_hook.train_iter_end(tr)
-        lr_hook.train_iter_end(tr)
-    torch.cuda.synchronize()
-    loss = float(tr.outputs['loss'].detach())
+    losses = three_steps(tr)
+    loss = losses[-1]
     assert loss == loss and abs(loss) < 1e4, loss
     p1 = flat_params()
     assert float((p1 - p0).abs().max()) > 0, 'parameters did not move'
@@ -101,7 +125,8 @@ def main():
     dist.barrier()
     if tr.rank == 0:
         # digest of the final parameters: the world-1 RCCL run must equal the collective-free run
-        print('DP-OK %s %.6f digest=%.17g' % (workload, loss, float(p1.sum())), flush=True)
+        print('DP-OK %s %.6f digest=%.17g losses=%s' % (workload, loss, float(p1.sum()),
+                                                       ','.join('%.9g' % l for l in losses)), flush=True)
     dist.destroy_process_group()
 
 

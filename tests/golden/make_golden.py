@@ -34,6 +34,9 @@ CASES = {
     'moco_v2_r50_small': dict(N=8, hw=64, K=1024, steps=3),
     # configs/moco/moco_v1_r50.yaml: LinearNeck, T = 0.07, lr 0.03 MultiStepDecay
     'moco_v1_r50_small': dict(N=8, hw=64, K=1024, steps=3, v1=True),
+    # BASELINE.json configs[1] (the benchmarked shape): bs=256, 2x224^2, K=65536; ONE step of the
+    # reference (a float64 re-evaluation at this size does not fit the build container's memory)
+    'moco_v2_r50_cfg2': dict(N=256, hw=224, K=65536, steps=1, f64=False),
 }
 V1 = dict(neck='LinearNeck', T=0.07, lr=0.03, milestones=[120 * 5004, 160 * 5004])
 WATCH = ['0.conv1.weight', '0.layer1.0.conv2.weight', '0.layer2.0.downsample.0.weight',
@@ -49,7 +52,7 @@ def views(gen, N, hw):
     return xq, xk
 
 
-def run_case(name, N, hw, K, steps, v1=False):
+def run_case(name, N, hw, K, steps, v1=False, f64=True):
     torch.manual_seed(0)
     okw = dict(V1) if v1 else {}
     watch = [n for n in WATCH if not n.startswith('1.')] + (['1.fc.weight', '1.fc.bias'] if v1 else
@@ -106,13 +109,18 @@ def run_case(name, N, hw, K, steps, v1=False):
     # R50 with batch-stat BN is ill-conditioned: fp32 and fp64 evaluations of the SAME algorithm
     # drift apart after the first update, so the tests bound |HIP - ref32| by a small multiple
     # of |ref32 - ref64| where that exceeds the nominal 1e-3.
-    o64 = MoCoOracle(K=K, seed=0, t_max=200 * 5004, **okw)
+    del model, res, grads
+    if not f64:
+        steps_f64 = 0
+    else:
+        steps_f64 = steps
+    o64 = MoCoOracle(K=K if f64 else 128, seed=0, t_max=200 * 5004, **okw)
     for d in (o64.q, o64.k):
         for n in d:
             d[n] = d[n].double()
     o64.queue = o64.queue.double()
     gen = torch.Generator().manual_seed(1234)
-    for s in range(steps):
+    for s in range(steps_f64):
         xq, xk = views(gen, N, hw)
         ptr0 = o64.queue_ptr
         r = o64.train_step(xq.double(), xk.double())
@@ -128,12 +136,76 @@ def run_case(name, N, hw, K, steps, v1=False):
             out[pre + 'qstat/' + n] = o64.q[n][:8].numpy().copy()
             out[pre + 'kstat/' + n] = o64.k[n][:8].numpy().copy()
         print(name, 'f64 step', s, 'loss %.6f' % out[pre + 'loss'])
+    del o64
+    if not v1:
+        out.update(bf16_steps(N, hw, K, steps, watch))
     out['meta'] = np.array([N, hw, K, steps], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
+def bf16_steps(N, hw, K, steps, watch):
+    """The same steps in the oracle's bf16-EMULATING mode (oracle/bf16.py): the reference's fp32
+    algorithm with round-to-nearest-even bfloat16 at the tensors the MI355X path stores in bf16.  The
+    reference has no bf16 MoCo path; these `s<k>_bf16_*` entries are what the product's bf16 mode is
+    held to (a tight bound) next to the fp32 reference values above (a loose sanity bound)."""
+    out = {}
+    # variant 'bf16': fp32 accumulation; 'bf16b': float64 accumulation of the same bf16 products — a second
+    # VALID evaluation of the same contract (only the FIRST step: it measures how ill-conditioned the
+    # step is with respect to summation order; the tests scale their bounds with |bf16 - bf16b|)
+    from oracle import resnet50 as R50
+    for tag, acc64, nsteps in (('bf16', False, steps), ('bf16b', True, 1)):
+        R50.ACCUM64 = acc64
+        try:
+            out.update(_bf16_variant(tag, N, hw, K, nsteps, watch))
+        finally:
+            R50.ACCUM64 = False
+    return out
+
+
+def _bf16_variant(tag, N, hw, K, steps, watch):
+    out = {}
+    ob = MoCoOracle(K=K, seed=0, t_max=200 * 5004, bf16=True)
+    gen = torch.Generator().manual_seed(1234)
+    for s in range(steps):
+        xq, xk = views(gen, N, hw)
+        ptr0 = ob.queue_ptr
+        r = ob.train_step(xq, xk)
+        pre = 's%d_%s_' % (s, tag)
+        out[pre + 'loss'] = np.float64(float(r['loss']))
+        out[pre + 'acc1'] = np.float64(float(r['acc1']))
+        out[pre + 'acc5'] = np.float64(float(r['acc5']))
+        out[pre + 'logits_head'] = r['logits'][:, :8].numpy().copy()
+        out[pre + 'logits_rowlse64'] = torch.logsumexp(r['logits'].double(), dim=1).numpy()
+        out[pre + 'queue_new'] = ob.queue[:, ptr0:ptr0 + N].numpy().copy()
+        for n in watch:
+            out[pre + 'gradnorm/' + n] = np.float64(r['grads'][n].double().norm().item())
+            out[pre + 'qnorm/' + n] = np.float64(ob.q[n].double().norm().item())
+            out[pre + 'knorm/' + n] = np.float64(ob.k[n].double().norm().item())
+        for n in WATCH_STATS:
+            out[pre + 'qstat/' + n] = ob.q[n][:8].numpy().astype(np.float64)
+            out[pre + 'kstat/' + n] = ob.k[n][:8].numpy().astype(np.float64)
+        print(tag, 'emulated step', s, 'loss %.6f' % out[pre + 'loss'], flush=True)
+        del r
+    return out
+
+
+def add_bf16(name, N, hw, K, steps, v1=False, f64=True):
+    """Add the bf16-emulated entries to an existing golden file without re-running the reference."""
+    path = os.path.join(HERE, name + '.npz')
+    z = dict(np.load(path))
+    z.update(bf16_steps(N, hw, K, steps, WATCH))
+    np.savez_compressed(path, **z)
+
+
 if __name__ == '__main__':
+    # python make_golden.py [case ...]            run the reference (+ f64 + bf16-emulated oracle)
+    # python make_golden.py --add-bf16 [case ...]  only (re)compute the bf16-emulated entries
+    args = sys.argv[1:]
+    if args and args[0] == '--add-bf16':
+        for name in (args[1:] or [n for n in CASES if not CASES[n].get('v1')]):
+            add_bf16(name, **CASES[name])
+        sys.exit(0)
     assert ref_runner.available(), 'needs /root/reference'
-    which = sys.argv[1:] or list(CASES)
+    which = args or list(CASES)
     for name in which:
         run_case(name, **CASES[name])

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.passl_hip_abi_version() == 5
+    assert lib.passl_hip_abi_version() == 6
     assert b'invalid' in lib.passl_hip_strerror(-1)
     assert lib.passl_hip_strerror(0) == b'ok'
 
@@ -65,7 +65,8 @@ def test_argument_errors_are_reported_without_a_gpu(lib):
     assert lib.passl_hip_conv_igemm(ctypes.byref(d), None) == -1
     w = L.WgradDesc()
     assert lib.passl_hip_conv_wgrad(ctypes.byref(w), None) == -1
-    assert lib.passl_hip_infonce_workspace_bytes(256, 65536) == 512 * 256 * 16
+    assert lib.passl_hip_infonce_workspace_bytes(256, 65536) == (512 + 1) * 256 * 16
+    assert lib.passl_hip_infonce_bwd_workspace_bytes(256, 65536) == (512 + 1) * 256 * 128 * 4
 
 
 def test_host_tensors_are_refused():
@@ -80,7 +81,8 @@ def test_every_entry_point_rejects_null_arguments(lib):
     arguments yield an error status (never a crash, never a launch) — checked without a GPU."""
     import ctypes as C
     skip = {'passl_hip_abi_version', 'passl_hip_strerror', 'passl_hip_set_option', 'passl_hip_prof_enable',
-            'passl_hip_infonce_workspace_bytes', 'passl_hip_clip_logits_ws_floats'}
+            'passl_hip_infonce_workspace_bytes', 'passl_hip_infonce_bwd_workspace_bytes',
+            'passl_hip_clip_logits_ws_floats'}
     checked = 0
     for name, (res, args) in sorted(L.SIGNATURES.items()):
         if name in skip:

@@ -53,7 +53,9 @@ def test_rccl_world1(workload):
     rccl = _run_worker(workload, 1, dict(PASSL_DP_FORCE='1', PASSL_EXPECT_BACKEND='nccl'))
     gloo = _run_worker(workload, 1, dict(PASSL_DP_FORCE='1', PASSL_DIST_BACKEND='gloo',
                                          PASSL_EXPECT_BACKEND='gloo'))
-    assert rccl.split('digest=')[1] == gloo.split('digest=')[1], (rccl, gloo)
+    plain = _run_worker(workload, 1, {}, launcher=False)        # no process group at all
+    assert rccl.split('digest=')[1] == plain.split('digest=')[1], (rccl, plain)
+    assert gloo.split('digest=')[1] == plain.split('digest=')[1], (gloo, plain)
 
 
 def test_bench_self_launch_gpus1_and_world1_launcher():

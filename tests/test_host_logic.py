@@ -229,7 +229,8 @@ def test_v2_train_one_step_facade():
     batch = [[torch.randn(4, 3, 8, 8), torch.randn(4, 3, 8, 8)], torch.zeros(4)]
     w0 = model.fc.weight.detach().clone()
     out, loss_dict = loop.train_one_step(batch)
-    assert out is None and 'loss' in loss_dict and loop.global_step == 1
+    assert out is None and 'loss' in loss_dict
+    assert loop.global_step == 0          # advanced by train_one_epoch (loop.py:282), not by the step itself
     assert not torch.equal(w0, model.fc.weight) and sched.last_epoch == 1
 
 
@@ -526,3 +527,83 @@ def test_reference_moco_v1_config_loads_and_builds_unchanged():
     assert abs(sched.get_lr() - 0.003) < 1e-12
     opt = build_optimizer(cfg.optimizer, sched, [model])
     assert opt.type == 'momentum' and opt._wd == 1e-4
+
+
+# ------------------------------------------------------------------ `passl` import name + v2 façade
+def test_passl_alias_resolves_reference_imports():
+    """tools_v110/train.py:22-25 style imports bind, and they are the SAME module objects as passl_amd's
+    (one set of registries)."""
+    from passl.utils.options import parse_args          # noqa: F401
+    from passl.utils.config import get_config as gc2
+    from passl.utils.setup import setup                  # noqa: F401
+    from passl.engine.trainer import Trainer as T2
+    import passl.modeling.architectures.builder as b1
+    import passl_amd.modeling.architectures.builder as b2
+    from passl_amd.engine.trainer import Trainer as T1
+    assert T1 is T2 and gc2 is get_config and b1.MODELS is b2.MODELS
+    # v2 surface + the loss homes named by BASELINE.json north_star
+    from passl.models import build_model, Model          # noqa: F401
+    from passl.engine.engine import Engine               # noqa: F401
+    from passl.engine.loops import ContrastiveLearningTrainingEpochLoop, TrainingEpochLoop
+    assert issubclass(ContrastiveLearningTrainingEpochLoop, TrainingEpochLoop)
+    from passl.core import grad_sync, param_sync         # noqa: F401
+    import passl.loss.moco, passl.loss.nt_xent, passl.loss.mae
+    assert callable(passl.loss.moco.info_nce) and callable(passl.loss.nt_xent.nt_xent)
+    assert callable(passl.loss.mae.masked_patch_loss)
+    with pytest.raises(ImportError):
+        import passl.no_such_module                       # noqa: F401
+    # the heads call into the loss homes
+    from passl_amd.modeling.heads import simclr_contrastive_head as h
+    assert h._NTXentFn is passl.loss.nt_xent._NTXentFn
+
+
+def test_v2_engine_runs_the_named_loop(tmp_path):
+    """Engine(config).train(): v2 schema -> model via passl.models.build_model -> loop resolved by name
+    -> run / train_one_epoch / train_one_step with accumulation, lr stepping and max_train_step."""
+    _register_dummies()
+    import passl_amd.models as M
+    from passl_amd.engine.engine import Engine
+    from passl_amd.modeling.architectures.builder import MODELS
+
+    class DummyV2(M.Model):
+        def __init__(self, dim=4):
+            super().__init__()
+            self.inner = MODELS.get('DummySSL')(dim)
+            self.saved = []
+
+        def forward(self, inputs):
+            return self.inner(*inputs)
+
+        def save(self, path, local_rank=0, rank=0):
+            self.saved.append(path)
+    M.dummy_v2 = lambda **kw: DummyV2(**kw)
+    try:
+        cfg = get_config(os.path.join(ROOT, 'configs/v2/moco_v2_resnet50_pt_synthetic.yaml'),
+                         ['Global.device=cpu', 'Global.epochs=2', 'Global.accum_steps=2', 'Global.save_interval=1',
+                          'Global.print_batch_step=1', 'Global.output_dir=%s' % tmp_path,
+                          'DataLoader.Train.sampler.batch_size=4', 'DataLoader.Train.dataset.num_samples=12',
+                          'DataLoader.Train.dataset.image_size=8'])
+        cfg.Model = AttrDict(name='dummy_v2', dim=4)
+        cfg.Optimizer = AttrDict(name='PlainSGD')
+        eng = Engine(cfg, mode='train')
+        eng.optimizer._parameter_list = eng.optimizer.params
+        assert eng.accum_steps == 2 and eng.lr_decay_unit == 'step' and eng.grad_reducer is None
+        assert type(eng.train_loop).__name__ == 'ContrastiveLearningTrainingEpochLoop'
+        assert eng.lr_scheduler.T_max == 2 * 3            # decays over epochs x iterations
+        w0 = eng.model.inner.fc.weight.detach().clone()
+        eng.train()
+        assert eng.global_step == 6 and eng.cur_epoch_id == 2 and eng.lr_scheduler.last_epoch == 6
+        assert not torch.equal(w0, eng.model.inner.fc.weight)
+        assert len(eng.model.saved) == 2                  # save_interval 1 -> one file per epoch
+        # each optimizer step saw accum_steps micro-batches of 2 samples
+        assert len(eng.model.inner.calls) == 12
+        # max_train_step ends the run early
+        cfg.Global.max_train_step = 4
+        eng2 = Engine(cfg, mode='train')
+        eng2.optimizer._parameter_list = eng2.optimizer.params
+        eng2.train()
+        assert eng2.global_step == 4
+        with pytest.raises(AttributeError):
+            M.build_model(dict(name='no_such_model'))
+    finally:
+        del M.dummy_v2

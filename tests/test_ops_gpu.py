@@ -157,17 +157,35 @@ def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
     ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo)
     assert relmax(yo.float(), nhwc(y.detach())) < tol(dtype)
     if dtype == torch.bfloat16:
-        # fused BatchNorm statistics of the conv epilogue: per-channel (sum, sum of squares) of the
-        # fp32 accumulators, spread over R replicas; same output as without statistics
-        for R in (1, 3):
-            st = torch.zeros(R, geom.cout, 2, dtype=torch.float32, device=DEV)
-            yo2 = torch.empty_like(yo)
-            ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo2, stats=st)
-            assert torch.equal(yo2, yo)
-            y64 = yo.double().cpu().reshape(-1, geom.cout)       # statistics of the STORED values
-            tot = st.sum(0).double().cpu()
-            assert relmax(tot[:, 0], y64.sum(0)) < 1e-5 * max(1.0, float(y64.abs().sum(0).max() / y64.sum(0).abs().max()))
-            assert relmax(tot[:, 1], (y64 * y64).sum(0)) < 1e-5
+        # fused BatchNorm statistics of the conv epilogue: per 128-row tile t the SHIFTED sums
+        # (sum (v - s), sum (v - s)^2) of the STORED values, s = the tile's first row; plain stores into
+        # a slab (no atomics, no zeroing) -> bit-identical run to run; same output as without statistics
+        st, tiles = ops.conv_stats_buffer(fd, DEV)
+        st.fill_(float('nan'))
+        yo2 = torch.empty_like(yo)
+        ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo2, stats=st)
+        assert torch.equal(yo2, yo)
+        assert not torch.isnan(st).any()
+        y64 = yo.double().cpu().reshape(-1, geom.cout)
+        M = y64.shape[0]
+        sums = st[:tiles * geom.cout * 2].view(tiles, geom.cout, 2).double().cpu()
+        shifts = st[tiles * geom.cout * 2:].view(tiles, geom.cout).double().cpu()
+        for t in range(tiles):
+            rows = y64[t * 128:min((t + 1) * 128, M)]
+            assert torch.equal(shifts[t], rows[0])
+            d = rows - rows[0]
+            assert (sums[t, :, 0] - d.sum(0)).abs().max() <= 1e-5 * max(1.0, float(d.abs().sum(0).max()))
+            assert (sums[t, :, 1] - (d * d).sum(0)).abs().max() <= 1e-5 * max(1.0, float((d * d).sum(0).max()))
+        st_b = torch.empty_like(st)
+        ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo2, stats=st_b)
+        assert torch.equal(st_b, st)                   # reproducible
+        # ... and the finalize kernel turns the slab into the statistics of the stored values
+        ga, be = torch.ones(geom.cout, device=DEV), torch.zeros(geom.cout, device=DEV)
+        rm, rv = torch.zeros(geom.cout, device=DEV), torch.ones(geom.cout, device=DEV)
+        _z, st4, _m = ops.bn_train_fwd(yo, ga, be, rm, rv, relu=False, partial=(st, tiles))
+        mu, var = y64.mean(0), y64.var(0, unbiased=False)
+        assert (st4[0].double().cpu() - mu).abs().max() < 1e-5 * max(1.0, float(mu.abs().max()))
+        assert relmax(st4[1], 1 / torch.sqrt(var + 1e-5)) < 1e-5
     # dgrad
     dya = nhwc(dy).to(DEV).to(dtype)
     dx = torch.full((N, H, W, geom.cin), float('nan'), dtype=dtype, device=DEV)
@@ -190,6 +208,13 @@ def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
         ops.conv_wgrad(P.wgrad_desc(geom, N, H, W), xa, dya.view(-1, geom.cout), dw, splits)
         ref = w.grad.permute(0, 2, 3, 1).reshape(geom.cout, -1)
         assert relmax(dw, ref) < (1e-4 if dtype == torch.float32 else 2e-3), splits
+        # split-M partial tiles are summed in slice order (workspace slabs): reproducible bit for bit,
+        # and the launch ACCUMULATES into dw
+        dw2 = torch.zeros_like(dw)
+        ops.conv_wgrad(P.wgrad_desc(geom, N, H, W), xa, dya.view(-1, geom.cout), dw2, splits)
+        assert torch.equal(dw2, dw), splits
+        ops.conv_wgrad(P.wgrad_desc(geom, N, H, W), xa, dya.view(-1, geom.cout), dw2, splits)
+        assert relmax(dw2, 2 * ref) < (1e-4 if dtype == torch.float32 else 2e-3), splits
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -332,6 +357,89 @@ def test_bn_fwd_bwd(dtype, shape, with_res):
             assert torch.equal(dres2, dres)
 
 
+@pytest.mark.parametrize('mode', [2, 3])
+@pytest.mark.parametrize('geom,nhw', [
+    (P.ConvGeom(64, 256, 1, 1, 0), (2, 28, 28)),      # conv3-style 1x1: dgrad is a dense 1x1
+    (P.ConvGeom(64, 64, 3, 1, 1), (3, 14, 14)),       # conv2 stride 1: one flipped-filter launch
+    (P.ConvGeom(128, 128, 3, 2, 1), (3, 28, 28)),     # conv2 stride 2: four residue-class launches
+    (P.ConvGeom(512, 128, 1, 1, 0), (2, 7, 7)),       # ring kernel, ragged M tile (M = 98)
+])
+def test_dgrad_fused_bn_backward(geom, nhw, mode):
+    """BatchNorm-backward statistics fused into the data-gradient launch (csrc/igemm_epi.h) against the
+    separate path: the stored gradient must be the masked gradient BIT FOR BIT, the slab must give
+    the same (dgamma, dbeta, dx) as bn_bwd_reduce to summation-order accuracy, reproducibly."""
+    dtype = torch.bfloat16
+    N, H, W = nhw
+    gen = torch.Generator().manual_seed(29)
+    Cin = geom.cin
+    # the BatchNorm in front of the conv: y -> z = relu(bn(y) [+ res]) -> conv
+    y = rnd(torch.randn(N, H, W, Cin, generator=gen) * 1.5 + 0.3, dtype).to(DEV).to(dtype)
+    res = rnd(torch.randn(N, H, W, Cin, generator=gen), dtype).to(DEV).to(dtype) if mode == 3 else None
+    gamma = (torch.rand(Cin, generator=gen) + 0.5).to(DEV)
+    beta = torch.randn(Cin, generator=gen).to(DEV)
+    rm, rv = torch.zeros(Cin, device=DEV), torch.ones(Cin, device=DEV)
+    z, st, mask = ops.bn_train_fwd(y, gamma, beta, rm, rv, residual=res, relu=True, want_mask=(mode == 3))
+    w = rnd(torch.randn(geom.cout, geom.cin, geom.k, geom.k, generator=gen) * 0.1, dtype)
+    dds, skipped = P.dgrad_plan(geom, N, H, W)
+    assert not skipped
+    packer = WeightPacker()
+    for d in dds:
+        packer.add(0, geom.cout, geom.k, geom.k, geom.cin, d.pack)
+    packer.build(DEV, dtype).run(w.permute(0, 2, 3, 1).contiguous().to(DEV).view(-1))
+    OP, OQ = geom.out_hw(H, W)
+    dy = rnd(torch.randn(N, OP, OQ, geom.cout, generator=gen), dtype).to(DEV).to(dtype)
+    extra = None
+    if len(dds) == 1:
+        extra = rnd(torch.randn(N, H, W, Cin, generator=gen), dtype).to(DEV).to(dtype)
+    # separate path: plain dgrad, then the BatchNorm backward masks and reduces
+    dz = torch.empty(N, H, W, Cin, dtype=dtype, device=DEV)
+    for d in dds:
+        ops.conv_igemm(d, dy, packer.view(d.pack, Cin), dz, residual=extra)
+    dg0, db0 = torch.zeros(Cin, device=DEV), torch.zeros(Cin, device=DEV)
+    dx0, dres0 = ops.bn_bwd(dz, mask, y, gamma, st[0], st[1], dg0, db0, relu=mode, want_dres=(mode == 3),
+                            scale=st[2], shift=st[3])
+    # fused path
+    def fused_run():
+        tiles = sum(ops.conv_tiles(d) for d in dds)
+        slab = torch.full((tiles * Cin * 2,), float('nan'), dtype=torch.float32, device=DEV)
+        g = torch.full((N, H, W, Cin), float('nan'), dtype=dtype, device=DEV)
+        off = 0
+        for d in dds:
+            ops.conv_igemm(d, dy, packer.view(d.pack, Cin), g, residual=extra,
+                           bnb=dict(y=y, mask=mask, mean=st[0], invstd=st[1], scale=st[2], shift=st[3],
+                                    relu=mode, partial=slab, tile_off=off))
+            off += ops.conv_tiles(d)
+        return g, slab, tiles
+    g, slab, tiles = fused_run()
+    assert not torch.isnan(slab).any() and not torch.isnan(g.float()).any()
+    keep = (z > 0)
+    assert torch.equal(g, torch.where(keep, dz, torch.zeros_like(dz)))
+    dg1, db1 = torch.zeros(Cin, device=DEV), torch.zeros(Cin, device=DEV)
+    dx1, dres1 = ops.bn_bwd(g, None, y, gamma, st[0], st[1], dg1, db1, relu=mode, want_dres=(mode == 3),
+                            scale=st[2], shift=st[3], fused=(slab, tiles))
+    assert relmax(dg1, dg0) < 2e-5 and relmax(db1, db0) < 2e-5
+    assert relmax(dx1.float(), dx0.float()) < 1e-2          # bf16 outputs of coefficients that differ by 1e-5
+    if mode == 3:
+        assert dres1 is g and torch.equal(dres1, dres0)      # the residual-branch gradient IS g: no copy
+    g2, slab2, _ = fused_run()
+    assert torch.equal(g2, g) and torch.equal(slab2, slab)   # reproducible
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_bn_statistics_large_mean(dtype):
+    """|mean| >> std: E[x^2] - mean^2 from fp32 sums would lose the variance; the shifted sums do not."""
+    gen = torch.Generator().manual_seed(5)
+    M, Cc = 4096, 16
+    x = rnd(torch.randn(M, Cc, generator=gen) * 0.25 + 200.0, dtype)
+    xd = x.to(DEV).to(dtype)
+    ga, be = torch.ones(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    rm, rv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    _z, st, _m = ops.bn_train_fwd(xd, ga, be, rm, rv, relu=False)
+    x64 = x.double()
+    assert relmax(st[0], x64.mean(0)) < 1e-6
+    assert relmax(st[1], 1 / torch.sqrt(x64.var(0, unbiased=False) + 1e-5)) < 1e-5
+
+
 # ---------------------------------------------------------------- pooling
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(2, 64, 112, 112), (3, 64, 33, 17), (1, 8, 5, 5)])
@@ -400,6 +508,10 @@ def test_infonce_fwd_bwd(N, K):
     assert relmax(dq, q.grad) < 1e-4
     dq2 = ops.infonce_bwd(q.detach().to(DEV), k.to(DEV), queue.to(DEV), lse, None, T)
     assert relmax(dq2, q.grad) < 1e-4
+    # no atomics anywhere (per-slice slabs + fixed-order sums): bit-reproducible loss and gradient
+    out_b, lse_b, _ = ops.infonce_fwd(q.detach().to(DEV), k.to(DEV), queue.to(DEV), T)
+    assert torch.equal(out_b.cpu(), out) and torch.equal(lse_b, lse)
+    assert torch.equal(ops.infonce_bwd(q.detach().to(DEV), k.to(DEV), queue.to(DEV), lse, gs, T), dq)
 
 
 def test_enqueue():
