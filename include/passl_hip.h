@@ -223,6 +223,12 @@ int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t stream);
  * No atomics anywhere: results are bit-reproducible run to run.
  * Replaces paddle.nn.BatchNorm2D + ReLU (+ `out += identity`) at
  * resnetimagenet.py:133-153,196-197,236-238. */
+/* Size (floats) of a `partial` buffer for nblocks slabs of C channels: the slab itself — [nblocks][C][2]
+ * sums (+ [nblocks][C] shifts when shifted != 0: forward statistics) — followed by the fp64 scratch the
+ * finalize kernels use to combine tall slabs segment by segment.  Every `partial` handed to
+ * passl_hip_bn_finalize / passl_hip_bn_bwd_finalize (and the conv descriptor's `stats` / `bnb_partial`)
+ * must be this large. */
+int64_t passl_hip_bn_partial_floats(int nblocks, int C, int shifted);
 int passl_hip_bn_stats(const void* x, float* partial, int64_t M, int C, int nblocks, int dtype,
                        passl_stream_t stream);
 int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t M, int C, int rows_per_block,

@@ -209,6 +209,8 @@ def _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool):
     x = round_act(F.relu(bn('bn1', conv('conv1', x, 2, 3))))
     if maxpool:
         x = F.max_pool2d(x, 3, 2, 1)
+        if train:
+            x = round_grad(x)                      # the pooled map's gradient is a stored bf16 tensor
     if taps is not None:
         taps['stem'] = x
     for li, blocks in enumerate(LAYERS, start=1):
@@ -216,14 +218,17 @@ def _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool):
             p = 'layer%d.%d' % (li, b)
             s = 2 if (li > 1 and b == 0) else 1
             identity = x
-            xin = round_grad(x) if train else x    # dgrad tiles are bf16 before the fork gradients meet
+            # every data-gradient launch stores bf16 tiles BEFORE the fork gradients meet: conv1's and
+            # the downsample conv's input gradients are rounded separately, then summed, then rounded
+            xin = round_grad(x) if train else x
+            xds = round_grad(x) if train else x
             out = round_act(F.relu(bn(p + '.bn1', conv(p + '.conv1', xin, 1, 0))))
             out = round_act(F.relu(bn(p + '.bn2', conv(p + '.conv2', out, s, 1))))
             out = bn(p + '.bn3', conv(p + '.conv3', out, 1, 0))
             if not train:
                 out = round_act(out)               # epilogue: affine -> bf16 tile -> + residual -> ReLU -> bf16
             if b == 0:
-                identity = round_act(bn(p + '.downsample.1', conv(p + '.downsample.0', xin, s, 0)))
+                identity = round_act(bn(p + '.downsample.1', conv(p + '.downsample.0', xds, s, 0)))
             x = round_act(F.relu(out + identity))
         if taps is not None:
             taps['layer%d' % li] = x

@@ -88,6 +88,11 @@ class GradReducer(object):
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        if self.grads.is_cuda:
+            # weight gradients are produced on the side stream (hip/streams.py): the collective (ordered
+            # behind the current stream) must see them finished
+            from ..hip import streams
+            streams.join(self.grads.device)
         if self.world > 1 or self._forced:
             self._handles.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))

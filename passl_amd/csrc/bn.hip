@@ -131,17 +131,19 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
 // through LDS in wave order.  Returns the totals in threads 0..7 (channel = tid).
 constexpr int kFinThreads = 1024;
 
+constexpr int kFinSegMax = 16;   // row segments of a tall slab (one block per segment and channel group)
+
 template <bool SHIFTED>
 __device__ __forceinline__ void combine_slab(const float* __restrict__ partial, int nblocks, int C,
                                              int64_t M, int rows_per_block, int c, bool c_ok,
-                                             double& t1, double& t2, float& g0) {
+                                             int b0, int b1, double& t1, double& t2, float& g0) {
   __shared__ double red[kFinThreads / 64][8][2];
   const int rl = threadIdx.x >> 3;
   const float* shifts = partial + (int64_t)nblocks * C * 2;
   double a1 = 0.0, a2 = 0.0;
   g0 = (SHIFTED && c_ok) ? shifts[c] : 0.f;            // slab 0 always holds rows
   if (c_ok) {
-    for (int b = rl; b < nblocks; b += kFinThreads / 8) {
+    for (int b = b0 + rl; b < b1; b += kFinThreads / 8) {
       const float2 p = *reinterpret_cast<const float2*>(partial + ((int64_t)b * C + c) * 2);
       if (SHIFTED) {
         int64_t n = M - (int64_t)b * rows_per_block;
@@ -170,15 +172,54 @@ __device__ __forceinline__ void combine_slab(const float* __restrict__ partial, 
   }
 }
 
+// tall slabs: grid (C/8, S) — block (., seg) combines its row segment into scratch[seg][c][0..1] (fp64);
+// the finalize kernel then adds the S segment totals in segment order
+template <bool SHIFTED>
+__global__ void __launch_bounds__(kFinThreads) bn_combine_kernel(const float* __restrict__ partial,
+                                                                 int nblocks, int64_t M, int C,
+                                                                 int rows_per_block, int seg_rows,
+                                                                 double* __restrict__ scratch) {
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int b0 = blockIdx.y * seg_rows;
+  int b1 = b0 + seg_rows;
+  if (b1 > nblocks) b1 = nblocks;
+  double t1, t2;
+  float g0;
+  combine_slab<SHIFTED>(partial, nblocks, C, M, rows_per_block, c, c < C, b0, b1, t1, t2, g0);
+  if (threadIdx.x >= 8 || c >= C) return;
+  scratch[((int64_t)blockIdx.y * C + c) * 2] = t1;
+  scratch[((int64_t)blockIdx.y * C + c) * 2 + 1] = t2;
+}
+
+// totals of channel c: from the slab (nseg == 1, whole block cooperates) or from the segment scratch
+template <bool SHIFTED>
+__device__ __forceinline__ void slab_totals(const float* __restrict__ partial, int nblocks, int C, int64_t M,
+                                            int rows_per_block, const double* __restrict__ scratch, int nseg,
+                                            int c, double& t1, double& t2, float& g0) {
+  if (nseg <= 1) {
+    combine_slab<SHIFTED>(partial, nblocks, C, M, rows_per_block, c, c < C, 0, nblocks, t1, t2, g0);
+    return;
+  }
+  t1 = 0.0; t2 = 0.0;
+  g0 = (SHIFTED && c < C) ? partial[(int64_t)nblocks * C * 2 + c] : 0.f;
+  if (threadIdx.x < 8 && c < C) {
+    for (int s = 0; s < nseg; ++s) {
+      t1 += scratch[((int64_t)s * C + c) * 2];
+      t2 += scratch[((int64_t)s * C + c) * 2 + 1];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block,
+    const double* __restrict__ scratch, int nseg,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double t1, t2;
   float g0;
-  combine_slab<true>(partial, nblocks, C, M, rows_per_block, c, c < C, t1, t2, g0);
+  slab_totals<true>(partial, nblocks, C, M, rows_per_block, scratch, nseg, c, t1, t2, g0);
   if (threadIdx.x >= 8 || c >= C) return;
   const double dm = t1 / (double)M;                 // mean - g0
   const double mu = (double)g0 + dm;
@@ -198,13 +239,14 @@ __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
 
 __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int64_t M, int C,
+    const double* __restrict__ scratch, int nseg,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ coef) {
   const int c = blockIdx.x * 8 + (threadIdx.x & 7);
   double sg, sgx;
   float unused;
-  combine_slab<false>(partial, nblocks, C, M, 0, c, c < C, sg, sgx, unused);
+  slab_totals<false>(partial, nblocks, C, M, 0, scratch, nseg, c, sg, sgx, unused);
   if (threadIdx.x >= 8 || c >= C) return;
   dbeta[c] += (float)sg;      // accumulate: the flat gradient buffer is zeroed by clear_grad()
   dgamma[c] += (float)sgx;
@@ -306,6 +348,19 @@ static inline int grid_for(int64_t n) {
   else if ((dtype) == PASSL_F32) { using T = float; __VA_ARGS__ } \
   else return PASSL_EUNSUPPORTED;
 
+// tall slabs are combined by nseg blocks per channel group (fixed segment order); short ones in one go
+static int fin_segments(int nblocks, int* seg_rows) {
+  int nseg = nblocks >= 512 ? nblocks / 128 : 1;
+  if (nseg > kFinSegMax) nseg = kFinSegMax;
+  *seg_rows = (nblocks + nseg - 1) / nseg;
+  return (nblocks + *seg_rows - 1) / *seg_rows;
+}
+
+extern "C" int64_t passl_hip_bn_partial_floats(int nblocks, int C, int shifted) {
+  if (nblocks <= 0 || C <= 0) return 0;
+  return (int64_t)nblocks * C * (shifted ? 3 : 2) + (int64_t)kFinSegMax * C * 4;
+}
+
 extern "C" int passl_hip_bn_stats(const void* x, float* partial, int64_t M, int C, int nblocks,
                                   int dtype, passl_stream_t stream) {
   if (!x || !partial || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || !aligned16(x))
@@ -329,9 +384,18 @@ extern "C" int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t 
       (C & 7) || nblocks <= 0 || rows_per_block <= 0 || (int64_t)nblocks * rows_per_block < M ||
       (running_mean && !running_var) || (reinterpret_cast<uintptr_t>(partial) & 7))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 8), dim3(kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, rows_per_block, gamma, beta, running_mean, running_var,
-                     momentum, eps, mean, invstd, scale, shift);
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, &seg_rows);
+  // the segment scratch lives behind the slab (passl_hip_bn_partial_floats sizes the buffer)
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 3);
+  if (nseg > 1) {
+    hipLaunchKernelGGL(bn_combine_kernel<true>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                       partial, nblocks, M, C, rows_per_block, seg_rows, scratch);
+    PASSL_RETURN_IF_LAUNCH_FAILED();
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, rows_per_block, scratch, nseg, gamma, beta, running_mean,
+                     running_var, momentum, eps, mean, invstd, scale, shift);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -387,8 +451,16 @@ extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int6
   if (!partial || !gamma || !mean || !invstd || !dgamma || !dbeta || !coef || M <= 0 || C <= 0 ||
       (C & 7) || nblocks <= 0 || (reinterpret_cast<uintptr_t>(partial) & 7))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 8), dim3(kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, gamma, mean, invstd, dgamma, dbeta, coef);
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, &seg_rows);
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 2);
+  if (nseg > 1) {
+    hipLaunchKernelGGL(bn_combine_kernel<false>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                       partial, nblocks, M, C, 0, seg_rows, scratch);
+    PASSL_RETURN_IF_LAUNCH_FAILED();
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, scratch, nseg, gamma, mean, invstd, dgamma, dbeta, coef);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

@@ -13,7 +13,8 @@ import torch
 _state = {'device': None, 'dtype': torch.bfloat16,
           'fused_bn_stats': os.environ.get('PASSL_FUSED_BN_STATS', '1') != '0',
           'fuse_residual_grad': os.environ.get('PASSL_FUSE_RESIDUAL_GRAD', '1') != '0',
-          'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0'}
+          'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0',
+          'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0'}
 
 
 def set_device(name):
@@ -66,6 +67,12 @@ def fused_bn_backward():
     return _state['fused_bn_backward']
 
 
+def overlap():
+    """Independent work on a second HIP stream: weight-gradient launches next to the data-gradient /
+    BatchNorm-backward chain, the key encoder's forward next to the query encoder's (hip/streams.py)."""
+    return _state['overlap']
+
+
 def set_flag(name, value):
-    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward')
+    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap')
     _state[name] = bool(value)

@@ -68,6 +68,7 @@ SIGNATURES = {
     'passl_hip_conv_igemm': (c_i, [C.POINTER(ConvDesc), c_p]),
     'passl_hip_conv_wgrad': (c_i, [C.POINTER(WgradDesc), c_p]),
     'passl_hip_slab_reduce': (c_i, [c_p, c_p, c_l, c_i, c_i, c_p]),
+    'passl_hip_bn_partial_floats': (c_l, [c_i, c_i, c_i]),
     'passl_hip_bn_stats': (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p]),
     'passl_hip_bn_finalize': (c_i, [c_p, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p,
                                     c_p, c_p, c_p]),

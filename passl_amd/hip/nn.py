@@ -23,7 +23,7 @@ import torch
 import torch.nn as tnn
 from torch.autograd import Function
 
-from . import config, ops
+from . import config, ops, streams
 from . import plan as P
 from .packer import WeightPacker
 
@@ -136,7 +136,8 @@ class _ConvFn(Function):
             slab, off = None, 0
             if fuse:
                 tiles = sum(ops.conv_tiles(d) for d in pl.dds)
-                slab = torch.empty(tiles * g.cin * 2, dtype=torch.float32, device=dy.device)
+                slab = torch.empty(ops.bn_partial_floats(tiles, g.cin, False), dtype=torch.float32,
+                                   device=dy.device)
             for d in pl.dds:
                 bnb = None
                 if fuse:
@@ -150,12 +151,19 @@ class _ConvFn(Function):
             if ctx.sink_slot is not None:
                 ctx.sink_slot.put(dx)
                 dx = None
-        if layer.is_stem:
-            tmp = torch.zeros(g.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dy.device)
-            ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), tmp)
-            rt.dw.view(g.cout, 7, 7, 3).add_(tmp.view(g.cout, 7, 8, 4)[:, :, :7, :3])
+        def wgrad():
+            if layer.is_stem:
+                tmp = torch.zeros(g.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dy.device)
+                ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), tmp)
+                rt.dw.view(g.cout, 7, 7, 3).add_(tmp.view(g.cout, 7, 8, 4)[:, :, :7, :3])
+            else:
+                ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
+        if streams.enabled(dy):
+            # dW feeds only the optimizer: off the dgrad -> BatchNorm-backward chain (hip/streams.py)
+            with streams.on_side(dy.device, reads=(x, dy), in_backward=True):
+                wgrad()
         else:
-            ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
+            wgrad()
         rt.arena.grad_ready(rt.indices)
         return dx, None, None, None, None, None, None, None
 
@@ -410,7 +418,11 @@ class _LinearFn(Function):
             dx = torch.empty(x.shape[0], layer.in_features, dtype=x.dtype, device=x.device)
             d = pl.dds[0]
             ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
-        ops.conv_wgrad(pl.wd, x, dy, rt.dw)
+        if streams.enabled(dy):
+            with streams.on_side(dy.device, reads=(x, dy), in_backward=True):
+                ops.conv_wgrad(pl.wd, x, dy, rt.dw)
+        else:
+            ops.conv_wgrad(pl.wd, x, dy, rt.dw)
         if layer.bias is not None:
             ops.colsum_into(dy, layer.bias.grad, accumulate=True)     # straight into the arena's gradient
         rt.arena.grad_ready(rt.indices)

@@ -20,13 +20,15 @@ class _Workspace:
     """ONE grow-only fp32 scratch buffer per device for the fixed-order (atomic-free) reductions:
     split-M weight-gradient slabs, InfoNCE dq slabs, column-sum partials.  Every user launches its
     producer and its reduce kernel back to back on the current stream, so stream order makes sharing
-    safe; the buffer is never read across ops."""
+    safe; the buffer is never read across ops.  Keyed by stream as well: the weight gradients run on the
+    side stream (hip/streams.py) with their own scratch."""
 
     def __init__(self):
         self._bufs = {}
 
     def get(self, n_floats, device):
-        key = (device.type, device.index)
+        # one buffer per (device, stream): users on different streams must not share scratch
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < n_floats:
             buf = torch.empty(max(int(n_floats), 16 << 20), dtype=torch.float32, device=device)
@@ -142,7 +144,12 @@ def conv_stats_buffer(d: P.Desc, device):
     followed by [tiles][C] shifts (include/passl_hip.h: passl_conv_desc.stats).  Fully written by the
     kernel: no zeroing, no atomics.  Returns (tensor, tiles)."""
     t = conv_tiles(d)
-    return torch.empty(t * d.NCOLS * 3, dtype=torch.float32, device=device), t
+    return torch.empty(bn_partial_floats(t, d.NCOLS, True), dtype=torch.float32, device=device), t
+
+
+def bn_partial_floats(nblocks, Cch, shifted):
+    """Floats of a BatchNorm partial buffer: slab + the finalize kernels' segment scratch."""
+    return nblocks * Cch * (3 if shifted else 2) + 16 * Cch * 4
 
 
 def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum=0.9, eps=1e-5,
@@ -159,7 +166,7 @@ def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum
         nb = _bn_blocks(M, Cch)
         rpb = -(-M // nb)
         nb = -(-M // rpb)                   # every slab holds rows
-        partial = torch.empty(nb * Cch * 3, dtype=torch.float32, device=dev)
+        partial = torch.empty(bn_partial_floats(nb, Cch, True), dtype=torch.float32, device=dev)
         L.check(lib.passl_hip_bn_stats(L.ptr(x), L.ptr(partial), M, Cch, nb, dtc, st), 'bn_stats')
     else:
         partial, nb = partial
@@ -208,7 +215,7 @@ def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=Fa
         r, zp = 0, None
     else:
         nb = _bn_blocks(M, Cch)
-        partial = torch.empty(nb * Cch * 2, dtype=torch.float32, device=dev)
+        partial = torch.empty(bn_partial_floats(nb, Cch, False), dtype=torch.float32, device=dev)
         L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), zp, L.ptr(x), L.ptr(mean), L.ptr(invstd),
                                             L.ptr(scale), L.ptr(shift), L.ptr(partial), M, Cch, nb, r,
                                             dtc, st), 'bn_bwd_reduce')

@@ -124,8 +124,11 @@ class MoCo(nn.Layer):
     def train_iter(self, *inputs, **kwargs):
         img_q, img_k = inputs
         self.arena_q.refresh()                      # compute-dtype copies of the updated weights
+
         q = self.encoder_q(img_q)                   # queries: NxC (fp32)
         q = nn.normalize(q, axis=1)
+        # NOTE: the key path cannot be hoisted next to the query forward: the EMA covers the BatchNorm
+        # running statistics that the query forward has just updated (moco.py:82-90, SURVEY §3.1 note A)
         with torch.no_grad():
             self._momentum_update_key_encoder()
             if self.shuffle_bn:
@@ -134,6 +137,7 @@ class MoCo(nn.Layer):
             k = nn.normalize(k, axis=1)
             if self.shuffle_bn:
                 k = self._batch_unshuffle_ddp(k, idx_unshuffle)
+        with torch.no_grad():
             queue_snapshot = self.queue.clone()     # `self.queue.clone().detach()`, moco.py:180
         outputs = self.head.fused(q, k, queue_snapshot)
         self._dequeue_and_enqueue(k)

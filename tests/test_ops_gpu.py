@@ -165,7 +165,7 @@ def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
         yo2 = torch.empty_like(yo)
         ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo2, stats=st)
         assert torch.equal(yo2, yo)
-        assert not torch.isnan(st).any()
+        assert not torch.isnan(st[:tiles * geom.cout * 3]).any()
         y64 = yo.double().cpu().reshape(-1, geom.cout)
         M = y64.shape[0]
         sums = st[:tiles * geom.cout * 2].view(tiles, geom.cout, 2).double().cpu()
@@ -178,7 +178,7 @@ def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
             assert (sums[t, :, 1] - (d * d).sum(0)).abs().max() <= 1e-5 * max(1.0, float((d * d).sum(0).max()))
         st_b = torch.empty_like(st)
         ops.conv_igemm(fd, xa, packer.view(fd.pack, geom.cout), yo2, stats=st_b)
-        assert torch.equal(st_b, st)                   # reproducible
+        assert torch.equal(st_b[:tiles * geom.cout * 3], st[:tiles * geom.cout * 3])     # reproducible
         # ... and the finalize kernel turns the slab into the statistics of the stored values
         ga, be = torch.ones(geom.cout, device=DEV), torch.zeros(geom.cout, device=DEV)
         rm, rv = torch.zeros(geom.cout, device=DEV), torch.ones(geom.cout, device=DEV)
@@ -303,7 +303,9 @@ def test_linear_as_conv(dtype):
 
 # ---------------------------------------------------------------- batch norm
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('shape', [(4, 56, 56, 64), (2, 7, 7, 2048), (3, 5, 5, 24), (8, 14, 14, 256)])
+# (5, 125, 128, 256): 625 row slabs -> the finalize kernels combine the slab in segments
+@pytest.mark.parametrize('shape', [(4, 56, 56, 64), (2, 7, 7, 2048), (3, 5, 5, 24), (8, 14, 14, 256),
+                                   (5, 125, 128, 256)])
 @pytest.mark.parametrize('with_res', [False, True])
 def test_bn_fwd_bwd(dtype, shape, with_res):
     N, H, W, Cc = shape
@@ -401,7 +403,8 @@ def test_dgrad_fused_bn_backward(geom, nhw, mode):
     # fused path
     def fused_run():
         tiles = sum(ops.conv_tiles(d) for d in dds)
-        slab = torch.full((tiles * Cin * 2,), float('nan'), dtype=torch.float32, device=DEV)
+        slab = torch.full((ops.bn_partial_floats(tiles, Cin, False),), float('nan'), dtype=torch.float32,
+                          device=DEV)
         g = torch.full((N, H, W, Cin), float('nan'), dtype=dtype, device=DEV)
         off = 0
         for d in dds:
@@ -411,7 +414,7 @@ def test_dgrad_fused_bn_backward(geom, nhw, mode):
             off += ops.conv_tiles(d)
         return g, slab, tiles
     g, slab, tiles = fused_run()
-    assert not torch.isnan(slab).any() and not torch.isnan(g.float()).any()
+    assert not torch.isnan(slab[:tiles * Cin * 2]).any() and not torch.isnan(g.float()).any()
     keep = (z > 0)
     assert torch.equal(g, torch.where(keep, dz, torch.zeros_like(dz)))
     dg1, db1 = torch.zeros(Cin, device=DEV), torch.zeros(Cin, device=DEV)
@@ -422,7 +425,7 @@ def test_dgrad_fused_bn_backward(geom, nhw, mode):
     if mode == 3:
         assert dres1 is g and torch.equal(dres1, dres0)      # the residual-branch gradient IS g: no copy
     g2, slab2, _ = fused_run()
-    assert torch.equal(g2, g) and torch.equal(slab2, slab)   # reproducible
+    assert torch.equal(g2, g) and torch.equal(slab2[:tiles * Cin * 2], slab[:tiles * Cin * 2])   # reproducible
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
