@@ -455,6 +455,23 @@ int passl_hip_clip_logits_fwd(const float* img, const float* txt, float* logit_s
 /* dimg, dtxt [B,D] fully written; dlogit_scale[0] += sum(dlogits .* logits). */
 int passl_hip_clip_logits_bwd(const float* dlogits, const float* logits, const float* ws, int B, int D,
                               float* dimg, float* dtxt, float* dlogit_scale, passl_stream_t stream);
+/* Building blocks of the CROSS-RANK form of the same logits (BASELINE configs[4]: the negatives of
+ * every rank; pattern of passl/models/mocov3.py:187-198 — gather the other modality's features, labels
+ * arange(B) + B*rank): image_logits = exp(s) * I^_local . T^_all^T  [B][W*B] and the text counterpart.
+ *   clip_scale:  alpha = exp(*logit_scale), then *logit_scale = clip(*logit_scale) (clip.py:309-311)
+ *   gemm_f32_nt: C[M][N] = *alpha * A[M][K] . B[N][K]^T        (exact-fp32 MFMA; K % 16 == 0)
+ *   gemm_f32_gx: C[M][N] = *alpha * op(G) . X[K][N], op(G) = G [M][K] (trans 0) or G^T, G [K][M] (trans 1)
+ *   dot_acc:     *out += sum_e a[e]*b[e]  (fixed order: <= 256 block partials in ws (>= 256 floats), then one sum)
+ * Row normalisation without epsilon = passl_hip_l2norm_fwd/bwd with eps 0; the row cross-entropy with
+ * offset labels = passl_hip_softmax_ce_fwd/bwd. */
+int passl_hip_clip_scale(float* logit_scale, float* alpha, float clip_lo, float clip_hi,
+                         passl_stream_t stream);
+int passl_hip_gemm_f32_nt(const float* A, const float* B, float* C, int M, int N, int K, const float* alpha,
+                          passl_stream_t stream);
+int passl_hip_gemm_f32_gx(const float* G, const float* X, float* C, int M, int N, int K, int trans,
+                          const float* alpha, passl_stream_t stream);
+int passl_hip_dot_acc(const float* a, const float* b, int64_t n, float* out, float* ws,
+                      passl_stream_t stream);
 /* CLIPHead (clip_head.py:24-36) with labels arange(B): out = {CE over the rows of logits (img_loss),
  * CE over its columns (= rows of text_logits; text_loss), their sum (loss)}; lse [2B] = row and
  * column log-sum-exp, saved for the backward. */

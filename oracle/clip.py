@@ -35,6 +35,9 @@ from .mae import layer_norm as _ln, warmup_cosine_lr  # noqa: F401  (same LayerN
 VIT_B_32 = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768,
                 vision_patch_size=32, context_length=77, vocab_size=49408, transformer_width=512,
                 transformer_heads=8, transformer_layers=12)
+# BASELINE.json configs[4]: "CLIP ViT-B/16" = configs/clip/vit-b-32.yaml with vision_patch_size 16
+# (197 image tokens; SURVEY appendix C: the reference ships only the B/32 yaml)
+VIT_B_16 = dict(VIT_B_32, vision_patch_size=16)
 SMALL = dict(embed_dim=64, image_resolution=64, vision_layers=2, vision_width=128,
              vision_patch_size=32, context_length=12, vocab_size=300, transformer_width=128,
              transformer_heads=2, transformer_layers=2)

@@ -395,6 +395,28 @@ __global__ void __launch_bounds__(kThreads) clip_dscale_kernel(const float* __re
   if (threadIdx.x == 0) atomicAdd(dscale, part[0] + part[1] + part[2] + part[3]);
 }
 
+// partial[b] = sum over block b's grid-stride elements of a[e] * b[e]  (fixed order inside the block)
+__global__ void __launch_bounds__(kThreads) dot_partial_kernel(const float* __restrict__ a,
+                                                               const float* __restrict__ b, int64_t total,
+                                                               float* __restrict__ partial) {
+  __shared__ float part[4];
+  float acc = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * kThreads)
+    acc += a[e] * b[e];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// out += partial[0] + partial[1] + ... (block order): the atomic-free end of a dot product
+__global__ void dot_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += partial[i];
+  *out += s;
+}
+
 }  // namespace
 
 extern "C" int passl_hip_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype,
@@ -559,6 +581,53 @@ extern "C" int passl_hip_clip_ce_bwd(const float* logits, const float* lse, cons
   if (!logits || !lse || !gloss || !dlogits || B <= 0) return PASSL_EINVAL;
   hipLaunchKernelGGL(clip_grad_kernel, dim3(grid_for((int64_t)B * B)), dim3(kThreads), 0,
                      as_stream(stream), logits, lse, gloss, B, dlogits);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+// ---- building blocks of the cross-rank CLIP InfoNCE (rectangular logits [B][W*B]): the same kernels
+// the square single-rank path uses, exposed one by one
+extern "C" int passl_hip_clip_scale(float* logit_scale, float* alpha, float clip_lo, float clip_hi,
+                                    passl_stream_t stream) {
+  if (!logit_scale || !alpha) return PASSL_EINVAL;
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, as_stream(stream), logit_scale, alpha, clip_lo,
+                     clip_hi);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_gemm_f32_nt(const float* A, const float* Bm, float* Cm, int M, int N, int K,
+                                     const float* alpha, passl_stream_t stream) {
+  if (!A || !Bm || !Cm || !alpha || M <= 0 || N <= 0 || K <= 0 || (K & 15) || !aligned16(A) || !aligned16(Bm))
+    return PASSL_EINVAL;
+  const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3((tiles + 3) / 4), dim3(kThreads), 0, as_stream(stream), A, Bm, Cm,
+                     M, N, K, alpha);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_gemm_f32_gx(const float* G, const float* X, float* Cm, int M, int N, int K,
+                                     int trans, const float* alpha, passl_stream_t stream) {
+  if (!G || !X || !Cm || !alpha || M <= 0 || N <= 0 || K <= 0) return PASSL_EINVAL;
+  const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+  if (trans)
+    hipLaunchKernelGGL(gemm_gx_kernel<true>, dim3((tiles + 3) / 4), dim3(kThreads), 0, as_stream(stream), G,
+                       X, Cm, M, N, K, alpha);
+  else
+    hipLaunchKernelGGL(gemm_gx_kernel<false>, dim3((tiles + 3) / 4), dim3(kThreads), 0, as_stream(stream), G,
+                       X, Cm, M, N, K, alpha);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_dot_acc(const float* a, const float* b, int64_t n, float* out, float* ws,
+                                 passl_stream_t stream) {
+  if (!a || !b || !out || !ws || n <= 0) return PASSL_EINVAL;
+  int blocks = grid_for(n);
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(blocks), dim3(kThreads), 0, as_stream(stream), a, b, n, ws);
+  hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), ws, blocks, out);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

@@ -113,6 +113,10 @@ SIGNATURES = {
     'passl_hip_clip_logits_ws_floats': (c_l, [c_i, c_i]),
     'passl_hip_clip_logits_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
     'passl_hip_clip_logits_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'passl_hip_clip_scale': (c_i, [c_p, c_p, c_f, c_f, c_p]),
+    'passl_hip_gemm_f32_nt': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    'passl_hip_gemm_f32_gx': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'passl_hip_dot_acc': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p]),
     'passl_hip_clip_ce_fwd': (c_i, [c_p, c_i, c_p, c_p, c_p]),
     'passl_hip_clip_ce_bwd': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p]),
     'passl_hip_mae_mask': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),

@@ -606,6 +606,38 @@ def clip_logits_bwd(dlogits, logits, ws, Dd, dlogit_scale):
     return dimg, dtxt
 
 
+def clip_scale(logit_scale, clip_lo=-4.6, clip_hi=4.6):
+    """-> alpha (device scalar) = exp(logit_scale) as used by this step; logit_scale is clipped in place."""
+    alpha = torch.empty(1, dtype=torch.float32, device=logit_scale.device)
+    L.check(_lib().passl_hip_clip_scale(L.ptr(logit_scale), L.ptr(alpha), clip_lo, clip_hi, L.stream()), 'clip_scale')
+    return alpha
+
+
+def gemm_f32_nt(a, b, alpha):
+    """alpha * a [M,K] @ b[N,K]^T -> [M,N] fp32 (exact-fp32 MFMA)."""
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    L.check(_lib().passl_hip_gemm_f32_nt(L.ptr(a), L.ptr(b), L.ptr(c), M, N, K, L.ptr(alpha), L.stream()), 'gemm_f32_nt')
+    return c
+
+
+def gemm_f32_gx(g, x, alpha, trans=False):
+    """alpha * op(g) @ x[K,N]: op(g) = g [M,K] or (trans) g^T with g [K,M]."""
+    K, N = x.shape
+    M = g.shape[1] if trans else g.shape[0]
+    c = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    L.check(_lib().passl_hip_gemm_f32_gx(L.ptr(g), L.ptr(x), L.ptr(c), M, N, K, 1 if trans else 0, L.ptr(alpha),
+                                         L.stream()), 'gemm_f32_gx')
+    return c
+
+
+def dot_acc(a, b, out):
+    """out[0] += sum(a * b), fixed summation order."""
+    ws = workspace.get(256, a.device)
+    L.check(_lib().passl_hip_dot_acc(L.ptr(a), L.ptr(b), a.numel(), L.ptr(out), L.ptr(ws), L.stream()), 'dot_acc')
+
+
 def clip_ce_fwd(logits):
     """-> out[3] = (img_loss, text_loss, loss), lse [2B]."""
     B = logits.shape[0]

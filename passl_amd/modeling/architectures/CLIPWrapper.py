@@ -3,7 +3,9 @@ text)`` builds labels ``arange(B)``, calls ``self.model(image, text, is_train=Tr
 two logits matrices to the head (CLIPHead).  Parameters live in one EncoderArena (flat fp32 master /
 gradient buffers for AdamW and the data-parallel reducer)."""
 import torch
+import torch.distributed as dist
 
+from ...core.sync_utils import collectives_active
 from ...hip import nn
 from ...hip.nn import EncoderArena
 from ..backbones import build_backbone
@@ -13,8 +15,12 @@ from .builder import MODELS
 
 @MODELS.register()
 class CLIPWrapper(nn.Layer):
-    def __init__(self, architecture=None, head=None):
+    def __init__(self, architecture=None, head=None, multi_rank=False):
+        """multi_rank (extension, default off = the reference): the contrastive loss sees the features of
+        every data-parallel rank (BASELINE configs[4] "cross-GPU InfoNCE"): all-gather over RCCL, labels
+        ``arange(B) + B*rank`` as in passl/models/mocov3.py:187-198."""
         super().__init__()
+        self.multi_rank = bool(multi_rank)
         self.model = build_backbone(architecture)
         self.automatic_optimization = False
         self.head = build_head(head)
@@ -31,6 +37,11 @@ class CLIPWrapper(nn.Layer):
         img_labels = torch.arange(len(image), device=image.device)
         text_labels = torch.arange(len(text), device=text.device)
         self.arena_q.refresh()
+        if self.multi_rank:
+            off = len(image) * dist.get_rank() if collectives_active() else 0
+            img_logits, text_logits = self.model(image, text, is_train=True, multi_rank=True)
+            return self.head(img_logits, text_logits, img_labels + off, text_labels + off)
+        img_labels._passl_is_arange = text_labels._passl_is_arange = True
         img_logits, text_logits = self.model(image, text, is_train=True)
         return self.head(img_logits, text_logits, img_labels, text_labels)
 

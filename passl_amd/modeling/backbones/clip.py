@@ -14,9 +14,11 @@ import math
 
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.nn as tnn
 from torch.autograd import Function
 
+from ...core.sync_utils import collectives_active
 from ...hip import config, nn, ops
 from .builder import BACKBONES
 from .vision_transformer import Transformer, VisionTransformer, alias_matrix_param
@@ -75,6 +77,66 @@ class _LogitsFn(Function):
         dimg, dtxt = ops.clip_logits_bwd(dlogits.contiguous(), logits, ws, ctx.D, s.grad)
         nn.param_grad_ready(s)
         return dimg, dtxt, None
+
+
+def _gather_rows_all(t):
+    """all_gather + concat along dim 0 (identity without an active process group)."""
+    if not collectives_active():
+        return t
+    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out
+
+
+def _reduce_scatter_rows(t, rows):
+    """Sum over ranks of t [W*rows, D], this rank's [rows, D] slice (identity without a process group)."""
+    if not collectives_active():
+        return t
+    out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.reduce_scatter_tensor(out, t.contiguous())
+    return out
+
+
+class _CrossRankLogitsFn(Function):
+    """CLIP.forward's logits against the features of EVERY rank (BASELINE configs[4]: cross-GPU InfoNCE;
+    the gather pattern of passl/models/mocov3.py:187-198 applied to both modalities):
+
+        image_logits = exp(s) * I^_local . T^_all^T   [B, W*B]      text_logits = exp(s) * T^_local . I^_all^T
+
+    with I^, T^ the L2-normalised features (no epsilon, clip.py:325-326) and s clipped in place after use
+    (clip.py:309-311).  Row i's positive is column B*rank + i.  Backward: the local rows' gradient plus the
+    reduce-scattered gradient of the gathered copies (every rank's text_logits contain this rank's image
+    features as columns, and vice versa).  World size 1 gives (L, L^T) — the reference's two matrices."""
+
+    @staticmethod
+    def forward(ctx, img, txt, logit_scale):
+        B, D = img.shape
+        img_n, img_norm = ops.l2norm_fwd(img.contiguous(), 0.0)
+        txt_n, txt_norm = ops.l2norm_fwd(txt.contiguous(), 0.0)
+        alpha = ops.clip_scale(logit_scale.detach())
+        img_all, txt_all = _gather_rows_all(img_n), _gather_rows_all(txt_n)
+        li = ops.gemm_f32_nt(img_n, txt_all, alpha)
+        lt = ops.gemm_f32_nt(txt_n, img_all, alpha)
+        ctx.save_for_backward(img_n, img_norm, txt_n, txt_norm, img_all, txt_all, alpha, li, lt)
+        ctx.scale = logit_scale
+        return li, lt
+
+    @staticmethod
+    def backward(ctx, dli, dlt):
+        img_n, img_norm, txt_n, txt_norm, img_all, txt_all, alpha, li, lt = ctx.saved_tensors
+        B = img_n.shape[0]
+        dli, dlt = dli.contiguous(), dlt.contiguous()
+        s = ctx.scale
+        if s.grad is None:
+            s.grad = torch.zeros_like(s)
+        ops.dot_acc(dli, li, s.grad)                       # d loss / d s = sum dL o L for both matrices
+        ops.dot_acc(dlt, lt, s.grad)
+        nn.param_grad_ready(s)
+        # row role (local rows) + column role (this rank's features inside every rank's other matrix)
+        dimg = ops.gemm_f32_gx(dli, txt_all, alpha) + _reduce_scatter_rows(ops.gemm_f32_gx(dlt, txt_n, alpha, trans=True), B)
+        dtxt = ops.gemm_f32_gx(dlt, img_all, alpha) + _reduce_scatter_rows(ops.gemm_f32_gx(dli, img_n, alpha, trans=True), B)
+        return (ops.l2norm_bwd(dimg, img_n, img_norm, torch.float32),
+                ops.l2norm_bwd(dtxt, txt_n, txt_norm, torch.float32), None)
 
 
 @BACKBONES.register()
@@ -149,10 +211,14 @@ class CLIP(nn.Layer):
     def clip_logit_scale(self):
         """clip.py:309-311 — performed inside the logits kernel sequence, right after exp(s) is taken."""
 
-    def forward(self, image, text, is_train=True):
+    def forward(self, image, text, is_train=True, multi_rank=False):
+        """multi_rank (an extension; the reference computes the loss over the local batch only): logits
+        against the gathered features of every rank -> (image_logits, text_logits) of shape [B, W*B]."""
         if not is_train:
             raise NotImplementedError('is_train=False (unit logit scale) is an evaluation path')
         image_features = self.encode_image(image)
         text_features = self.encode_text(text)
+        if multi_rank:
+            return _CrossRankLogitsFn.apply(image_features, text_features, self.logit_scale)
         image_logits = _LogitsFn.apply(image_features, text_features, self.logit_scale)
         return image_logits, image_logits.t()

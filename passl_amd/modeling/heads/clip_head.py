@@ -3,11 +3,29 @@ img_labels) + CE(text_logits, text_labels)`` with outputs ``img_loss / text_loss
 
 HIP execution: CLIP.forward returns ``text_logits`` as the transpose view of ``img_logits`` and
 CLIPWrapper's labels are ``arange(B)``, so both cross-entropies run over ONE matrix (rows and
-columns) in csrc/clip.hip; other inputs raise instead of silently computing something else."""
+columns) in csrc/clip.hip.  Rectangular logits [B, W*B] (cross-rank negatives, labels
+``arange(B) + B*rank``) take the row cross-entropy kernel of csrc/clas.hip once per matrix; anything
+else raises instead of silently computing something else."""
+import torch
 from torch.autograd import Function
 
 from ...hip import nn, ops
 from .builder import HEADS
+
+
+class _RowCEFn(Function):
+    """mean_i ( logsumexp(logits[i]) - logits[i, labels[i]] ) over fp32 rows."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        out, lse = ops.softmax_ce_fwd(logits.contiguous(), labels)
+        ctx.save_for_backward(logits, lse, labels)
+        return out[0:1]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        logits, lse, labels = ctx.saved_tensors
+        return ops.softmax_ce_bwd(logits, lse, labels, gloss.contiguous().float()), None
 
 
 class _SymmetricCEFn(Function):
@@ -32,12 +50,27 @@ class CLIPHead(nn.Layer):
 
     def forward(self, img_logits, text_logits, img_labels, text_labels):
         B = img_logits.shape[0]
+        if img_logits.shape[1] != B or text_logits.data_ptr() != img_logits.data_ptr():
+            # two separate matrices (cross-rank negatives): CE(img_logits, img_labels) + CE(text_logits, text_labels)
+            if img_labels.numel() != B or text_labels.numel() != B or text_logits.shape != img_logits.shape:
+                raise ValueError('labels must have one entry per row')
+            outputs = dict()
+            outputs['img_loss'] = _RowCEFn.apply(img_logits, img_labels.contiguous().long())
+            outputs['text_loss'] = _RowCEFn.apply(text_logits, text_labels.contiguous().long())
+            outputs['loss'] = outputs['img_loss'] + outputs['text_loss']
+            return outputs
         same = (text_logits.data_ptr() == img_logits.data_ptr() and text_logits.shape == img_logits.shape and
                 text_logits.stride() == img_logits.stride()[::-1] and img_logits.is_contiguous())
         if not same:
             raise NotImplementedError('CLIPHead runs on the (logits, logits.t()) pair CLIP.forward returns')
         if img_labels.numel() != B or text_labels.numel() != B:
             raise ValueError('labels must have one entry per row')
+        # the fused kernel has labels == arange(B) built in: CLIPWrapper marks the tensors it builds that
+        # way; foreign label tensors are checked (one small device->host compare)
+        for lab in (img_labels, text_labels):
+            if not getattr(lab, '_passl_is_arange', False) and \
+                    not bool((lab.reshape(-1).cpu() == torch.arange(B)).all()):
+                raise NotImplementedError('the fused symmetric cross-entropy needs labels == arange(B)')
         img_loss, text_loss, loss = _SymmetricCEFn.apply(img_logits)
         outputs = dict()
         outputs['img_loss'] = img_loss

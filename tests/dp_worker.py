@@ -65,6 +65,9 @@ def plain_run(tr, workload):
                                                    ','.join('%.9g' % l for l in losses)), flush=True)
 
 
+OVERRIDES['clipx'] = OVERRIDES['clip']        # + multi_rank: cross-rank InfoNCE (BASELINE configs[4])
+
+
 def main():
     workload = sys.argv[1]
     from passl_amd.engine.trainer import Trainer
@@ -74,6 +77,8 @@ def main():
     # a non-zero seed: `seed: 0` means UNSEEDED in the reference's Trainer (trainer.py:105), and the
     # single-rank arms of test_rccl_world1 must start from the same weights in separate processes
     cfg = get_config(os.path.join(ROOT, path), ov + ['compute_dtype=fp32', 'seed=7'])
+    if workload == 'clipx':
+        cfg.model.multi_rank = True
     if workload == 'mae':
         cfg.model.architecture.img_size = 64
     if workload == 'moco':

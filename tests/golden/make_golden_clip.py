@@ -20,12 +20,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from oracle import ref_runner                                  # noqa: E402
-from oracle.clip import CLIPOracle, VIT_B_32, SMALL, make_text  # noqa: E402
+from oracle.clip import CLIPOracle, VIT_B_16, VIT_B_32, SMALL, make_text  # noqa: E402
 
 CASES = {
     'clip_small': dict(cfg=SMALL, N=8, steps=3),
     # configs/clip/vit-b-32.yaml architecture (ViT-B/32: 50 image tokens; 77 text tokens, causal)
     'clip_vit_b32': dict(cfg=VIT_B_32, N=4, steps=2),
+    # BASELINE.json configs[4] architecture: ViT-B/16 (197 image tokens) + the same text tower
+    'clip_vit_b16': dict(cfg=VIT_B_16, N=4, steps=2),
 }
 SOLVER = dict(lr=1e-3, beta1=0.9, beta2=0.98, weight_decay=0.0005)
 STD_CAP = 0.05

@@ -238,6 +238,71 @@ def test_golden_vit_b32_bf16():
     _run_against_golden('clip_vit_b32', OC.VIT_B_32, torch.bfloat16, 1, TOL_BF16)
 
 
+def test_golden_vit_b16_fp32():
+    """BASELINE configs[4] architecture: ViT-B/16 (197 image tokens) — golden from the reference's own code."""
+    _run_against_golden('clip_vit_b16', OC.VIT_B_16, torch.float32, 2, TOL_F32)
+
+
+def test_golden_vit_b16_bf16():
+    _run_against_golden('clip_vit_b16', OC.VIT_B_16, torch.bfloat16, 1, TOL_BF16)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_multi_rank_world1_equals_the_reference_path(dtype):
+    """CLIPWrapper(multi_rank=True) — the cross-GPU InfoNCE of BASELINE configs[4] — in a single process:
+    gathered features = local features, labels = arange(B), so losses and every gradient must equal the
+    fused single-matrix path (which is pinned to the reference goldens above)."""
+    cfg = OC.SMALL
+    oracle0 = OC.CLIPOracle(cfg, seed=0, text_std_cap=U.STD_CAP, **U.SOLVER)
+    gen = torch.Generator().manual_seed(4242)
+    image = torch.randn(8, 3, cfg['image_resolution'], cfg['image_resolution'], generator=gen).to(DEV)
+    text = OC.make_text(gen, 8, cfg['context_length'], cfg['vocab_size']).to(DEV)
+    res = []
+    for multi in (False, True):
+        model, opt = U.build_product(cfg, dtype)
+        model.multi_rank = multi
+        U.load_oracle_state(model, oracle0)
+        model.train()
+        out = model(image, text, mode='train')
+        opt.clear_grad()
+        out['loss'].backward()
+        torch.cuda.synchronize()
+        res.append(({k: float(v.detach()) for k, v in out.items()}, model.arena_q.grads.clone(),
+                    float(model.model.logit_scale.detach())))
+    (o0, g0, s0), (o1, g1, s1) = res
+    for k in ('loss', 'img_loss', 'text_loss'):
+        assert abs(o0[k] - o1[k]) < 2e-5 * max(1.0, abs(o0[k])), (k, o0[k], o1[k])
+    assert s0 == s1                                                         # clipped the same way
+    rel = float((g0 - g1).norm() / g0.norm())
+    assert rel < (1e-5 if dtype == torch.float32 else 2e-2), rel
+
+
+def test_cross_rank_building_blocks():
+    """The exposed kernels of the rectangular logits path against torch fp64."""
+    gen = torch.Generator().manual_seed(3)
+    B, WB, D = 24, 72, 64
+    a = torch.randn(B, D, generator=gen); b = torch.randn(WB, D, generator=gen)
+    alpha = torch.tensor([1.7], device=DEV)
+    c = ops.gemm_f32_nt(a.to(DEV), b.to(DEV), alpha)
+    assert relmax(c, 1.7 * a.double() @ b.double().t()) < 1e-5
+    g = torch.randn(B, WB, generator=gen)
+    assert relmax(ops.gemm_f32_gx(g.to(DEV), b.to(DEV), alpha), 1.7 * g.double() @ b.double()) < 1e-5
+    assert relmax(ops.gemm_f32_gx(g.to(DEV), a.to(DEV), alpha, trans=True), 1.7 * g.double().t() @ a.double()) < 1e-5
+    out = torch.tensor([0.5], device=DEV)
+    ops.dot_acc(g.to(DEV), c, out)
+    ref = 0.5 + float((g.double() * c.double().cpu()).sum())
+    assert abs(float(out) - ref) < 1e-4 * abs(ref)
+    out2 = torch.tensor([0.5], device=DEV)
+    ops.dot_acc(g.to(DEV), c, out2)
+    assert torch.equal(out, out2)                                           # fixed-order sum
+    s = torch.tensor([5.0], device=DEV)
+    al = ops.clip_scale(s)
+    assert abs(float(al) - math.exp(5.0)) < 1e-3 and abs(float(s) - 4.6) < 1e-6
+    # rows without epsilon: x / |x|
+    y, nrm = ops.l2norm_fwd(a.to(DEV), 0.0)
+    assert relmax(y, a / a.norm(dim=1, keepdim=True)) < 1e-6
+
+
 def test_trainer_runs_clip_config_end_to_end(tmp_path):
     """The v110 Trainer + hook bus drive the CLIP config (CLIPWrapper, CLIPHead, AdamW, LinearWarmup o
     CosineAnnealingDecay) on synthetic image-text pairs; the loss goes down."""

@@ -212,3 +212,90 @@ def test_simclr_head_cross_rank_gather():
         e1, e2, loss = ret[rank]
         assert e1 < 1e-5 and e2 < 1e-5, (rank, e1, e2)
         assert loss > 0
+
+
+def _clip_gather_case(rank, world):
+    """CLIPWrapper(multi_rank=True)'s collective pattern on two gloo ranks — all-gather of both
+    modalities' normalised features, labels arange(N) + N*rank, reduce-scatter of the gathered copies'
+    gradients — with the HIP kernels replaced by torch restatements of their contracts, against ONE
+    process that evaluates every rank's loss on the full 2N x 2N logit matrix (BASELINE configs[4];
+    pattern of passl/models/mocov3.py:187-198)."""
+    import math
+    import torch.nn.functional as F
+    from passl_amd.hip import ops
+    from passl_amd.modeling.backbones.clip import _CrossRankLogitsFn
+    from passl_amd.modeling.heads.clip_head import CLIPHead
+
+    def l2norm_fwd(x, eps=0.0):
+        n = x.norm(dim=1).clamp_min(eps)
+        return x / n[:, None], n
+
+    def l2norm_bwd(dy, y, norm, dtype):
+        return (dy - y * (dy * y).sum(1, keepdim=True)) / norm[:, None]
+
+    def clip_scale(s, lo=-4.6, hi=4.6):
+        a = s.detach().exp().clone()
+        s.clamp_(lo, hi)
+        return a
+
+    def ce_fwd(scores, labels):
+        lse = torch.logsumexp(scores, 1)
+        loss = (lse - scores[torch.arange(scores.shape[0]), labels]).mean()
+        return torch.stack([loss, torch.zeros(()), torch.zeros(())]), lse
+
+    def ce_bwd(scores, lse, labels, g):
+        p = (scores - lse[:, None]).exp()
+        p[torch.arange(scores.shape[0]), labels] -= 1.0
+        return p * g.reshape(()) / scores.shape[0]
+
+    def dot_acc(a, b, out):
+        out += (a * b).sum()
+
+    ops.l2norm_fwd, ops.l2norm_bwd, ops.clip_scale = l2norm_fwd, l2norm_bwd, clip_scale
+    ops.gemm_f32_nt = lambda a, b, alpha: alpha * (a @ b.t())
+    ops.gemm_f32_gx = lambda g, x, alpha, trans=False: alpha * ((g.t() if trans else g) @ x)
+    ops.dot_acc, ops.softmax_ce_fwd, ops.softmax_ce_bwd = dot_acc, ce_fwd, ce_bwd
+
+    gen = torch.Generator().manual_seed(9)
+    N, D = 5, 32
+    full_i = torch.randn(world * N, D, generator=gen)
+    full_t = torch.randn(world * N, D, generator=gen)
+    s0 = 1.3
+    img = full_i[rank * N:(rank + 1) * N].clone().requires_grad_(True)
+    txt = full_t[rank * N:(rank + 1) * N].clone().requires_grad_(True)
+    scale = torch.tensor([s0], requires_grad=True)
+    li, lt = _CrossRankLogitsFn.apply(img, txt, scale)
+    assert li.shape == (N, world * N) and lt.shape == (N, world * N)
+    labels = torch.arange(N) + N * rank
+    out = CLIPHead()(li, lt, labels, labels)
+    out['loss'].backward()
+    ds = scale.grad.clone()
+    dist.all_reduce(ds)                                      # sum over ranks of d loss_r / d s
+    # single-process reference on the full matrices: sum over ranks of loss_r
+    fi = full_i.clone().requires_grad_(True)
+    ft = full_t.clone().requires_grad_(True)
+    sr = torch.tensor([s0], requires_grad=True)
+    L = sr.exp() * F.normalize(fi, dim=1) @ F.normalize(ft, dim=1).t()
+    total, mine = 0.0, None
+    for r in range(world):
+        rows = slice(r * N, (r + 1) * N)
+        lab = torch.arange(N) + N * r
+        lr = F.cross_entropy(L[rows], lab) + F.cross_entropy(L.t()[rows], lab)
+        total = total + lr
+        if r == rank:
+            mine = float(lr)
+    total.backward()
+    rows = slice(rank * N, (rank + 1) * N)
+    e_loss = abs(float(out['loss']) - mine)
+    e_img = float((img.grad - fi.grad[rows]).abs().max())
+    e_txt = float((txt.grad - ft.grad[rows]).abs().max())
+    e_s = abs(float(ds) - float(sr.grad))
+    return e_loss, e_img, e_txt, e_s, abs(float(scale.detach()) - s0)
+
+
+def test_clip_cross_rank_infonce():
+    ret = _spawn(_clip_gather_case)
+    for rank in (0, 1):
+        e_loss, e_img, e_txt, e_s, e_clip = ret[rank]
+        assert e_loss < 1e-5 and e_img < 1e-5 and e_txt < 1e-5 and e_s < 1e-4, (rank, ret[rank])
+        assert e_clip < 1e-7            # 1.3 is inside the clip range: unchanged

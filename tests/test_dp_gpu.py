@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize('workload', ['moco', 'simclr', 'mae', 'clip', 'linprobe'])
+@pytest.mark.parametrize('workload', ['moco', 'simclr', 'mae', 'clip', 'clipx', 'linprobe'])
 def test_two_ranks_one_gpu(workload):
     _run_worker(workload, 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0'))
 

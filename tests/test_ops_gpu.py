@@ -169,7 +169,7 @@ def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
         y64 = yo.double().cpu().reshape(-1, geom.cout)
         M = y64.shape[0]
         sums = st[:tiles * geom.cout * 2].view(tiles, geom.cout, 2).double().cpu()
-        shifts = st[tiles * geom.cout * 2:].view(tiles, geom.cout).double().cpu()
+        shifts = st[tiles * geom.cout * 2:tiles * geom.cout * 3].view(tiles, geom.cout).double().cpu()
         for t in range(tiles):
             rows = y64[t * 128:min((t + 1) * 128, M)]
             assert torch.equal(shifts[t], rows[0])
@@ -342,11 +342,21 @@ def test_bn_fwd_bwd(dtype, shape, with_res):
     dx, dres = ops.bn_bwd(dz.to(DEV).to(dtype), z, xd, gamma.detach().to(DEV), mean, invstd,
                           dgamma, dbeta, relu=True, want_dres=with_res)
     t = 1e-4 if dtype == torch.float32 else 3e-2
-    assert relmax(dx.float(), x.grad) < t
-    assert relmax(dgamma, gamma.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
-    assert relmax(dbeta, beta.grad) < (1e-4 if dtype == torch.float32 else 1e-2)
+    # elements whose pre-activation is within rounding of zero may take either side of the ReLU (the
+    # product evaluates x*scale + shift + res in fp32, the reference in float64): with 20 M elements a
+    # handful always do, and there dx legitimately differs by a whole gradient value — leave them out
+    sure = (pre.detach().abs() > 1e-5 * float(pre.detach().abs().max())).to(DEV)
+    xg = x.grad.to(DEV)
+    assert float(sure.double().mean()) > 0.999
+    assert relmax(torch.where(sure, dx.double(), xg), xg) < t
+    # (one ReLU-ambiguous element moves a channel's sum by a whole gradient value: visible at 1e-4 only
+    # in the tall case)
+    tsum = 1e-2 if (dtype != torch.float32 or not bool(sure.all())) else 1e-4
+    assert relmax(dgamma, gamma.grad) < tsum
+    assert relmax(dbeta, beta.grad) < tsum
     if with_res:
-        assert relmax(dres.float(), res.grad) < t
+        rg = res.grad.to(DEV)
+        assert relmax(torch.where(sure, dres.double(), rg), rg) < t
     # the other mask sources must reproduce the z-based result bit for bit: 3 = bit mask,
     # 2 = recomputed from x*scale+shift (BN+ReLU without residual only)
     for mode in ([3] if with_res else [3, 2]):
