@@ -59,9 +59,28 @@ def accuracy(scores, labels, topk=(1, 5)):
     return [(rank < k).double().sum() * 100.0 / scores.shape[0] for k in topk]
 
 
-def clas_forward(st, img, labels):
-    with torch.no_grad():
-        feat = trunk_forward(backbone_state(st), img, use_global_stats=True)     # [N, 2048, h, w]
+def frozen_keys(st, frozen_stages):
+    """Parameters _freeze_stages (resnet.py:90-106) makes non-trainable: conv1/bn1 for frozen_stages >= 0
+    plus layer1..layer<frozen_stages>; BatchNorm running statistics are never trainable."""
+    out = set()
+    for k in st:
+        if k.endswith('._mean') or k.endswith('._variance'):
+            out.add(k)
+        elif k.startswith('backbone.') and frozen_stages >= 0:
+            name = k[len('backbone.'):]
+            stage = int(name[5]) if name.startswith('layer') else 0
+            if stage <= frozen_stages:
+                out.add(k)
+    return out
+
+
+def clas_forward(st, img, labels, frozen_stages=4, new_stats=None):
+    if frozen_stages >= 4:
+        with torch.no_grad():
+            feat = trunk_forward(backbone_state(st), img, use_global_stats=True)     # [N, 2048, h, w]
+    else:
+        feat = trunk_forward(backbone_state(st), img, use_global_stats=False, new_stats=new_stats,
+                             frozen_stages=frozen_stages)
     x = feat.mean(dim=(2, 3))
     scores = x @ st['head.fc_cls.weight'] + st['head.fc_cls.bias']
     loss = F.cross_entropy(scores, labels)
@@ -74,7 +93,9 @@ def multistep_lr(base_lr, epoch, milestones, gamma=0.1):
 
 
 class ClasOracle:
-    def __init__(self, num_classes=1000, seed=0, lr=30.0, momentum=0.9, dtype=torch.float32, width_div=1):
+    def __init__(self, num_classes=1000, seed=0, lr=30.0, momentum=0.9, dtype=torch.float32, width_div=1,
+                 frozen_stages=4):
+        self.frozen_stages = frozen_stages
         gen = torch.Generator().manual_seed(seed)
         self.st = OrderedDict((k, v.to(dtype)) for k, v in init_state(gen, num_classes, width_div).items())
         self.lr_value, self.mu = lr, momentum
@@ -85,11 +106,16 @@ class ClasOracle:
         return self.lr_value(self.step_count) if callable(self.lr_value) else self.lr_value
 
     def train_step(self, img, labels):
-        tk = ['head.fc_cls.weight', 'head.fc_cls.bias']
+        fz = frozen_keys(self.st, self.frozen_stages)
+        tk = [n for n in self.st if n not in fz]
         for n in tk:
             self.st[n] = self.st[n].detach().requires_grad_(True)
-        out = clas_forward(self.st, img, labels)
+        new_stats = {}
+        out = clas_forward(self.st, img, labels, self.frozen_stages, new_stats)
         out['loss'].backward()
+        with torch.no_grad():
+            for k, v in new_stats.items():        # running statistics of the BatchNorms still training
+                self.st['backbone.' + k[2:]] = v
         grads = OrderedDict((n, self.st[n].grad.detach().clone()) for n in tk)
         lr = self.lr()
         with torch.no_grad():

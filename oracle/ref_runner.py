@@ -236,11 +236,13 @@ def load_clip_state(model, oracle):
             sd[n].copy_(t.detach())
 
 
-def build_reference_clas(num_classes=1000):
+def build_reference_clas(num_classes=1000, frozen_stages=4):
     """The reference's Classification model built by its MODELS registry from the `model:` block of
-    configs/moco/moco_clas_r50.yaml (frozen_stages = 4)."""
+    configs/moco/moco_clas_r50.yaml (frozen_stages = 4; 0..3 = partially frozen trunk,
+    passl_v110/modeling/backbones/resnet.py:90-106)."""
     ns = load()
-    return ns.build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50, frozen_stages=4),
+    return ns.build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50,
+                                                                    frozen_stages=frozen_stages),
                                head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048,
                                          num_classes=num_classes)))
 

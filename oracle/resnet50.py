@@ -127,7 +127,8 @@ def batch_norm(x, st, prefix, use_global_stats, new_stats=None, affine_form=Fals
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=True, bf16=False):
+def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=True, bf16=False,
+                  frozen_stages=-1):
     """ResNet-50 trunk (keys '0.*'): [N,3,H,W] -> layer4 map.  ``maxpool=False`` is the
     SimCLR variant (passl_v110/modeling/backbones/resnetcifar.py:275 comments the stem pool
     out, forward :321-333).
@@ -145,7 +146,11 @@ def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=Tr
         return F.conv2d(x, st['0.' + name + '.weight'], None, stride, pad)
 
     def bn(name, x):
-        return batch_norm(x, st, '0.' + name, use_global_stats, new_stats)
+        # resnet.py:90-106 (_freeze_stages): frozen_stages >= 0 freezes the stem's BatchNorm, and
+        # layer1..layer<frozen_stages> — their BatchNorms use the running statistics
+        stage = 0 if not name.startswith('layer') else int(name[5])
+        frozen = frozen_stages >= 0 and stage <= frozen_stages
+        return batch_norm(x, st, '0.' + name, use_global_stats or frozen, new_stats)
 
     x = F.relu(bn('bn1', conv('conv1', x, 2, 3)))
     if maxpool:

@@ -696,6 +696,13 @@ class EncoderArena:
                 params.append((mod, name, kind))
         stats = [(mod, n) for mod in module.modules() if isinstance(mod, _BatchNormBase)
                  for n in ('_mean', '_variance')]
+        if not params:
+            raise ValueError('EncoderArena over a module without parameters')
+        if trainable and any(not m._parameters[n].requires_grad for m, n, _k in params):
+            raise NotImplementedError(
+                'a trainable EncoderArena holds only trainable parameters: frozen sub-layers (e.g. '
+                'ResNet(frozen_stages >= 0)) belong in their own non-trainable arena — see '
+                'modeling/architectures/clas.py; the pre-training architectures use frozen_stages -1')
         dev = params[0][0]._parameters[params[0][1]].device
         self.device = dev
 

@@ -2,12 +2,12 @@
 passl_v110/modeling/architectures/clas.py:25-77: ``train_iter(img, label)`` = backbone -> head ->
 ``head.loss``; ``test_iter`` returns the class scores; modes train / test / extract / infer.
 
-HIP execution for the linear-probe configs (configs/moco/moco_clas_r50.yaml: ``frozen_stages: 4``): the
-frozen trunk lives in a non-trainable EncoderArena and runs the fused inference path (BatchNorm with
-running statistics + ReLU + residual folded into the conv epilogues: one kernel per conv), only the
-head's arena is trainable (momentum-SGD / data-parallel reducer see just the fc).  A trainable
-backbone (supervised training, frozen_stages -1) raises: its BN-statistics path is built for the
-pre-training architectures only."""
+HIP execution: the frozen part of the trunk (``backbone.frozen_stages``, resnet.py:90-106; 4 = all of it
+for the linear-probe configs, configs/moco/moco_clas_r50.yaml) lives in a non-trainable EncoderArena and
+runs the fused inference path (BatchNorm with running statistics + ReLU + residual folded into the conv
+epilogues: one kernel per conv); the trainable remainder (layer<frozen_stages+1>..layer4, or the whole
+trunk for frozen_stages -1) shares ONE trainable arena with the head — what the optimizer and the
+data-parallel reducer see."""
 import torch
 
 from ...hip import nn
@@ -27,15 +27,18 @@ class Classification(nn.Layer):
             raise NotImplementedError('with_sobel is a TODO in the reference (clas.py:35-37)')
         self.with_sobel = with_sobel
         self.backbone = build_backbone(backbone)
-        if not getattr(self.backbone, 'fully_frozen', False):
-            raise NotImplementedError('Classification is built for the frozen-trunk linear probe '
-                                      '(backbone.frozen_stages: 4)')
         if head is None:
             raise NotImplementedError('Classification without a head')
         self.head = build_head(head)
-        self.arena_k = EncoderArena(self.backbone, trainable=False)   # frozen trunk (name as in MoCo)
-        self.arena_k.update_bn_affine()
-        self.arena_q = EncoderArena(self.head, trainable=True)        # what the optimizer / reducer see
+        frozen = self.backbone.frozen_modules() if hasattr(self.backbone, 'frozen_modules') else []
+        live = self.backbone.trainable_modules() if hasattr(self.backbone, 'trainable_modules') else []
+        # arenas over plain lists of sub-layers (containers that do not re-parent the modules)
+        self.arena_k = None
+        if frozen:
+            self.arena_k = EncoderArena(torch.nn.ModuleList(frozen), trainable=False)   # name as in MoCo
+            self.arena_k.update_bn_affine()
+        object.__setattr__(self, '_live', torch.nn.ModuleList(list(live) + [self.head]))
+        self.arena_q = EncoderArena(self._live, trainable=True)        # what the optimizer / reducer see
 
     def load_state_dict(self, state_dict, strict=True):
         r = super().load_state_dict(state_dict, strict=strict)
@@ -44,8 +47,9 @@ class Classification(nn.Layer):
 
     def sync_runtime_state(self):
         """Call after weights were written from outside (checkpoint / pretrained backbone load)."""
-        self.arena_k.refresh()
-        self.arena_k.update_bn_affine()
+        if self.arena_k is not None:
+            self.arena_k.refresh()
+            self.arena_k.update_bn_affine()
         self.arena_q.refresh()
 
     def backbone_forward(self, x):

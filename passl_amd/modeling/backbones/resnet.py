@@ -143,20 +143,30 @@ class ResNet(nn.Layer):
                     init.constant_init(m.bn3, 0)
 
     def _freeze_stages(self):
-        """resnet.py:90-106.  Built: -1 (nothing frozen: pre-training) and 4 (everything frozen: the
-        linear-probe configs, e.g. configs/moco/moco_clas_r50.yaml) — then every BatchNorm uses its
-        running statistics, no parameter is trainable and forward() runs the fused inference path."""
+        """resnet.py:90-106: ``frozen_stages >= 0`` freezes the stem (conv1 / bn1), every further unit
+        layer1..layer<frozen_stages>: their parameters are not trainable and their BatchNorms use the
+        running statistics.  4 = the whole trunk (linear-probe configs, configs/moco/moco_clas_r50.yaml).
+        The frozen prefix always runs the fused inference path (BatchNorm + ReLU + residual folded into
+        the conv epilogues, one kernel per conv, nothing saved for backward)."""
         self.fully_frozen = False
         if self.frozen_stages < 0:
             return
-        if self.frozen_stages < 4:
-            raise NotImplementedError('partially frozen trunks (frozen_stages 0..3) are not built; '
-                                      'supported: -1 (pre-training) and 4 (linear probe)')
-        freeze_batchnorm_statictis(self)
-        for p in self.parameters():
-            p.requires_grad_(False)
-        self.fully_frozen = True
+        for m in self.frozen_modules():
+            freeze_batchnorm_statictis(m)
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self.fully_frozen = self.frozen_stages >= 4
         get_logger().info('Frozen layer before stage {}'.format(self.frozen_stages + 1))
+
+    def frozen_modules(self):
+        """Sub-layers _freeze_stages freezes, in forward order."""
+        if self.frozen_stages < 0:
+            return []
+        return [self.conv1, self.bn1] + [getattr(self, 'layer%d' % i) for i in range(1, min(self.frozen_stages, 4) + 1)]
+
+    def trainable_modules(self):
+        return [getattr(self, 'layer%d' % i) for i in range(max(self.frozen_stages, 0) + 1, 5)] \
+            if self.frozen_stages >= 0 else [self.conv1, self.bn1, self.layer1, self.layer2, self.layer3, self.layer4]
 
     def _all_bn_frozen(self):
         return all(m.uses_global_stats() for m in self.modules() if isinstance(m, nn._BatchNormBase))
@@ -168,13 +178,19 @@ class ResNet(nn.Layer):
         N, _, H, W = x.shape
         _Hp, Wp = P.stem_padded_hw(H, W)
         xp = ops.nchw_to_nhwc_pad(x.contiguous().float(), P.STEM_PAD, Wp, P.STEM_CP, dtype)
-        frozen = self._all_bn_frozen()
-        if frozen and (self.fully_frozen or not torch.is_grad_enabled()):
+        stages = (self.layer1, self.layer2, self.layer3, self.layer4)
+        # number of leading stages that run frozen: all of them for a key encoder under no_grad (every
+        # BatchNorm on running statistics), the _freeze_stages prefix otherwise
+        if self._all_bn_frozen() and (self.fully_frozen or not torch.is_grad_enabled()):
+            n_frozen = 4
+        else:
+            n_frozen = min(self.frozen_stages, 4)
+        if n_frozen >= 0:
             with torch.no_grad():
                 y = self.conv1.infer(xp, self.bn1, relu=True, hw=(H, W))
                 if self.stem_pool:
                     y = self.maxpool(y)
-                for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for stage in stages[:n_frozen]:
                     for blk in stage:
                         y = blk.forward_frozen(y)
         else:
@@ -182,9 +198,9 @@ class ResNet(nn.Layer):
             y = self.bn1(y, relu=True, stats=st)
             if self.stem_pool:
                 y = self.maxpool(y)
-            for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
-                for blk in stage:
-                    y = blk(y)
+        for stage in stages[max(n_frozen, 0):]:
+            for blk in stage:
+                y = blk(y)
         if self.with_pool:
             y = self.avgpool(y)
         return y

@@ -8,11 +8,12 @@ from passl_amd.solver.optimizer import Momentum
 LR, MU = 0.002, 0.9                                   # tests/golden/make_golden_clas.py
 
 
-def build_product(num_classes, dtype, device='gpu'):
+def build_product(num_classes, dtype, device='gpu', frozen_stages=4):
     hip_config.set_device(device)
     hip_config.set_compute_dtype(dtype)
     torch.manual_seed(0)
-    model = build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50, frozen_stages=4),
+    model = build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50,
+                                                                    frozen_stages=frozen_stages),
                              head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048,
                                        num_classes=num_classes)))
     opt = Momentum(LR, momentum=MU, parameters=list(model.parameters()), weight_decay=0.0)

@@ -112,6 +112,47 @@ def test_golden_small_fp32():
     _run_against_golden('clas_r50_small', torch.float32, 3, TOL_F32)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_golden_partially_frozen_trunk(dtype):
+    """frozen_stages = 2 (passl_v110/modeling/backbones/resnet.py:90-106): stem + layer1-2 frozen — fused
+    inference kernels, parameters and BatchNorm statistics untouched — layer3-4 and the head trained with
+    batch statistics; golden from the reference's own Classification / ResNet sources."""
+    z = np.load(os.path.join(GOLDEN, 'clas_r50_frozen2.npz'))
+    N, size, ncls, steps = [int(v) for v in z['meta']]
+    oracle0 = OC.ClasOracle(num_classes=ncls, seed=0, lr=U.LR, momentum=U.MU, frozen_stages=2)
+    model, opt = U.build_product(ncls, dtype, frozen_stages=2)
+    U.load_oracle_state(model, oracle0)
+    model.train()
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert trainable == set(oracle0.st) - OC.frozen_keys(oracle0.st, 2)
+    f32 = dtype == torch.float32
+    gen = torch.Generator().manual_seed(909)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    for s in range(steps):
+        img = torch.randn(N, 3, size, size, generator=gen)
+        lab = torch.randint(0, ncls, (N,), generator=gen)
+        out = U.product_step(model, opt, img.to(DEV), lab.to(DEV))
+        pre = 's%d_' % s
+        assert abs(float(out['loss'].detach()) - float(z[pre + 'loss'])) < ((1e-4 if s == 0 else 5e-3) if f32 else 1e-1)
+        ps = dict(model.named_parameters())
+        sd = model.state_dict()
+        for key in z.files:
+            if key.startswith(pre + 'gradnorm/') and not key.startswith(pre + 'f64'):
+                n = key[len(pre + 'gradnorm/'):]
+                g = ps[n].grad.double().norm().item()
+                assert abs(g - float(z[key])) <= ((1e-3 if s == 0 else 5e-2) if f32 else 1e-1) * float(z[key]), (n, g, float(z[key]))
+            if key.startswith(pre + 'stat/'):
+                n = key[len(pre + 'stat/'):]
+                err = np.abs(sd[n][:8].double().cpu().numpy() - z[key]).max()
+                assert err < ((1e-4 if s == 0 else 5e-3) if f32 else 5e-2), (n, err)
+    sd = model.state_dict()
+    for n in ('backbone.conv1.weight', 'backbone.bn1._mean', 'backbone.layer1.0.conv1.weight',
+              'backbone.layer2.3.bn3._variance', 'backbone.layer2.3.bn3.weight'):
+        assert torch.equal(sd[n], sd0[n]), n                    # the frozen prefix never moves
+    assert not torch.equal(sd['backbone.layer3.0.conv1.weight'], sd0['backbone.layer3.0.conv1.weight'])
+    assert not torch.equal(sd['backbone.layer3.0.bn1._mean'], sd0['backbone.layer3.0.bn1._mean'])
+
+
 def test_golden_b16_fp32():
     """configs/moco/moco_clas_r50.yaml shapes: 224^2 images, 1000 classes."""
     _run_against_golden('clas_r50_b16', torch.float32, 2, TOL_F32)

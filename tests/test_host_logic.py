@@ -438,8 +438,13 @@ def test_clip_mask_and_registry_guards():
                               transformer_layers=1, qkv_bias=True)
     head = HEADS.get('CLIPHead')()
     a = torch.zeros(4, 4)
-    with pytest.raises(NotImplementedError):          # not the (logits, logits.t()) pair
-        head(a, torch.zeros(4, 4), torch.arange(4), torch.arange(4))
+    from passl_amd.hip.lib import PasslHipError
+    with pytest.raises(PasslHipError):                # two separate matrices = the cross-rank form: a HIP
+        head(a, torch.zeros(4, 4), torch.arange(4), torch.arange(4))      # path, refused on host tensors
+    with pytest.raises(ValueError):                   # one label per row
+        head(a, torch.zeros(4, 4), torch.arange(3), torch.arange(4))
+    with pytest.raises(NotImplementedError):          # the fused (logits, logits.t()) kernel has arange(B) built in
+        head(a, a.t(), torch.tensor([0, 1, 3, 2]), torch.arange(4))
 
 
 def test_synthetic_image_text_dataset():
@@ -484,12 +489,26 @@ def test_reference_linear_probe_config_loads_and_builds_unchanged():
     opt = build_optimizer(cfg.optimizer, sched, [model])
     assert opt.type == 'momentum' and opt._wd == 0.0 and opt._momentum == 0.9 and len(opt._parameter_list) == 2
     assert isinstance(build_hook(dict(cfg.custom_config[0])), EvaluateHook)
+    # partially frozen trunk (resnet.py:90-106): stem + layer1-2 frozen, the rest trains with the head
+    m2 = build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50, frozen_stages=2),
+                          head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048)))
+    tr = {n for n, p in m2.named_parameters() if p.requires_grad}
+    assert 'backbone.layer3.0.conv1.weight' in tr and 'backbone.layer4.2.bn3.bias' in tr and 'head.fc_cls.weight' in tr
+    assert not any(n.startswith(('backbone.conv1', 'backbone.bn1', 'backbone.layer1', 'backbone.layer2')) for n in tr)
+    bb = m2.backbone
+    assert bb.layer2[0].bn1.uses_global_stats() and not bb.layer3[0].bn1.uses_global_stats() and not bb.fully_frozen
+    assert m2.arena_k is not None and not m2.arena_k.trainable and m2.arena_q.trainable
+    assert sum(n for _o, n in m2.arena_q.param_slices) == sum(p.numel() for p in m2.parameters() if p.requires_grad)
+    assert sorted(m2.state_dict()) == sorted(model.state_dict())           # same checkpoint keys
+    # a trainable trunk (supervised training) = one arena for trunk + head, no frozen arena
+    m3 = build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50),
+                          head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048)))
+    assert m3.arena_k is None and all(p.requires_grad for p in m3.parameters())
+    # the pre-training architectures keep ONE trainable arena: a frozen prefix there is refused loudly
     with pytest.raises(NotImplementedError):
-        build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50, frozen_stages=2),
-                         head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048)))
-    with pytest.raises(NotImplementedError):
-        build_model(dict(name='Classification', backbone=dict(name='ResNet', depth=50),
-                         head=dict(name='ClasHead', with_avg_pool=True, in_channels=2048)))
+        build_model(dict(name='MoCo', backbone=dict(name='ResNet', depth=50, frozen_stages=1),
+                         neck=dict(name='NonLinearNeckV1', in_channels=2048, hid_channels=2048, out_channels=128,
+                                   with_avg_pool=True), head=dict(name='ContrastiveHead', temperature=0.2)))
 
 
 def test_synthetic_labeled_dataset_and_evaluate_contract():

@@ -36,6 +36,34 @@ def _against(name, max_steps):
             assert abs(o.st[n].double().norm().item() - float(z[pre + 'pnorm/' + n])) < 1e-5, n
 
 
+def test_oracle_matches_golden_partially_frozen():
+    """frozen_stages = 2 (resnet.py:90-106): stem + layer1-2 frozen (parameters AND BatchNorm statistics),
+    layer3-4 + head trained with batch statistics — golden from the reference's own code."""
+    z = np.load(os.path.join(GOLDEN, 'clas_r50_frozen2.npz'))
+    N, size, ncls, steps = [int(v) for v in z['meta']]
+    o = C.ClasOracle(num_classes=ncls, seed=0, lr=LR, momentum=MU, frozen_stages=2)
+    gen = torch.Generator().manual_seed(909)
+    for s in range(steps):
+        img = torch.randn(N, 3, size, size, generator=gen)
+        lab = torch.randint(0, ncls, (N,), generator=gen)
+        out = o.train_step(img, lab)
+        pre = 's%d_' % s
+        assert abs(float(out['loss']) - float(z[pre + 'loss'])) < (2e-5 if s == 0 else 2e-3)
+        for key in z.files:
+            if key.startswith(pre + 'gradnorm/'):
+                n = key[len(pre + 'gradnorm/'):]
+                g = out['grads'][n].double().norm().item()
+                assert abs(g - float(z[key])) <= (1e-4 if s == 0 else 2e-2) * max(g, 1e-9), n
+            if key.startswith(pre + 'stat/'):
+                n = key[len(pre + 'stat/'):]
+                np.testing.assert_allclose(o.st[n][:8].double().numpy(), z[key], atol=1e-5 if s == 0 else 1e-3)
+    # the frozen stages' statistics never moved, the training ones did
+    o0 = C.ClasOracle(num_classes=ncls, seed=0, lr=LR, momentum=MU, frozen_stages=2)
+    assert torch.equal(o.st['backbone.layer2.3.bn3._variance'], o0.st['backbone.layer2.3.bn3._variance'])
+    assert not torch.equal(o.st['backbone.layer3.0.bn1._mean'], o0.st['backbone.layer3.0.bn1._mean'])
+    assert torch.equal(o.st['backbone.layer1.0.conv1.weight'], o0.st['backbone.layer1.0.conv1.weight'])
+
+
 def test_oracle_matches_golden_small():
     _against('clas_r50_small', 3)
 
