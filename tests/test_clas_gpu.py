@@ -140,7 +140,7 @@ def test_golden_partially_frozen_trunk(dtype):
             if key.startswith(pre + 'gradnorm/') and not key.startswith(pre + 'f64'):
                 n = key[len(pre + 'gradnorm/'):]
                 g = ps[n].grad.double().norm().item()
-                assert abs(g - float(z[key])) <= ((1e-3 if s == 0 else 5e-2) if f32 else 1e-1) * float(z[key]), (n, g, float(z[key]))
+                assert abs(g - float(z[key])) <= ((3e-3 if s == 0 else 5e-2) if f32 else 1e-1) * float(z[key]), (n, g, float(z[key]))
             if key.startswith(pre + 'stat/'):
                 n = key[len(pre + 'stat/'):]
                 err = np.abs(sd[n][:8].double().cpu().numpy() - z[key]).max()
