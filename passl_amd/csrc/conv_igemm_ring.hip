@@ -70,7 +70,8 @@ struct Params {
   const float* bnb_shift;
   float* bnb_partial;
   int bnb_relu, bnb_tile_off;
-  uint32_t a_bytes, b_bytes;
+  int64_t a_total;            // bytes of the whole A tensor (may exceed 32 bits: every workgroup rebases its buffer)
+  uint32_t b_bytes;
   int M, NCOLS, KDIM;
   int OP, OQ, S, C, IH, IW, sh, sw, ph, pw;
   int a_sn2, a_sh2, a_sw2;      // BYTE strides of A (fit 32 bits, checked on the host)
@@ -143,7 +144,14 @@ __global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 
   const int l15 = lane & 15, l4 = lane >> 4;
   const int opq = p.OP * p.OQ;
 
-  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
+  // A may be larger than a buffer descriptor can address (32-bit byte offsets): the descriptor of this
+  // workgroup starts at the first image (dense: first row) its tile touches, lane offsets are relative to
+  // that; the host guarantees that one tile's span stays below 2 GB
+  const int nb = p.dense ? 0 : fdiv(m0 < p.M ? m0 : p.M - 1, p.d_opq);
+  const int64_t a_off0 = p.dense ? (int64_t)m0 * (p.C * 2) : (int64_t)nb * p.a_sn2;
+  const int64_t a_left = p.a_total - a_off0;
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.a) + a_off0, 0, (uint32_t)(a_left < 0x7ffffff0ll ? a_left : 0x7ffffff0ll), 0x00020000);
   __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.b), 0, p.b_bytes, 0x00020000);
 
   // ---- static DMA geometry.  Instruction q = i*WAVES + wave covers tile rows 8q .. 8q+7;
@@ -161,7 +169,7 @@ __global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 
     const uint32_t chunk = (uint32_t)(((lane % CPRW) ^ (BK == 64 ? ((row >> 1) & 7) : swz32(row))) * 16);
     if (m < p.M) {
       if (p.dense) {
-        a_base[i] = (uint32_t)m * (uint32_t)(p.C * 2) + chunk;
+        a_base[i] = (uint32_t)(m - m0) * (uint32_t)(p.C * 2) + chunk;
         ih0[i] = 0; iw0[i] = 0;
       } else {
         const int n = fdiv(m, p.d_opq);
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 
         const int oq = rem - op * p.OQ;
         ih0[i] = op * p.sh - p.ph;
         iw0[i] = oq * p.sw - p.pw;
-        a_base[i] = (uint32_t)n * (uint32_t)p.a_sn2 + (uint32_t)(ih0[i] * p.a_sh2) +
+        a_base[i] = (uint32_t)(n - nb) * (uint32_t)p.a_sn2 + (uint32_t)(ih0[i] * p.a_sh2) +
                     (uint32_t)(iw0[i] * p.a_sw2) + chunk;
       }
     } else {
@@ -437,7 +445,14 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
   const int64_t a_bytes = (int64_t)d->N * d->a_sn * 2;
   const int64_t b_bytes = (int64_t)d->NCOLS * K64 * 2;
   const int64_t lim = 0x7ffffff0ll;
-  if (a_bytes <= 0 || a_bytes >= lim || b_bytes >= lim) return PASSL_EUNSUPPORTED;
+  if (a_bytes <= 0 || b_bytes >= lim) return PASSL_EUNSUPPORTED;
+  {
+    // every workgroup addresses A relative to the first image its (<= 256-row) tile touches: the images a
+    // tile can span must fit 31 bits of byte offset (the tensor itself may be far larger)
+    const int64_t opq = (int64_t)d->OP * d->OQ;
+    const int64_t span_images = 256 / opq + 2;
+    if (d->a_sn * 2 * span_images >= lim || d->a_sn * 2 >= lim) return PASSL_EUNSUPPORTED;
+  }
   const int bn = d->NCOLS <= 64 ? 64 : 128;
   const int tiles_n = (d->NCOLS + bn - 1) / bn;
   const int bm = g_ring_bm;
@@ -456,7 +471,7 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
   p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
   p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
-  p.a_bytes = (uint32_t)a_bytes; p.b_bytes = (uint32_t)b_bytes;
+  p.a_total = a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.S = d->S; p.C = d->C;
   p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;

@@ -539,8 +539,8 @@ __device__ __forceinline__ uint2 lds_read_tr64(uint32_t addr) {
 }
 
 template <int BMo, int BNo, int BKM, int NST, bool DENSE>
-__global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p, uint32_t a_bytes,
-                                                                 uint32_t dy_bytes) {
+__global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p, int64_t a_total,
+                                                                 int64_t dy_total) {
   constexpr int KS = BKM / 32;                         // 16x16x32 MFMA k-steps per stage
   static_assert((BKM == 32 || BKM == 64) && NST >= 2 && NST <= 4, "ring shape");
   constexpr int WM = BMo / 2, WN = BNo / 2;
@@ -579,8 +579,19 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
   if (kt_begin >= kt_end) return;
   const int nk = kt_end - kt_begin;
 
-  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, dy_bytes, 0x00020000);
+  // Both operands may exceed what a buffer descriptor addresses (32-bit byte offsets): this workgroup's
+  // descriptors start at the first row (x gathered: the first image) of ITS M-slice and every lane offset is
+  // relative to that; the host sizes the slices so that one slice spans < 2 GB of each operand.
+  const int m_begin = kt_begin * BKM;
+  const int nb0 = m_begin / opq;
+  const uint32_t dy_pitch = (uint32_t)(p.dy_ld * 2), x_pitch = (uint32_t)(p.C * 2);
+  const int64_t dy_off0 = (int64_t)m_begin * dy_pitch;
+  const int64_t a_off0 = DENSE ? (int64_t)m_begin * x_pitch : (int64_t)nb0 * p.a_sn * 2;
+  const int64_t dy_left = dy_total - dy_off0, a_left = a_total - a_off0;
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.a) + a_off0, 0, (uint32_t)(a_left < 0x7ffffff0ll ? a_left : 0x7ffffff0ll), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.dy) + dy_off0, 0, (uint32_t)(dy_left < 0x7ffffff0ll ? dy_left : 0x7ffffff0ll), 0x00020000);
 
   // ---- static per-thread DMA geometry (rows advance by 32 per tile: the swizzle term is invariant)
   int a_row[NIA]; uint32_t a_col[NIA];                 // dy tile
@@ -611,8 +622,6 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
       b_col[i] = j < p.KDIM ? (uint32_t)(j - rs * p.C) * 2u : kOOB;
     }
   }
-  const uint32_t dy_pitch = (uint32_t)(p.dy_ld * 2), x_pitch = (uint32_t)(p.C * 2);
-
   auto fill_rowinfo = [&](int t) {                     // tile t (relative), slot t & 3
     if (!DENSE && tid < BKM) {
       const int m = (kt_begin + t) * BKM + tid;
@@ -622,7 +631,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
         const int rem = m - n * opq;
         const int op = rem / p.OQ;
         const int oq = rem - op * p.OQ;
-        ri.base = (uint32_t)((int64_t)n * p.a_sn * 2);
+        ri.base = (uint32_t)((int64_t)(n - nb0) * p.a_sn * 2);
         ri.ih0 = op * p.sh - p.ph;
         ri.iw0 = oq * p.sw - p.pw;
         ri.valid = 1;
@@ -641,7 +650,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
       const int m = mbase + a_row[i];
-      const uint32_t off = (m < p.M && a_col[i] != kOOB) ? (uint32_t)m * dy_pitch + a_col[i] : kOOB;
+      const uint32_t off = (m < p.M && a_col[i] != kOOB) ? (uint32_t)(m - m_begin) * dy_pitch + a_col[i] : kOOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rs_dy, (__attribute__((address_space(3))) void*)(Ab + (i * 4 + wave) * 1024), 16, off, 0, 0, 0);
     }
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
       uint32_t off = kOOB;
       if (DENSE) {
         const int m = mbase + b_row[i];
-        if (m < p.M && b_col[i] != kOOB) off = (uint32_t)m * x_pitch + b_col[i];
+        if (m < p.M && b_col[i] != kOOB) off = (uint32_t)(m - m_begin) * x_pitch + b_col[i];
       } else {
         // read right after the iteration's `vmcnt(0)` + barrier: no DMA is outstanding, so the
         // compiler's conservative wait in front of this LDS read costs nothing
@@ -783,7 +792,7 @@ __global__ void __launch_bounds__(kThreads, 2) wgrad_pipe_kernel(const WParams p
 }
 
 template <int BMo, int BNo, int BKM, int NST, bool DENSE>
-int launch_pipe(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
+int launch_pipe(const WParams& p, int splits, int64_t a_bytes, int64_t dy_bytes, hipStream_t st) {
   constexpr int LDS = NST * BKM * (BMo + BNo) * 2 + (DENSE ? 0 : 4 * 64 * (int)sizeof(RowInfo2));
   static bool attr_set = false;
   if (!attr_set) {
@@ -799,6 +808,14 @@ int launch_pipe(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_byte
   q.grid_j = (p.KDIM + BNo - 1) / BNo;
   q.grid_oc = (p.NCOLS + BMo - 1) / BMo;
   q.nsplits = splits;
+  {
+    // one M-slice must stay inside a 2 GB window of each operand (descriptors are rebased per slice)
+    const int64_t lim = 0x7ffffff0ll;
+    const int64_t rows = (int64_t)q.tiles_per_split * BKM;
+    const int64_t opq = (int64_t)p.OP * p.OQ;
+    const int64_t x_span = DENSE ? rows * p.C * 2 : (rows / opq + 2) * p.a_sn * 2;
+    if (rows * p.dy_ld * 2 >= lim || x_span >= lim) return PASSL_EUNSUPPORTED;
+  }
   t_eff_splits = splits;
   hipLaunchKernelGGL((wgrad_pipe_kernel<BMo, BNo, BKM, NST, DENSE>), dim3(q.grid_j * q.grid_oc * splits),
                      dim3(kThreads), LDS, st, q, a_bytes, dy_bytes);
@@ -837,7 +854,9 @@ bool dense_rows(const WParams& p) {
          p.a_sn == (int64_t)p.IH * p.IW * p.C;
 }
 
-int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes, hipStream_t st) {
+int dispatch_dma(const WParams& p, int splits, int64_t a_bytes, int64_t dy_bytes, hipStream_t st) {
+  const int64_t lim32 = 0x7ffffff0ll;
+  const bool small = a_bytes < lim32 && dy_bytes < lim32;     // the first-generation kernel addresses globally
   if (g_wgrad_pipe && g_wgrad_tile == 0) {
     const bool m64 = p.NCOLS <= 64, n64 = p.KDIM <= 64;
     if (g_wgrad_pipe == 1 && dense_rows(p) && !m64 && !n64)
@@ -855,15 +874,17 @@ int dispatch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_byt
       return launch_pipe<128, 128, 64, 2, false>(p, splits, a_bytes, dy_bytes, st);
     }
   }
-  if (g_wgrad_tile == 1) return launch_dma<64, 64>(p, splits, a_bytes, dy_bytes, st);
-  if (g_wgrad_tile == 2) return launch_dma<64, 128>(p, splits, a_bytes, dy_bytes, st);
-  if (g_wgrad_tile == 3) return launch_dma<128, 64>(p, splits, a_bytes, dy_bytes, st);
-  if (g_wgrad_tile == 4) return launch_dma<128, 128>(p, splits, a_bytes, dy_bytes, st);
+  if (!small) return PASSL_EUNSUPPORTED;
+  const uint32_t a32 = (uint32_t)a_bytes, dy32 = (uint32_t)dy_bytes;
+  if (g_wgrad_tile == 1) return launch_dma<64, 64>(p, splits, a32, dy32, st);
+  if (g_wgrad_tile == 2) return launch_dma<64, 128>(p, splits, a32, dy32, st);
+  if (g_wgrad_tile == 3) return launch_dma<128, 64>(p, splits, a32, dy32, st);
+  if (g_wgrad_tile == 4) return launch_dma<128, 128>(p, splits, a32, dy32, st);
   const bool m64 = p.NCOLS <= 64, n64 = p.KDIM <= 64;
-  if (m64 && n64) return launch_dma<64, 64>(p, splits, a_bytes, dy_bytes, st);
-  if (m64) return launch_dma<64, 128>(p, splits, a_bytes, dy_bytes, st);
-  if (n64) return launch_dma<128, 64>(p, splits, a_bytes, dy_bytes, st);
-  return launch_dma<128, 128>(p, splits, a_bytes, dy_bytes, st);
+  if (m64 && n64) return launch_dma<64, 64>(p, splits, a32, dy32, st);
+  if (m64) return launch_dma<64, 128>(p, splits, a32, dy32, st);
+  if (n64) return launch_dma<128, 64>(p, splits, a32, dy32, st);
+  return launch_dma<128, 128>(p, splits, a32, dy32, st);
 }
 
 }  // namespace
@@ -929,9 +950,11 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
   const int64_t a_bytes = ((int64_t)d->N * d->a_sn) * 2;
   const int64_t dy_bytes = (M64 * d->dy_ld) * 2;
   const int64_t lim = 0x7ffffff0ll;
-  if (d->dtype == PASSL_BF16 && use_dma && a_bytes < lim && dy_bytes < lim && a_bytes > 0)
-    rc = dispatch_dma(p, splits, (uint32_t)a_bytes, (uint32_t)dy_bytes, st);
-  else
+  (void)lim;
+  rc = PASSL_EUNSUPPORTED;
+  if (d->dtype == PASSL_BF16 && use_dma && a_bytes > 0)
+    rc = dispatch_dma(p, splits, a_bytes, dy_bytes, st);       // EUNSUPPORTED: a slice spans >= 2 GB
+  if (rc == PASSL_EUNSUPPORTED)
     rc = d->dtype == PASSL_BF16 ? dispatch<bf16_t>(p, splits, st) : dispatch<float>(p, splits, st);
   // several slices wrote slabs: dw += slab 0 + slab 1 + ... in slice order (one slice wrote dw itself)
   if (rc == PASSL_OK && p.ws && t_eff_splits > 1)

@@ -123,7 +123,8 @@ def conv_wgrad(d: P.Desc, a, dy, dw, splits=None):
     s.dtype = L.dt(a)
     M = d.N * d.OP * d.OQ
     bkm = 64 if a.dtype == torch.bfloat16 else 32
-    s.splits = splits or P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm)
+    s.splits = splits or P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm,
+                                        row_bytes=max(d.NCOLS, d.C * d.sh * d.sw) * a.element_size())
     # split-M partial tiles go to slabs of the shared workspace and are added in slice order
     need = s.splits * d.NCOLS * d.R * d.S * d.C
     ws = workspace.get(need, dw.device) if s.splits > 1 else None

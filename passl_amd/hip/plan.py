@@ -182,7 +182,7 @@ def stem_desc(cout, N, H, W) -> Desc:
                           c_pad=STEM_CP, size=cout * STEM_K * 8 * STEM_CP))
 
 
-def wgrad_splits(M, ncols, kdim, bkm, target_blocks=512):
+def wgrad_splits(M, ncols, kdim, bkm, target_blocks=512, row_bytes=0):
     """Number of reduction slices so that the grid has ~target_blocks workgroups (2 per CU on
     256 CUs = one resident wave of workgroups).  Every slice adds a full fp32 tile of global
     atomics — measured on MI355X: 1024 blocks cost ~35 us of atomics per launch, 512 blocks ~18 us
@@ -190,4 +190,8 @@ def wgrad_splits(M, ncols, kdim, bkm, target_blocks=512):
     tiles = ((ncols + 127) // 128) * ((kdim + 127) // 128)
     nk = (M + bkm - 1) // bkm
     s = max(1, min(nk, target_blocks // max(tiles, 1)))
+    # the LDS-DMA kernel addresses each M-slice through a rebased 32-bit buffer window: keep a slice's
+    # rows below 1 GB of the wider operand (row_bytes = max row pitch of x / dy in bytes)
+    if row_bytes:
+        s = max(s, min(nk, -(-(M * row_bytes) // (1 << 30))))
     return s

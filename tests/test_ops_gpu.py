@@ -535,3 +535,55 @@ def test_enqueue():
     ops.enqueue(qd, keys.to(DEV), 96)
     queue[:, 96:128] = keys.t()
     assert (qd.cpu() - queue).abs().max() == 0
+
+
+@pytest.mark.parametrize('k', [1, 3])
+def test_conv_operands_beyond_2gb(k):
+    """Tensors larger than a buffer descriptor's 32-bit byte window (BASELINE configs[2] at bs 512 per GPU:
+    1024 x 112^2 x 256 channels = 6.6 GB): the LDS-DMA kernels rebase their descriptors per workgroup /
+    per M-slice.  The same launch over the whole batch and over two halves (each below 2 GB, i.e. the
+    classic addressing) must agree — bit for bit for the forward (same tiles, same order)."""
+    dtype = torch.bfloat16
+    N, H, Cin, Cout = 176, 112, 512, 64                    # x: 176*112*112*512*2 B = 2.26 GB
+    geom = P.ConvGeom(Cin, Cout, k, 1, k // 2)
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(N, H, H, Cin, device=DEV, dtype=dtype)
+    assert x.numel() * 2 > (1 << 31)
+    w = (torch.randn(Cout, k, k, Cin, generator=gen) * 0.05).to(DEV)
+    fd = P.fwd_desc(geom, N, H, H)
+    fh = P.fwd_desc(geom, N // 2, H, H)
+    packer = WeightPacker()
+    packer.add(0, Cout, k, k, Cin, fd.pack)
+    packer.build(DEV, dtype).run(w.view(-1))
+    wb = packer.view(fd.pack, Cout)
+    y = torch.empty(N, H, H, Cout, device=DEV, dtype=dtype)
+    ops.conv_igemm(fd, x, wb, y)
+    yh = torch.empty_like(y)
+    ops.conv_igemm(fh, x[:N // 2], wb, yh[:N // 2])
+    ops.conv_igemm(fh, x[N // 2:], wb, yh[N // 2:])
+    assert torch.equal(y, yh)
+    # weight gradient: dy small, x > 2 GB
+    dy = torch.randn(N, H, H, Cout, device=DEV, dtype=dtype)
+    dw = torch.zeros(Cout, k * k * Cin, device=DEV)
+    ops.conv_wgrad(P.wgrad_desc(geom, N, H, H), x, dy.view(-1, Cout), dw)
+    dwh = torch.zeros_like(dw)
+    wdh = P.wgrad_desc(geom, N // 2, H, H)
+    ops.conv_wgrad(wdh, x[:N // 2], dy[:N // 2].reshape(-1, Cout), dwh)
+    ops.conv_wgrad(wdh, x[N // 2:], dy[N // 2:].reshape(-1, Cout), dwh)
+    assert relmax(dw, dwh) < 1e-3
+    # data gradient of the transposed shape: the OUTPUT (dx) is the > 2 GB tensor, rows addressed 64-bit
+    if k == 1:
+        g2 = P.ConvGeom(Cout, Cin, 1, 1, 0)                  # conv 64 -> 512: dgrad reads dy2 [.,512] > 2 GB
+        dds, _ = P.dgrad_plan(g2, N, H, H)
+        dh, _ = P.dgrad_plan(g2, N // 2, H, H)
+        pk = WeightPacker()
+        for d in dds + dh:
+            pk.add(0, Cin, 1, 1, Cout, d.pack)
+        w2 = (torch.randn(Cin, 1, 1, Cout, generator=gen) * 0.05).to(DEV)
+        pk.build(DEV, dtype).run(w2.view(-1))
+        dx = torch.empty(N, H, H, Cout, device=DEV, dtype=dtype)
+        dxh = torch.empty_like(dx)
+        ops.conv_igemm(dds[0], x, pk.view(dds[0].pack, Cout), dx)            # x plays dy2 (2.05 GB, K = 512: ring)
+        ops.conv_igemm(dh[0], x[:N // 2], pk.view(dh[0].pack, Cout), dxh[:N // 2])
+        ops.conv_igemm(dh[0], x[N // 2:], pk.view(dh[0].pack, Cout), dxh[N // 2:])
+        assert torch.equal(dx, dxh)
