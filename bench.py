@@ -13,8 +13,9 @@ all-reduce (N>1), momentum-SGD, lr step — driven through the Trainer's whole h
 Two loops:
   1. the TIMED loop: exactly --steps steps, nothing but the product path between a barrier +
      torch.cuda.synchronize() on both sides -> `value`, `ms_per_step`;
-  2. an INSTRUMENTED loop afterwards (HIP events around every launch of the dominant kernel class on
-     its launch stream + a FLOP counter on the descriptors) -> `roofline`.  It never contributes to
+  2. an INSTRUMENTED loop afterwards (HIP events around every launch of the three MFMA kernels on
+     their launch stream; the library sums each launch's algorithmic FLOPs / bytes from its
+     descriptor) -> `roofline` (the dominant kernel) + the two next ones.  It never contributes to
      `value`.
 Prints ONE JSON line (rank 0).  `value` = images/s over all ranks, where one image = one two-view
 sample (PASSL's own `ips`, passl/engine/loops/loop.py:102-104).
@@ -33,6 +34,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE = 32.77e9      # 2*[(3+1)*(4.0871+0.00446) + 2*0.00839] GMAC
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured streaming ceiling)
 PMC_TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')
 
 # workload -> (config, default per-GPU batch, algorithmic FLOP per sample, metric text, workload text)
@@ -133,17 +135,21 @@ def cpu_baseline():
 
 
 def pmc_traffic(args):
-    """(bytes per igemm-class launch, source) from the committed rocprofv3 --pmc passes of this same
-    command (tools/pmc_summary.py).  PMC counters need the profiler, so this number is NOT measured
-    by this run — the source says so; (None, None) for any other workload / shape."""
+    """{'ring' | 'igemm' | 'wgrad': {hbm_bytes_per_launch, source}} from the committed rocprofv3 --pmc
+    passes of this same command (tools/pmc_summary.py).  PMC counters need the profiler, so these numbers
+    are NOT measured by this run — the source string says so; None for any other workload / shape."""
     path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
     if args.workload != 'moco' or args.batch != 256 or args.dtype != 'bf16' or not os.path.exists(path):
-        return None, None
+        return None
     with open(path) as f:
         z = json.load(f)
-    return (z['igemm_all_variants']['hbm_bytes_per_launch'],
-            '%s (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + WRITE_SIZE; '
-            'not measured by this run)' % PMC_TRAFFIC_FILE)
+    src = ('%s (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + WRITE_SIZE; '
+           'not measured by this run)' % PMC_TRAFFIC_FILE)
+    out = {}
+    for k in ('ring', 'igemm', 'wgrad'):
+        if k in z.get('classes', {}):
+            out[k] = {'hbm_bytes_per_launch': z['classes'][k]['hbm_bytes_per_launch'], 'source': src}
+    return out
 
 
 def main():
@@ -221,32 +227,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # ---- 2. instrumented loop (rank 0's kernels; every rank runs the steps so collectives match)
-    kern, flops, rsteps = {}, {'igemm': 0.0}, 0
+    # ---- 2. instrumented loop (rank 0's kernels; every rank runs the steps so collectives match).
+    # HIP events around every launch of the MFMA kernel classes on their launch stream; the library sums
+    # the launches' algorithmic FLOPs / bytes itself.  The side stream is off here so that a kernel's
+    # duration is its own (in the timed loop the weight gradients run next to the main chain).
+    kern, rsteps, instr_elapsed = {}, 0, 0.0
     if not args.no_kernel_timing and args.roofline_steps > 0:
         import ctypes
+        from passl_amd.hip import config as hip_config
         lib = L.load()
         rsteps = args.roofline_steps
-        lib.passl_hip_prof_enable(1)
-        real_igemm = ops.conv_igemm
-
-        def counting_igemm(d, *a, **k):
-            kdim = 147 if (d.R, d.S, d.C) == (7, 1, 32) else d.R * d.S * d.C   # stem: real taps
-            flops['igemm'] += 2.0 * d.N * d.OP * d.OQ * d.NCOLS * kdim
-            return real_igemm(d, *a, **k)
-        ops.conv_igemm = counting_igemm
+        overlap_was = hip_config.overlap()
+        hip_config.set_flag('overlap', False)
+        step()
         barrier()
+        lib.passl_hip_prof_enable(1)
         t1 = time.perf_counter()
         for _ in range(rsteps):
             step()
         barrier()
         instr_elapsed = time.perf_counter() - t1
-        ops.conv_igemm = real_igemm
-        for cls, name in ((0, 'igemm'), (1, 'wgrad')):
+        for cls, name in ((0, 'ring'), (1, 'wgrad'), (2, 'igemm')):
             ms, n = ctypes.c_double(), ctypes.c_int64()
+            fl, by = ctypes.c_double(), ctypes.c_double()
             lib.passl_hip_prof_collect(cls, ctypes.byref(ms), ctypes.byref(n))
-            kern[name] = (ms.value, n.value)
+            lib.passl_hip_prof_collect_work(cls, ctypes.byref(fl), ctypes.byref(by))
+            kern[name] = dict(ms=ms.value, n=n.value, flops=fl.value, bytes=by.value)
         lib.passl_hip_prof_enable(0)
+        hip_config.set_flag('overlap', overlap_was)
 
     if rank == 0:
         ips = args.batch * world * args.steps / elapsed
@@ -267,23 +275,49 @@ def main():
                 'achieved_tflops_per_gpu': round(ips / world * flop_per_sample / 1e12, 2),
                 'frac_of_peak': round(ips / world * flop_per_sample / 1e12 / peak, 5)},
         }
-        if kern.get('igemm', (0, 0))[1] > 0:
-            ms, n = kern['igemm']
-            ach = flops['igemm'] / (ms * 1e-3) / 1e12
-            traffic, source = pmc_traffic(args)
-            out['roofline'] = {
-                'kernel': 'igemm class (implicit-GEMM conv fwd + dgrad + linear; all tile variants)',
-                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 5), 'traffic': traffic,
-                'traffic_unit': 'HBM bytes per launch', 'traffic_source': source,
-                'measured_over': '%d instrumented steps after the timed loop (%.3f ms/step with the HIP '
-                                 'events in place)' % (rsteps, 1000 * instr_elapsed / rsteps),
-                'launches': int(n), 'avg_launch_us': round(1000 * ms / n, 2),
-                'algorithmic_gflop_per_launch': round(flops['igemm'] / n / 1e9, 3),
-                'igemm_kernel_ms_per_step': round(ms / rsteps, 3)}
-            wms, wn = kern.get('wgrad', (0, 0))
-            if wn:
-                out['roofline']['wgrad_kernel_ms_per_step'] = round(wms / rsteps, 3)
+        if kern and kern['ring']['n'] + kern['igemm']['n'] > 0:
+            traffic = pmc_traffic(args)
+
+            def block(k, title, bound):
+                d = kern[k]
+                if d['n'] == 0:
+                    return None
+                sec = d['ms'] * 1e-3
+                tf, gbs = d['flops'] / sec / 1e12, d['bytes'] / sec / 1e9
+                b = {'kernel': title, 'bound': bound,
+                     'achieved': round(tf if bound == 'mfma' else gbs, 2),
+                     'peak': peak if bound == 'mfma' else PEAK_HBM_GBS,
+                     'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                     'frac': round((tf / peak) if bound == 'mfma' else (gbs / PEAK_HBM_GBS), 5),
+                     'launches': int(d['n']), 'avg_launch_us': round(1000 * d['ms'] / d['n'], 2),
+                     'algorithmic_gflop_per_launch': round(d['flops'] / d['n'] / 1e9, 3),
+                     'algorithmic_mb_per_launch': round(d['bytes'] / d['n'] / 1e6, 2),
+                     'achieved_tflops': round(tf, 2), 'achieved_algorithmic_gbs': round(gbs, 1),
+                     'kernel_ms_per_step': round(d['ms'] / rsteps, 3)}
+                t = (traffic or {}).get(k)
+                b['traffic'] = t['hbm_bytes_per_launch'] if t else None
+                b['traffic_unit'] = 'HBM bytes per launch'
+                b['traffic_source'] = t['source'] if t else None
+                return b
+            # the dominant kernel (largest share of the step): the LDS-DMA ring implicit GEMM, MFMA-bound
+            out['roofline'] = block('ring', 'igemm_ring_kernel (LDS-DMA ring implicit GEMM: every conv fwd / dgrad '
+                                    'and Linear with a reduction of >= 512: all 3x3 layers, the wide 1x1 layers)', 'mfma')
+            if out['roofline'] is None:          # no launch took the ring kernel (fp32): the dense kernel is the MFMA one
+                out['roofline'] = block('igemm', 'igemm_kernel (register-staged implicit GEMM)', 'mfma')
+            out['roofline']['measured_over'] = (
+                '%d instrumented steps after the timed loop, side stream off (%.3f ms/step with the HIP '
+                'events in place)' % (rsteps, 1000 * instr_elapsed / rsteps))
+            # second largest: the register-staged implicit GEMM of the short-reduction 1x1 layers — HBM-bound
+            out['roofline_hbm_kernel'] = block('igemm', 'igemm_kernel (register-staged implicit GEMM: 1x1 layers with '
+                                               'a reduction < 512, stem)', 'hbm')
+            out['roofline_wgrad_kernel'] = block('wgrad', 'wgrad_pipe_kernel (weight gradients, split over M + '
+                                                 'fixed-order slab reduction)', 'mfma')
+            ig = {k: kern['ring'][k] + kern['igemm'][k] for k in ('ms', 'n', 'flops', 'bytes')}
+            out['igemm_class'] = {
+                'what': 'both implicit-GEMM kernels together (the r01 roofline definition)',
+                'achieved_tflops': round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12, 2),
+                'frac_of_mfma_peak': round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12 / peak, 5),
+                'kernel_ms_per_step': round(ig['ms'] / rsteps, 3), 'launches': int(ig['n'])}
         if world == 1 and not args.no_cpu_baseline and args.workload == 'moco':
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

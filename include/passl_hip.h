@@ -418,6 +418,10 @@ int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, flo
  * accumulated kernel time (ms) and launch count per kernel class (0 = igemm, 1 = wgrad). */
 int passl_hip_prof_enable(int on);
 int passl_hip_prof_collect(int kernel_class, double* total_ms, int64_t* launches);
+/* Algorithmic work of the launches timed since the last call for this class: FLOPs (2 x MACs of the real
+ * taps) and HBM bytes (every operand element once).  Classes: 0 igemm_ring_kernel, 1 weight gradients,
+ * 2 igemm_kernel (register-staged). */
+int passl_hip_prof_collect_work(int kernel_class, double* flops, double* bytes);
 
 /* ---------------------------------------------------------------- CLIP
  * Reference: class CLIP, passl_v110/modeling/backbones/clip.py:183-336; QuickGELU

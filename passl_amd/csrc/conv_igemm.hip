@@ -491,18 +491,31 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
                      d->y_sw == d->NCOLS && d->y_sh == (int64_t)d->OQ * d->NCOLS &&
                      d->y_sn == (int64_t)d->OP * d->OQ * d->NCOLS;
   hipStream_t st = as_stream(stream);
+  // algorithmic work of this launch (bench.py's roofline): FLOPs of the real taps (the stem's padded
+  // 8th tap / 4th channel do not count) and HBM bytes = every operand element once
+  const int es_out = d->out_f32 ? 4 : es;
+  const double kreal = (d->R == 7 && d->S == 1 && d->C == 32) ? 147.0 : (double)K64;
+  const double w_flops = 2.0 * (double)M64 * d->NCOLS * kreal;
+  double in_px = (double)d->N * d->IH * d->IW;
+  if ((double)M64 * d->R * d->S < in_px) in_px = (double)M64 * d->R * d->S;     // strided 1x1: a sub-lattice
+  const double w_bytes = in_px * d->C * es + (double)d->NCOLS * K64 * es +
+                         (double)M64 * d->NCOLS * es_out * (1 + (d->residual ? 1 : 0)) +
+                         (d->bnb_partial ? (double)M64 * d->NCOLS * es : 0.0);
   passl_prof_begin(0, st);
   int rc = passl_igemm_ring_try(d, st);        // large-tile LDS-DMA ring kernel when it applies
   if (rc != PASSL_EUNSUPPORTED) {
+    passl_prof_work(0, w_flops, w_bytes);
     passl_prof_end(0, st);
     return rc;
   }
+  passl_prof_retag(0, 2);
   const int nk = (p.KDIM + bk - 1) / bk;
   const bool of32 = d->out_f32 != 0;
   if (d->dtype == PASSL_BF16)
     rc = narrow ? dispatch<bf16_t, 64>(p, generic, of32, dense, nk, st) : dispatch<bf16_t, 128>(p, generic, of32, dense, nk, st);
   else
     rc = narrow ? dispatch<float, 64>(p, generic, of32, dense, nk, st) : dispatch<float, 128>(p, generic, of32, dense, nk, st);
-  passl_prof_end(0, st);
+  passl_prof_work(2, w_flops, w_bytes);
+  passl_prof_end(2, st);
   return rc;
 }

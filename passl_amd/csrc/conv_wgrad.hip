@@ -961,6 +961,9 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
     rc = passl_slab_reduce_launch(p.ws, p.dw, n_out, t_eff_splits, 1, st);
   else if (rc == PASSL_OK && p.ws && t_eff_splits == 1)
     rc = passl_slab_reduce_launch(p.ws, p.dw, n_out, 1, 1, st);
+  passl_prof_work(1, 2.0 * (double)M64 * d->NCOLS * (double)K64,
+                  ((double)d->N * d->IH * d->IW * d->C + (double)M64 * d->NCOLS) * (d->dtype == PASSL_BF16 ? 2 : 4) +
+                      (double)d->NCOLS * K64 * 4);
   passl_prof_end(1, st);
   return rc;
 }

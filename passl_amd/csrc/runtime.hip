@@ -10,11 +10,30 @@ bool g_on = false;
 std::mutex g_mu;
 std::vector<Pair> g_used;
 std::vector<Pair> g_free;
-Pair g_cur[2];
-bool g_open[2] = {false, false};
-double g_ms[2] = {0, 0};
-int64_t g_n[2] = {0, 0};
+Pair g_cur[kProfClasses];
+bool g_open[kProfClasses] = {false, false, false};
+double g_ms[kProfClasses] = {0, 0, 0};
+int64_t g_n[kProfClasses] = {0, 0, 0};
+double g_flops[kProfClasses] = {0, 0, 0};
+double g_bytes[kProfClasses] = {0, 0, 0};
 }  // namespace
+
+void passl_prof_retag(int from, int to) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_open[from]) return;
+  g_cur[to] = g_cur[from];
+  g_cur[to].cls = to;
+  g_open[to] = true;
+  g_open[from] = false;
+}
+
+void passl_prof_work(int cls, double flops, double bytes) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_flops[cls] += flops;
+  g_bytes[cls] += bytes;
+}
 
 void passl_prof_begin(int cls, hipStream_t st) {
   if (!g_on) return;
@@ -44,7 +63,7 @@ extern "C" int passl_hip_prof_enable(int on) {
 }
 
 extern "C" int passl_hip_prof_collect(int cls, double* total_ms, int64_t* launches) {
-  if (cls < 0 || cls > 1 || !total_ms || !launches) return PASSL_EINVAL;
+  if (cls < 0 || cls >= kProfClasses || !total_ms || !launches) return PASSL_EINVAL;
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& p : g_used) {
     (void)hipEventSynchronize(p.b);
@@ -56,6 +75,16 @@ extern "C" int passl_hip_prof_collect(int cls, double* total_ms, int64_t* launch
   *total_ms = g_ms[cls];
   *launches = g_n[cls];
   g_ms[cls] = 0; g_n[cls] = 0;
+  return PASSL_OK;
+}
+
+// algorithmic FLOPs / HBM bytes of the launches timed since the last collect_work of this class
+extern "C" int passl_hip_prof_collect_work(int cls, double* flops, double* bytes) {
+  if (cls < 0 || cls >= kProfClasses || !flops || !bytes) return PASSL_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  *flops = g_flops[cls];
+  *bytes = g_bytes[cls];
+  g_flops[cls] = 0; g_bytes[cls] = 0;
   return PASSL_OK;
 }
 

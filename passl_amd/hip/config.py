@@ -69,7 +69,7 @@ def fused_bn_backward():
 
 def overlap():
     """Independent work on a second HIP stream: weight-gradient launches next to the data-gradient /
-    BatchNorm-backward chain, the key encoder's forward next to the query encoder's (hip/streams.py)."""
+    BatchNorm-backward chain (hip/streams.py)."""
     return _state['overlap']
 
 

@@ -132,6 +132,7 @@ SIGNATURES = {
     'passl_hip_softmax_ce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),
     'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),
+    'passl_hip_prof_collect_work': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -54,17 +54,22 @@ def main():
             per[k] = {'launches': calls, 'fetch_bytes_per_launch': round(2.0 * fkb * 1024 / calls),
                       'write_bytes_per_launch': round(wkb * 1024 / calls),
                       'avg_launch_us': round(dur / 1e3 / calls, 2)}
-        gemm = [k for k in per if 'igemm' in k]
-        n = sum(per[k]['launches'] for k in gemm)
-        agg = {'launches': n,
-               'hbm_bytes_per_launch': round(sum(per[k]['launches'] * (per[k]['fetch_bytes_per_launch'] +
-                                                                         per[k]['write_bytes_per_launch'])
-                                                 for k in gemm) / max(n, 1)),
-               'kernels': sorted(gemm)}
+        def klass(sel):
+            ks = [k for k in per if sel(k)]
+            n = sum(per[k]['launches'] for k in ks)
+            return {'launches': n,
+                    'hbm_bytes_per_launch': round(sum(per[k]['launches'] * (per[k]['fetch_bytes_per_launch'] +
+                                                                              per[k]['write_bytes_per_launch'])
+                                                      for k in ks) / max(n, 1)),
+                    'kernels': sorted(ks)}
+        classes = {'ring': klass(lambda k: 'igemm_ring_kernel' in k),
+                   'igemm': klass(lambda k: k.startswith('igemm_kernel')),
+                   'wgrad': klass(lambda k: 'wgrad' in k)}
         json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 '
                              '(gfx950 128-byte requests are tallied at 64 B), per launch',
                    'steps_profiled': steps, 'fetch_gb_per_step': round(tf, 2), 'write_gb_per_step': round(tw, 2),
-                   'igemm_all_variants': agg, 'per_kernel': per}, open(sys.argv[4], 'w'), indent=1)
+                   'classes': classes, 'igemm_all_variants': klass(lambda k: 'igemm' in k), 'per_kernel': per},
+                  open(sys.argv[4], 'w'), indent=1)
 
 
 if __name__ == '__main__':
