@@ -11,6 +11,8 @@
 //
 // Algorithmic bytes per activation (bf16): stats 2, apply 4 (+2 with residual),
 // bwd_reduce 6, bwd_apply 8 (+2 with residual).
+#include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -334,6 +336,119 @@ __global__ void __launch_bounds__(kThreads) bn_bwd_apply_kernel(
   }
 }
 
+// ---- streaming kernels, tile form (the default when 256 % (C/8) == 0, i.e. every power-of-two C up
+// to 2048).  One workgroup owns U * 256 CONSECUTIVE 16-byte chunks, a lane takes chunks
+// base + u * 256: every lane keeps ONE channel group (per-channel constants loaded once, ahead of the
+// data), the U data loads of a lane are issued back to back (U x 16 B in flight per lane instead of
+// one load per grid-stride iteration), and there is no loop.  g_stream_variant: 0 = the grid-stride
+// kernels above, U = 2 / 4 / 8 otherwise (passl_hip_set_option("bn_stream_unroll", U)).
+template <typename T, int U>
+__global__ void __launch_bounds__(kThreads) bn_apply_tile_kernel(const T* __restrict__ x,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const T* __restrict__ res,
+                                                                 T* __restrict__ z,
+                                                                 uint8_t* __restrict__ mask,
+                                                                 int64_t nchunks, int cols, int relu) {
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
+  const int col = (int)base & (cols - 1);      // cols divides 256: a power of two
+  const float4 s0 = *reinterpret_cast<const float4*>(scale + col * 8);
+  const float4 s1 = *reinterpret_cast<const float4*>(scale + col * 8 + 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(shift + col * 8);
+  const float4 b1 = *reinterpret_cast<const float4*>(shift + col * 8 + 4);
+  const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  // branch-free loads (a lane past the end re-reads the last chunk): all U loads are in flight together
+  float v[U][8], r[U][8];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + u * kThreads;
+    ElemTraits<T>::load8(x + (i < nchunks ? i : nchunks - 1) * 8, v[u]);
+  }
+  if (res) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = base + u * kThreads;
+      ElemTraits<T>::load8(res + (i < nchunks ? i : nchunks - 1) * 8, r[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + u * kThreads;
+    if (i >= nchunks) break;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[u][e] = v[u][e] * sc[e] + sh[e];
+    if (res) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] += r[u][e];
+    }
+    if (relu) {
+      if (mask) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bits |= (v[u][e] > 0.f ? 1u : 0u) << e;
+        mask[i] = (uint8_t)bits;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] = fmaxf(v[u][e], 0.f);
+    }
+    ElemTraits<T>::store8(z + i * 8, v[u]);
+  }
+}
+
+template <typename T, int U>
+__global__ void __launch_bounds__(kThreads) bn_bwd_apply_tile_kernel(
+    const T* __restrict__ dz, const void* __restrict__ z, const T* __restrict__ x,
+    const float* __restrict__ coef, const float* __restrict__ scale,
+    const float* __restrict__ shift, T* __restrict__ dx, T* __restrict__ dres, int64_t nchunks,
+    int cols, int C, int relu) {
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * U) + threadIdx.x;
+  const int col = (int)base & (cols - 1);      // cols divides 256: a power of two
+  float cA[8], cB[8], cC[8], sc[8], sh[8];
+  {
+    const float4* ca = reinterpret_cast<const float4*>(coef + col * 8);
+    const float4* cb = reinterpret_cast<const float4*>(coef + C + col * 8);
+    const float4* cc = reinterpret_cast<const float4*>(coef + 2 * C + col * 8);
+    const float4 a0 = ca[0], a1 = ca[1], b0 = cb[0], b1 = cb[1], c0 = cc[0], c1 = cc[1];
+    cA[0] = a0.x; cA[1] = a0.y; cA[2] = a0.z; cA[3] = a0.w; cA[4] = a1.x; cA[5] = a1.y; cA[6] = a1.z; cA[7] = a1.w;
+    cB[0] = b0.x; cB[1] = b0.y; cB[2] = b0.z; cB[3] = b0.w; cB[4] = b1.x; cB[5] = b1.y; cB[6] = b1.z; cB[7] = b1.w;
+    cC[0] = c0.x; cC[1] = c0.y; cC[2] = c0.z; cC[3] = c0.w; cC[4] = c1.x; cC[5] = c1.y; cC[6] = c1.z; cC[7] = c1.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = relu == 2 ? scale[col * 8 + e] : 0.f;
+    sh[e] = relu == 2 ? shift[col * 8 + e] : 0.f;
+  }
+  float g[U][8], v[U][8];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + u * kThreads;
+    const int64_t ic = i < nchunks ? i : nchunks - 1;
+    ElemTraits<T>::load8(dz + ic * 8, g[u]);
+    ElemTraits<T>::load8(x + ic * 8, v[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + u * kThreads;
+    if (i >= nchunks) break;
+    if (relu) apply_relu_mask<T>(g[u], v[u], relu, z, i, sc, sh);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = cA[e] * g[u][e] + cB[e] * v[u][e] + cC[e];
+    ElemTraits<T>::store8(dx + i * 8, o);
+    if (dres) ElemTraits<T>::store8(dres + i * 8, g[u]);
+  }
+}
+
+static int g_stream_unroll = -1;
+static inline int stream_unroll() {
+  if (g_stream_unroll < 0) {
+    const char* e = getenv("PASSL_BN_STREAM_UNROLL");
+    g_stream_unroll = e ? atoi(e) : 4;
+  }
+  return g_stream_unroll;
+}
+
 static inline int grid_for(int64_t n) {
   int64_t b = (n + kThreads - 1) / kThreads;
   if (b > 4096) b = 4096;
@@ -342,6 +457,16 @@ static inline int grid_for(int64_t n) {
 }
 
 }  // namespace
+
+// passl_hip_set_option("bn_stream_unroll", 0 | 2 | 4 | 8)   (runtime.hip dispatches)
+int passl_bn_option(const char* name, int value) {
+  if (!strcmp(name, "bn_stream_unroll")) {
+    if (value != 0 && value != 2 && value != 4 && value != 8) return PASSL_EINVAL;
+    g_stream_unroll = value;
+    return PASSL_OK;
+  }
+  return PASSL_EINVAL;
+}
 
 #define DISPATCH_DTYPE(dtype, ...)                          \
   if ((dtype) == PASSL_BF16) { using T = bf16_t; __VA_ARGS__ } \
@@ -408,12 +533,26 @@ extern "C" int passl_hip_bn_apply(const void* x, const float* scale, const float
     return PASSL_EINVAL;
   if (relu_mask && !relu) return PASSL_EINVAL;
   const int64_t nchunks = M * (C >> 3);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(nchunks)),
-                                           dim3(kThreads), 0, as_stream(stream),
-                                           reinterpret_cast<const T*>(x), scale, shift,
-                                           reinterpret_cast<const T*>(residual),
-                                           reinterpret_cast<T*>(z), relu_mask, nchunks, C >> 3,
-                                           relu);)
+  const int U = (kThreads % (C >> 3)) == 0 ? stream_unroll() : 0;
+#define PASSL_BN_APPLY_TILE(UU)                                                                          \
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_tile_kernel<T, UU>),                               \
+                                           dim3((unsigned)((nchunks + kThreads * UU - 1) / (kThreads * UU))), \
+                                           dim3(kThreads), 0, as_stream(stream),                        \
+                                           reinterpret_cast<const T*>(x), scale, shift,                 \
+                                           reinterpret_cast<const T*>(residual),                        \
+                                           reinterpret_cast<T*>(z), relu_mask, nchunks, C >> 3, relu);)
+  if (U == 2) { PASSL_BN_APPLY_TILE(2) }
+  else if (U == 4) { PASSL_BN_APPLY_TILE(4) }
+  else if (U == 8) { PASSL_BN_APPLY_TILE(8) }
+  else {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(grid_for(nchunks)),
+                                             dim3(kThreads), 0, as_stream(stream),
+                                             reinterpret_cast<const T*>(x), scale, shift,
+                                             reinterpret_cast<const T*>(residual),
+                                             reinterpret_cast<T*>(z), relu_mask, nchunks, C >> 3,
+                                             relu);)
+  }
+#undef PASSL_BN_APPLY_TILE
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -473,12 +612,27 @@ extern "C" int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void*
       (C & 7) || !aligned16(dz) || !aligned16(x) || !aligned16(dx) || (dres && !aligned16(dres)))
     return PASSL_EINVAL;
   const int64_t nchunks = M * (C >> 3);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(nchunks)),
-                                           dim3(kThreads), 0, as_stream(stream),
-                                           reinterpret_cast<const T*>(dz), z,
-                                           reinterpret_cast<const T*>(x), coef, scale, shift,
-                                           reinterpret_cast<T*>(dx), reinterpret_cast<T*>(dres),
+  const int U = (kThreads % (C >> 3)) == 0 ? stream_unroll() : 0;
+#define PASSL_BN_BWD_APPLY_TILE(UU)                                                                      \
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_tile_kernel<T, UU>),                           \
+                                           dim3((unsigned)((nchunks + kThreads * UU - 1) / (kThreads * UU))), \
+                                           dim3(kThreads), 0, as_stream(stream),                        \
+                                           reinterpret_cast<const T*>(dz), z,                           \
+                                           reinterpret_cast<const T*>(x), coef, scale, shift,           \
+                                           reinterpret_cast<T*>(dx), reinterpret_cast<T*>(dres),        \
                                            nchunks, C >> 3, C, relu);)
+  if (U == 2) { PASSL_BN_BWD_APPLY_TILE(2) }
+  else if (U == 4) { PASSL_BN_BWD_APPLY_TILE(4) }
+  else if (U == 8) { PASSL_BN_BWD_APPLY_TILE(8) }
+  else {
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(nchunks)),
+                                             dim3(kThreads), 0, as_stream(stream),
+                                             reinterpret_cast<const T*>(dz), z,
+                                             reinterpret_cast<const T*>(x), coef, scale, shift,
+                                             reinterpret_cast<T*>(dx), reinterpret_cast<T*>(dres),
+                                             nchunks, C >> 3, C, relu);)
+  }
+#undef PASSL_BN_BWD_APPLY_TILE
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
