@@ -30,7 +30,10 @@ def timeit(fn, iters=10):
 
 tot = {'fwd': [0, 0], 'dgrad': [0, 0], 'wgrad': [0, 0]}
 print('%-28s %8s | %8s %7s | %8s %7s | %8s %7s' % ('shape', 'GFLOP', 'fwd us', 'TF', 'dgrad us', 'TF', 'wgrad us', 'TF'))
+ONLY = set(os.environ.get('ONLY', '').split(',')) - {''}
 for cin, cout, k, stv, pad, H, cnt in SHAPES:
+    if ONLY and ('%d-%d-%d' % (cin, cout, k)) not in ONLY:
+        continue
     g = P.ConvGeom(cin, cout, k, stv, pad)
     fd = P.fwd_desc(g, N, H, H)
     dds, skipped = P.dgrad_plan(g, N, H, H)
