@@ -421,6 +421,7 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
 }  // namespace
 
 int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st);   // conv_igemm_ring.hip
+int passl_stem_try(const passl_conv_desc* d, hipStream_t st);         // conv_stem.hip
 
 extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream) {
   if (!d || !d->a || !d->b || !d->y) return PASSL_EINVAL;
@@ -509,12 +510,15 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
     return rc;
   }
   passl_prof_retag(0, 2);
-  const int nk = (p.KDIM + bk - 1) / bk;
-  const bool of32 = d->out_f32 != 0;
-  if (d->dtype == PASSL_BF16)
-    rc = narrow ? dispatch<bf16_t, 64>(p, generic, of32, dense, nk, st) : dispatch<bf16_t, 128>(p, generic, of32, dense, nk, st);
-  else
-    rc = narrow ? dispatch<float, 64>(p, generic, of32, dense, nk, st) : dispatch<float, 128>(p, generic, of32, dense, nk, st);
+  rc = passl_stem_try(d, st);                  // the spatially tiled stem kernel when it applies
+  if (rc == PASSL_EUNSUPPORTED) {
+    const int nk = (p.KDIM + bk - 1) / bk;
+    const bool of32 = d->out_f32 != 0;
+    if (d->dtype == PASSL_BF16)
+      rc = narrow ? dispatch<bf16_t, 64>(p, generic, of32, dense, nk, st) : dispatch<bf16_t, 128>(p, generic, of32, dense, nk, st);
+    else
+      rc = narrow ? dispatch<float, 64>(p, generic, of32, dense, nk, st) : dispatch<float, 128>(p, generic, of32, dense, nk, st);
+  }
   passl_prof_work(2, w_flops, w_bytes);
   passl_prof_end(2, st);
   return rc;

@@ -270,6 +270,57 @@ def test_stem_conv_and_wgrad(dtype, hw):
     assert relmax(got, w.grad.permute(0, 2, 3, 1)) < (1e-4 if dtype == torch.float32 else 2e-3)
 
 
+@pytest.mark.parametrize('hw', [(224, 224), (64, 96)])
+def test_stem_kernel_against_generic_kernel(hw):
+    """The spatially tiled stem kernel (csrc/conv_stem.hip) walks K in the same 32-wide steps as the
+    generic implicit-GEMM kernel: outputs must agree BIT FOR BIT (plain, and with the fused affine + ReLU
+    of the key encoder); its fused BatchNorm statistics (one slab row per 8 x 16 tile) must finalize to the
+    statistics of a separate pass over the stored output."""
+    from passl_amd.hip import lib as L
+    lib = L.load()
+    dtype = torch.bfloat16
+    H, W = hw
+    N, cout = 3, 64
+    gen = torch.Generator().manual_seed(17)
+    x = rnd(torch.randn(N, 3, H, W, generator=gen) * 1.3 + 0.2, dtype)
+    w = rnd(torch.randn(cout, 3, 7, 7, generator=gen) * 0.1, dtype)
+    d = P.stem_desc(cout, N, H, W)
+    _Hp, Wp = P.stem_padded_hw(H, W)
+    xp = ops.nchw_to_nhwc_pad(x.to(DEV), P.STEM_PAD, Wp, P.STEM_CP, dtype)
+    packer = WeightPacker()
+    packer.add(0, cout, 7, 7, 3, d.pack)
+    packer.build(DEV, dtype).run(w.permute(0, 2, 3, 1).contiguous().view(-1).to(DEV))
+    scale = (torch.rand(cout, generator=gen) + 0.5).to(DEV)
+    shift = torch.randn(cout, generator=gen).to(DEV)
+
+    def run():
+        y = torch.full((N, d.OP, d.OQ, cout), float('nan'), dtype=dtype, device=DEV)
+        slab, tiles = ops.conv_stats_buffer(d, DEV)
+        slab.fill_(float('nan'))
+        ops.conv_igemm(d, xp, packer.view(d.pack, cout), y, stats=slab)
+        y2 = torch.full_like(y, float('nan'))
+        ops.conv_igemm(d, xp, packer.view(d.pack, cout), y2, scale=scale, shift=shift, relu=True)
+        g, b = torch.ones(cout, device=DEV), torch.zeros(cout, device=DEV)
+        rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+        _z, st, _ = ops.bn_train_fwd(y, g, b, rm, rv, relu=False, partial=(slab, tiles))
+        return y, y2, st, rm, rv
+    try:
+        assert lib.passl_hip_set_option(b'stem_kernel', 0) == 0
+        y0, y20, st0, rm0, rv0 = run()
+        assert lib.passl_hip_set_option(b'stem_kernel', 1) == 0
+        y1, y21, st1, rm1, rv1 = run()
+    finally:
+        lib.passl_hip_set_option(b'stem_kernel', 1)
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    assert relmax(y1.float(), nhwc(ref)) < tol(dtype)
+    assert torch.equal(y0, y1) and torch.equal(y20, y21)
+    assert relmax(st1[0], st0[0]) < 1e-5 and relmax(st1[1], st0[1]) < 1e-5
+    assert relmax(rm1, rm0) < 1e-5 and relmax(rv1, rv0) < 1e-5
+    yf = y1.float().view(-1, cout).double()
+    assert relmax(st1[0], yf.mean(0)) < 1e-5
+    assert relmax(st1[1], (yf.var(0, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_linear_as_conv(dtype):
     """Linear 2048->128 with bias on [256, 2048] rows (projector), fwd + dgrad + wgrad."""
