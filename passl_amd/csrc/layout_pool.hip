@@ -27,89 +27,121 @@ __global__ void __launch_bounds__(kThreads) nchw_to_nhwc_pad_kernel(
   }
 }
 
-// 3x3 s2 p1 max pool; one thread per (n,p,q, 8-channel chunk).
+// 3x3 s2 p1 max pool; one thread per (n,p,q, 8-channel chunk), one pass per thread (no grid-stride
+// loop).  Branch-free: the 9 taps are loaded from CLAMPED coordinates back to back (9 x 16 B in flight
+// per lane) and an out-of-range tap simply never wins.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) maxpool_fwd_kernel(const T* __restrict__ x,
                                                                T* __restrict__ y,
                                                                uint8_t* __restrict__ idx, int N,
                                                                int H, int W, int C, int P, int Q) {
-  const int cc = C >> 3;
-  const int64_t total = (int64_t)N * P * Q * cc;
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
-    const int c8 = (int)(i % cc);
-    int64_t t = i / cc;
-    const int q = (int)(t % Q); t /= Q;
-    const int p = (int)(t % P);
-    const int n = (int)(t / P);
-    float best[8];
-    int bi[8];
+  const uint32_t cc = (uint32_t)C >> 3;
+  const uint32_t total = (uint32_t)N * P * Q * cc;       // < 2^31 (checked on the host): 32-bit index math
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int c8 = (int)(i % cc);
+  uint32_t t = i / cc;
+  const int q = (int)(t % (uint32_t)Q); t /= (uint32_t)Q;
+  const int p = (int)(t % (uint32_t)P);
+  const int n = (int)(t / (uint32_t)P);
+  float v[9][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
-    bool first = true;
-    for (int r = 0; r < 3; ++r) {
-      const int h = p * 2 - 1 + r;
-      if (h < 0 || h >= H) continue;
-      for (int s = 0; s < 3; ++s) {
-        const int w = q * 2 - 1 + s;
-        if (w < 0 || w >= W) continue;
-        float v[8];
-        ElemTraits<T>::load8(x + (((int64_t)n * H + h) * W + w) * C + c8 * 8, v);
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          // first max wins (strictly greater replaces), NaN propagates like torch
-          if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }
-        }
-        first = false;
-      }
+    for (int s = 0; s < 3; ++s) {
+      int h = p * 2 - 1 + r, w = q * 2 - 1 + s;
+      h = h < 0 ? 0 : (h >= H ? H - 1 : h);
+      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+      ElemTraits<T>::load8(x + (((int64_t)n * H + h) * W + w) * C + c8 * 8, v[r * 3 + s]);
     }
-    const int64_t o = (((int64_t)n * P + p) * Q + q) * C + c8 * 8;
-    ElemTraits<T>::store8(y + o, best);
-    uint2 packed;
-    packed.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
-    packed.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
-    *reinterpret_cast<uint2*>(idx + o) = packed;
-  }
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+  bool first = true;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int h = p * 2 - 1 + r, w = q * 2 - 1 + s;
+      const bool valid = h >= 0 && h < H && w >= 0 && w < W;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // first max wins (strictly greater replaces), NaN propagates like torch
+        const float u = v[r * 3 + s][e];
+        if (valid && (first || u > best[e] || u != u)) { best[e] = u; bi[e] = r * 3 + s; }
+      }
+      first = first && !valid;
+    }
+  const int64_t o = (((int64_t)n * P + p) * Q + q) * C + c8 * 8;
+  ElemTraits<T>::store8(y + o, best);
+  uint2 packed;
+  packed.x = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+  packed.y = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+  *reinterpret_cast<uint2*>(idx + o) = packed;
 }
 
-// gather-style backward: one thread per input (n,h,w, 8-channel chunk); no atomics.
+// gather-style backward, no atomics: one thread per 2 x 2 block of input pixels (rows 2p', 2p'+1,
+// columns 2q', 2q'+1) x 8 channels.  Row 2p' lies only in window row p' (tap r = 1); row 2p'+1 in
+// p' (r = 2) and p'+1 (r = 0); the same along w: the block needs the 2 x 2 windows (p'+a, q'+b), each
+// loaded ONCE (index bytes + gradient, branch-free from clamped coordinates) for four outputs.  Every
+// output adds its windows in the order (p0,q0), (p0,q1), (p1,q0), (p1,q1) = ascending (p, q).
 template <typename T>
 __global__ void __launch_bounds__(kThreads) maxpool_bwd_kernel(const T* __restrict__ dy,
                                                                const uint8_t* __restrict__ idx,
                                                                T* __restrict__ dx, int N, int H,
                                                                int W, int C, int P, int Q) {
-  const int cc = C >> 3;
-  const int64_t total = (int64_t)N * H * W * cc;
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += stride) {
-    const int c8 = (int)(i % cc);
-    int64_t t = i / cc;
-    const int w = (int)(t % W); t /= W;
-    const int h = (int)(t % H);
-    const int n = (int)(t / H);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // windows (p,q) with p*2-1+r == h  ->  r = h+1-2p in [0,3)
-    for (int p = h / 2; p <= (h + 1) / 2 && p < P; ++p) {
-      const int r = h + 1 - 2 * p;
-      if (r < 0 || r > 2) continue;
-      for (int q = w / 2; q <= (w + 1) / 2 && q < Q; ++q) {
-        const int s = w + 1 - 2 * q;
-        if (s < 0 || s > 2) continue;
-        const int64_t o = (((int64_t)n * P + p) * Q + q) * C + c8 * 8;
-        const uint2 packed = *reinterpret_cast<const uint2*>(idx + o);
-        float g[8];
-        ElemTraits<T>::load8(dy + o, g);
-        const int tap = r * 3 + s;
+  const uint32_t cc = (uint32_t)C >> 3;
+  const uint32_t H2 = (uint32_t)(H + 1) >> 1, W2 = (uint32_t)(W + 1) >> 1;
+  const uint32_t total = (uint32_t)N * H2 * W2 * cc;     // < 2^31 (checked on the host): 32-bit index math
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int c8 = (int)(i % cc);
+  uint32_t t = i / cc;
+  const int q2 = (int)(t % W2); t /= W2;
+  const int p2 = (int)(t % H2);
+  const int n = (int)(t / H2);
+  uint2 packed[2][2];
+  float g[2][2][8];
+  bool pv[2], qv[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const uint32_t word = e < 4 ? packed.x : packed.y;
-          const int b = (int)((word >> (8 * (e & 3))) & 0xffu);
-          if (b == tap) acc[e] += g[e];
-        }
-      }
-    }
-    ElemTraits<T>::store8(dx + (((int64_t)n * H + h) * W + w) * C + c8 * 8, acc);
+  for (int a = 0; a < 2; ++a) {
+    pv[a] = p2 + a < P;
+    qv[a] = q2 + a < Q;
   }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int pc = pv[a] ? p2 + a : P - 1, qc = qv[b] ? q2 + b : Q - 1;
+      const int64_t o = (((int64_t)n * P + pc) * Q + qc) * C + c8 * 8;
+      packed[a][b] = *reinterpret_cast<const uint2*>(idx + o);
+      ElemTraits<T>::load8(dy + o, g[a][b]);
+    }
+#pragma unroll
+  for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 2; ++dw) {
+      const int h = 2 * p2 + dh, w = 2 * q2 + dw;
+      if (h >= H || w >= W) continue;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int a = 0; a <= dh; ++a)
+#pragma unroll
+        for (int b = 0; b <= dw; ++b) {
+          const int r = dh == 0 ? 1 : (a == 0 ? 2 : 0);
+          const int sx = dw == 0 ? 1 : (b == 0 ? 2 : 0);
+          const int tap = r * 3 + sx;
+          const bool valid = pv[a] && qv[b];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t word = e < 4 ? packed[a][b].x : packed[a][b].y;
+            const int bsel = (int)((word >> (8 * (e & 3))) & 0xffu);
+            if (valid && bsel == tap) acc[e] += g[a][b][e];
+          }
+        }
+      ElemTraits<T>::store8(dx + (((int64_t)n * H + h) * W + w) * C + c8 * 8, acc);
+    }
 }
 
 // y[n][c] = mean_hw x[n][hw][c]; one thread per (n, 8-channel chunk)
@@ -247,7 +279,8 @@ extern "C" int passl_hip_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, 
     return PASSL_EINVAL;
   const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)N * P * Q * (C >> 3);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for(total)),
+  if (total > 0x7fffffffll) return PASSL_EUNSUPPORTED;       // the kernels index with 32 bits
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3((unsigned)((total + kThreads - 1) / kThreads)),
                                            dim3(kThreads), 0, as_stream(stream),
                                            reinterpret_cast<const T*>(x), reinterpret_cast<T*>(y),
                                            idx, N, H, W, C, P, Q);)
@@ -261,8 +294,9 @@ extern "C" int passl_hip_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, vo
       !aligned16(dx))
     return PASSL_EINVAL;
   const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)N * H * W * (C >> 3);
-  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)),
+  const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 3);   // 2 x 2 input pixels per thread
+  if (total > 0x7fffffffll) return PASSL_EUNSUPPORTED;       // the kernels index with 32 bits
+  DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3((unsigned)((total + kThreads - 1) / kThreads)),
                                            dim3(kThreads), 0, as_stream(stream),
                                            reinterpret_cast<const T*>(dy), idx,
                                            reinterpret_cast<T*>(dx), N, H, W, C, P, Q);)
