@@ -221,6 +221,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     loss = float(trainer.outputs['loss'].detach())
+    mem = torch.cuda.memory_stats()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     if world > 1:
@@ -268,6 +269,9 @@ def main():
             'config': {'workload': workload_fmt % (args.dtype, args.batch),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'views_per_sec': round(2 * ips, 2), 'final_loss': round(loss, 4),
+                       'hbm_allocated_gb': round(mem.get('allocated_bytes.all.peak', 0) / 2 ** 30, 1),
+                       'hbm_reserved_gb': round(mem.get('reserved_bytes.all.peak', 0) / 2 ** 30, 1),
+                       'allocator_retries': int(mem.get('num_alloc_retries', 0)),
                        'timed_region': 'product path only (full hook bus); kernel instrumentation runs '
                                        'in a separate loop afterwards'},
             'step_flop_roofline': {

@@ -83,18 +83,30 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
       }
     }
     if (rl < lanes) {
-      for (int64_t r = row0 + rl; r < row1; r += lanes) {
-        float v[8];
-        ElemTraits<T>::load8(x + r * C + col * 8, v);
-        if (MODE == 0) {
+      // 4 rows per trip: their loads are issued back to back (branch-free, a row past the slab
+      // re-reads the last one) and accumulated in row order — the same sums as one row per trip
+      constexpr int U = 4;
+      for (int64_t r = row0 + rl; r < row1; r += (int64_t)U * lanes) {
+        float v[U][8], g[U][8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float d = v[e] - mu[e]; a0[e] += d; a1[e] += d * d; }
-        } else {
-          float g[8];
-          ElemTraits<T>::load8(dz + r * C + col * 8, g);
-          apply_relu_mask<T>(g, v, relu, z, r * cols + col, sc, sh);
+        for (int u = 0; u < U; ++u) {
+          const int64_t rr = r + (int64_t)u * lanes;
+          const int64_t rc = rr < row1 ? rr : row1 - 1;
+          ElemTraits<T>::load8(x + rc * C + col * 8, v[u]);
+          if (MODE == 1) ElemTraits<T>::load8(dz + rc * C + col * 8, g[u]);
+        }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { a0[e] += g[e]; a1[e] += g[e] * (v[e] - mu[e]) * is[e]; }
+        for (int u = 0; u < U; ++u) {
+          const int64_t rr = r + (int64_t)u * lanes;
+          if (rr >= row1) break;
+          if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[u][e] - mu[e]; a0[e] += d; a1[e] += d * d; }
+          } else {
+            apply_relu_mask<T>(g[u], v[u], relu, z, rr * cols + col, sc, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] += g[u][e]; a1[e] += g[u][e] * (v[u][e] - mu[e]) * is[e]; }
+          }
         }
       }
     }

@@ -11,13 +11,27 @@ launch hangs off that chain without feeding it:
 just updated, moco.py:82-90 — a true dependency.)  Side work is issued on ONE side stream per device,
 so that its workgroups fill the CUs next to the main chain's (different bottlenecks share a CU:
 LDS-heavy GEMM workgroups + register-light streaming workgroups) instead of extending the chain.  Ordering: the side stream waits for an event recorded on
-the main stream at the hand-off point (its inputs are complete), tensors it reads are
-``record_stream``-ed (the caching allocator must not recycle them early), and the main stream waits
+the main stream at the hand-off point (its inputs are complete), and the main stream waits
 for the side stream before anything consumes the results (``join``): at the end of every backward
 pass (autograd engine callback) and before a gradient bucket is all-reduced.  Every kernel stays
 deterministic; only the interleaving changes.
+
+Memory.  The tensors a hand-off reads (allocated on the main stream) must not be recycled while the
+side stream still reads them.  ``Tensor.record_stream`` would do that, but the host enqueues a whole
+backward pass long before the GPU executes it, so a recorded block is never seen as finished when
+the allocator looks and NOTHING the side stream touched is reused inside a step: at SimCLR batch
+512 the reserved pool grew from 177 GB to the 288 GB of the device and the allocator started to
+free and re-allocate (measured 3-10x slower steps).  Instead a hand-off keeps REFERENCES to those
+tensors until the held bytes exceed a budget (8 % of the device memory: every hand-off of a batch-256
+MoCo step fits — a lag of 2 / 8 / 16 layers measured 9541 / 9691 / 9698 img/s, all of them 9817 —
+while SimCLR at batch 512 retires after ~10 layers); when the oldest hand-off retires, the main
+stream first waits (on the GPU) for its event — everything the main stream enqueues afterwards is
+ordered behind the side stream's reads, so the plain stream-ordered reuse of the caching allocator is
+safe again.
 """
+import collections
 import contextlib
+import os
 
 import torch
 
@@ -25,6 +39,10 @@ from . import config
 
 _streams = {}
 _dirty = {}
+_pending = {}       # device index -> deque of (event recorded on the side stream, tensors kept alive)
+_HOLD_FRAC = float(os.environ.get('PASSL_OVERLAP_HOLD_FRAC', '0.08'))
+_held_bytes = {}
+_budget = {}
 
 
 def side_stream(device):
@@ -48,10 +66,21 @@ def on_side(device, reads=(), in_backward=False):
     s.wait_event(main.record_event())
     with torch.cuda.stream(s):
         yield s
-    for t in reads:
-        if t is not None:
-            t.record_stream(s)
-    _dirty[s.device.index] = True
+    key = s.device.index
+    q = _pending.setdefault(key, collections.deque())
+    held = tuple(t for t in reads if t is not None)
+    nbytes = sum(t.numel() * t.element_size() for t in held)
+    q.append((s.record_event(), held, nbytes))
+    _held_bytes[key] = _held_bytes.get(key, 0) + nbytes
+    budget = _budget.get(key)
+    if budget is None:
+        budget = _budget[key] = int(_HOLD_FRAC * torch.cuda.get_device_properties(key).total_memory)
+    while _held_bytes[key] > budget and len(q) > 1:
+        done, held, nbytes = q.popleft()
+        main.wait_event(done)       # later main-stream work (and its allocations) is ordered behind those reads
+        _held_bytes[key] -= nbytes
+        del held
+    _dirty[key] = True
     if in_backward:
         # join at the end of this backward pass: whoever reads .grad afterwards sees finished work
         # (one callback per hand-off; all but the first find nothing left to wait for)
@@ -67,3 +96,7 @@ def join(device):
     if _dirty.get(key):
         torch.cuda.current_stream(device).wait_stream(s)
         _dirty[key] = False
+    q = _pending.get(key)
+    if q:
+        q.clear()                   # ordered behind the wait above
+        _held_bytes[key] = 0

@@ -1,0 +1,12 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+show() { python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); c=d['config']; print(d['metric'][:50], d['value'], d['ms_per_step'], 'alloc', c.get('hbm_allocated_gb'), 'resv', c.get('hbm_reserved_gb'), 'retries', c.get('allocator_retries'))
+"; }
+for lag in 0.08; do echo "frac $lag"; PASSL_OVERLAP_HOLD_FRAC=$lag python bench.py --no-cpu-baseline --no-kernel-timing --steps 50 --warmup 6 2>/dev/null | show; done
+for lag in 0.08 0.15; do echo "frac $lag"; PASSL_OVERLAP_HOLD_FRAC=$lag timeout 600 python bench.py --workload simclr --batch 512 --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 6 2>/dev/null | show; done
+timeout 600 python bench.py --workload clip16 --batch 1024 --no-cpu-baseline --no-kernel-timing --steps 10 --warmup 6 2>/dev/null | show
+timeout 600 python -m pytest tests/test_moco_gpu.py tests/test_dp_gpu.py -q -x 2>&1 | tail -3
