@@ -14,7 +14,8 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fused_bn_stats': os.environ.get('PASSL_FUSED_BN_STATS', '1') != '0',
           'fuse_residual_grad': os.environ.get('PASSL_FUSE_RESIDUAL_GRAD', '1') != '0',
           'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0',
-          'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0'}
+          'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
+          'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0'}
 
 
 def set_device(name):
@@ -73,6 +74,12 @@ def overlap():
     return _state['overlap']
 
 
+def fork_downsample():
+    """With `overlap`: the downsample branch of a bottleneck block (1x1 conv + BatchNorm of the block
+    input) runs on the second HIP stream next to conv1..conv3, forward and backward."""
+    return _state['fork_downsample']
+
+
 def set_flag(name, value):
-    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap')
+    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample')
     _state[name] = bool(value)

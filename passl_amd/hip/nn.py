@@ -57,11 +57,12 @@ class GradSlot:
     checked: a `take` from a slot that was armed but never filled raises instead of silently
     dropping a gradient."""
 
-    __slots__ = ('armed', 'grad')
+    __slots__ = ('armed', 'grad', 'ready')
 
     def __init__(self):
         self.armed = False
         self.grad = None
+        self.ready = None
 
     def arm(self):
         self.armed = True
@@ -70,6 +71,9 @@ class GradSlot:
         if not self.armed or self.grad is not None:
             raise RuntimeError('GradSlot.put: slot not armed or already filled')
         self.grad = g
+        # the two ends may run on different streams (a downsample branch on the side stream,
+        # hip/streams.py): the taker waits for the producer's launches
+        self.ready = torch.cuda.current_stream(g.device).record_event() if g.is_cuda else None
 
     def take(self):
         if not self.armed:
@@ -78,6 +82,11 @@ class GradSlot:
             raise RuntimeError('GradSlot.take: the residual-branch gradient has not been produced '
                                'yet (autograd executed the fork in an unexpected order)')
         g, self.grad, self.armed = self.grad, None, False
+        if self.ready is not None:
+            cur = torch.cuda.current_stream(g.device)
+            cur.wait_event(self.ready)
+            g.record_stream(cur)        # no-op when it was allocated on this stream
+            self.ready = None
         return g
 
 

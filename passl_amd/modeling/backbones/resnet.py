@@ -15,7 +15,7 @@ epilogue, i.e. one kernel per conv and no extra pass over the activations.
 """
 import torch
 
-from ...hip import config, nn, ops, plan as P
+from ...hip import config, nn, ops, plan as P, streams
 from ...modules import init
 from ...utils.logger import get_logger
 from ...modules.freeze import freeze_batchnorm_statictis
@@ -52,6 +52,13 @@ class BottleneckBlock(nn.Layer):
         # conv1's data-gradient launch yields the COMPLETE gradient of x only when the identity /
         # downsample branch is folded in through the slot: then it may also do the backward reduction
         # of the BatchNorm that produced x (nn.BNLink); conv2 / conv3 are sole consumers of bn1 / bn2
+        # the downsample branch (conv + BatchNorm of x) is independent of conv1..conv3: with the side
+        # stream on it is issued there (AFTER the main branch on the host, so that its backward nodes
+        # still run first and fill the GradSlot; on the GPU it starts as soon as x is complete) and
+        # joined before bn3.  Autograd runs its backward on the side stream as well.
+        fork = (self.downsample is not None and torch.is_grad_enabled() and x.requires_grad and
+                streams.enabled(x) and config.fork_downsample())
+        x_ready = torch.cuda.current_stream(x.device).record_event() if fork else None
         out, st = self.conv1(x, want_stats=True, add_slot=slot,
                              producer=nn.bn_link(x) if slot is not None else None)
         out = self.bn1(out, relu=True, stats=st)
@@ -59,17 +66,38 @@ class BottleneckBlock(nn.Layer):
         out = self.bn2(out, relu=True, stats=st)
         out, st3 = self.conv3(out, want_stats=True, producer=nn.bn_link(out))
         if self.downsample is not None:
-            idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
-            identity = self.downsample[1](idn, relu=False, stats=st)
+            if fork:
+                main = torch.cuda.current_stream(x.device)
+                side = streams.side_stream(x.device)
+                side.wait_event(x_ready)
+                with torch.cuda.stream(side):
+                    idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
+                    identity = self.downsample[1](idn, relu=False, stats=st)
+                main.wait_event(side.record_event())
+                identity.record_stream(main)      # allocated on the side stream, read by bn3 on the main one
+            else:
+                idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
+                identity = self.downsample[1](idn, relu=False, stats=st)
             return self.bn3(out, residual=identity, relu=True, stats=st3)
         return self.bn3(out, residual=x, relu=True, stats=st3, res_slot=slot)   # out += identity; relu
 
     def forward_frozen(self, x):
         """Same block with running-stat BN folded into the conv epilogues (3-4 kernels)."""
+        fork = self.downsample is not None and streams.enabled(x) and config.fork_downsample()
+        x_ready = torch.cuda.current_stream(x.device).record_event() if fork else None
         out = self.conv1.infer(x, self.bn1, relu=True)
         out = self.conv2.infer(out, self.bn2, relu=True)
         identity = x
-        if self.downsample is not None:
+        if fork:
+            # downsample conv next to conv1 / conv2 on the side stream; joined before conv3 (whose
+            # epilogue adds it), so x outlives the side stream's reads
+            main, side = torch.cuda.current_stream(x.device), streams.side_stream(x.device)
+            side.wait_event(x_ready)
+            with torch.cuda.stream(side):
+                identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
+            main.wait_event(side.record_event())
+            identity.record_stream(main)
+        elif self.downsample is not None:
             identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
         return self.conv3.infer(out, self.bn3, residual=identity, relu=True)
 
