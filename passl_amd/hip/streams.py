@@ -42,6 +42,7 @@ _dirty = {}
 _pending = {}       # device index -> deque of (event recorded on the side stream, tensors kept alive)
 _HOLD_FRAC = float(os.environ.get('PASSL_OVERLAP_HOLD_FRAC', '0.08'))
 _held_bytes = {}
+_owners = {}
 _budget = {}
 
 
@@ -50,6 +51,22 @@ def side_stream(device):
     s = _streams.get(key)
     if s is None:
         s = _streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+_fork_streams = {}
+
+
+def fork_stream(device):
+    """Stream of forked forward/backward branches (a bottleneck block's downsample branch): the
+    weight-gradient stream.  A stream of its own (PASSL_FORK_OWN_STREAM=1), so that a branch's backward
+    chain does not queue behind weight-gradient launches, measured no better (9871 vs 9913 img/s)."""
+    if os.environ.get('PASSL_FORK_OWN_STREAM', '0') != '1':
+        return side_stream(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _fork_streams.get(key)
+    if s is None:
+        s = _fork_streams[key] = torch.cuda.Stream(device=device)
     return s
 
 
@@ -71,13 +88,19 @@ def on_side(device, reads=(), in_backward=False):
     held = tuple(t for t in reads if t is not None)
     nbytes = sum(t.numel() * t.element_size() for t in held)
     q.append((s.record_event(), held, nbytes))
+    owners = _owners.setdefault(key, [])
+    if main != s and main not in owners:
+        owners.append(main)         # streams that hand work over (the main stream, the fork stream)
     _held_bytes[key] = _held_bytes.get(key, 0) + nbytes
     budget = _budget.get(key)
     if budget is None:
         budget = _budget[key] = int(_HOLD_FRAC * torch.cuda.get_device_properties(key).total_memory)
     while _held_bytes[key] > budget and len(q) > 1:
         done, held, nbytes = q.popleft()
-        main.wait_event(done)       # later main-stream work (and its allocations) is ordered behind those reads
+        # the held tensors may come from the pool of any handing-off stream (a forked branch reads the
+        # main stream's block input): later work of ALL of them is ordered behind the side stream's reads
+        for owner in owners:
+            owner.wait_event(done)
         _held_bytes[key] -= nbytes
         del held
     _dirty[key] = True
@@ -98,5 +121,10 @@ def join(device):
         _dirty[key] = False
     q = _pending.get(key)
     if q:
-        q.clear()                   # ordered behind the wait above
+        cur = torch.cuda.current_stream(device)
+        last = q[-1][0]
+        for owner in _owners.get(key, ()):
+            if owner != cur:
+                owner.wait_event(last)
+        q.clear()                   # every handing-off stream is ordered behind the side stream's reads
         _held_bytes[key] = 0

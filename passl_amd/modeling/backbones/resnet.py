@@ -68,7 +68,7 @@ class BottleneckBlock(nn.Layer):
         if self.downsample is not None:
             if fork:
                 main = torch.cuda.current_stream(x.device)
-                side = streams.side_stream(x.device)
+                side = streams.fork_stream(x.device)
                 side.wait_event(x_ready)
                 with torch.cuda.stream(side):
                     idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
@@ -91,7 +91,7 @@ class BottleneckBlock(nn.Layer):
         if fork:
             # downsample conv next to conv1 / conv2 on the side stream; joined before conv3 (whose
             # epilogue adds it), so x outlives the side stream's reads
-            main, side = torch.cuda.current_stream(x.device), streams.side_stream(x.device)
+            main, side = torch.cuda.current_stream(x.device), streams.fork_stream(x.device)
             side.wait_event(x_ready)
             with torch.cuda.stream(side):
                 identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
