@@ -124,6 +124,9 @@ class MoCo(nn.Layer):
     def train_iter(self, *inputs, **kwargs):
         img_q, img_k = inputs
         self.arena_q.refresh()                      # compute-dtype copies of the updated weights
+        if not self.shuffle_bn and hasattr(self.encoder_k[0], 'stage_input'):
+            # the key view's layout conversion does not depend on the EMA: side stream, under the query forward
+            img_k = self.encoder_k[0].stage_input(img_k)
 
         q = self.encoder_q(img_q)                   # queries: NxC (fp32)
         q = nn.normalize(q, axis=1)

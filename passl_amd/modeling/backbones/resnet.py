@@ -102,6 +102,14 @@ class BottleneckBlock(nn.Layer):
         return self.conv3.infer(out, self.bn3, residual=identity, relu=True)
 
 
+class _StagedInput:
+    """An image batch already converted by ResNet.stage_input (tensor, size, completion event)."""
+    __slots__ = ('xp', 'H', 'W', 'ready')
+
+    def __init__(self, xp, H, W, ready):
+        self.xp, self.H, self.W, self.ready = xp, H, W, ready
+
+
 @BACKBONES.register()
 class ResNet(nn.Layer):
     stem_pool = True          # ResNetsimclr (resnetcifar.py:275) drops the stem max-pool
@@ -199,13 +207,33 @@ class ResNet(nn.Layer):
     def _all_bn_frozen(self):
         return all(m.uses_global_stats() for m in self.modules() if isinstance(m, nn._BatchNormBase))
 
+    def _stem_input(self, x):
+        rt = nn._need_rt(self.conv1)
+        _, _, H, W = x.shape
+        _Hp, Wp = P.stem_padded_hw(H, W)
+        return ops.nchw_to_nhwc_pad(x.contiguous().float(), P.STEM_PAD, Wp, P.STEM_CP, rt.arena.dtype), H, W
+
+    def stage_input(self, x):
+        """Layout conversion of an image batch (NCHW fp32 -> zero-padded NHWC in the compute dtype) ahead
+        of time, on the side stream: MoCo converts the key view while the query encoder runs.  Returns
+        what ``forward`` accepts in place of x (x itself when the side stream is off)."""
+        if not streams.enabled(x):
+            return x
+        main, side = torch.cuda.current_stream(x.device), streams.side_stream(x.device)
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
+            xp, H, W = self._stem_input(x)
+        return _StagedInput(xp, H, W, side.record_event())
+
     def forward(self, x):
         """x: [N,3,H,W] fp32 (reference layout) -> [N,H/32,W/32,2048] NHWC in the compute dtype."""
-        rt = nn._need_rt(self.conv1)
-        dtype = rt.arena.dtype
-        N, _, H, W = x.shape
-        _Hp, Wp = P.stem_padded_hw(H, W)
-        xp = ops.nchw_to_nhwc_pad(x.contiguous().float(), P.STEM_PAD, Wp, P.STEM_CP, dtype)
+        if isinstance(x, _StagedInput):
+            xp, H, W = x.xp, x.H, x.W
+            main = torch.cuda.current_stream(xp.device)
+            main.wait_event(x.ready)
+            xp.record_stream(main)        # allocated on the side stream, read by the stem conv here
+        else:
+            xp, H, W = self._stem_input(x)
         stages = (self.layer1, self.layer2, self.layer3, self.layer4)
         # number of leading stages that run frozen: all of them for a key encoder under no_grad (every
         # BatchNorm on running statistics), the _freeze_stages prefix otherwise
