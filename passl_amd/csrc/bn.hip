@@ -235,9 +235,10 @@ __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
   float g0;
   slab_totals<true>(partial, nblocks, C, M, rows_per_block, scratch, nseg, c, t1, t2, g0);
   if (threadIdx.x >= 8 || c >= C) return;
-  const double dm = t1 / (double)M;                 // mean - g0
+  const double inv_m = 1.0 / (double)M;             // one fp64 division instead of three
+  const double dm = t1 * inv_m;                     // mean - g0
   const double mu = (double)g0 + dm;
-  double var = t2 / (double)M - dm * dm;            // biased; centred on a sample value: no cancellation
+  double var = t2 * inv_m - dm * dm;                // biased; centred on a sample value: no cancellation
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = (float)mu;
@@ -266,9 +267,10 @@ __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
   dgamma[c] += (float)sgx;
   // dx = gamma*invstd*( g - sg/M - xhat*sgx/M ),  xhat = (x-mean)*invstd
   const double gi = (double)gamma[c] * (double)invstd[c];
+  const double inv_m = 1.0 / (double)M;
   const double A = gi;
-  const double B = -gi * (double)invstd[c] * sgx / (double)M;
-  const double Cc = -gi * sg / (double)M - B * (double)mean[c];
+  const double B = -gi * (double)invstd[c] * sgx * inv_m;
+  const double Cc = -gi * sg * inv_m - B * (double)mean[c];
   coef[c] = (float)A;
   coef[C + c] = (float)B;
   coef[2 * C + c] = (float)Cc;
