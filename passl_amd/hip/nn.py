@@ -83,9 +83,10 @@ class GradSlot:
                                'yet (autograd executed the fork in an unexpected order)')
         g, self.grad, self.armed = self.grad, None, False
         if self.ready is not None:
-            cur = torch.cuda.current_stream(g.device)
-            cur.wait_event(self.ready)
-            g.record_stream(cur)        # no-op when it was allocated on this stream
+            # g may come from the side stream's pool (a forked downsample branch): ordered by the event; its
+            # block is recycled behind later side-stream work only, all of which waits on main-stream events
+            # recorded after this launch (hip/streams.py, "Memory") — no record_stream
+            torch.cuda.current_stream(g.device).wait_event(self.ready)
             self.ready = None
         return g
 

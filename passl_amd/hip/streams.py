@@ -27,7 +27,10 @@ MoCo step fits — a lag of 2 / 8 / 16 layers measured 9541 / 9691 / 9698 img/s,
 while SimCLR at batch 512 retires after ~10 layers); when the oldest hand-off retires, the main
 stream first waits (on the GPU) for its event — everything the main stream enqueues afterwards is
 ordered behind the side stream's reads, so the plain stream-ordered reuse of the caching allocator is
-safe again.
+safe again.  The opposite direction (tensors from the SIDE stream's pool read on the main stream: a
+forked branch's output, its input gradient, a staged input) needs nothing: every piece of side-stream
+work begins with a wait on a main-stream event recorded at its hand-off, i.e. after the main-stream
+readers were enqueued.
 """
 import collections
 import contextlib
@@ -70,8 +73,21 @@ def fork_stream(device):
     return s
 
 
+_TIGHT_FRAC = float(os.environ.get('PASSL_OVERLAP_MAX_RESERVED_FRAC', '0.8'))
+_capacity = {}
+
+
 def enabled(t):
-    return config.overlap() and t.is_cuda
+    """Side-stream work for tensor t's device?  Off when the caching allocator already holds most of the
+    device (a second stream means a second pool of cached blocks: +60 GB at SimCLR batch 512): the launches
+    then stay on the current stream and draw from its pool."""
+    if not (config.overlap() and t.is_cuda):
+        return False
+    key = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    cap = _capacity.get(key)
+    if cap is None:
+        cap = _capacity[key] = torch.cuda.get_device_properties(key).total_memory
+    return torch.cuda.memory_reserved(key) < _TIGHT_FRAC * cap
 
 
 @contextlib.contextmanager

@@ -74,7 +74,10 @@ class BottleneckBlock(nn.Layer):
                     idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
                     identity = self.downsample[1](idn, relu=False, stats=st)
                 main.wait_event(side.record_event())
-                identity.record_stream(main)      # allocated on the side stream, read by bn3 on the main one
+                # `identity` comes from the side stream's pool and is read by bn3 on the main stream.  No
+                # record_stream (hip/streams.py, "Memory"): every later piece of side-stream work starts with
+                # a wait on a main-stream event recorded after this point, so the pool's stream-ordered
+                # reuse is already behind bn3
             else:
                 idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
                 identity = self.downsample[1](idn, relu=False, stats=st)
@@ -95,8 +98,7 @@ class BottleneckBlock(nn.Layer):
             side.wait_event(x_ready)
             with torch.cuda.stream(side):
                 identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
-            main.wait_event(side.record_event())
-            identity.record_stream(main)
+            main.wait_event(side.record_event())     # (no record_stream: see forward())
         elif self.downsample is not None:
             identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
         return self.conv3.infer(out, self.bn3, residual=identity, relu=True)
@@ -230,8 +232,7 @@ class ResNet(nn.Layer):
         if isinstance(x, _StagedInput):
             xp, H, W = x.xp, x.H, x.W
             main = torch.cuda.current_stream(xp.device)
-            main.wait_event(x.ready)
-            xp.record_stream(main)        # allocated on the side stream, read by the stem conv here
+            main.wait_event(x.ready)      # xp: side-stream pool, read by the stem conv here (no record_stream: see BottleneckBlock.forward)
         else:
             xp, H, W = self._stem_input(x)
         stages = (self.layer1, self.layer2, self.layer3, self.layer4)
