@@ -60,6 +60,17 @@ const char* passl_hip_strerror(int status);
 int passl_hip_ema_update(float* k, const float* q, void* k_lp, int64_t n, float m,
                          passl_stream_t stream);
 
+/* Inference-form BatchNorm affine of ALL layers of an encoder in one launch (the key encoder's fused
+ * BN: scale folded into the conv epilogues): for i < n
+ *   scale[i] = flat[gamma_idx[i]] * rsqrt(flat[var_idx[i]] + eps)
+ *   shift[i] = flat[beta_idx[i]] - flat[mean_idx[i]] * scale[i]
+ * The index lists address the encoder's flat parameter/statistics buffer.  Replaces the per-layer
+ * running-statistics BatchNorm of the frozen key encoder (passl_v110/modules/freeze.py:18-23 +
+ * paddle.nn.BatchNorm2D in eval form). */
+int passl_hip_bn_fold(const float* flat, const int64_t* gamma_idx, const int64_t* beta_idx,
+                      const int64_t* mean_idx, const int64_t* var_idx, int64_t n, float eps,
+                      float* scale, float* shift, passl_stream_t stream);
+
 /* Momentum-SGD with L2 decay folded into the gradient, over flat fp32 buffers:
  *   g' = g*grad_scale + wd*p;  v = mu*v + g';  p = p - lr*v
  * Replaces paddle.optimizer.Momentum.step() called from

@@ -348,6 +348,31 @@ extern "C" int passl_hip_ema_update(float* k, const float* q, void* k_lp, int64_
   return PASSL_OK;
 }
 
+__global__ void __launch_bounds__(kThreads) bn_fold_kernel(const float* __restrict__ flat,
+                                                           const int64_t* __restrict__ gi,
+                                                           const int64_t* __restrict__ bi,
+                                                           const int64_t* __restrict__ mi,
+                                                           const int64_t* __restrict__ vi, int64_t n,
+                                                           float eps, float* __restrict__ scale,
+                                                           float* __restrict__ shift) {
+  const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const float sc = flat[gi[i]] * rsqrtf(flat[vi[i]] + eps);
+  scale[i] = sc;
+  shift[i] = flat[bi[i]] - flat[mi[i]] * sc;
+}
+
+extern "C" int passl_hip_bn_fold(const float* flat, const int64_t* gamma_idx, const int64_t* beta_idx,
+                                 const int64_t* mean_idx, const int64_t* var_idx, int64_t n, float eps,
+                                 float* scale, float* shift, passl_stream_t stream) {
+  if (!flat || !gamma_idx || !beta_idx || !mean_idx || !var_idx || !scale || !shift || n <= 0)
+    return PASSL_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     as_stream(stream), flat, gamma_idx, beta_idx, mean_idx, var_idx, n, eps, scale, shift);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
 extern "C" int passl_hip_momentum_sgd(float* p, const float* g, float* v, int64_t n, float lr,
                                       float mu, float wd, float grad_scale,
                                       passl_stream_t stream) {

@@ -866,9 +866,17 @@ class EncoderArena:
     def update_bn_affine(self):
         if self._bn_idx is None:
             return
-        g, b, m, v = (self.flat[i] for i in self._bn_idx)
-        scale = g * torch.rsqrt(v + self._bn_eps)
-        self.bn_affine = (scale, b - m * scale)
+        n = self._bn_idx[0].numel()
+        if self.bn_affine is None or self.bn_affine[0].numel() != n:
+            self.bn_affine = (torch.empty(n, dtype=torch.float32, device=self.flat.device),
+                              torch.empty(n, dtype=torch.float32, device=self.flat.device))
+        if self.flat.is_cuda:
+            ops.bn_fold(self.flat, self._bn_idx, self._bn_eps, *self.bn_affine)    # one launch, in place
+        else:       # host-side model construction only (nothing runs there)
+            g, b, m, v = (self.flat[i] for i in self._bn_idx)
+            scale = g * torch.rsqrt(v + self._bn_eps)
+            self.bn_affine[0].copy_(scale)
+            self.bn_affine[1].copy_(b - m * scale)
 
     def clear_grad(self):
         if self.grads is not None:

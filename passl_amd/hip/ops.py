@@ -352,6 +352,14 @@ def ema_update(k_flat, q_flat, m, k_lp=None):
                                         k_flat.numel(), m, L.stream()), 'ema_update')
 
 
+def bn_fold(flat, idx, eps, scale, shift):
+    """scale / shift of every inference-form BatchNorm of an encoder (idx = (gamma, beta, mean, var) int64
+    index lists into `flat`), one launch."""
+    gi, bi, mi, vi = idx
+    L.check(_lib().passl_hip_bn_fold(L.ptr(flat), L.ptr(gi), L.ptr(bi), L.ptr(mi), L.ptr(vi), gi.numel(),
+                                     float(eps), L.ptr(scale), L.ptr(shift), L.stream()), 'bn_fold')
+
+
 def momentum_sgd(p, g, v, lr, mu, wd, grad_scale=1.0):
     L.check(_lib().passl_hip_momentum_sgd(L.ptr(p), L.ptr(g), L.ptr(v), p.numel(), lr, mu, wd,
                                           grad_scale, L.stream()), 'momentum_sgd')

@@ -352,6 +352,21 @@ def test_linear_as_conv(dtype):
     assert relmax(db, dy.double().sum(0)) < 1e-5
 
 
+def test_bn_fold():
+    """Inference-form BatchNorm affine of all layers in one launch against the torch formula."""
+    gen = torch.Generator().manual_seed(3)
+    flat = torch.randn(5000, generator=gen)
+    flat[3000:4000] = flat[3000:4000].abs() + 0.1            # variances
+    gi, bi = torch.arange(0, 1000), torch.arange(1000, 2000)
+    mi, vi = torch.arange(2000, 3000), torch.arange(3000, 4000)
+    idx = tuple(t.to(DEV) for t in (gi, bi, mi, vi))
+    scale, shift = torch.empty(1000, device=DEV), torch.empty(1000, device=DEV)
+    ops.bn_fold(flat.to(DEV), idx, 1e-5, scale, shift)
+    ref_s = flat[gi].double() / (flat[vi].double() + 1e-5).sqrt()
+    ref_b = flat[bi].double() - flat[mi].double() * ref_s
+    assert relmax(scale, ref_s) < 1e-6 and relmax(shift, ref_b) < 1e-6
+
+
 # ---------------------------------------------------------------- batch norm
 @pytest.mark.parametrize('dtype', DTYPES)
 # (5, 125, 128, 256): 625 row slabs -> the finalize kernels combine the slab in segments
