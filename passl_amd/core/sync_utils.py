@@ -73,6 +73,7 @@ class GradReducer(object):
         self._ready = set()
         self._handles = []
         self._active = False
+        self._home = None
         arena.reducer = self
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
@@ -84,14 +85,20 @@ class GradReducer(object):
         self._ready = set()
         self._handles = []
         self._active = True
+        self._home = torch.cuda.current_stream(self.grads.device) if self.grads.is_cuda else None
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
         if self.grads.is_cuda:
-            # weight gradients are produced on the side stream (hip/streams.py): the collective (ordered
-            # behind the current stream) must see them finished
+            # the collective is ordered behind the CURRENT stream only.  Weight gradients are produced on
+            # the side stream (hip/streams.py), BatchNorm / bias gradients on the stream backward() was
+            # called on, and this call may come from a backward node that autograd runs on the side stream
+            # (a forked downsample branch): wait for both
             from ..hip import streams
+            cur = torch.cuda.current_stream(self.grads.device)
+            if self._home is not None and cur != self._home:
+                cur.wait_stream(self._home)
             streams.join(self.grads.device)
         if self.world > 1 or self._forced:
             self._handles.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM,
