@@ -38,25 +38,36 @@ inline unsigned grid_for(int64_t n, int per_block = kThreads) {
 // ------------------------------------------------------------------ QuickGELU
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// tile form (see gelu_kernel, vit.hip): U x 256 consecutive chunks per workgroup, loads back to back
+constexpr int kEltU = 4;
+
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(kThreads) quick_gelu_kernel(const T* __restrict__ x,
                                                               const T* __restrict__ dy,
                                                               T* __restrict__ out, int64_t nchunks) {
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
-    float v[8], o[8];
-    ElemTraits<T>::load8(x + i * 8, v);
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * kEltU) + threadIdx.x;
+  float v[kEltU][8], d[kEltU][8];
+#pragma unroll
+  for (int u = 0; u < kEltU; ++u) {
+    const int64_t i = base + u * kThreads;
+    const int64_t ic = i < nchunks ? i : nchunks - 1;
+    ElemTraits<T>::load8(x + ic * 8, v[u]);
+    if (BWD) ElemTraits<T>::load8(dy + ic * 8, d[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < kEltU; ++u) {
+    const int64_t i = base + u * kThreads;
+    if (i >= nchunks) break;
+    float o[8];
     if (BWD) {
-      float d[8];
-      ElemTraits<T>::load8(dy + i * 8, d);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float s = sigm(1.702f * v[e]);
-        o[e] = d[e] * (s + 1.702f * v[e] * s * (1.0f - s));
+        const float sg = sigm(1.702f * v[u][e]);
+        o[e] = d[u][e] * (sg + 1.702f * v[u][e] * sg * (1.0f - sg));
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = v[e] * sigm(1.702f * v[e]);
+      for (int e = 0; e < 8; ++e) o[e] = v[u][e] * sigm(1.702f * v[u][e]);
     }
     ElemTraits<T>::store8(out + i * 8, o);
   }
@@ -422,7 +433,7 @@ __global__ void dot_finish_kernel(const float* __restrict__ partial, int n, floa
 extern "C" int passl_hip_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype,
                                         passl_stream_t stream) {
   if (!x || !y || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(y)) return PASSL_EINVAL;
-  CLIP_DISPATCH(dtype, hipLaunchKernelGGL((quick_gelu_kernel<T, false>), dim3(grid_for(n >> 3)),
+  CLIP_DISPATCH(dtype, hipLaunchKernelGGL((quick_gelu_kernel<T, false>), dim3((unsigned)(((n >> 3) + kThreads * kEltU - 1) / (kThreads * kEltU))),
                                           dim3(kThreads), 0, as_stream(stream),
                                           reinterpret_cast<const T*>(x), nullptr,
                                           reinterpret_cast<T*>(y), n >> 3);)
@@ -434,7 +445,7 @@ extern "C" int passl_hip_quick_gelu_bwd(const void* dy, const void* x, void* dx,
                                         passl_stream_t stream) {
   if (!dy || !x || !dx || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(dy) || !aligned16(dx))
     return PASSL_EINVAL;
-  CLIP_DISPATCH(dtype, hipLaunchKernelGGL((quick_gelu_kernel<T, true>), dim3(grid_for(n >> 3)),
+  CLIP_DISPATCH(dtype, hipLaunchKernelGGL((quick_gelu_kernel<T, true>), dim3((unsigned)(((n >> 3) + kThreads * kEltU - 1) / (kThreads * kEltU))),
                                           dim3(kThreads), 0, as_stream(stream),
                                           reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy),
                                           reinterpret_cast<T*>(dx), n >> 3);)

@@ -88,20 +88,26 @@ __global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
     float mu[RPI], rs[RPI];
 #pragma unroll
     for (int u = 0; u < RPI; ++u) {
-      mu[u] = ok[u] ? mean[rows[u]] : 0.f;
-      rs[u] = ok[u] ? rstd[rows[u]] : 0.f;
+      const int rsafe = ok[u] ? rows[u] : r0;
+      const float mu_l = mean[rsafe], rs_l = rstd[rsafe];       // unconditional loads, selected below
+      mu[u] = ok[u] ? mu_l : 0.f;
+      rs[u] = ok[u] ? rs_l : 0.f;
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         const int c = lane * 8 + k * 512;
-        if (ok[u] && c < C) {
-          ld8(x + (int64_t)rows[u] * C + c, xv[u][k]);
-          ld8(dy + (int64_t)rows[u] * C + c, dv[u][k]);
-          // fetched with the other operands: a load issued after the row reductions would put a
-          // second full memory round trip on the critical path of every iteration
-          if (dres) ld8(dres + (int64_t)rows[u] * C + c, rv[u][k]);
-        } else {
+        // branch-free: a load behind `if (ok && c < C)` compiles to load - s_waitcnt vmcnt(0) - next load;
+        // out-of-range lanes read a valid address (row r0 / column 0) and are zeroed by a select
+        const bool live = ok[u] && c < C;
+        const int64_t off = (int64_t)(ok[u] ? rows[u] : r0) * C + (c < C ? c : 0);
+        ld8(x + off, xv[u][k]);
+        ld8(dy + off, dv[u][k]);
+        // fetched with the other operands: a load issued after the row reductions would put a
+        // second full memory round trip on the critical path of every iteration
+        ld8((dres ? dres : dy) + off, rv[u][k]);          // no residual: a second (L1-resident) read of dy, unused
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { xv[u][k][e] = 0.f; dv[u][k][e] = 0.f; }
+        for (int e = 0; e < 8; ++e) {
+          xv[u][k][e] = live ? xv[u][k][e] : 0.f;
+          dv[u][k][e] = live ? dv[u][k][e] : 0.f;
         }
       }
     }
@@ -175,22 +181,35 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
 
+// Tile form (as the BatchNorm streaming kernels, bn.hip): a workgroup owns U x 256 consecutive 16-byte
+// chunks, a lane the chunks base + u * 256; all loads are issued back to back, branch-free (a lane past
+// the end re-reads the last chunk), no loop.
+constexpr int kEltU = 4;
+
 template <typename T, bool BWD>
 __global__ void __launch_bounds__(kThreads) gelu_kernel(const T* __restrict__ x,
                                                         const T* __restrict__ dy,
                                                         T* __restrict__ out, int64_t nchunks) {
-  const int64_t stride = (int64_t)gridDim.x * kThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += stride) {
-    float v[8], o[8];
-    ld8(x + i * 8, v);
-    if (BWD) {
-      float d[8];
-      ld8(dy + i * 8, d);
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * kEltU) + threadIdx.x;
+  float v[kEltU][8], d[kEltU][8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = d[e] * gelu_grad_f(v[e]);
+  for (int u = 0; u < kEltU; ++u) {
+    const int64_t i = base + u * kThreads;
+    const int64_t ic = i < nchunks ? i : nchunks - 1;
+    ld8(x + ic * 8, v[u]);
+    if (BWD) ld8(dy + ic * 8, d[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < kEltU; ++u) {
+    const int64_t i = base + u * kThreads;
+    if (i >= nchunks) break;
+    float o[8];
+    if (BWD) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = d[u][e] * gelu_grad_f(v[u][e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = gelu_f(v[e]);
+      for (int e = 0; e < 8; ++e) o[e] = gelu_f(v[u][e]);
     }
     ElemTraits<T>::store8(out + i * 8, o);
   }
@@ -460,6 +479,9 @@ static inline int grid_for(int64_t n) {
   if (b < 1) b = 1;
   return (int)b;
 }
+static inline unsigned elt_grid(int64_t nchunks) {
+  return (unsigned)((nchunks + kThreads * kEltU - 1) / (kThreads * kEltU));
+}
 
 }  // namespace
 
@@ -511,7 +533,7 @@ extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const floa
 
 extern "C" int passl_hip_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream) {
   if (!x || !y || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(y)) return PASSL_EINVAL;
-  VIT_DISPATCH(dtype, hipLaunchKernelGGL((gelu_kernel<T, false>), dim3(grid_for(n >> 3)), dim3(kThreads),
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL((gelu_kernel<T, false>), dim3(elt_grid(n >> 3)), dim3(kThreads),
                                          0, as_stream(stream), reinterpret_cast<const T*>(x), nullptr,
                                          reinterpret_cast<T*>(y), n >> 3);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
@@ -522,7 +544,7 @@ extern "C" int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64
                                   passl_stream_t stream) {
   if (!dy || !x || !dx || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(dy) || !aligned16(dx))
     return PASSL_EINVAL;
-  VIT_DISPATCH(dtype, hipLaunchKernelGGL((gelu_kernel<T, true>), dim3(grid_for(n >> 3)), dim3(kThreads),
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL((gelu_kernel<T, true>), dim3(elt_grid(n >> 3)), dim3(kThreads),
                                          0, as_stream(stream), reinterpret_cast<const T*>(x),
                                          reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx),
                                          n >> 3);)

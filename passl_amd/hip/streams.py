@@ -74,20 +74,24 @@ def fork_stream(device):
 
 
 _TIGHT_FRAC = float(os.environ.get('PASSL_OVERLAP_MAX_RESERVED_FRAC', '0.8'))
-_capacity = {}
+_tight = {}          # device index -> [calls, tight?, capacity]
 
 
 def enabled(t):
     """Side-stream work for tensor t's device?  Off when the caching allocator already holds most of the
     device (a second stream means a second pool of cached blocks: +60 GB at SimCLR batch 512): the launches
-    then stay on the current stream and draw from its pool."""
+    then stay on the current stream and draw from its pool.  The allocator is asked every 256th call only
+    (memory_reserved() assembles the full statistics dictionary: ~0.1 ms of host time)."""
     if not (config.overlap() and t.is_cuda):
         return False
     key = t.device.index if t.device.index is not None else torch.cuda.current_device()
-    cap = _capacity.get(key)
-    if cap is None:
-        cap = _capacity[key] = torch.cuda.get_device_properties(key).total_memory
-    return torch.cuda.memory_reserved(key) < _TIGHT_FRAC * cap
+    st = _tight.get(key)
+    if st is None:
+        st = _tight[key] = [0, False, torch.cuda.get_device_properties(key).total_memory]
+    if st[0] % 256 == 0:
+        st[1] = torch.cuda.memory_reserved(key) >= _TIGHT_FRAC * st[2]
+    st[0] += 1
+    return not st[1]
 
 
 @contextlib.contextmanager
