@@ -188,5 +188,13 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a
+    Stream object through several Python layers (9 us per call measured: ~4 ms of host time in a
+    1500-launch CLIP step that is host-bound); the raw getter is the same handle in ~0.3 us."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
