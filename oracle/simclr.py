@@ -42,6 +42,7 @@ import torch
 import torch.nn.functional as F
 
 from . import resnet50 as R
+from .bf16 import round_act, round_weight, round_grad
 
 LARGE_NUM = 1e9
 
@@ -82,13 +83,22 @@ def fluid_l2_normalize(x, axis=-1, eps=1e-12):
     return x * torch.rsqrt(x.pow(2).sum(dim=axis, keepdim=True) + eps)
 
 
-def encoder_forward(st, x, new_stats=None, taps=None):
+def encoder_forward(st, x, new_stats=None, taps=None, bf16=False):
     """ResNetsimclr(depth=50, with_pool=True) + NonLinearNeckfc3(with_avg_pool=False), train-mode
-    BN everywhere (SimCLR has a single encoder)."""
-    x = R.trunk_forward(st, x, False, new_stats, taps, maxpool=False)
+    BN everywhere (SimCLR has a single encoder).
+    ``bf16``: bf16-emulating mode (oracle/bf16.py, resnet50.trunk_forward): the trunk's storage points,
+    then the product's projector contract — pooled features and the inputs of the 2nd / 3rd Linear are
+    stored in bf16 (value and gradient rounded), Linear operands are the bf16 weight copies, Linear
+    outputs / BatchNorm1D / ReLU / normalisation are fp32, and the gradient entering a Linear's backward
+    is rounded (its GEMM operands are bf16)."""
+    x = R.trunk_forward(st, x, False, new_stats, taps, maxpool=False, bf16=bf16)
     x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)      # backbone avgpool + squeeze
     for i_fc, i_bn, relu in ((0, 1, True), (3, 4, True), (6, 7, False)):
-        x = x @ st['1.mlp.%d.weight' % i_fc] + st['1.mlp.%d.bias' % i_fc]
+        if bf16:
+            x = round_act(x)
+            x = round_grad(R._matmul(x, round_weight(st['1.mlp.%d.weight' % i_fc]))) + st['1.mlp.%d.bias' % i_fc]
+        else:
+            x = x @ st['1.mlp.%d.weight' % i_fc] + st['1.mlp.%d.bias' % i_fc]
         x = R.batch_norm(x, st, '1.mlp.%d' % i_bn, False, new_stats)
         if relu:
             x = F.relu(x)
@@ -181,9 +191,11 @@ def paddle_param_names(keys):
 class SimCLROracle:
     def __init__(self, T=0.1, lr=64.0, warmup_steps=3127, t_max=28152, momentum=0.9,
                  lars_coeff=0.001, lars_weight_decay=1e-4, epsilon=0.0,
-                 exclude=('scale', 'offset', '.bias'), seed=0):
+                 exclude=('scale', 'offset', '.bias'), seed=0, bf16=False):
         gen = torch.Generator().manual_seed(seed)
         self.T = T
+        # bf16=True: bf16-emulating encoder (encoder_forward); head, LARS and lr stay fp32 as in the product
+        self.bf16 = bf16
         self.lr0, self.warmup_steps, self.t_max = lr, warmup_steps, t_max
         self.mu, self.coeff, self.wd, self.eps = momentum, lars_coeff, lars_weight_decay, epsilon
         self.st = init_encoder_state(gen)
@@ -200,7 +212,7 @@ class SimCLROracle:
         for n in tkeys:
             self.st[n] = self.st[n].detach().requires_grad_(True)
         new_stats = {}
-        con = encoder_forward(self.st, torch.cat([img_q, img_k]), new_stats, taps)
+        con = encoder_forward(self.st, torch.cat([img_q, img_k]), new_stats, taps, bf16=self.bf16)
         con = fluid_l2_normalize(con, -1)                    # simclr.py:57 (second normalisation)
         q, k = con[:img_q.shape[0]], con[img_q.shape[0]:]
         loss, acc1, mats = simclr_head(q, k, self.T)

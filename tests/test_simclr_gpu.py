@@ -147,6 +147,10 @@ TOL_F32 = dict(loss=1e-3, emb=1e-3, logits=1e-3, grad=1e-2, param=1e-3, stat=1e-
 # The loss itself (sum of log-sum-exps of those logits) is the most sensitive scalar: two bf16 runs
 # that differ only in the summation order of the BN statistics land 0.6-1.3 from the fp32 value.
 # What IS exact in bf16 mode is the head given the embeddings: checked against the fp64 oracle.
+# (r02) oracle.simclr has a bf16-emulating mode like MoCo's (SimCLROracle(bf16=True)); it does NOT give a
+# tighter reference here: its fp32-accumulate and fp64-accumulate evaluations of the same bf16 contract
+# differ by 1.13 in loss / 0.19 in embeddings for the small case and 0.60 / 0.13 for b32 — any noise-scaled
+# bound would be wider than the sanity bounds below.
 TOL_BF16 = dict(loss=3.0, emb=6e-1, logits=6.0, grad=4e-1, param=3e-1, grad_bias=8e-1, stat=1e-1)
 
 
