@@ -88,8 +88,8 @@ __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1
 
 // DENSE: 1x1 / stride 1 / no padding with dense A and Y: row m lives at m*C resp. m*NCOLS, no
 // (n,op,oq) decomposition at all.
-template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE>
-__global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false>
+__global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) ? 3 : 2))
     igemm_kernel(const Params p) {
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;          // elements per 16-byte slot
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
   }
 
   uint4 ra[ACH], rb[BCH];
-  const int nk = (p.KDIM + BK - 1) / BK;
+  const int nk = LEAN ? 1 : (p.KDIM + BK - 1) / BK;     // LEAN: single K-tile launches only
 
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
@@ -369,11 +369,11 @@ __global__ void __launch_bounds__(kThreads, (STAGES == 1 && !EPI32) ? 3 : 2)
     }
   } else {
     // ---- bf16 epilogue (shared with the ring kernel): igemm_epi.h
-    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
+    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, LEAN>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
   }
 }
 
-template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE>
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false>
 int launch(const Params& p, hipStream_t st) {
   constexpr int STAGE = STAGES * (BM + BN) * kRowBytes;
   constexpr int EPI = EPI32 ? BM * (BN + 4) * 4 : BM * (BN + 8) * 2;
@@ -381,11 +381,11 @@ int launch(const Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE>),
+        reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE>), dim3(p.ntiles),
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN>), dim3(p.ntiles),
                      dim3(kThreads), LDS, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
@@ -410,6 +410,13 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
       return generic ? PASSL_EUNSUPPORTED : launch<T, 128, BN, false, 2, true, false>(p, st);
     if (generic) return launch<T, 128, BN, true, 2, false, false>(p, st);
     const bool one = nk <= nk1_threshold();
+    // LEAN: single-K-tile dense launches without residual / BatchNorm-backward work in the epilogue (the
+    // K = 64 forward 1x1 layers of stage 1) fit 116 VGPRs -> 4 workgroups per CU instead of 3: these
+    // launches are bound by how many operand waits / epilogues a CU has in flight;
+    // 64->256 @56: 117.6 -> 101.1 us, with statistics 152.9 -> 127.0 us.  PASSL_IGEMM_LEAN=0 disables.
+    static const bool lean_on = !(getenv("PASSL_IGEMM_LEAN") && atoi(getenv("PASSL_IGEMM_LEAN")) == 0);
+    if (dense && lean_on && nk == 1 && !p.res && !p.bnb_partial)
+      return launch<T, 128, BN, false, 1, false, true, true>(p, st);
     if (dense)
       return one ? launch<T, 128, BN, false, 1, false, true>(p, st)
                  : launch<T, 128, BN, false, 2, false, true>(p, st);

@@ -32,7 +32,7 @@ __device__ __forceinline__ uint4 pack8(const float (&a)[8]) {
 // bnb_shift, bnb_partial, bnb_relu, bnb_tile_off, M (rows) and stats_tiles (= ceil(M / 128)).
 // smem: the kernel's dynamic LDS (main-loop tiles are dead); rowoff[BM]: element offset of each
 // output row (-1 = out of range).  mt = index of this workgroup's 128-row tile.
-template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, typename P>
+template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, bool LEAN = false, typename P>
 __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int64_t* rowoff,
                                               const f32x4 (&acc)[FM][FN], int wm, int wn, int lane,
                                               int tid, int n0, int mt) {
@@ -46,8 +46,9 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
   // ---- phase 1: affine (+ReLU when nothing else follows) on the fp32 accumulators; each lane packs
   // its 4 consecutive channels and writes 8 bytes (ds_write_b64) into out[BM][LDOB]
   char* outc = smem;
-  const bool bnb = p.bnb_partial != nullptr;
-  const bool relu_now = p.relu && !p.res;
+  const bool bnb = !LEAN && p.bnb_partial != nullptr;
+  const bool has_res = !LEAN && p.res != nullptr;
+  const bool relu_now = p.relu && !has_res;
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int col = wn * WN + j * 16 + l4 * 4;
@@ -84,13 +85,13 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
     ry[t] = make_uint4(0, 0, 0, 0);
     rmask[t] = 0xffu;
   }
-  if (p.res || bnb) {
+  if (has_res || bnb) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int row = (tid + t * NTHREADS) / CPR;
       const int64_t roff = rowoff[row];
       if (roff < 0 || !col_ok) continue;
-      if (p.res)
+      if (has_res)
         rres[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.res) + roff + gcol);
       if (bnb) {
         ry[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_y) + roff + gcol);
@@ -127,7 +128,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
     if (roff < 0 || !col_ok) continue;
     const int64_t o = roff + gcol;
     uint4 v = *reinterpret_cast<const uint4*>(outb + row * LDOB + cc * 8);
-    if (p.res) {
+    if (has_res) {
       float a[8], rr[8];
       unpack8(v, a);
       unpack8(rres[t], rr);
