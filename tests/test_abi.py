@@ -107,3 +107,16 @@ def test_every_entry_point_rejects_null_arguments(lib):
     assert lib.passl_hip_attention_fwd(p, p, p, 1, 16, 1, 48, 0.125, 0, L.F32, None) == -3      # head dim
     assert lib.passl_hip_layernorm_bwd(p, p, p, p, p, None, p, p, p, 4, 4096, L.F32, None) == -1  # C > 2048
     assert lib.passl_hip_set_option(b'no_such_option', 1) == -1
+
+
+def test_tuning_options_validate_their_values(lib):
+    """passl_hip_set_option: known names accept their documented values and reject others; unknown
+    names are refused (no launch involved: runs without a GPU)."""
+    ok = [(b'bn_stream_unroll', 0), (b'bn_stream_unroll', 2), (b'bn_stream_unroll', 8), (b'bn_stream_unroll', 4),
+          (b'stem_kernel', 0), (b'stem_kernel', 1), (b'igemm_ring_bm', 256), (b'igemm_ring_bm', 128),
+          (b'igemm_ring_min_nk', 8)]
+    for name, v in ok:
+        assert lib.passl_hip_set_option(name, v) == 0, (name, v)
+    bad = [(b'bn_stream_unroll', 3), (b'igemm_ring_bm', 7), (b'no_such_option', 1)]
+    for name, v in bad:
+        assert lib.passl_hip_set_option(name, v) != 0, (name, v)
