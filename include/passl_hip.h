@@ -46,8 +46,17 @@ int passl_hip_abi_version(void);
  *   "igemm_ring_min_tiles" n    ... and launches with at least n output tiles (1)
  *   "igemm_ring_bm" 128|256     row-tile of the ring kernel: 128 (4 waves, 2 LDS stages, two
  *                               workgroups per CU; default) or 256 (8 waves, 3 stages, one)
+ *   "igemm_8p" 0|1|2            the 256 x 256-tile 8-phase kernel: never / when its cost model prefers it to
+ *                               the ring kernel (default) / whenever the launch is inside its envelope
+ *   "igemm_8p_min_nk" n         ... (mode 1) only for reductions of at least n 64-element K-tiles (8)
+ *   "igemm_8p_tk" / "_te" / "_ring_tk" / "_ring_te" / "_margin"   the cost model's constants (0.01 us per K-tile and
+ *                               per tile of either kernel, margin in %: conv_igemm_8p.hip)
  * Returns PASSL_EINVAL for an unknown name. */
 int passl_hip_set_option(const char* name, int value);
+/* Which kernel the most recent passl_hip_conv_igemm call of this process launched: 0 = igemm_kernel
+ * (register-staged), 1 = igemm_ring_kernel, 2 = stem_kernel, 3 = igemm_8p_kernel; -1 before the first call.
+ * Diagnostics for tests and benchmarks (not thread-safe). */
+int passl_hip_last_igemm_kernel(void);
 /* Human readable text for a passl_status. */
 const char* passl_hip_strerror(int status);
 
@@ -426,7 +435,8 @@ int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, flo
 
 /* When enabled, every passl_hip_conv_igemm / passl_hip_conv_wgrad launch is bracketed by HIP
  * events on its own stream; passl_hip_prof_collect synchronises those events and returns the
- * accumulated kernel time (ms) and launch count per kernel class (0 = igemm, 1 = wgrad). */
+ * accumulated kernel time (ms) and launch count per kernel class (0 = ring igemm, 1 = wgrad, 2 = register-staged
+ * igemm / stem, 3 = 8-phase igemm). */
 int passl_hip_prof_enable(int on);
 int passl_hip_prof_collect(int kernel_class, double* total_ms, int64_t* launches);
 /* Algorithmic work of the launches timed since the last call for this class: FLOPs (2 x MACs of the real

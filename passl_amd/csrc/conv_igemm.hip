@@ -428,7 +428,11 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
 }  // namespace
 
 int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st);   // conv_igemm_ring.hip
+int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st);     // conv_igemm_8p.hip
 int passl_stem_try(const passl_conv_desc* d, hipStream_t st);         // conv_stem.hip
+
+static int g_last_kernel = -1;
+extern "C" int passl_hip_last_igemm_kernel(void) { return g_last_kernel; }
 
 extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream) {
   if (!d || !d->a || !d->b || !d->y) return PASSL_EINVAL;
@@ -510,14 +514,24 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
                          (double)M64 * d->NCOLS * es_out * (1 + (d->residual ? 1 : 0)) +
                          (d->bnb_partial ? (double)M64 * d->NCOLS * es : 0.0);
   passl_prof_begin(0, st);
-  int rc = passl_igemm_ring_try(d, st);        // large-tile LDS-DMA ring kernel when it applies
+  int rc = passl_igemm_8p_try(d, st);          // 256 x 256 tiles, 8-phase schedule: wide, deep GEMMs
+  if (rc != PASSL_EUNSUPPORTED) {
+    passl_prof_retag(0, 3);
+    passl_prof_work(3, w_flops, w_bytes);
+    passl_prof_end(3, st);
+    g_last_kernel = 3;
+    return rc;
+  }
+  rc = passl_igemm_ring_try(d, st);            // 128-row tiles, LDS-DMA ring kernel when it applies
   if (rc != PASSL_EUNSUPPORTED) {
     passl_prof_work(0, w_flops, w_bytes);
     passl_prof_end(0, st);
+    g_last_kernel = 1;
     return rc;
   }
   passl_prof_retag(0, 2);
   rc = passl_stem_try(d, st);                  // the spatially tiled stem kernel when it applies
+  g_last_kernel = rc == PASSL_EUNSUPPORTED ? 0 : 2;
   if (rc == PASSL_EUNSUPPORTED) {
     const int nk = (p.KDIM + bk - 1) / bk;
     const bool of32 = d->out_f32 != 0;

@@ -1,0 +1,379 @@
+// Implicit-GEMM convolution / Linear, bf16, 256 x 256 output tiles with an 8-phase schedule (gfx950).
+//
+// Same contract and the same bits as igemm_ring_kernel (conv_igemm_ring.hip): Y[m][col] =
+// epi(sum_k A[m][k] B[col][k]), m = (n, op, oq) gathered from an NHWC tensor, k = (r, s, c) walked in
+// 64-element K-tiles, fp32 accumulation in ascending k, the shared epilogue of igemm_epi.h (affine,
+// residual, ReLU, fused BatchNorm statistics per 128-row half).  What differs is the schedule — the
+// structure /opt/skills/guides/cdna_hip_programming.md gives for large GEMMs on this chip:
+//
+//  * one workgroup per CU: 512 threads = 8 waves as 2 (M) x 4 (N), two waves per SIMD; a wave owns a
+//    64-row strip in EACH 128-row half of the A tile and a 32-column strip in EACH 128-column half of
+//    the B tile, i.e. four 64 x 32 quadrants (A-half i, B-half j) = 32 accumulator fragments (128 VGPRs);
+//  * LDS = 2 K-tile buffers x 4 half-tiles (A0, A1, B0, B1; 128 rows x 128 B = 16 KB each), filled by
+//    `buffer_load_dwordx4 ... lds` (2 instructions per wave per half-tile), rows XOR-swizzled through the
+//    SOURCE address exactly as in the ring kernel; fragments come out with inline-asm ds_read_b128;
+//  * a K-tile is FOUR phases, one quadrant (16 MFMAs per wave) each:
+//        q0: read B0 (4) + A0 (8)   issue A1(t+1)   MFMA A0 x B0
+//        q1: read B1 (4)            issue B0(t+2)   MFMA A0 x B1
+//        q2: read A1 (8)            issue A0(t+2)   MFMA A1 x B1
+//        q3: -                      issue B1(t+2)   MFMA A1 x B0      + the only vmcnt wait of the K-tile
+//    and a phase is {fragment reads, one half-tile of DMA} | barrier | {16 MFMAs at raised priority} |
+//    barrier.  The two wave groups (wr = 0 / 1: one wave of each per SIMD) run ONE BARRIER APART, so that on
+//    every SIMD one wave multiplies while the other reads LDS and issues DMA;
+//  * hazards (segment s = the interval between barriers s-1 and s; group 0 reads phase p in segment 2p and
+//    multiplies in 2p+1, group 1 one segment later):
+//      RAW  every wave waits `vmcnt(6)` (three half-tiles of tile t+2 may stay in flight) before the first
+//           barrier of q3: its own DMA of tile t+1 has landed; all waves have passed that wait one barrier
+//           later, the first read of tile t+1 is two barriers later;
+//      WAR  a half-tile is re-staged two phases after its last read (the read is retired by the lgkmcnt(0)
+//           behind the phase's first barrier, i.e. before the second barrier of that phase for group 0 and
+//           the first barrier of the next phase for group 1), or ONE phase after for B0, whose 4 reads are
+//           issued first in q0 and retired by `lgkmcnt(8)` in front of the barrier.
+//
+// Dispatched by passl_hip_conv_igemm ahead of the ring kernel when the launch has >= 256 output columns and
+// its 256 x 256 tiles fill the 256 CUs well enough (passl_igemm_8p_try).
+#include "igemm_dma.h"
+#include "igemm_epi.h"
+
+namespace g8 {
+
+using ring::Params;
+using ring::bf16x8_t;
+using ring::u32x4;
+using ring::fdiv;
+using ring::kOOB;
+using ring::lds_read_b128;
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int kThreads = 512;
+constexpr int HALF = 16384;                 // one half-tile: 128 rows x 128 bytes
+constexpr int BUF = 2 * HALF;               // per operand and K-tile buffer: two half-tiles
+constexpr int A_REGION = 0, B_REGION = 4 * HALF;
+constexpr int LDS_TILES = 8 * HALF;         // 128 KB
+constexpr int LDS_BYTES = LDS_TILES + BM * 8;
+
+template <int N>
+__device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef std::integral_constant<int, 0> I0;
+typedef std::integral_constant<int, 1> I1;
+
+__global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t* rowoff = reinterpret_cast<int64_t*>(smem + LDS_TILES);
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+
+  // ---- XCD-aware tile mapping (bijective for any ntiles), column tiles fastest
+  int tile;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = p.ntiles >> 3, r = p.ntiles & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    tile = start + local;
+  }
+  const int mt = fdiv(tile, p.d_tn), nt = tile - mt * p.tiles_n;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int opq = p.OP * p.OQ;
+
+  // A beyond 2 GB: the descriptor starts at the first image (dense: row) of this tile (see the ring kernel)
+  const int nb = p.dense ? 0 : fdiv(m0 < p.M ? m0 : p.M - 1, p.d_opq);
+  const int64_t a_off0 = p.dense ? (int64_t)m0 * (p.C * 2) : (int64_t)nb * p.a_sn2;
+  const int64_t a_left = p.a_total - a_off0;
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.a) + a_off0, 0, (uint32_t)(a_left < 0x7ffffff0ll ? a_left : 0x7ffffff0ll), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.b), 0, p.b_bytes, 0x00020000);
+
+  // ---- static DMA geometry.  Half-tile h, instruction i of this wave covers half rows (i*8 + wave)*8 .. +7:
+  // lane -> row + (lane >> 3), LDS slot lane & 7, SOURCE chunk (lane & 7) ^ ((row >> 1) & 7).
+  uint32_t a_base[4];
+  int ih0[4], iw0[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int hrow = ((x & 1) * 8 + wave) * 8 + (lane >> 3);
+    const int m = m0 + (x >> 1) * 128 + hrow;
+    const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((hrow >> 1) & 7)) * 16);
+    if (m < p.M) {
+      if (p.dense) {
+        a_base[x] = (uint32_t)(m - m0) * (uint32_t)(p.C * 2) + chunk;
+        ih0[x] = 0; iw0[x] = 0;
+      } else {
+        const int n = fdiv(m, p.d_opq);
+        const int rem = m - n * opq;
+        const int op = fdiv(rem, p.d_oq);
+        const int oq = rem - op * p.OQ;
+        ih0[x] = op * p.sh - p.ph;
+        iw0[x] = oq * p.sw - p.pw;
+        a_base[x] = (uint32_t)(n - nb) * (uint32_t)p.a_sn2 + (uint32_t)(ih0[x] * p.a_sh2) +
+                    (uint32_t)(iw0[x] * p.a_sw2) + chunk;
+      }
+    } else {
+      a_base[x] = 0; ih0[x] = -(1 << 28); iw0[x] = 0;
+    }
+  }
+  uint32_t b_off[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int hrow = ((x & 1) * 8 + wave) * 8 + (lane >> 3);
+    const int col = n0 + (x >> 1) * 128 + hrow;
+    const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((hrow >> 1) & 7)) * 16);
+    b_off[x] = col < p.NCOLS ? (uint32_t)col * (uint32_t)(p.KDIM * 2) + chunk : kOOB;
+  }
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int64_t off = -1;
+    if (m < p.M) {
+      if (p.dense) {
+        off = (int64_t)m * p.NCOLS;
+      } else {
+        const int n = fdiv(m, p.d_opq);
+        const int rem = m - n * opq;
+        const int op = fdiv(rem, p.d_oq);
+        const int oq = rem - op * p.OQ;
+        off = (int64_t)n * p.y_sn + (int64_t)op * p.y_sh + (int64_t)oq * p.y_sw;
+      }
+    }
+    rowoff[tid] = off;
+  }
+
+  const int nk = p.KDIM / BK;
+
+  // ---- DMA issue.  The A0 and A1 half-tiles of one K-tile go out in different phases: each stream walks
+  // the (r, s, c0) taps on its own (wave-uniform scalars)
+  int r0 = 0, s0 = 0, c0 = 0;       // next K-tile of the A0 stream
+  int r1 = 0, s1 = 0, c1 = 0;       // next K-tile of the A1 stream
+  auto issue_a = [&](auto PB, auto H, int& tr, int& ts, int& tc) {
+    constexpr int PB_ = decltype(PB)::value, H_ = decltype(H)::value;
+    const uint32_t tap = (uint32_t)(tr * p.a_sh2 + ts * p.a_sw2 + tc * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int x = H_ * 2 + i;
+      const bool ok = (uint32_t)(ih0[x] + tr) < (uint32_t)p.IH && (uint32_t)(iw0[x] + ts) < (uint32_t)p.IW;
+      const uint32_t off = ok ? a_base[x] + tap : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_a, (__attribute__((address_space(3))) void*)(smem + A_REGION + PB_ * BUF + H_ * HALF + (i * 8 + wave) * 1024),
+          16, off, 0, 0, 0);
+    }
+    tc += BK;
+    if (tc == p.C) { tc = 0; if (++ts == p.S) { ts = 0; ++tr; } }
+  };
+  auto issue_b = [&](auto PB, auto H, int t) {
+    constexpr int PB_ = decltype(PB)::value, H_ = decltype(H)::value;
+    const uint32_t koff = (uint32_t)t * (uint32_t)(BK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int x = H_ * 2 + i;
+      const uint32_t off = b_off[x] == kOOB ? kOOB : b_off[x] + koff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rs_b, (__attribute__((address_space(3))) void*)(smem + B_REGION + PB_ * BUF + H_ * HALF + (i * 8 + wave) * 1024),
+          16, off, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses: row r of a half, k-step ks: slot (ks*4 + l4) ^ ((r >> 1) & 7); the other
+  // fragments / halves / buffers are immediate offsets (fragment +16 rows = 2048 B keeps the swizzle term)
+  uint32_t a_rd[2], b_rd[2];
+  {
+    const int ra = wr * 64 + l15, rb = wc * 32 + l15;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a_rd[ks] = lds0 + (uint32_t)(A_REGION + ra * 128 + (((ks * 4 + l4) ^ ((ra >> 1) & 7)) << 4));
+      b_rd[ks] = lds0 + (uint32_t)(B_REGION + rb * 128 + (((ks * 4 + l4) ^ ((rb >> 1) & 7)) << 4));
+    }
+  }
+
+  f32x4 acc[2][4][4];              // [A half][A fragment][B half * 2 + B fragment]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 af[2][4];                  // [k-step][fragment] of the current A half
+  u32x4 bf0[2][2], bf1[2][2];      // B0 / B1: [k-step][fragment]
+
+  auto read_a = [&](auto PB, auto H) {
+    constexpr int OFF = decltype(PB)::value * BUF + decltype(H)::value * HALF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      af[ks][0] = lds_read_b128<OFF>(a_rd[ks]);
+      af[ks][1] = lds_read_b128<OFF + 2048>(a_rd[ks]);
+      af[ks][2] = lds_read_b128<OFF + 4096>(a_rd[ks]);
+      af[ks][3] = lds_read_b128<OFF + 6144>(a_rd[ks]);
+    }
+  };
+  auto read_b = [&](auto PB, auto H, u32x4 (&bf)[2][2]) {
+    constexpr int OFF = decltype(PB)::value * BUF + decltype(H)::value * HALF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf[ks][0] = lds_read_b128<OFF>(b_rd[ks]);
+      bf[ks][1] = lds_read_b128<OFF + 2048>(b_rd[ks]);
+    }
+  };
+  // one quadrant: 16 MFMAs, operands swapped (first operand := weight fragment) so that
+  // acc[..][r] = C[row = .. + l15][col = .. + l4*4 + r] (igemm_epi.h's layout)
+  auto mma = [&](auto AH, auto BH, const u32x4 (&bf)[2][2]) {
+    constexpr int AH_ = decltype(AH)::value, BH_ = decltype(BH)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[AH_][i][BH_ * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8_t, bf[ks][j]), __builtin_bit_cast(bf16x8_t, af[ks][i]),
+              acc[AH_][i][BH_ * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // segment boundaries: nothing may be scheduled across them
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto ktile = [&](auto PB, int t) {
+    typedef std::integral_constant<int, 1 - decltype(PB)::value> PO;    // the other buffer
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- q0: A0 x B0
+    read_b(PB, I0{}, bf0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(PB, I0{});
+    if (more1) issue_a(PO{}, I1{}, r1, s1, c1);             // A1(t+1)
+    wait_lgkm<8>();                                        // the four B0 reads are retired: B0 may be re-staged in q1
+    bar();
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I0{}, I0{}, bf0);
+    bar();
+    // ---- q1: A0 x B1
+    read_b(PB, I1{}, bf1);
+    if (more2) issue_b(PB, I0{}, t + 2);                    // B0(t+2)
+    bar();
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I0{}, I1{}, bf1);
+    bar();
+    // ---- q2: A1 x B1
+    read_a(PB, I1{});
+    if (more2) issue_a(PB, I0{}, r0, s0, c0);              // A0(t+2)
+    bar();
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I1{}, I1{}, bf1);
+    bar();
+    // ---- q3: A1 x B0; tile t+1 must have landed (A1(t+1) is the oldest DMA still counted)
+    if (more2) {
+      issue_b(PB, I1{}, t + 2);                             // B1(t+2)
+      wait_vm<6>();
+    } else {
+      wait_vm<0>();
+    }
+    bar();
+    mma(I1{}, I0{}, bf0);
+    bar();
+  };
+
+  // ---- prologue: tile 0 complete, then the three half-tiles of tile 1 that q3 of a "tile -1" would have
+  // issued (B0, A0, B1 — the steady-state order), so that the loop starts in its steady state
+  issue_b(I0{}, I0{}, 0);
+  issue_a(I0{}, I0{}, r0, s0, c0);
+  issue_b(I0{}, I1{}, 0);
+  issue_a(I0{}, I1{}, r1, s1, c1);
+  if (nk > 1) {
+    issue_b(I1{}, I0{}, 1);
+    issue_a(I1{}, I0{}, r0, s0, c0);
+    issue_b(I1{}, I1{}, 1);
+    wait_vm<6>();
+  } else {
+    wait_vm<0>();
+  }
+  bar();
+  if (wr == 1) bar();               // the second wave group runs one barrier behind the first
+  for (int kt = 0; kt < nk; kt += 2) {
+    ktile(I0{}, kt);
+    if (kt + 1 < nk) ktile(I1{}, kt + 1);
+  }
+  if (wr == 0) bar();
+  __syncthreads();                  // every fragment read is done: the tile buffers become the output staging area
+
+  // ---- epilogue: the two 128-row halves one after the other through igemm_epi.h (statistics slabs are per
+  // 128-row tile: half h of tile mt is slab row 2*mt + h)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (m0 + h * 128 < p.M) {
+      epi::epilogue_bf16<128, BN, kThreads, 4, 4, 64, 32, false, 2, 128>(p, smem, rowoff + h * 128, acc[h], wr, wc, lane,
+                                                                        tid, n0, mt * 2 + h);
+    }
+    __syncthreads();
+  }
+}
+
+static int launch(const Params& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_8p_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(igemm_8p_kernel, dim3(p.ntiles), dim3(kThreads), LDS_BYTES, st, p);
+  return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+}  // namespace g8
+
+// igemm_8p: 0 = never, 1 = when the cost model below prefers it (default), 2 = whenever the launch is inside
+// the kernel's envelope.  The model (fitted to profiles/r03_8p_vs_ring.txt, times in 0.01 us):
+//   8-phase: one workgroup per CU, rounds of 256 tiles in lockstep: ceil(tiles / 256) x (nk x tk + te)
+//   ring:    two workgroups per CU drifting apart:                  max(1, tiles / 512) x (nk x rtk + rte)
+// with nk = 64-element K-tiles, tk / rtk the time of one K-tile and te / rte the exposed prologue + epilogue of
+// a tile (the 8-phase kernel's is larger: nothing else runs on the CU while a tile is stored).
+static int g_8p_mode = -1, g_8p_min_nk = 8, g_8p_tk = 145, g_8p_te = 1000, g_8p_rtk = 112, g_8p_rte = 420,
+           g_8p_margin = 105;
+
+int passl_igemm_8p_option(const char* name, int value) {
+  if (!strcmp(name, "igemm_8p")) {
+    if (value < 0 || value > 2) return PASSL_EINVAL;
+    g_8p_mode = value;
+    return PASSL_OK;
+  }
+  int* slot = !strcmp(name, "igemm_8p_min_nk") ? &g_8p_min_nk : !strcmp(name, "igemm_8p_tk") ? &g_8p_tk :
+              !strcmp(name, "igemm_8p_te") ? &g_8p_te : !strcmp(name, "igemm_8p_ring_tk") ? &g_8p_rtk :
+              !strcmp(name, "igemm_8p_ring_te") ? &g_8p_rte : !strcmp(name, "igemm_8p_margin") ? &g_8p_margin : nullptr;
+  if (!slot) return PASSL_EINVAL;
+  if (value <= 0) return PASSL_EINVAL;
+  *slot = value;
+  return PASSL_OK;
+}
+
+int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st) {
+  if (g_8p_mode < 0) {
+    const char* e = getenv("PASSL_IGEMM_8P");
+    g_8p_mode = e ? atoi(e) : 1;
+    if (g_8p_mode < 0 || g_8p_mode > 2) g_8p_mode = 1;
+  }
+  if (g_8p_mode == 0) return PASSL_EUNSUPPORTED;
+  ring::Params p;
+  if (!ring::fill_params(d, g8::BM, g8::BN, p)) return PASSL_EUNSUPPORTED;
+  if (g_8p_mode == 1) {
+    const int nk = p.KDIM / g8::BK;
+    if (nk < g_8p_min_nk) return PASSL_EUNSUPPORTED;       // short reductions: igemm_kernel's territory
+    const int64_t t8 = p.ntiles;
+    const int64_t tr = ((int64_t)(p.M + 127) / 128) * ((d->NCOLS + 127) / 128);
+    const double time8 = (double)((t8 + 255) / 256) * ((double)nk * g_8p_tk + g_8p_te);
+    const double rr = (double)tr / 512.0;
+    const double timer = (rr < 1.0 ? 1.0 : rr) * ((double)nk * g_8p_rtk + g_8p_rte);
+    if (time8 * g_8p_margin >= timer * 100.0) return PASSL_EUNSUPPORTED;
+  }
+  return g8::launch(p, st);
+}

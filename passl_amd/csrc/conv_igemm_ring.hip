@@ -22,71 +22,10 @@
 //
 // Used when the launch has enough 256-row tiles to fill the chip and the operands are addressable
 // with 32-bit byte offsets; passl_hip_conv_igemm falls back to igemm_kernel otherwise.
-#include <stdlib.h>
-#include <string.h>
-#include <type_traits>
-#include "common.h"
+#include "igemm_dma.h"
 #include "igemm_epi.h"
 
 namespace ring {
-
-constexpr int kRowBytes = 128;
-constexpr uint32_t kOOB = 0x7ffffff0u;
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-struct FastDiv { uint32_t mul, sh1, sh2; };
-static inline FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f = {0, 0, 0};
-  if (d > 1) {
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l;
-    f.mul = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-    f.sh1 = 1;
-    f.sh2 = l - 1;
-  }
-  return f;
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv f) {
-  const uint32_t t = __umulhi(f.mul, (uint32_t)n);
-  return (int)((t + (((uint32_t)n - t) >> f.sh1)) >> f.sh2);
-}
-
-struct Params {
-  const char* a;
-  const char* b;
-  char* y;
-  const float* scale;
-  const float* shift;
-  const char* res;
-  float* stats;      // fused BatchNorm statistics slab (igemm_epi.h)
-  int stats_tiles;
-  const char* bnb_y;
-  const uint8_t* bnb_mask;
-  const float* bnb_mean;
-  const float* bnb_invstd;
-  const float* bnb_scale;
-  const float* bnb_shift;
-  float* bnb_partial;
-  int bnb_relu, bnb_tile_off;
-  int64_t a_total;            // bytes of the whole A tensor (may exceed 32 bits: every workgroup rebases its buffer)
-  uint32_t b_bytes;
-  int M, NCOLS, KDIM;
-  int OP, OQ, S, C, IH, IW, sh, sw, ph, pw;
-  int a_sn2, a_sh2, a_sw2;      // BYTE strides of A (fit 32 bits, checked on the host)
-  int64_t y_sn, y_sh, y_sw;
-  int relu, dense;
-  int tiles_n, ntiles;
-  FastDiv d_opq, d_oq, d_tn;
-};
-
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-  return v;
-}
 
 // BK = K-elements per ring stage.  64: LDS rows of 128 B, 8 chunks, slot ^= (row >> 1) & 7.
 // 32: LDS rows of 64 B, 4 chunks, slot ^= g((row >> 2) & 3) with g = {0, 3, 2, 1}: for every one of
@@ -435,59 +374,16 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
     if (t) g_ring_min_tiles = atoi(t);
   }
   const int enabled = g_ring_enabled, min_tiles = g_ring_min_tiles;
-  if (!enabled || d->dtype != PASSL_BF16 || d->out_f32) return PASSL_EUNSUPPORTED;
-  if ((d->C % 64) != 0) return PASSL_EUNSUPPORTED;
+  if (!enabled) return PASSL_EUNSUPPORTED;
   // short reductions are dominated by the prologue/epilogue: igemm_kernel's single-stage variant
   // (3 workgroups per CU) wins there (measured per layer: profiles/r01_ring_vs_igemm_bs256.txt)
   if ((int64_t)d->R * d->S * d->C < 64ll * g_ring_min_nk) return PASSL_EUNSUPPORTED;
-  const int64_t M64 = (int64_t)d->N * d->OP * d->OQ;
-  const int64_t K64 = (int64_t)d->R * d->S * d->C;
-  const int64_t a_bytes = (int64_t)d->N * d->a_sn * 2;
-  const int64_t b_bytes = (int64_t)d->NCOLS * K64 * 2;
-  const int64_t lim = 0x7ffffff0ll;
-  if (a_bytes <= 0 || b_bytes >= lim) return PASSL_EUNSUPPORTED;
-  {
-    // every workgroup addresses A relative to the first image its (<= 256-row) tile touches: the images a
-    // tile can span must fit 31 bits of byte offset (the tensor itself may be far larger)
-    const int64_t opq = (int64_t)d->OP * d->OQ;
-    const int64_t span_images = 256 / opq + 2;
-    if (d->a_sn * 2 * span_images >= lim || d->a_sn * 2 >= lim) return PASSL_EUNSUPPORTED;
-  }
   const int bn = d->NCOLS <= 64 ? 64 : 128;
-  const int tiles_n = (d->NCOLS + bn - 1) / bn;
   const int bm = g_ring_bm;
   if (bm != 128 && (d->stats || d->bnb_partial)) return PASSL_EUNSUPPORTED;   // slabs are per 128-row tile
-  const int64_t tiles_m = (M64 + bm - 1) / bm;
-  if (tiles_m * tiles_n < min_tiles) return PASSL_EUNSUPPORTED;
-
   ring::Params p;
-  p.a = reinterpret_cast<const char*>(d->a);
-  p.b = reinterpret_cast<const char*>(d->b);
-  p.y = reinterpret_cast<char*>(d->y);
-  p.scale = d->scale; p.shift = d->shift;
-  p.res = reinterpret_cast<const char*>(d->residual);
-  p.stats = d->stats; p.stats_tiles = (int)((M64 + 127) / 128);
-  p.bnb_y = reinterpret_cast<const char*>(d->bnb_y); p.bnb_mask = d->bnb_mask;
-  p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
-  p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
-  p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
-  p.a_total = a_bytes; p.b_bytes = (uint32_t)b_bytes;
-  p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
-  p.OP = d->OP; p.OQ = d->OQ; p.S = d->S; p.C = d->C;
-  p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
-  p.a_sn2 = (int)(d->a_sn * 2); p.a_sh2 = (int)(d->a_sh * 2); p.a_sw2 = (int)(d->a_sw * 2);
-  p.y_sn = d->y_sn; p.y_sh = d->y_sh; p.y_sw = d->y_sw;
-  p.relu = d->relu;
-  p.dense = d->R == 1 && d->S == 1 && d->sh == 1 && d->sw == 1 && d->ph == 0 && d->pw == 0 &&
-            d->IH == d->OP && d->IW == d->OQ && d->a_sw == d->C &&
-            d->a_sh == (int64_t)d->IW * d->C && d->a_sn == (int64_t)d->IH * d->IW * d->C &&
-            d->y_sw == d->NCOLS && d->y_sh == (int64_t)d->OQ * d->NCOLS &&
-            d->y_sn == (int64_t)d->OP * d->OQ * d->NCOLS;
-  p.tiles_n = tiles_n;
-  p.ntiles = (int)(tiles_m * tiles_n);
-  p.d_opq = ring::make_fastdiv((uint32_t)(d->OP * d->OQ));
-  p.d_oq = ring::make_fastdiv((uint32_t)d->OQ);
-  p.d_tn = ring::make_fastdiv((uint32_t)tiles_n);
+  if (!ring::fill_params(d, bm, bn, p)) return PASSL_EUNSUPPORTED;
+  if (p.ntiles < min_tiles) return PASSL_EUNSUPPORTED;
   if (bm == 256) return bn == 64 ? ring::launch<256, 64, 3>(p, st) : ring::launch<256, 128, 3>(p, st);
   if (g_ring_bk == 32 && g_ring_stages32 == 3)
     return bn == 64 ? ring::launch<128, 64, 3, 32>(p, st) : ring::launch<128, 128, 3, 32>(p, st);

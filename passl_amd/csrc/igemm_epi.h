@@ -32,7 +32,11 @@ __device__ __forceinline__ uint4 pack8(const float (&a)[8]) {
 // bnb_shift, bnb_partial, bnb_relu, bnb_tile_off, M (rows) and stats_tiles (= ceil(M / 128)).
 // smem: the kernel's dynamic LDS (main-loop tiles are dead); rowoff[BM]: element offset of each
 // output row (-1 = out of range).  mt = index of this workgroup's 128-row tile.
-template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, bool LEAN = false, typename P>
+// Column of accumulator fragment j: (j / FNH) * CH + wn * WN + (j % FNH) * 16 (+ 4 * (lane >> 4)); the
+// defaults (FNH = FN, CH = 0) are one contiguous WN-wide strip per wave, the 8-phase kernel's waves own one
+// 32-column strip in each 128-column half of the tile (FNH = 2, CH = 128).
+template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, bool LEAN = false, int FNH = FN, int CH = 0,
+          typename P>
 __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int64_t* rowoff,
                                               const f32x4 (&acc)[FM][FN], int wm, int wn, int lane,
                                               int tid, int n0, int mt) {
@@ -51,7 +55,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
   const bool relu_now = p.relu && !has_res;
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int col = wn * WN + j * 16 + l4 * 4;
+    const int col = (j / FNH) * CH + wn * WN + (j % FNH) * 16 + l4 * 4;
     const int gcol = n0 + col;
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gcol < p.NCOLS) {

@@ -11,11 +11,11 @@ std::mutex g_mu;
 std::vector<Pair> g_used;
 std::vector<Pair> g_free;
 Pair g_cur[kProfClasses];
-bool g_open[kProfClasses] = {false, false, false};
-double g_ms[kProfClasses] = {0, 0, 0};
-int64_t g_n[kProfClasses] = {0, 0, 0};
-double g_flops[kProfClasses] = {0, 0, 0};
-double g_bytes[kProfClasses] = {0, 0, 0};
+bool g_open[kProfClasses] = {};
+double g_ms[kProfClasses] = {};
+int64_t g_n[kProfClasses] = {};
+double g_flops[kProfClasses] = {};
+double g_bytes[kProfClasses] = {};
 }  // namespace
 
 void passl_prof_retag(int from, int to) {
@@ -89,6 +89,7 @@ extern "C" int passl_hip_prof_collect_work(int cls, double* flops, double* bytes
 }
 
 int passl_igemm_ring_option(const char* name, int value);    // conv_igemm_ring.hip
+int passl_igemm_8p_option(const char* name, int value);      // conv_igemm_8p.hip
 int passl_wgrad_option(const char* name, int value);         // conv_wgrad.hip
 int passl_bn_option(const char* name, int value);            // bn.hip
 int passl_stem_option(const char* name, int value);          // conv_stem.hip
@@ -98,10 +99,11 @@ extern "C" int passl_hip_set_option(const char* name, int value) {
   if (passl_wgrad_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_bn_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_stem_option(name, value) == PASSL_OK) return PASSL_OK;
+  if (passl_igemm_8p_option(name, value) == PASSL_OK) return PASSL_OK;
   return passl_igemm_ring_option(name, value);
 }
 
-extern "C" int passl_hip_abi_version(void) { return 7; }
+extern "C" int passl_hip_abi_version(void) { return 8; }
 
 extern "C" const char* passl_hip_strerror(int status) {
   switch (status) {

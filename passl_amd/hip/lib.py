@@ -60,6 +60,7 @@ SIGNATURES = {
     'passl_hip_abi_version': (c_i, []),
     'passl_hip_strerror': (C.c_char_p, [c_i]),
     'passl_hip_set_option': (c_i, [C.c_char_p, c_i]),
+    'passl_hip_last_igemm_kernel': (c_i, []),
     'passl_hip_ema_update': (c_i, [c_p, c_p, c_p, c_l, c_f, c_p]),
     'passl_hip_bn_fold': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_p]),
     'passl_hip_momentum_sgd': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p]),

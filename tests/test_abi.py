@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.passl_hip_abi_version() == 7
+    assert lib.passl_hip_abi_version() == 8
     assert b'invalid' in lib.passl_hip_strerror(-1)
     assert lib.passl_hip_strerror(0) == b'ok'
 
@@ -81,6 +81,7 @@ def test_every_entry_point_rejects_null_arguments(lib):
     arguments yield an error status (never a crash, never a launch) — checked without a GPU."""
     import ctypes as C
     skip = {'passl_hip_abi_version', 'passl_hip_strerror', 'passl_hip_set_option', 'passl_hip_prof_enable',
+            'passl_hip_last_igemm_kernel',
             'passl_hip_infonce_workspace_bytes', 'passl_hip_infonce_bwd_workspace_bytes',
             'passl_hip_bn_partial_floats',
             'passl_hip_clip_logits_ws_floats'}
