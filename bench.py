@@ -248,7 +248,7 @@ def main():
             step()
         barrier()
         instr_elapsed = time.perf_counter() - t1
-        for cls, name in ((0, 'ring'), (1, 'wgrad'), (2, 'igemm')):
+        for cls, name in ((0, 'ring'), (1, 'wgrad'), (2, 'igemm'), (3, 'g8p')):
             ms, n = ctypes.c_double(), ctypes.c_int64()
             fl, by = ctypes.c_double(), ctypes.c_double()
             lib.passl_hip_prof_collect(cls, ctypes.byref(ms), ctypes.byref(n))
@@ -279,7 +279,7 @@ def main():
                 'achieved_tflops_per_gpu': round(ips / world * flop_per_sample / 1e12, 2),
                 'frac_of_peak': round(ips / world * flop_per_sample / 1e12 / peak, 5)},
         }
-        if kern and kern['ring']['n'] + kern['igemm']['n'] > 0:
+        if kern and kern['ring']['n'] + kern['igemm']['n'] + kern['g8p']['n'] > 0:
             traffic = pmc_traffic(args)
 
             def block(k, title, bound):
@@ -303,10 +303,19 @@ def main():
                 b['traffic_unit'] = 'HBM bytes per launch'
                 b['traffic_source'] = t['source'] if t else None
                 return b
-            # the dominant kernel (largest share of the step): the LDS-DMA ring implicit GEMM, MFMA-bound
-            out['roofline'] = block('ring', 'igemm_ring_kernel (LDS-DMA ring implicit GEMM: every conv fwd / dgrad '
-                                    'and Linear with a reduction of >= 512: all 3x3 layers, the wide 1x1 layers)', 'mfma')
-            if out['roofline'] is None:          # no launch took the ring kernel (fp32): the dense kernel is the MFMA one
+            # the dominant kernel (largest share of the step's kernel time): one of the two LDS-DMA implicit GEMMs,
+            # MFMA-bound — the 128-row ring kernel (R50) or the 256 x 256 8-phase kernel (the ViT workloads)
+            ring_b = block('ring', 'igemm_ring_kernel (LDS-DMA ring implicit GEMM, 128-row tiles: conv fwd / dgrad and '
+                           'Linear with a reduction of >= 512 that the 8-phase kernel does not take)', 'mfma')
+            g8_b = block('g8p', 'igemm_8p_kernel (LDS-DMA implicit GEMM, 256 x 256 tiles, 8-phase schedule: wide and '
+                         'deep conv fwd / dgrad and Linear launches)', 'mfma')
+            out['roofline'] = ring_b
+            if g8_b is not None and (ring_b is None or kern['g8p']['ms'] > kern['ring']['ms']):
+                out['roofline'] = g8_b
+            other = g8_b if out['roofline'] is ring_b else ring_b
+            if other is not None:
+                out['roofline_8p_kernel' if other is g8_b else 'roofline_ring_kernel'] = other
+            if out['roofline'] is None:          # neither LDS-DMA kernel ran (fp32): the dense kernel is the MFMA one
                 out['roofline'] = block('igemm', 'igemm_kernel (register-staged implicit GEMM)', 'mfma')
             out['roofline']['measured_over'] = (
                 '%d instrumented steps after the timed loop, side stream off (%.3f ms/step with the HIP '
@@ -316,9 +325,9 @@ def main():
                                                'a reduction < 512, stem)', 'hbm')
             out['roofline_wgrad_kernel'] = block('wgrad', 'wgrad_pipe_kernel (weight gradients, split over M + '
                                                  'fixed-order slab reduction)', 'mfma')
-            ig = {k: kern['ring'][k] + kern['igemm'][k] for k in ('ms', 'n', 'flops', 'bytes')}
+            ig = {k: kern['ring'][k] + kern['igemm'][k] + kern['g8p'][k] for k in ('ms', 'n', 'flops', 'bytes')}
             out['igemm_class'] = {
-                'what': 'both implicit-GEMM kernels together (the r01 roofline definition)',
+                'what': 'all implicit-GEMM kernels together (the r01 roofline definition)',
                 'achieved_tflops': round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12, 2),
                 'frac_of_mfma_peak': round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12 / peak, 5),
                 'kernel_ms_per_step': round(ig['ms'] / rsteps, 3), 'launches': int(ig['n'])}

@@ -97,15 +97,16 @@ all_ok = True
 print('== exactness / race screen (reference = the ring kernel wherever it applies)')
 lib.passl_hip_set_option(b'igemm_ring_min_nk', 1)
 for args in [(256, 256, 3, 1, 1, 14, 8), (512, 512, 3, 1, 1, 7, 32), (512, 512, 3, 2, 1, 14, 8), (1024, 256, 1, 1, 0, 14, 16),
-             (256, 1024, 1, 1, 0, 14, 5), (2048, 512, 1, 1, 0, 7, 11), (512, 2048, 1, 1, 0, 7, 32), (64, 256, 1, 1, 0, 56, 1),
+             (256, 1024, 1, 1, 0, 14, 5), (2048, 512, 1, 1, 0, 7, 11), (512, 2048, 1, 1, 0, 7, 32),
              (128, 320, 3, 1, 1, 9, 3)]:
     all_ok &= conv_case(*args)
-for M, cin, cout in [(12800, 768, 2304), (12800, 3072, 768), (50432, 512, 1536), (1000, 768, 768), (257, 64, 264), (4096, 4096, 4096)]:
+for M, cin, cout in [(12800, 768, 2304), (12800, 3072, 768), (50432, 512, 1536), (1000, 768, 768), (257, 64, 264), (4096, 4096, 4096),
+                     (70000, 192, 520), (66000, 128, 256), (3000, 320, 8)]:
     all_ok &= linear_case(M, cin, cout)
 print('ALL EXACT' if all_ok else 'SOME FAILED', flush=True)
 lib.passl_hip_set_option(b'igemm_ring_min_nk', 8)
 
-print('== timing (us, TFLOP/s): ring | 8p forced | auto')
+print('== timing (us, TFLOP/s): ring | 8p staged (forced) | 8p persistent (forced) | auto (cost model)')
 SH = [(12800, 768, 2304, 'mae-enc qkv'), (12800, 768, 768, 'mae-enc proj'), (12800, 768, 3072, 'mae-enc fc1'),
       (12800, 3072, 768, 'mae-enc fc2'), (50432, 512, 1536, 'mae-dec qkv'), (50432, 512, 512, 'mae-dec proj'),
       (50432, 512, 2048, 'mae-dec fc1'), (50432, 2048, 512, 'mae-dec fc2'),
@@ -121,8 +122,9 @@ for M, cin, cout, label in SH:
     f = lambda: ops.conv_igemm(fd, x, packer.view(fd.pack, cout), y)
     fl = 2.0 * M * cin * cout
     out = []
-    for m in (0, 2, 1):
-        mode(m); t = run(f); out.append('%7.1f %5.0f k%d' % (t, fl / t / 1e6, lib.passl_hip_last_igemm_kernel()))
+    for m, dr in ((0, 1), (2, 0), (2, 1), (1, 1)):
+        mode(m); lib.passl_hip_set_option(b'igemm_8p_direct', dr)
+        t = run(f); out.append('%7.1f %5.0f k%d' % (t, fl / t / 1e6, lib.passl_hip_last_igemm_kernel()))
     print('%-14s M=%5d %4d->%4d %7.1f GF | ' % (label, M, cin, cout, fl / 1e9) + ' | '.join(out), flush=True)
 
 R50 = [(256, 256, 3, 2, 1, 28), (256, 256, 3, 1, 1, 14), (1024, 256, 1, 1, 0, 14), (256, 1024, 1, 1, 0, 14), (512, 1024, 1, 2, 0, 28),
@@ -145,8 +147,10 @@ for cin, cout, k, st, pad, H in R50:
     row = []
     for nm, fn in (('fwd+stats', f), ('dgrad', dg)):
         o = []
-        for m in (0, 2, 1):
-            mode(m); t = run(fn); o.append('%6.1f %4.0f k%d' % (t, fl / t / 1e6, lib.passl_hip_last_igemm_kernel()))
+        for m, dr in ((0, 1), (2, 0), (2, 1), (1, 1)):
+            if nm == 'fwd+stats' and (m, dr) == (2, 1): continue      # statistics keep the staged epilogue
+            mode(m); lib.passl_hip_set_option(b'igemm_8p_direct', dr)
+            t = run(fn); o.append('%6.1f %4.0f k%d' % (t, fl / t / 1e6, lib.passl_hip_last_igemm_kernel()))
         row.append(nm + ' ' + ' | '.join(o))
     print('%4d->%4d k%d s%d @%2d  %5.1f GF  ' % (cin, cout, k, st, H, fl / 1e9) + '  ||  '.join(row), flush=True)
 mode(1)

@@ -129,6 +129,141 @@ def test_conv_ring_kernel_epilogue(bm, force_ring_kernel):
     test_conv_epilogue_affine_residual_relu_f32out(torch.bfloat16)
 
 
+@pytest.fixture
+def kernel_8p():
+    """Select the 256 x 256-tile 8-phase kernel: mode 0 never / 1 cost model / 2 whenever it applies; `direct`
+    0 keeps the staged epilogue even where the persistent form would run."""
+    from passl_amd.hip import lib as L
+    lib = L.load()
+
+    def select(mode, direct=1):
+        assert lib.passl_hip_set_option(b'igemm_8p', mode) == 0
+        assert lib.passl_hip_set_option(b'igemm_8p_direct', direct) == 0
+        return lib
+    yield select
+    assert lib.passl_hip_set_option(b'igemm_8p', 1) == 0
+    assert lib.passl_hip_set_option(b'igemm_8p_direct', 1) == 0
+    assert lib.passl_hip_set_option(b'igemm_ring_min_nk', 8) == 0
+    assert lib.passl_hip_set_option(b'igemm_8p', 3) != 0
+
+
+@pytest.mark.parametrize('geom,nhw', [g for g in GEOMS if g[0].cin % 64 == 0])
+def test_conv_8p_kernel(geom, nhw, kernel_8p):
+    """every GEOMS shape inside the 8-phase kernel's envelope, forced through it (persistent form)"""
+    kernel_8p(2)
+    test_conv_fwd_dgrad_wgrad(geom, nhw, torch.bfloat16)
+
+
+@pytest.mark.parametrize('direct', [0, 1])
+def test_conv_8p_kernel_epilogue(direct, kernel_8p):
+    kernel_8p(2, direct)
+    test_conv_epilogue_affine_residual_relu_f32out(torch.bfloat16)
+
+
+def _bits(t):
+    return t.view(torch.int16 if t.dtype == torch.bfloat16 else torch.int32)
+
+
+# (M, K, N): several tiles per workgroup of the persistent form (> 256 tiles), odd / minimal K-tile counts,
+# ragged last row tile and last column tile, one ViT shape
+LINEAR_8P = [(70000, 192, 520), (66000, 128, 256), (12800, 768, 2304), (1000, 3072, 768), (257, 64, 264)]
+
+
+@pytest.mark.parametrize('M,K,N', LINEAR_8P)
+def test_8p_kernel_bit_identical_to_ring_kernel(M, K, N, kernel_8p):
+    """The 8-phase kernel (staged and persistent forms) accumulates in the same order and applies the same epilogue
+    arithmetic as the ring kernel: bias + residual + ReLU outputs are bit-identical, and repeated launches agree
+    with each other (race screen of the DMA / barrier schedule)."""
+    lib = kernel_8p(0)
+    assert lib.passl_hip_set_option(b'igemm_ring_min_nk', 1) == 0
+    gen = torch.Generator().manual_seed(M + K)
+    g = P.ConvGeom(K, N, 1, 1, 0)
+    fd = P.fwd_desc(g, M, 1, 1)
+    packer = WeightPacker()
+    packer.add(0, N, 1, 1, K, fd.pack)
+    packer.build(DEV, torch.bfloat16).run((torch.randn(N * K, generator=gen) * 0.05).to(DEV))
+    x = torch.randn(M, K, generator=gen).to(DEV).to(torch.bfloat16)
+    b = torch.randn(N, generator=gen).to(DEV)
+    res = torch.randn(M, N, generator=gen).to(DEV).to(torch.bfloat16)
+    y = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+
+    def launch(**kw):
+        y.fill_(float('nan'))
+        ops.conv_igemm(fd, x, packer.view(fd.pack, N), y, **kw)
+        return y.clone(), lib.passl_hip_last_igemm_kernel()
+    for kw in (dict(), dict(shift=b, residual=res, relu=True)):
+        kernel_8p(0)
+        ref, k_ref = launch(**kw)
+        assert k_ref in (0, 1)
+        want = x.float() @ packer.view(fd.pack, N).float().t()
+        if kw:
+            want = torch.relu(want + b + res.float())
+        assert relmax(ref, want) < 2e-2
+        for direct in (0, 1):
+            kernel_8p(2, direct)
+            for rep in range(4):
+                out, k_out = launch(**kw)
+                assert k_out == 3
+                assert torch.equal(_bits(out), _bits(ref)), (direct, rep, kw.keys())
+
+
+def test_8p_kernel_fused_statistics_bit_identical(kernel_8p):
+    """conv + fused BatchNorm statistics and data-gradient + fused BatchNorm-backward slabs through the staged form
+    of the 8-phase kernel: outputs and slabs equal the ring kernel's bit for bit (128 columns per ring tile)."""
+    lib = kernel_8p(0)
+    assert lib.passl_hip_set_option(b'igemm_ring_min_nk', 1) == 0
+    gen = torch.Generator().manual_seed(5)
+    for cin, cout, k, st, H, N in ((256, 256, 3, 1, 14, 8), (128, 320, 3, 1, 9, 3), (512, 256, 1, 1, 7, 11)):
+        g = P.ConvGeom(cin, cout, k, st, k // 2)
+        fd = P.fwd_desc(g, N, H, H)
+        dds, skipped = P.dgrad_plan(g, N, H, H)
+        assert len(dds) == 1 and not skipped
+        packer = WeightPacker()
+        for d in [fd] + dds:
+            packer.add(0, cout, k, k, cin, d.pack)
+        packer.build(DEV, torch.bfloat16).run((torch.randn(cout * k * k * cin, generator=gen) * 0.05).to(DEV))
+        x = torch.randn(N, H, H, cin, generator=gen).to(DEV).to(torch.bfloat16)
+        y = torch.zeros(N, fd.OP, fd.OQ, cout, device=DEV, dtype=torch.bfloat16)
+        dy = torch.randn(N, fd.OP, fd.OQ, cout, generator=gen).to(DEV).to(torch.bfloat16)
+        dx = torch.zeros(N, H, H, cin, device=DEV, dtype=torch.bfloat16)
+        slab, tiles = ops.conv_stats_buffer(fd, DEV)
+        d = dds[0]
+        td = ops.conv_tiles(d)
+        part = torch.zeros(ops.bn_partial_floats(td, cin, False), device=DEV)
+        yb = torch.randn(N, H, H, cin, generator=gen).to(DEV).to(torch.bfloat16)
+        bnb = dict(y=yb, mask=None, mean=torch.randn(cin, generator=gen).to(DEV) * 0.1,
+                   invstd=torch.rand(cin, generator=gen).to(DEV) + 0.5, scale=torch.rand(cin, generator=gen).to(DEV) + 0.5,
+                   shift=torch.randn(cin, generator=gen).to(DEV) * 0.3, relu=2, partial=part, tile_off=0)
+        got = {}
+        for mode in (0, 2):
+            kernel_8p(mode)
+            slab.fill_(float('nan')); part.fill_(float('nan'))
+            ops.conv_igemm(fd, x, packer.view(fd.pack, cout), y, stats=slab)
+            kf = lib.passl_hip_last_igemm_kernel()
+            ops.conv_igemm(d, dy, packer.view(d.pack, cin), dx, bnb=bnb)
+            kd = lib.passl_hip_last_igemm_kernel()
+            assert (kf, kd) == ((1, 1) if mode == 0 else (3, 3))
+            got[mode] = [t.clone() for t in (y, slab[:tiles * cout * 3], dx, part[:td * cin * 2])]
+        for a, b in zip(got[0], got[2]):
+            assert not torch.isnan(b.float()).any()
+            assert torch.equal(_bits(a), _bits(b))
+
+
+def test_8p_cost_model_dispatch(kernel_8p):
+    """mode 1: wide and deep launches whose 256 x 256 tiles fill the chip go to the 8-phase kernel, short reductions
+    and launches with too few tiles do not."""
+    lib = kernel_8p(1)
+    for (M, K, N), want in (((50432, 768, 2304), 3), ((50176, 1024, 256), 3), ((50176, 256, 1024), 0),
+                            ((12544, 2048, 512), 1), ((200704, 512, 128), 1)):
+        g = P.ConvGeom(K, N, 1, 1, 0)
+        fd = P.fwd_desc(g, M, 1, 1)
+        w = torch.zeros(N, K, device=DEV, dtype=torch.bfloat16)
+        x = torch.zeros(M, K, device=DEV, dtype=torch.bfloat16)
+        y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.conv_igemm(fd, x, w, y)
+        assert lib.passl_hip_last_igemm_kernel() == want, (M, K, N)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('geom,nhw', GEOMS)
 def test_conv_fwd_dgrad_wgrad(geom, nhw, dtype):
