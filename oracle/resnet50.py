@@ -128,7 +128,7 @@ def batch_norm(x, st, prefix, use_global_stats, new_stats=None, affine_form=Fals
 
 
 def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=True, bf16=False,
-                  frozen_stages=-1):
+                  frozen_stages=-1, rec=None):
     """ResNet-50 trunk (keys '0.*'): [N,3,H,W] -> layer4 map.  ``maxpool=False`` is the
     SimCLR variant (passl_v110/modeling/backbones/resnetcifar.py:275 comments the stem pool
     out, forward :321-333).
@@ -140,7 +140,7 @@ def trunk_forward(st, x, use_global_stats, new_stats=None, taps=None, maxpool=Tr
     back.  With frozen-statistics BatchNorm (key encoder) the affine is applied to the unrounded
     accumulator and only the block output is rounded (conv epilogue fusion)."""
     if bf16:
-        return _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool)
+        return _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool, rec)
 
     def conv(name, x, stride, pad):
         return F.conv2d(x, st['0.' + name + '.weight'], None, stride, pad)
@@ -192,7 +192,7 @@ def _matmul(x, w):
     return x @ w
 
 
-def _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool):
+def _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool, rec=None):
     """trunk_forward with the product path's bf16 storage points (see trunk_forward).
 
     Training mode (query encoder): conv output rounded (stored, BatchNorm statistics are those of the
@@ -203,19 +203,31 @@ def _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool):
     the residual add + ReLU, rounded again (conv epilogue order)."""
     train = not use_global_stats
 
+    def keep(key, t):
+        """``rec`` (per-layer teacher forcing, tests/test_layers_gpu.py): every stored tensor of the training-mode
+        forward is kept with its gradient retained — after backward, ``t.grad`` is the gradient w.r.t. the STORED
+        tensor in fp32 (what the consuming backward kernel rounds to bf16 and reads)."""
+        if rec is not None and t.requires_grad:
+            t.retain_grad()
+        if rec is not None:
+            rec[key] = t
+        return t
+
     def conv(name, x, stride, pad):
+        keep(name + '.x', x)
         y = _conv(x, round_weight(st['0.' + name + '.weight']), stride, pad)
-        return round_act(y) if train else y       # training: the conv output is stored (bf16)
+        return keep(name + '.y', round_act(y)) if train else y       # training: the conv output is stored (bf16)
 
     def bn(name, x):
         return batch_norm(x, st, '0.' + name, use_global_stats, new_stats, affine_form=True)
 
     x = round_act(x)                              # bf16 NHWC image
-    x = round_act(F.relu(bn('bn1', conv('conv1', x, 2, 3))))
+    x = keep('bn1.z', round_act(F.relu(bn('bn1', conv('conv1', x, 2, 3)))))
     if maxpool:
         x = F.max_pool2d(x, 3, 2, 1)
         if train:
             x = round_grad(x)                      # the pooled map's gradient is a stored bf16 tensor
+        keep('maxpool.z', x)
     if taps is not None:
         taps['stem'] = x
     for li, blocks in enumerate(LAYERS, start=1):
@@ -227,14 +239,18 @@ def _trunk_forward_bf16(st, x, use_global_stats, new_stats, taps, maxpool):
             # the downsample conv's input gradients are rounded separately, then summed, then rounded
             xin = round_grad(x) if train else x
             xds = round_grad(x) if train else x
-            out = round_act(F.relu(bn(p + '.bn1', conv(p + '.conv1', xin, 1, 0))))
-            out = round_act(F.relu(bn(p + '.bn2', conv(p + '.conv2', out, s, 1))))
+            out = keep(p + '.bn1.z', round_act(F.relu(bn(p + '.bn1', conv(p + '.conv1', xin, 1, 0)))))
+            out = keep(p + '.bn2.z', round_act(F.relu(bn(p + '.bn2', conv(p + '.conv2', out, s, 1)))))
             out = bn(p + '.bn3', conv(p + '.conv3', out, 1, 0))
             if not train:
                 out = round_act(out)               # epilogue: affine -> bf16 tile -> + residual -> ReLU -> bf16
             if b == 0:
-                identity = round_act(bn(p + '.downsample.1', conv(p + '.downsample.0', xds, s, 0)))
-            x = round_act(F.relu(out + identity))
+                identity = keep(p + '.downsample.1.z',
+                                round_act(bn(p + '.downsample.1', conv(p + '.downsample.0', xds, s, 0))))
+            elif rec is not None:
+                identity = x.clone()               # own autograd node: its gradient is the residual branch's alone
+            keep(p + '.bn3.res', identity)
+            x = keep(p + '.bn3.z', round_act(F.relu(out + identity)))
         if taps is not None:
             taps['layer%d' % li] = x
     return x

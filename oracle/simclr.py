@@ -83,7 +83,7 @@ def fluid_l2_normalize(x, axis=-1, eps=1e-12):
     return x * torch.rsqrt(x.pow(2).sum(dim=axis, keepdim=True) + eps)
 
 
-def encoder_forward(st, x, new_stats=None, taps=None, bf16=False):
+def encoder_forward(st, x, new_stats=None, taps=None, bf16=False, rec=None):
     """ResNetsimclr(depth=50, with_pool=True) + NonLinearNeckfc3(with_avg_pool=False), train-mode
     BN everywhere (SimCLR has a single encoder).
     ``bf16``: bf16-emulating mode (oracle/bf16.py, resnet50.trunk_forward): the trunk's storage points,
@@ -91,17 +91,27 @@ def encoder_forward(st, x, new_stats=None, taps=None, bf16=False):
     stored in bf16 (value and gradient rounded), Linear operands are the bf16 weight copies, Linear
     outputs / BatchNorm1D / ReLU / normalisation are fp32, and the gradient entering a Linear's backward
     is rounded (its GEMM operands are bf16)."""
-    x = R.trunk_forward(st, x, False, new_stats, taps, maxpool=False, bf16=bf16)
+    x = R.trunk_forward(st, x, False, new_stats, taps, maxpool=False, bf16=bf16, rec=rec)
     x = F.adaptive_avg_pool2d(x, 1).reshape(x.shape[0], -1)      # backbone avgpool + squeeze
+
+    def keep(key, t):
+        # per-layer teacher forcing (tests/test_layers_gpu.py): stored tensor + its gradient
+        if rec is not None:
+            t.retain_grad()
+            rec[key] = t
+        return t
+
     for i_fc, i_bn, relu in ((0, 1, True), (3, 4, True), (6, 7, False)):
         if bf16:
-            x = round_act(x)
+            x = keep('mlp.%d.x' % i_fc, round_act(x))
             x = round_grad(R._matmul(x, round_weight(st['1.mlp.%d.weight' % i_fc]))) + st['1.mlp.%d.bias' % i_fc]
         else:
             x = x @ st['1.mlp.%d.weight' % i_fc] + st['1.mlp.%d.bias' % i_fc]
+        x = keep('mlp.%d.y' % i_fc, x)
         x = R.batch_norm(x, st, '1.mlp.%d' % i_bn, False, new_stats)
         if relu:
             x = F.relu(x)
+        x = keep('mlp.%d.z' % i_bn, x)
     return fluid_l2_normalize(x, -1)
 
 

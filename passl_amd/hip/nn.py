@@ -123,6 +123,9 @@ class _ConvFn(Function):
         ctx.save_for_backward(x)
         ctx.layer, ctx.pl, ctx.hw = layer, pl, hw
         ctx.add_slot, ctx.sink_slot, ctx.producer = add_slot, sink_slot, producer
+        # latched: forward and backward of one step agree about the side stream even if the allocator-pressure
+        # back-off of streams.enabled() flips in between
+        ctx.side = streams.enabled(x)
         return y
 
     @staticmethod
@@ -168,7 +171,7 @@ class _ConvFn(Function):
                 rt.dw.view(g.cout, 7, 7, 3).add_(tmp.view(g.cout, 7, 8, 4)[:, :, :7, :3])
             else:
                 ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
-        if streams.enabled(dy):
+        if ctx.side:
             # dW feeds only the optimizer: off the dgrad -> BatchNorm-backward chain (hip/streams.py)
             with streams.on_side(dy.device, reads=(x, dy), in_backward=True):
                 wgrad()
@@ -411,6 +414,7 @@ class _LinearFn(Function):
         ctx.save_for_backward(x, y if relu else None)
         ctx.layer, ctx.pl, ctx.relu = layer, pl, relu
         ctx.has_res = residual is not None
+        ctx.side = streams.enabled(x)              # latched for the backward (see _ConvFn)
         return y
 
     @staticmethod
@@ -428,7 +432,7 @@ class _LinearFn(Function):
             dx = torch.empty(x.shape[0], layer.in_features, dtype=x.dtype, device=x.device)
             d = pl.dds[0]
             ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
-        if streams.enabled(dy):
+        if ctx.side:
             with streams.on_side(dy.device, reads=(x, dy), in_backward=True):
                 ops.conv_wgrad(pl.wd, x, dy, rt.dw)
         else:

@@ -28,10 +28,11 @@ class _Workspace:
 
     def get(self, n_floats, device):
         # one buffer per (device, stream): users on different streams must not share scratch
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == 'cuda' else 0)
+        key = (device.type, device.index, L.stream() if device.type == 'cuda' else 0)     # raw handle: ~0.3 us
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < n_floats:
-            buf = torch.empty(max(int(n_floats), 16 << 20), dtype=torch.float32, device=device)
+            # grow-only with a 4 MB floor (most users need a few KB; the largest weight-gradient slabs ask for more)
+            buf = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=device)
             self._bufs[key] = buf
         return buf
 

@@ -13,7 +13,7 @@ so that its workgroups fill the CUs next to the main chain's (different bottlene
 LDS-heavy GEMM workgroups + register-light streaming workgroups) instead of extending the chain.  Ordering: the side stream waits for an event recorded on
 the main stream at the hand-off point (its inputs are complete), and the main stream waits
 for the side stream before anything consumes the results (``join``): at the end of every backward
-pass (autograd engine callback) and before a gradient bucket is all-reduced.  Every kernel stays
+pass (autograd engine callback), before a gradient bucket is all-reduced and before the optimizer's update kernel.  Every kernel stays
 deterministic; only the interleaving changes.
 
 Memory.  The tensors a hand-off reads (allocated on the main stream) must not be recycled while the
@@ -41,7 +41,6 @@ import torch
 from . import config
 
 _streams = {}
-_dirty = {}
 _pending = {}       # device index -> deque of (event recorded on the side stream, tensors kept alive)
 _HOLD_FRAC = float(os.environ.get('PASSL_OVERLAP_HOLD_FRAC', '0.08'))
 _held_bytes = {}
@@ -123,7 +122,6 @@ def on_side(device, reads=(), in_backward=False):
             owner.wait_event(done)
         _held_bytes[key] -= nbytes
         del held
-    _dirty[key] = True
     if in_backward:
         # join at the end of this backward pass: whoever reads .grad afterwards sees finished work
         # (one callback per hand-off; all but the first find nothing left to wait for)
@@ -131,20 +129,27 @@ def on_side(device, reads=(), in_backward=False):
 
 
 def join(device):
-    """Make the current stream wait for everything issued on the side stream so far."""
+    """Make the current stream wait for everything issued so far on the side stream (and the fork stream, when it
+    is a stream of its own).  Unconditional once such a stream exists: work can reach the side stream without
+    passing through ``on_side`` — autograd runs the backward of a forked downsample branch there by stream
+    affinity, BatchNorm gradients included — so a "dirty" flag kept by ``on_side`` would miss it (round-2 advisor
+    finding).  A wait on an idle stream costs a few microseconds of host time."""
     if not device.type == 'cuda':
         return
-    s = side_stream(device)
-    key = s.device.index
-    if _dirty.get(key):
-        torch.cuda.current_stream(device).wait_stream(s)
-        _dirty[key] = False
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(device)
+    waited = False
+    for table in (_streams, _fork_streams):
+        s = table.get(key)
+        if s is not None and s != cur:
+            cur.wait_stream(s)
+            waited = True
     q = _pending.get(key)
     if q:
-        cur = torch.cuda.current_stream(device)
         last = q[-1][0]
         for owner in _owners.get(key, ()):
             if owner != cur:
                 owner.wait_event(last)
         q.clear()                   # every handing-off stream is ordered behind the side stream's reads
         _held_bytes[key] = 0
+    return waited

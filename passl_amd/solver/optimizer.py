@@ -9,7 +9,7 @@ passl/optimizer/momentum.py:150-158.
 """
 import torch
 
-from ..hip import ops
+from ..hip import ops, streams
 from .builder import OPTIMIZERS
 from .lr_scheduler import LRScheduler
 
@@ -27,6 +27,16 @@ def _load_flat_state(dst, sd, key):
         raise ValueError('optimizer state %r has %d elements, the arena holds %d'
                          % (key, src.numel(), dst.numel()))
     dst.copy_(src.reshape(dst.shape).to(dst.dtype))
+
+
+def _grads_complete(arena):
+    """Everything that writes this arena's gradients is ordered before the update kernel: outstanding gradient
+    collectives (GradReducer.finish) and work on the side stream — weight gradients, the backward of a forked
+    downsample branch (hip/streams.py)."""
+    if arena.reducer is not None:
+        arena.reducer.finish()
+    if arena.grads is not None and arena.grads.is_cuda:
+        streams.join(arena.grads.device)
 
 
 @OPTIMIZERS.register()
@@ -76,8 +86,7 @@ class Momentum(object):
     def step(self):
         lr = self.get_lr()
         for a, v in zip(self._arenas, self._velocity):
-            if a.reducer is not None:
-                a.reducer.finish()
+            _grads_complete(a)
             ops.momentum_sgd(a.flat[:a.n_train], a.grads, v, lr, self._momentum, self._wd,
                              self.grad_scale * self._rescale)
 
@@ -199,8 +208,7 @@ class LarsMomentumOptimizer(object):
     def step(self):
         lr = self.get_lr()
         for a, v, t in zip(self._arenas, self._velocity, self._tables):
-            if a.reducer is not None:
-                a.reducer.finish()
+            _grads_complete(a)
             ops.lars_momentum(a.flat[:a.n_train], a.grads, v, t, lr, self._momentum, self._coeff,
                               self._eps, self.grad_scale * self._rescale)
 
@@ -274,8 +282,7 @@ class AdamW(object):
         self._t += 1
         b1p, b2p = self._b1 ** self._t, self._b2 ** self._t
         for a, m, v in zip(self._arenas, self._m, self._v):
-            if a.reducer is not None:
-                a.reducer.finish()
+            _grads_complete(a)
             ops.adamw(a.flat[:a.n_train], a.grads, m, v, lr, self._b1, self._b2, self._eps, self._wd, b1p, b2p,
                       self.grad_scale)
 

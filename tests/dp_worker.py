@@ -66,6 +66,7 @@ def plain_run(tr, workload):
 
 
 OVERRIDES['clipx'] = OVERRIDES['clip']        # + multi_rank: cross-rank InfoNCE (BASELINE configs[4])
+OVERRIDES['moco_shuffle'] = OVERRIDES['moco']  # + shuffle_bn: the cross-rank batch shuffle of moco.py:107-152
 
 
 def main():
@@ -81,8 +82,10 @@ def main():
         cfg.model.multi_rank = True
     if workload == 'mae':
         cfg.model.architecture.img_size = 64
-    if workload == 'moco':
+    if workload in ('moco', 'moco_shuffle'):
         cfg.model.K = 256
+    if workload == 'moco_shuffle':
+        cfg.model.shuffle_bn = True
     if workload == 'linprobe':
         cfg.model.head.num_classes = 16
         cfg.custom_config = []                        # no EvaluateHook in the 3-step run
@@ -126,7 +129,7 @@ def main():
     assert float((p1 - p0).abs().max()) > 0, 'parameters did not move'
     # identical averaged gradients on every rank <=> replicas stay bit-identical
     same_everywhere(p1, 'parameters after 3 steps')
-    if workload == 'moco':
+    if workload in ('moco', 'moco_shuffle'):
         same_everywhere(tr.model.queue.double(), 'queue (gathered keys)')
         assert tr.model._ptr == 3 * 8 * tr.world_size
     dist.barrier()

@@ -43,6 +43,23 @@ def _run_worker(workload, nproc, env_extra, launcher=True):
     return line
 
 
+def test_two_ranks_shuffle_bn_is_output_neutral():
+    """MoCo's cross-rank batch shuffle (reference passl_v110/modeling/architectures/moco.py:107-152): all-gather
+    the key view, a permutation drawn on rank 0 and broadcast, every rank encodes its slice of the permuted batch,
+    the keys are gathered back and un-permuted.  The key encoder's BatchNorm runs on running statistics in PASSL
+    (SURVEY 3.1 note A), so a key does not depend on its batch mates: the two-rank run with the shuffle on must
+    reproduce the two-rank run without it — which it can only do if gather / broadcast / slice / inverse permutation
+    are all right (a key attached to the wrong image moves the loss by O(0.1)).  Not bit for bit: a sample's
+    position in the batch changes the rounding of its key in the 7th digit (the single-process check,
+    test_moco_gpu.py::test_shuffle_bn_is_output_neutral, sees the same), and the tiny random-init net amplifies that
+    through every update — the first step is held to 1e-5, the second to 5e-4."""
+    env = dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0')
+    plain = _run_worker('moco', 2, env)
+    shuffled = _run_worker('moco_shuffle', 2, env)
+    la, lb = ([float(v) for v in line.split('losses=')[1].split(',')] for line in (plain, shuffled))
+    assert abs(la[0] - lb[0]) < 1e-5 and abs(la[1] - lb[1]) < 5e-4, (plain, shuffled)
+
+
 @pytest.mark.parametrize('workload', ['moco', 'simclr'])
 def test_rccl_world1(workload):
     """RCCL itself (backend "nccl") on the hardware: ONE rank on the one GPU, every data-parallel

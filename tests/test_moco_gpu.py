@@ -412,3 +412,53 @@ def test_v2_train_one_step_on_hip_moco(accum):
                 assert d < 5e-2, (n, float(d))
         # the arena's gradients were cleared after the step (clear_grad, loop line 84)
         assert float(model.arch.arena_q.grads.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dtype,tol', [('fp32', 1e-3), ('bf16', 3e-2)])
+def test_v2_engine_train_on_hip_moco(dtype, tol, tmp_path):
+    """``Engine(config).train()`` end to end on the real HIP model (reference passl/engine/engine.py:46-377 over
+    passl/engine/loops/loop.py:207-311): configs/v2/moco_v2_resnet50_pt_synthetic.yaml (v2 schema: Global / Model /
+    LRScheduler / Optimizer / DataLoader) builds model, loader, cosine schedule, Momentum and the
+    ContrastiveLearningTrainingEpochLoop by name; three steps (max_train_step) on the loader's resident synthetic
+    batch must reproduce the oracle's losses, queue, pointer, key encoder and lr schedule."""
+    import os
+    from passl.engine.engine import Engine
+    from passl_amd.utils.config import get_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    K, N, hw, steps = 512, 16, 64, 3
+    cfg = get_config(os.path.join(root, 'configs', 'v2', 'moco_v2_resnet50_pt_synthetic.yaml'),
+                     ['Global.epochs=1', 'Global.compute_dtype=%s' % dtype,
+                      'Global.output_dir=%s' % tmp_path, 'Global.print_batch_step=1', 'Model.K=%d' % K,
+                      'DataLoader.Train.dataset.image_size=%d' % hw, 'DataLoader.Train.dataset.num_samples=%d' % (N * 40),
+                      'DataLoader.Train.sampler.batch_size=%d' % N])
+    cfg['Global']['max_train_step'] = steps          # engine.py:77 reads it with .get(): optional in the yaml
+    eng = Engine(cfg, mode='train')
+    assert type(eng.train_loop).__name__ == 'ContrastiveLearningTrainingEpochLoop'
+    assert len(eng.train_dataloader) == 40 and eng.lr_scheduler.T_max == 40
+    oracle = MoCoOracle(K=K, seed=5, t_max=40, bf16=(dtype == 'bf16'))
+    U.load_oracle_state(eng.model.arch, oracle)
+    xq, xk = (t.cpu() for t in eng.train_dataloader.inner._cache[0])
+    assert xq.shape == (N, 3, hw, hw)
+    losses = []
+    inner = eng.train_loop.train_one_step
+
+    def spy(batch):
+        out, ld = inner(batch)
+        losses.append(ld['loss'].detach().reshape(()).clone())
+        return out, ld
+    eng.train_loop.train_one_step = spy
+    eng.train()
+    assert eng.training is False and eng.global_step == steps and len(losses) == steps
+    ref = [oracle.train_step(xq, xk) for _ in range(steps)]
+    got = [float(v) for v in losses]
+    for s in range(steps):
+        # later steps run through updates of an ill-conditioned random-init net: see _run_against_golden
+        assert abs(got[s] - float(ref[s]['loss'])) < tol * (1 if s == 0 else 20), (s, got, [float(r['loss']) for r in ref])
+    arch = eng.model.arch
+    assert arch._ptr == oracle.queue_ptr == (steps * N) % K
+    assert (arch.queue[:, :N].cpu() - oracle.queue[:, :N]).abs().max() < tol            # the first step's keys
+    assert eng.lr_scheduler.last_epoch == steps == oracle.step_count
+    assert abs(eng.optimizer.get_lr() - oracle.lr()) < 1e-9
+    ksd = arch.encoder_k.state_dict()
+    for n in ('0.conv1.weight', '0.layer4.2.conv3.weight', '1.mlp.2.weight', '0.bn1._mean'):
+        assert (ksd[n].cpu() - oracle.k[n]).abs().max() < (1e-3 if dtype == 'fp32' else 2e-2), n

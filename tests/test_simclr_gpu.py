@@ -151,7 +151,12 @@ TOL_F32 = dict(loss=1e-3, emb=1e-3, logits=1e-3, grad=1e-2, param=1e-3, stat=1e-
 # tighter reference here: its fp32-accumulate and fp64-accumulate evaluations of the same bf16 contract
 # differ by 1.13 in loss / 0.19 in embeddings for the small case and 0.60 / 0.13 for b32 — any noise-scaled
 # bound would be wider than the sanity bounds below.
-TOL_BF16 = dict(loss=3.0, emb=6e-1, logits=6.0, grad=4e-1, param=3e-1, grad_bias=8e-1, stat=1e-1)
+# (r03) The bf16 PARITY bound of the SimCLR path is tests/test_layers_gpu.py::test_r50_layers_teacher_forced_bf16
+# [simclr]: every layer of the pool-free trunk and of the projector is fed the bf16-emulating oracle's own input /
+# output gradient and must reproduce the oracle's output within 2 bf16 ulp (mean 1/2 ulp) — a chaotic end-to-end
+# run cannot be bounded, a single layer can.  The whole-step check below is a SMOKE check (finite, right order of
+# magnitude, the step runs end to end in bf16), nothing more.
+TOL_BF16_SMOKE = dict(loss=3.0, emb=6e-1, logits=6.0, grad=4e-1, param=3e-1, grad_bias=8e-1, stat=1e-1)
 
 
 def _run_against_golden(name, dtype, steps_cap, tol):
@@ -242,11 +247,11 @@ def test_golden_b32_fp32():
 
 
 def test_golden_small_bf16():
-    _run_against_golden('simclr_r50_small', torch.bfloat16, 1, TOL_BF16)
+    _run_against_golden('simclr_r50_small', torch.bfloat16, 1, TOL_BF16_SMOKE)
 
 
 def test_golden_b32_bf16():
-    _run_against_golden('simclr_r50_b32', torch.bfloat16, 2, TOL_BF16)
+    _run_against_golden('simclr_r50_b32', torch.bfloat16, 2, TOL_BF16_SMOKE)
 
 
 def test_live_oracle_fp32_two_steps():
