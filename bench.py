@@ -83,8 +83,13 @@ def parse():
                          'linear-probe rows (extra measurements)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the captured HIP graph of the step (passl_amd/hip/graph.py) instead of launching '
+                         'it kernel by kernel from Python; same as PASSL_GRAPH=1')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='skip the instrumented loop (use under rocprofv3)')
+    ap.add_argument('--dp-buckets', type=int, default=0,
+                    help='number of gradient all-reduce buckets (default: 28 MB buckets = 4 for MoCo)')
     ap.add_argument('--roofline-steps', type=int, default=10,
                     help='steps of the instrumented loop that follows the timed loop')
     return ap.parse_args()
@@ -154,6 +159,11 @@ def pmc_traffic(args):
 
 def main():
     args = parse()
+    # multi-process GPU work on this stack needs dmabuf IPC (RCCL across ranks); set here too, not only in
+    # self_launch: the driver starts the ranks with torch.distributed.run itself
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if args.dp_buckets:
+        os.environ['PASSL_DP_BUCKETS'] = str(args.dp_buckets)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
 
@@ -189,6 +199,8 @@ def main():
                      ['dataloader.train.sampler.batch_size=%d' % args.batch,
                       'compute_dtype=%s' % args.dtype])
     cfg.timestamp = ''
+    if args.graph:
+        cfg.hip_graph = True
     trainer = Trainer(cfg)
     trainer.mode = 'train'
     trainer.model.train()
@@ -201,8 +213,7 @@ def main():
         trainer.inner_iter = trainer.current_iter % trainer.iters_per_epoch
         trainer.current_iter += 1
         trainer.call_hook('train_iter_begin')
-        trainer.outputs = trainer.model(*data, total_iters=trainer.total_iters,
-                                        current_iter=trainer.current_iter, mixup_fn=trainer.mixup_fn)
+        trainer.train_step(data)          # eager, or the captured HIP graph of the step (passl_amd/hip/graph.py)
         trainer.call_hook('train_iter_end')
 
     def barrier():
@@ -218,6 +229,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_elapsed = time.perf_counter() - t0          # the host is done enqueueing; the GPU may still be running
     barrier()
     elapsed = time.perf_counter() - t0
     loss = float(trainer.outputs['loss'].detach())
@@ -240,6 +252,9 @@ def main():
         rsteps = args.roofline_steps
         overlap_was = hip_config.overlap()
         hip_config.set_flag('overlap', False)
+        graph_was = trainer.step_graph.enabled if trainer.step_graph is not None else None
+        if trainer.step_graph is not None:
+            trainer.step_graph.enabled = False          # per-launch HIP events need the eager step
         step()
         barrier()
         lib.passl_hip_prof_enable(1)
@@ -256,6 +271,35 @@ def main():
             kern[name] = dict(ms=ms.value, n=n.value, flops=fl.value, bytes=by.value)
         lib.passl_hip_prof_enable(0)
         hip_config.set_flag('overlap', overlap_was)
+        if trainer.step_graph is not None:
+            trainer.step_graph.enabled = graph_was
+
+    # ---- 3. who took part (every rank reports its device) and what the gradient all-reduce cost in the open
+    dist_info = None
+    if world > 1 or dist.is_initialized():
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        me = {'rank': rank, 'device': torch.cuda.current_device(), 'name': props.name,
+              'uuid': str(getattr(props, 'uuid', '')), 'pci_bus_id': getattr(props, 'pci_bus_id', None),
+              'host': socket.gethostname(), 'pid': os.getpid()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        exposed = None
+        red = getattr(trainer, 'grad_reducer', None)
+        if red is not None:
+            red.measure = True
+            for _ in range(3):
+                step()
+            exposed = red.exposed_ms()
+            red.measure = False
+        ex = torch.tensor([exposed if exposed is not None else -1.0], dtype=torch.float64, device='cuda')
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        dist_info = {'backend': dist.get_backend(), 'world': dist.get_world_size(), 'ranks': everyone,
+                     'distinct_devices': len({(e['host'], e['uuid'] or e['device']) for e in everyone}),
+                     'grad_buckets': len(red.buckets) if red is not None else 0,
+                     'grad_bytes': int(red.grads.numel() * 4) if red is not None else 0,
+                     'allreduce_exposed_ms': round(float(ex.item()), 3) if float(ex.item()) >= 0 else None,
+                     'allreduce_exposed_what': 'max over ranks of the time the compute stream waits for gradient '
+                                               'collectives after backward has finished (3 extra steps, HIP events)'}
 
     if rank == 0:
         ips = args.batch * world * args.steps / elapsed
@@ -273,7 +317,12 @@ def main():
                        'hbm_reserved_gb': round(mem.get('reserved_bytes.all.peak', 0) / 2 ** 30, 1),
                        'allocator_retries': int(mem.get('num_alloc_retries', 0)),
                        'timed_region': 'product path only (full hook bus); kernel instrumentation runs '
-                                       'in a separate loop afterwards'},
+                                       'in a separate loop afterwards',
+                       'host_enqueue_ms_per_step': round(1000 * host_elapsed / args.steps, 3),
+                       'step_launch': ('HIP graph replay (forward + backward + optimizer captured once, %d replays '
+                                       'in this process)' % trainer.step_graph.replays)
+                       if (trainer.step_graph is not None and trainer.step_graph.captured)
+                       else 'eager (one launch per kernel from the host)'},
             'step_flop_roofline': {
                 'algorithmic_gflop_per_sample': flop_per_sample / 1e9,
                 'achieved_tflops_per_gpu': round(ips / world * flop_per_sample / 1e12, 2),
@@ -331,6 +380,8 @@ def main():
                 'achieved_tflops': round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12, 2),
                 'frac_of_mfma_peak': round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12 / peak, 5),
                 'kernel_ms_per_step': round(ig['ms'] / rsteps, 3), 'launches': int(ig['n'])}
+        if dist_info is not None:
+            out['dist'] = dist_info
         if world == 1 and not args.no_cpu_baseline and args.workload == 'moco':
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

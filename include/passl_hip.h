@@ -87,6 +87,12 @@ int passl_hip_bn_fold(const float* flat, const int64_t* gamma_idx, const int64_t
  * passl/optimizer/momentum.py:150-158). */
 int passl_hip_momentum_sgd(float* p, const float* g, float* v, int64_t n, float lr, float mu,
                            float wd, float grad_scale, passl_stream_t stream);
+/* The same update with the learning rate read from DEVICE memory (hyper[0]) when the kernel runs: the value of
+ * a launch is not frozen at enqueue time, so a captured HIP graph of the training step can be replayed while the
+ * schedule (reference passl_v110/hooks/lr_scheduler_hook.py:26-28, stepped every iteration) moves on — the host
+ * writes the new value into pinned memory, a captured H2D copy node carries it to `hyper`. */
+int passl_hip_momentum_sgd_dev(float* p, const float* g, float* v, int64_t n, const float* hyper, float mu,
+                               float wd, float grad_scale, passl_stream_t stream);
 
 /* LARS momentum over a flat fp32 buffer holding many parameter tensors ("segments").
  * The buffer is cut into blocks of at most 4096 elements, each inside ONE segment
@@ -105,6 +111,11 @@ int passl_hip_lars_momentum(float* p, const float* g, float* v, const int64_t* b
                             const float* seg_wd, int n_seg, float* norms, float lr, float mu,
                             float lars_coeff, float epsilon, float grad_scale,
                             passl_stream_t stream);
+/* ... with lr = hyper[0] read on the device (see passl_hip_momentum_sgd_dev). */
+int passl_hip_lars_momentum_dev(float* p, const float* g, float* v, const int64_t* blk_off,
+                                const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
+                                const float* seg_wd, int n_seg, float* norms, const float* hyper, float mu,
+                                float lars_coeff, float epsilon, float grad_scale, passl_stream_t stream);
 
 /* dst_bf16[i] = bf16(src[i]) (round-to-nearest-even). */
 int passl_hip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, passl_stream_t stream);
@@ -341,6 +352,11 @@ int passl_hip_infonce_bwd(const float* q, const float* k, const float* queue,
  * MoCo._dequeue_and_enqueue, moco.py:101-102 (the pointer arithmetic stays on the host). */
 int passl_hip_enqueue(float* queue, const float* keys, int D, int K, int ptr, int B,
                       passl_stream_t stream);
+/* The same with the pointer in DEVICE memory (MoCo's `queue_ptr` buffer itself, int64[1], moco.py:80): the launch
+ * reads *ptr, writes the keys and then advances *ptr = (*ptr + B) % K — nothing about the step's position in
+ * the queue is frozen at enqueue time (HIP-graph replay).  K % B == 0 (moco.py:99). */
+int passl_hip_enqueue_dev(float* queue, const float* keys, int D, int K, int64_t* ptr, int B,
+                          passl_stream_t stream);
 
 /* Fused NT-Xent + CO2 head of SimCLR (passl_v110/modeling/heads/simclr_contrastive_head.py:42-102).
  * a, b: [B][D] fp32 rows of this rank (hidden1, hidden2); a_all, b_all: [BL][D] the column sets
@@ -430,6 +446,10 @@ int passl_hip_mae_loss_bwd(const float* img, const float* pred, const float* mas
 int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                     float beta2, float epsilon, float weight_decay, float beta1_pow, float beta2_pow,
                     float grad_scale, passl_stream_t stream);
+/* ... with the step-dependent scalars read on the device: hyper = {lr, beta1^t, beta2^t} (see
+ * passl_hip_momentum_sgd_dev).  Both forms derive sqrt(1-b2^t) etc. inside the kernel: identical bits. */
+int passl_hip_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                        float beta2, float epsilon, float weight_decay, float grad_scale, passl_stream_t stream);
 
 /* ---------------------------------------------------------------- measurement hooks */
 

@@ -57,6 +57,12 @@ def _install_tensor_patches():
         with torch.no_grad():
             return self.clamp_(lo, hi)
 
+    _orig_copy = _T.copy_
+
+    def copy_(self, src, *blocking, **kw):        # Tensor.copy_(src, blocking) in Paddle
+        with torch.no_grad():
+            return _orig_copy(self, src)
+    _T.copy_ = copy_
     _T.norm, _T.argmax, _T.clip_ = norm, argmax, clip_
     _T._share_buffer_to = lambda self, other: None
     _T.transpose = transpose
@@ -140,8 +146,10 @@ class _BatchNormBase(Layer):
         super().__init__()
         self._momentum, self._epsilon = momentum, epsilon
         self._use_global_stats = use_global_stats
-        self.weight = torch.nn.Parameter(torch.ones(num_features))
-        self.bias = torch.nn.Parameter(torch.zeros(num_features))
+        # weight_attr / bias_attr = False: no affine parameter (BatchNorm1D(dim2, weight_attr=False, bias_attr=False),
+        # passl/models/mocov3.py:149-151)
+        self.weight = None if weight_attr is False else torch.nn.Parameter(torch.ones(num_features))
+        self.bias = None if bias_attr is False else torch.nn.Parameter(torch.zeros(num_features))
         self._mean = torch.nn.Parameter(torch.zeros(num_features), requires_grad=False)
         self._variance = torch.nn.Parameter(torch.ones(num_features), requires_grad=False)
 
@@ -160,8 +168,10 @@ class _BatchNormBase(Layer):
                 self._mean.copy_(m * self._mean + (1 - m) * mean)
                 self._variance.copy_(m * self._variance + (1 - m) * var)
         inv = torch.rsqrt(var + self._epsilon)
-        return (x - mean.reshape(shape)) * (inv * self.weight).reshape(shape) \
-            + self.bias.reshape(shape)
+        if self.weight is not None:
+            inv = inv * self.weight
+        y = (x - mean.reshape(shape)) * inv.reshape(shape)
+        return y if self.bias is None else y + self.bias.reshape(shape)
 
 
 class BatchNorm2D(_BatchNormBase):
@@ -435,6 +445,25 @@ def install():
     tensor_mod = mod('paddle.tensor')
     paddle.tensor = tensor_mod
     tensor_mod.triu = lambda x, diagonal=0: torch.triu(x, diagonal)
+    # v2 tree (passl/models/{vision_transformer,mocov3}.py, passl/nn/init.py, passl/models/utils/averaged_model.py)
+    rnd = mod('paddle.tensor.random')
+    tensor_mod.random = rnd
+    rnd.gaussian = lambda shape, mean=0.0, std=1.0, dtype=None: torch.randn(*shape) * std + mean
+    rnd.uniform = lambda shape, min=-1.0, max=1.0, dtype=None: torch.rand(*shape) * (max - min) + min
+    paddle.float32, paddle.float64, paddle.int64, paddle.int32 = torch.float32, torch.float64, torch.int64, torch.int32
+    paddle.float16, paddle.bfloat16 = torch.float16, torch.bfloat16
+    paddle.sin, paddle.cos = torch.sin, torch.cos
+    paddle.meshgrid = lambda *xs: torch.meshgrid(*xs, indexing='ij')       # paddle.meshgrid is 'ij'  [Paddle-semantics]
+    paddle.is_floating_point = lambda t: t.is_floating_point()
+    paddle.lerp = lambda a, b, w: torch.lerp(a, b, w)
+    amp = mod('paddle.amp')
+    paddle.amp = amp
+    import contextlib as _ctx
+    amp.auto_cast = lambda *a, **k: _ctx.nullcontext()
+    nn.Identity = type('Identity', (torch.nn.Identity, Layer), {})
+    nn.Tanh = type('Tanh', (torch.nn.Tanh, Layer), {})
+    Layer.named_sublayers = lambda self, prefix='', include_self=False: (
+        (n, m) for n, m in self.named_modules(prefix=prefix) if include_self or m is not self)
     paddle.get_default_dtype = lambda: torch.get_default_dtype()
     paddle.shape = lambda x: list(x.shape)
     F.sigmoid = torch.sigmoid
@@ -443,6 +472,10 @@ def install():
     paddle.distributed = dist
     dist.get_world_size = lambda: 1
     dist.get_rank = lambda: 0
+
+    def all_gather(out_list, t):
+        out_list.append(t)
+    dist.all_gather = all_gather
 
     class ParallelEnv:
         local_rank = 0

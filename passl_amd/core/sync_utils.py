@@ -45,7 +45,12 @@ def collectives_active(group=None):
 class GradReducer(object):
     """Bucketed, overlapped all-reduce over a flat gradient buffer."""
 
-    def __init__(self, arena, optimizer=None, bucket_elems=7 * 1024 * 1024, group=None):
+    def __init__(self, arena, optimizer=None, bucket_elems=None, group=None):
+        """bucket_elems: fp32 gradients per bucket (default 7 Mi = 28 MB, i.e. 4 buckets for R50 + projector);
+        ``PASSL_DP_BUCKETS=n`` asks for n equal buckets instead (bench.py --dp-buckets)."""
+        if bucket_elems is None:
+            n_b = int(os.environ.get('PASSL_DP_BUCKETS', '0') or 0)
+            bucket_elems = -(-arena.n_train // n_b) if n_b > 0 else 7 * 1024 * 1024
         self.arena = arena
         self.group = group
         self.world = _ws(group)
@@ -74,6 +79,8 @@ class GradReducer(object):
         self._handles = []
         self._active = False
         self._home = None
+        self.measure = False          # bench.py: time what the compute stream waits for in finish()
+        self._exposed = []
         arena.reducer = self
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
@@ -125,10 +132,29 @@ class GradReducer(object):
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
+        timed = self.measure and self.grads.is_cuda and self._handles
+        if timed:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
         for h in self._handles:
             h.wait()
+        if timed:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self._exposed.append((t0, t1))
         self._handles = []
         self._active = False
+
+    def exposed_ms(self):
+        """Average time per step that the compute stream spent between "backward finished" and "every gradient
+        collective finished" over the finish() calls made with ``measure`` on: the all-reduce time that backward
+        did NOT hide (the last bucket can only start when backward ends).  Synchronises."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(ms) / len(ms)
 
 
 @torch.no_grad()

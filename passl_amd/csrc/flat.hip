@@ -83,8 +83,10 @@ __global__ void __launch_bounds__(kThreads) slab_reduce_kernel(const float* __re
 // g' = g*gs + wd*p; v = mu*v + g'; p -= lr*v.   20 bytes per element.
 __global__ void __launch_bounds__(kThreads) sgd_kernel(float* __restrict__ p,
                                                        const float* __restrict__ g,
-                                                       float* __restrict__ v, int64_t n, float lr,
-                                                       float mu, float wd, float gs) {
+                                                       float* __restrict__ v, int64_t n, float lr_val,
+                                                       const float* __restrict__ hyper, float mu, float wd,
+                                                       float gs) {
+  const float lr = hyper ? hyper[0] : lr_val;       // device-resident learning rate: HIP-graph replays (passl_hip.h)
   const int64_t nv = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += stride) {
@@ -203,7 +205,9 @@ __global__ void __launch_bounds__(kThreads) lars_update_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
     const int64_t* __restrict__ blk_off, const int32_t* __restrict__ blk_len,
     const int32_t* __restrict__ blk_seg, const float* __restrict__ seg_wd,
-    const float* __restrict__ norms, float lr, float mu, float coeff, float eps, float gs) {
+    const float* __restrict__ norms, float lr_val, const float* __restrict__ hyper, float mu, float coeff,
+    float eps, float gs) {
+  const float lr = hyper ? hyper[0] : lr_val;
   const int seg = blk_seg[blockIdx.x];
   const float wd = seg_wd[seg];
   const float pn = sqrtf(norms[2 * seg]), gn = sqrtf(norms[2 * seg + 1]);
@@ -380,7 +384,18 @@ extern "C" int passl_hip_momentum_sgd(float* p, const float* g, float* v, int64_
     return PASSL_EINVAL;
   if (n == 0) return PASSL_OK;
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n >> 2)), dim3(kThreads), 0, as_stream(stream), p,
-                     g, v, n, lr, mu, wd, grad_scale);
+                     g, v, n, lr, (const float*)nullptr, mu, wd, grad_scale);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_momentum_sgd_dev(float* p, const float* g, float* v, int64_t n, const float* hyper,
+                                          float mu, float wd, float grad_scale, passl_stream_t stream) {
+  if (!p || !g || !v || !hyper || n < 0 || !aligned16(p) || !aligned16(g) || !aligned16(v))
+    return PASSL_EINVAL;
+  if (n == 0) return PASSL_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n >> 2)), dim3(kThreads), 0, as_stream(stream), p,
+                     g, v, n, 0.f, hyper, mu, wd, grad_scale);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -413,9 +428,9 @@ extern "C" int passl_hip_pack_weights(const float* src, void* dst, int dtype,
   return PASSL_OK;
 }
 
-extern "C" int passl_hip_lars_momentum(float* p, const float* g, float* v, const int64_t* blk_off,
+static int lars_impl(float* p, const float* g, float* v, const int64_t* blk_off,
                                        const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
-                                       const float* seg_wd, int n_seg, float* norms, float lr,
+                                       const float* seg_wd, int n_seg, float* norms, float lr, const float* hyper,
                                        float mu, float lars_coeff, float epsilon, float grad_scale,
                                        passl_stream_t stream) {
   if (!p || !g || !v || !blk_off || !blk_len || !blk_seg || !seg_wd || !norms || n_blocks < 0 ||
@@ -432,7 +447,26 @@ extern "C" int passl_hip_lars_momentum(float* p, const float* g, float* v, const
                      (int)n_blocks, norms);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   hipLaunchKernelGGL(lars_update_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, v, blk_off,
-                     blk_len, blk_seg, seg_wd, norms, lr, mu, lars_coeff, epsilon, grad_scale);
+                     blk_len, blk_seg, seg_wd, norms, lr, hyper, mu, lars_coeff, epsilon, grad_scale);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
+}
+
+extern "C" int passl_hip_lars_momentum(float* p, const float* g, float* v, const int64_t* blk_off,
+                                       const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
+                                       const float* seg_wd, int n_seg, float* norms, float lr,
+                                       float mu, float lars_coeff, float epsilon, float grad_scale,
+                                       passl_stream_t stream) {
+  return lars_impl(p, g, v, blk_off, blk_len, blk_seg, n_blocks, seg_wd, n_seg, norms, lr, nullptr, mu, lars_coeff,
+                   epsilon, grad_scale, stream);
+}
+
+extern "C" int passl_hip_lars_momentum_dev(float* p, const float* g, float* v, const int64_t* blk_off,
+                                           const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
+                                           const float* seg_wd, int n_seg, float* norms, const float* hyper,
+                                           float mu, float lars_coeff, float epsilon, float grad_scale,
+                                           passl_stream_t stream) {
+  if (!hyper) return PASSL_EINVAL;
+  return lars_impl(p, g, v, blk_off, blk_len, blk_seg, n_blocks, seg_wd, n_seg, norms, 0.f, hyper, mu, lars_coeff,
+                   epsilon, grad_scale, stream);
 }

@@ -262,13 +262,20 @@ __global__ void __launch_bounds__(kThreads, 2) infonce_bwd_kernel(
 
 __global__ void __launch_bounds__(kThreads) enqueue_kernel(float* __restrict__ queue,
                                                            const float* __restrict__ keys, int Dd,
-                                                           int K, int ptr, int B) {
+                                                           int K, int ptr, const int64_t* __restrict__ ptr_dev,
+                                                           int B) {
+  if (ptr_dev) ptr = (int)*ptr_dev;          // device-resident pointer: HIP-graph replays (passl_hip_enqueue_dev)
   const int64_t total = (int64_t)Dd * B;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * kThreads) {
     const int b = (int)(i % B), d = (int)(i / B);
     queue[(int64_t)d * K + ptr + b] = keys[(int64_t)b * Dd + d];
   }
+}
+
+// queue_ptr = (queue_ptr + B) % K, after the enqueue kernel of the same stream has read it
+__global__ void advance_ptr_kernel(int64_t* ptr, int B, int K) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ptr = (*ptr + B) % K;
 }
 
 // one wave per row
@@ -380,7 +387,21 @@ extern "C" int passl_hip_enqueue(float* queue, const float* keys, int Dd, int K,
   int grid = (int)((total + kThreads - 1) / kThreads);
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(enqueue_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), queue, keys,
-                     Dd, K, ptr, B);
+                     Dd, K, ptr, (const int64_t*)nullptr, B);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_enqueue_dev(float* queue, const float* keys, int Dd, int K, int64_t* ptr, int B,
+                                     passl_stream_t stream) {
+  if (!queue || !keys || !ptr || Dd <= 0 || K <= 0 || B <= 0 || (K % B) != 0) return PASSL_EINVAL;
+  const int64_t total = (int64_t)Dd * B;
+  int grid = (int)((total + kThreads - 1) / kThreads);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(enqueue_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), queue, keys,
+                     Dd, K, 0, (const int64_t*)ptr, B);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(64), 0, as_stream(stream), ptr, B, K);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

@@ -443,8 +443,16 @@ __global__ void __launch_bounds__(kThreads) mae_loss_kernel(
 __global__ void __launch_bounds__(kThreads) adamw_kernel(float* __restrict__ p,
                                                          const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v,
-                                                         int64_t n, float decay, float b1, float b2,
-                                                         float lr_t, float eps_t, float gs) {
+                                                         int64_t n, float lr, float b1p, float b2p,
+                                                         const float* __restrict__ hyper, float wd, float eps,
+                                                         float b1, float b2, float gs) {
+  // the step-dependent scalars come by value or from device memory (hyper = {lr, beta1^t, beta2^t}: HIP-graph
+  // replays); the derived ones are computed here either way (correctly rounded sqrt / divide: same bits as on the host)
+  if (hyper) { lr = hyper[0]; b1p = hyper[1]; b2p = hyper[2]; }
+  const float c2 = sqrtf(1.f - b2p);
+  const float decay = 1.f - lr * wd;
+  const float lr_t = lr * c2 / (1.f - b1p);
+  const float eps_t = eps * c2;
   const int64_t nv = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * kThreads;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += stride) {
@@ -660,20 +668,32 @@ extern "C" int passl_hip_mae_loss_bwd(const float* img, const float* pred, const
   return PASSL_OK;
 }
 
-extern "C" int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
-                               float beta1, float beta2, float epsilon, float weight_decay,
-                               float beta1_pow, float beta2_pow, float grad_scale,
-                               passl_stream_t stream) {
+static int adamw_impl(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1_pow,
+                      float beta2_pow, const float* hyper, float beta1, float beta2, float epsilon,
+                      float weight_decay, float grad_scale, passl_stream_t stream) {
   if (!p || !g || !m || !v || n < 0 || !aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v))
     return PASSL_EINVAL;
   if (n == 0) return PASSL_OK;
-  const float c2 = sqrtf(1.f - beta2_pow);
   int64_t b = ((n >> 2) + kThreads - 1) / kThreads;
   if (b > 2048) b = 2048;
   if (b < 1) b = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)b), dim3(kThreads), 0, as_stream(stream), p, g, m, v, n,
-                     1.f - lr * weight_decay, beta1, beta2, lr * c2 / (1.f - beta1_pow), epsilon * c2,
-                     grad_scale);
+                     lr, beta1_pow, beta2_pow, hyper, weight_decay, epsilon, beta1, beta2, grad_scale);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
+}
+
+extern "C" int passl_hip_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                               float beta1, float beta2, float epsilon, float weight_decay,
+                               float beta1_pow, float beta2_pow, float grad_scale,
+                               passl_stream_t stream) {
+  return adamw_impl(p, g, m, v, n, lr, beta1_pow, beta2_pow, nullptr, beta1, beta2, epsilon, weight_decay,
+                    grad_scale, stream);
+}
+
+extern "C" int passl_hip_adamw_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                   float beta1, float beta2, float epsilon, float weight_decay, float grad_scale,
+                                   passl_stream_t stream) {
+  if (!hyper) return PASSL_EINVAL;
+  return adamw_impl(p, g, m, v, n, 0.f, 0.f, 0.f, hyper, beta1, beta2, epsilon, weight_decay, grad_scale, stream);
 }

@@ -64,6 +64,7 @@ SIGNATURES = {
     'passl_hip_ema_update': (c_i, [c_p, c_p, c_p, c_l, c_f, c_p]),
     'passl_hip_bn_fold': (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_p]),
     'passl_hip_momentum_sgd': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p]),
+    'passl_hip_momentum_sgd_dev': (c_i, [c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_f, c_p]),
     'passl_hip_cast_f32_to_bf16': (c_i, [c_p, c_p, c_l, c_p]),
     'passl_hip_pack_weights': (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p]),
     'passl_hip_nchw_to_nhwc_pad': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -94,8 +95,11 @@ SIGNATURES = {
     'passl_hip_infonce_bwd_workspace_bytes': (c_l, [c_i, c_i]),
     'passl_hip_infonce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     'passl_hip_enqueue': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_enqueue_dev': (c_i, [c_p, c_p, c_i, c_i, c_p, c_i, c_p]),
     'passl_hip_lars_momentum': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_f, c_f,
                                       c_f, c_f, c_f, c_p]),
+    'passl_hip_lars_momentum_dev': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_f,
+                                          c_f, c_f, c_f, c_p]),
     'passl_hip_ntxent_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
     'passl_hip_ntxent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p,
                                    c_p, c_p, c_p, c_p]),
@@ -130,6 +134,7 @@ SIGNATURES = {
     'passl_hip_mae_loss_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'passl_hip_mae_loss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'passl_hip_adamw': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
+    'passl_hip_adamw_dev': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
     'passl_hip_softmax_ce_fwd': (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     'passl_hip_softmax_ce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),

@@ -366,6 +366,19 @@ def momentum_sgd(p, g, v, lr, mu, wd, grad_scale=1.0):
                                           grad_scale, L.stream()), 'momentum_sgd')
 
 
+def momentum_sgd_dev(p, g, v, hyper, mu, wd, grad_scale=1.0):
+    """hyper: device float32 tensor, [0] = learning rate (read when the kernel runs: HIP-graph replays)."""
+    L.check(_lib().passl_hip_momentum_sgd_dev(L.ptr(p), L.ptr(g), L.ptr(v), p.numel(), L.ptr(hyper), mu, wd,
+                                              grad_scale, L.stream()), 'momentum_sgd_dev')
+
+
+def enqueue_dev(queue, keys, ptr_dev):
+    """ptr_dev: int64[1] device tensor (MoCo's queue_ptr buffer); read and advanced on the device."""
+    Dd, K = queue.shape
+    L.check(_lib().passl_hip_enqueue_dev(L.ptr(queue), L.ptr(keys), Dd, K, L.ptr(ptr_dev), keys.shape[0],
+                                         L.stream()), 'enqueue_dev')
+
+
 def cast_bf16(src, dst):
     L.check(_lib().passl_hip_cast_f32_to_bf16(L.ptr(src), L.ptr(dst), src.numel(), L.stream()),
             'cast_f32_to_bf16')
@@ -411,6 +424,16 @@ def lars_momentum(p, g, v, table, lr, mu, coeff, eps, grad_scale=1.0):
                                            table['blk_off'].numel(), L.ptr(table['seg_wd']),
                                            table['seg_wd'].numel(), L.ptr(table['norms']), lr, mu,
                                            coeff, eps, grad_scale, L.stream()), 'lars_momentum')
+
+
+def lars_momentum_dev(p, g, v, table, hyper, mu, coeff, eps, grad_scale=1.0):
+    """lars_momentum with lr = hyper[0] read on the device."""
+    assert table['norms'].numel() >= 2 * (table['seg_wd'].numel() + table['blk_off'].numel())
+    L.check(_lib().passl_hip_lars_momentum_dev(L.ptr(p), L.ptr(g), L.ptr(v), L.ptr(table['blk_off']),
+                                               L.ptr(table['blk_len']), L.ptr(table['blk_seg']),
+                                               table['blk_off'].numel(), L.ptr(table['seg_wd']),
+                                               table['seg_wd'].numel(), L.ptr(table['norms']), L.ptr(hyper), mu,
+                                               coeff, eps, grad_scale, L.stream()), 'lars_momentum_dev')
 
 
 # ------------------------------------------------------------------ ViT / MAE
@@ -539,6 +562,12 @@ def mae_loss_bwd(img, pred, mask, gscale, p, norm_pix, denom):
 def adamw(p, g, m, v, lr, b1, b2, eps, wd, b1pow, b2pow, grad_scale=1.0):
     L.check(_lib().passl_hip_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, b1, b2, eps, wd,
                                    b1pow, b2pow, grad_scale, L.stream()), 'adamw')
+
+
+def adamw_dev(p, g, m, v, hyper, b1, b2, eps, wd, grad_scale=1.0):
+    """hyper: device float32 [lr, beta1^t, beta2^t], read when the kernel runs."""
+    L.check(_lib().passl_hip_adamw_dev(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(hyper), b1, b2, eps,
+                                       wd, grad_scale, L.stream()), 'adamw_dev')
 
 
 # ------------------------------------------------------------------ CLIP

@@ -128,6 +128,16 @@ def on_side(device, reads=(), in_backward=False):
         torch.autograd.Variable._execution_engine.queue_callback(lambda: join(device))
 
 
+def reset():
+    """Forget every hand-off in flight and every stream that handed work over (call with the device idle).
+    hip/graph.py calls it around a capture: a stream left in ``_owners`` by earlier EAGER steps (the default
+    stream) must not be made to wait on an event recorded inside the capture — the wait would pull it into the
+    capture, nothing would join it back, and ending the capture fails."""
+    _pending.clear()
+    _owners.clear()
+    _held_bytes.clear()
+
+
 def join(device):
     """Make the current stream wait for everything issued so far on the side stream (and the fork stream, when it
     is a stream of its own).  Unconditional once such a stream exists: work can reach the side stream without

@@ -11,6 +11,14 @@ class OptimizerHook(Hook):
         self.priority = priority
 
     def train_iter_end(self, trainer):
+        if getattr(trainer, '_step_done', False):
+            # Trainer.train_step already ran forward + this hook's body as one unit (hip/graph.py: the whole
+            # step is captured in a HIP graph and replayed)
+            trainer._step_done = False
+            return
+        self.optimize(trainer)
+
+    def optimize(self, trainer):
         if 'Lars' in trainer.cfg['optimizer']['name']:
             trainer.optimizer.clear_gradients()
         else:

@@ -68,6 +68,7 @@ class MoCo(nn.Layer):
         self.register_buffer('queue', queue.to(dev))
         self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.int64, device=dev))
         self._ptr = 0     # host mirror of queue_ptr: no device->host sync in the step
+        self._enqueued = 0
 
     # -- state ------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -92,11 +93,17 @@ class MoCo(nn.Layer):
     def _dequeue_and_enqueue(self, keys):
         keys = concat_all_gather(keys)
         batch_size = keys.shape[0]
-        ptr = self._ptr
         assert self.K % batch_size == 0  # for simplicity
-        ops.enqueue(self.queue, keys.contiguous(), ptr)
-        self._ptr = (ptr + batch_size) % self.K
-        self.queue_ptr.fill_(self._ptr)
+        # the pointer lives on the device (the `queue_ptr` buffer itself): the kernel reads it, writes the keys and
+        # advances it, so that a captured HIP graph of the step can be replayed; `_ptr` is the host's mirror of it
+        # (kept without a device sync)
+        ops.enqueue_dev(self.queue, keys.contiguous(), self.queue_ptr)
+        self._enqueued = batch_size
+        self._ptr = (self._ptr + batch_size) % self.K
+
+    def on_graph_replay(self):
+        """hip/graph.py: the captured step was replayed (no Python of train_iter ran): advance the host mirror."""
+        self._ptr = (self._ptr + self._enqueued) % self.K
 
     # -- moco.py:107-152 (output-neutral here; see module docstring) -------------------------
     @torch.no_grad()

@@ -56,8 +56,11 @@ class BottleneckBlock(nn.Layer):
         # stream on it is issued there (AFTER the main branch on the host, so that its backward nodes
         # still run first and fill the GradSlot; on the GPU it starts as soon as x is complete) and
         # joined before bn3.  Autograd runs its backward on the side stream as well.
+        # (not while the step is being captured into a HIP graph: ending a capture in which autograd ran a branch's
+        # backward on the side stream by stream affinity crashes this ROCm build — profiles/r03_negative_results.txt;
+        # the weight-gradient side stream and the frozen encoder's fork, which are ordered by our own events, capture fine)
         fork = (self.downsample is not None and torch.is_grad_enabled() and x.requires_grad and
-                streams.enabled(x) and config.fork_downsample())
+                streams.enabled(x) and config.fork_downsample() and not torch.cuda.is_current_stream_capturing())
         x_ready = torch.cuda.current_stream(x.device).record_event() if fork else None
         out, st = self.conv1(x, want_stats=True, add_slot=slot,
                              producer=nn.bn_link(x) if slot is not None else None)

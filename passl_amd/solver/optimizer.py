@@ -39,8 +39,59 @@ def _grads_complete(arena):
         streams.join(arena.grads.device)
 
 
+class _DeviceHyper(object):
+    """Step-dependent scalars of an optimizer — {lr, beta1^t, beta2^t, unused} — held in DEVICE memory and read by
+    the update kernel when it runs (ops.*_dev): nothing about the schedule is frozen into a kernel launch, so the
+    whole training step can be captured once in a HIP graph and replayed (hip/graph.py) while the reference's
+    per-iteration schedule (passl_v110/hooks/lr_scheduler_hook.py:26-28) moves on.
+
+    ``push_hyper()`` = one host-side update of the step state (``_host_values``) + one asynchronous H2D copy from a
+    ring of pinned slots (the host may run several steps ahead of the GPU: a slot is re-used only after the copy
+    that read it has completed).  ``step()`` calls it itself unless the caller already did (graph replay: the copy
+    is stream-ordered in front of the graph launch, never part of the graph)."""
+
+    _RING = 16
+
+    def _init_hyper(self, device):
+        self._hyper_dev = torch.zeros(4, dtype=torch.float32, device=device)
+        self._hyper_host = None
+        self._hyper_ev = [None] * self._RING
+        self._hyper_slot = 0
+        self._hyper_pushed = False
+
+    def _host_values(self):
+        """-> (lr, beta1^t, beta2^t); advances host-side step state (AdamW's t)."""
+        return self.get_lr(), 0.0, 0.0
+
+    def push_hyper(self):
+        dev = self._hyper_dev
+        vals = self._host_values()
+        if dev.is_cuda:
+            if self._hyper_host is None:
+                self._hyper_host = torch.zeros(self._RING, 4, dtype=torch.float32).pin_memory()
+            i = self._hyper_slot
+            if self._hyper_ev[i] is not None:
+                self._hyper_ev[i].synchronize()          # the copy that read this slot RING steps ago is done
+            h = self._hyper_host[i]
+            h[0], h[1], h[2] = vals
+            dev.copy_(h, non_blocking=True)
+            ev = self._hyper_ev[i] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev.device))
+            self._hyper_ev[i] = ev
+            self._hyper_slot = (i + 1) % self._RING
+        else:
+            dev[0], dev[1], dev[2] = vals
+        self._hyper_pushed = True
+
+    def _hyper_for_step(self):
+        if not self._hyper_pushed:
+            self.push_hyper()
+        self._hyper_pushed = False
+        return self._hyper_dev
+
+
 @OPTIMIZERS.register()
-class Momentum(object):
+class Momentum(_DeviceHyper):
     type = 'momentum'
 
     def __init__(self, learning_rate=0.001, momentum=0.9, parameters=None, use_nesterov=False,
@@ -70,6 +121,7 @@ class Momentum(object):
         self._arenas = arenas
         self._velocity = [torch.zeros_like(a.flat[:a.n_train]) for a in arenas]
         self.grad_scale = 1.0      # set by the DP reducer to 1/world_size (sum -> mean)
+        self._init_hyper(arenas[0].device if arenas else torch.device('cpu'))
 
     # ---- paddle.optimizer API used by the hooks
     def get_lr(self):
@@ -84,11 +136,11 @@ class Momentum(object):
 
     @torch.no_grad()
     def step(self):
-        lr = self.get_lr()
+        hyper = self._hyper_for_step()
         for a, v in zip(self._arenas, self._velocity):
             _grads_complete(a)
-            ops.momentum_sgd(a.flat[:a.n_train], a.grads, v, lr, self._momentum, self._wd,
-                             self.grad_scale * self._rescale)
+            ops.momentum_sgd_dev(a.flat[:a.n_train], a.grads, v, hyper, self._momentum, self._wd,
+                                 self.grad_scale * self._rescale)
 
     def state_dict(self):
         sd = {'velocity_%d' % i: v.detach().cpu() for i, v in enumerate(self._velocity)}
@@ -131,7 +183,7 @@ def _paddle_auto_names(arena):
 
 
 @OPTIMIZERS.register()
-class LarsMomentumOptimizer(object):
+class LarsMomentumOptimizer(_DeviceHyper):
     """paddle.fluid.optimizer.LarsMomentumOptimizer (registered by the reference at
     passl_v110/solver/optimizer.py:25, built with ``parameter_list=`` at solver/builder.py:198-201,
     driven through ``minimize(loss)`` / ``clear_gradients()`` by hooks/optimizer_hook.py:26-45)
@@ -175,6 +227,7 @@ class LarsMomentumOptimizer(object):
         self._velocity = [torch.zeros_like(a.flat[:a.n_train]) for a in arenas]
         self._tables = [self._build_table(a) for a in arenas]
         self.grad_scale = 1.0
+        self._init_hyper(arenas[0].device if arenas else torch.device('cpu'))
 
     def _build_table(self, arena, chunk=4096):
         names = _paddle_auto_names(arena)
@@ -206,11 +259,11 @@ class LarsMomentumOptimizer(object):
 
     @torch.no_grad()
     def step(self):
-        lr = self.get_lr()
+        hyper = self._hyper_for_step()
         for a, v, t in zip(self._arenas, self._velocity, self._tables):
             _grads_complete(a)
-            ops.lars_momentum(a.flat[:a.n_train], a.grads, v, t, lr, self._momentum, self._coeff,
-                              self._eps, self.grad_scale * self._rescale)
+            ops.lars_momentum_dev(a.flat[:a.n_train], a.grads, v, t, hyper, self._momentum, self._coeff,
+                                  self._eps, self.grad_scale * self._rescale)
 
     def minimize(self, loss=None, startup_program=None, parameters=None, no_grad_set=None):
         """Dygraph ``minimize``: the gradients already exist (the hook called backward())."""
@@ -230,7 +283,7 @@ class LarsMomentumOptimizer(object):
 
 
 @OPTIMIZERS.register()
-class AdamW(object):
+class AdamW(_DeviceHyper):
     """paddle.optimizer.AdamW (registered by the reference at passl_v110/solver/optimizer.py:22) as ONE
     launch over the flat arena.  adamw op  [Paddle-semantics]:
         p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
@@ -265,6 +318,11 @@ class AdamW(object):
         self._v = [torch.zeros_like(a.flat[:a.n_train]) for a in arenas]
         self._t = 0
         self.grad_scale = 1.0
+        self._init_hyper(arenas[0].device if arenas else torch.device('cpu'))
+
+    def _host_values(self):
+        self._t += 1
+        return self.get_lr(), self._b1 ** self._t, self._b2 ** self._t
 
     def get_lr(self):
         lr = self._learning_rate
@@ -278,13 +336,11 @@ class AdamW(object):
 
     @torch.no_grad()
     def step(self):
-        lr = self.get_lr()
-        self._t += 1
-        b1p, b2p = self._b1 ** self._t, self._b2 ** self._t
+        hyper = self._hyper_for_step()
         for a, m, v in zip(self._arenas, self._m, self._v):
             _grads_complete(a)
-            ops.adamw(a.flat[:a.n_train], a.grads, m, v, lr, self._b1, self._b2, self._eps, self._wd, b1p, b2p,
-                      self.grad_scale)
+            ops.adamw_dev(a.flat[:a.n_train], a.grads, m, v, hyper, self._b1, self._b2, self._eps, self._wd,
+                          self.grad_scale)
 
     def state_dict(self):
         sd = {'t': self._t}

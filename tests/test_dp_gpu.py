@@ -92,3 +92,28 @@ def test_bench_self_launch_gpus1_and_world1_launcher():
         assert len(lines) == 1, lines
         out = json.loads(lines[0])
         assert out['n_gpus'] == 1 and out['steps'] == 2 and out['value'] > 0 and 'roofline' in out
+
+
+def test_bench_two_ranks_one_gpu_reports_its_ranks():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), here two ranks on
+    the one GPU over gloo: the JSON line proves who took part (`dist.ranks`: device uuid / host / pid of EVERY rank,
+    all-gathered), names the backend, counts the gradient buckets (--dp-buckets) and prices the part of the
+    gradient all-reduce that backward does not hide (`allreduce_exposed_ms`); `value` is the whole-job rate."""
+    import json
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '16', '--no-cpu-baseline',
+           '--roofline-steps', '0', '--dp-buckets', '3']
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0')
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 32 and out['value'] > 0
+    d = out['dist']
+    assert d['backend'] == 'gloo' and d['world'] == 2 and len(d['ranks']) == 2
+    assert sorted(e['rank'] for e in d['ranks']) == [0, 1] and len({e['pid'] for e in d['ranks']}) == 2
+    assert d['distinct_devices'] == 1                      # both ranks on the single GPU of the test box
+    assert d['grad_buckets'] == 3 and d['grad_bytes'] > 100e6
+    assert d['allreduce_exposed_ms'] is not None and d['allreduce_exposed_ms'] >= 0

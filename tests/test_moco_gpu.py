@@ -462,3 +462,53 @@ def test_v2_engine_train_on_hip_moco(dtype, tol, tmp_path):
     ksd = arch.encoder_k.state_dict()
     for n in ('0.conv1.weight', '0.layer4.2.conv3.weight', '1.mlp.2.weight', '0.bn1._mean'):
         assert (ksd[n].cpu() - oracle.k[n]).abs().max() < (1e-3 if dtype == 'fp32' else 2e-2), n
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_step_graph_replay_is_bit_identical(dtype):
+    """hip/graph.py: the step (forward, EMA, key forward, InfoNCE, enqueue, clear_grad, backward incl. the side
+    stream, momentum-SGD) captured ONCE as a HIP graph and replayed equals the eager step bit for bit — loss,
+    accuracies, every parameter, the key encoder, the queue and its pointer — over steps that each see a NEW
+    batch and a NEW learning rate (both live outside the graph's launch parameters)."""
+    from passl_amd.hip.graph import StepGraph
+    K, N, steps = 512, 16, 6
+    gen = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(N, 3, 64, 64, generator=gen).to(DEV), torch.randn(N, 3, 64, 64, generator=gen).to(DEV))
+               for _ in range(steps)]
+    results = {}
+    for mode in ('eager', 'graph'):
+        oracle = MoCoOracle(K=K, seed=2, t_max=50)
+        model, opt, _ = U.build_product(K, dtype)
+        from passl_amd.solver.lr_scheduler import CosineAnnealingDecay
+        from passl_amd.solver.optimizer import Momentum
+        sched = CosineAnnealingDecay(0.03, T_max=20)              # a schedule that visibly moves in 6 steps
+        opt = Momentum(sched, parameters=list(model.parameters()), weight_decay=1e-4)
+        U.load_oracle_state(model, oracle)
+        model.train()
+
+        def full_step(xq, xk):
+            out = model(xq, xk, mode='train')
+            opt.clear_grad()
+            out['loss'].backward()
+            opt.step()
+            return out
+        sg = StepGraph(full_step, optimizers=[opt], replay_hooks=[model.on_graph_replay], warmup=1,
+                       enabled=(mode == 'graph'))
+        losses = []
+        for xq, xk in batches:
+            out = sg.run(xq, xk)
+            losses.append(torch.stack([out['loss'].detach().reshape(()), out['acc1'].detach().reshape(()).float()]))
+            sched.step()
+        torch.cuda.synchronize()
+        if mode == 'graph':
+            assert sg.captured and sg.replays == steps - 2          # 1 eager warm-up call, 1 capture call
+        results[mode] = dict(losses=torch.stack(losses).cpu(), q=model.arena_q.flat.clone().cpu(),
+                             k=model.arena_k.flat.clone().cpu(), queue=model.queue.clone().cpu(),
+                             ptr=int(model.queue_ptr[0].item()), host_ptr=model._ptr)
+        del sg, model, opt
+        torch.cuda.empty_cache()
+    a, b = results['eager'], results['graph']
+    assert a['ptr'] == b['ptr'] == a['host_ptr'] == b['host_ptr'] == (steps * N) % K
+    for key in ('losses', 'q', 'k', 'queue'):
+        assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), key
+    assert float(a['losses'][0, 0]) != float(a['losses'][-1, 0])
