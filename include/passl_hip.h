@@ -387,11 +387,14 @@ int passl_hip_layernorm_fwd(const void* x, const float* gamma, const float* beta
                             float* mean, float* rstd, int64_t M, int C, float eps, int dtype,
                             passl_stream_t stream);
 /* dx (+ dres when non-NULL: the gradient arriving through the residual branch that forked off x, so
- * that `x + f(LN(x))` needs no separate add); dgamma/dbeta (fp32 [C]) are ACCUMULATED into (atomics).
- * C <= 2048. */
+ * that `x + f(LN(x))` needs no separate add); dgamma/dbeta (fp32 [C]) are ACCUMULATED into: every block writes
+ * its column sums to a slab of `ws` (>= passl_hip_layernorm_bwd_ws_floats(M, C) floats) and a second launch adds
+ * the slabs in block order — no floating-point atomics, the result is bit-reproducible.  C <= 2048. */
+int64_t passl_hip_layernorm_bwd_ws_floats(int64_t M, int C);
 int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                             const float* rstd, const void* dres, void* dx, float* dgamma,
-                            float* dbeta, int64_t M, int C, int dtype, passl_stream_t stream);
+                            float* dbeta, int64_t M, int C, int dtype, float* ws, int64_t ws_floats,
+                            passl_stream_t stream);
 /* exact (erf) GELU and its backward dx = dy * gelu'(x); n % 8 == 0. */
 int passl_hip_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream);
 int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,
@@ -415,7 +418,8 @@ int passl_hip_mae_mask(const float* noise, int B, int L, int len_keep, int32_t* 
  * pos[1+ids_keep[b,k]];  x [B,L,D], pos [L+1,D], out [B,K+1,D]. */
 int passl_hip_mae_gather(const void* x, const float* cls, const float* pos, const int32_t* ids_keep,
                          void* out, int B, int L, int K, int D, int dtype, passl_stream_t stream);
-/* its backward: dx [B,L,D] fully written (zeros at masked patches), dcls += sum_b dout[b,0]. */
+/* its backward: dx [B,L,D] fully written (zeros at masked patches), dcls += sum_b dout[b,0] (images added in
+ * a fixed order). */
 int passl_hip_mae_gather_bwd(const void* dout, const int32_t* ids_restore, void* dx, float* dcls,
                              int B, int L, int K, int D, int dtype, passl_stream_t stream);
 /* decoder input (mae.py:516-527): out[b,0] = x[b,0] + pos[0]; out[b,1+l] = (r = ids_restore[b,l]) < K
@@ -423,20 +427,22 @@ int passl_hip_mae_gather_bwd(const void* dout, const int32_t* ids_restore, void*
 int passl_hip_mae_unshuffle(const void* x, const float* mask_token, const float* pos,
                             const int32_t* ids_restore, void* out, int B, int L, int K, int D,
                             int dtype, passl_stream_t stream);
-/* its backward: dx [B,K+1,D] fully written, dmask_token += sum over masked positions. */
+/* its backward: dx [B,K+1,D] fully written, dmask_token += sum over masked positions (token-block slabs in
+ * `ws`, >= 1024 * D floats, added in order: no atomics). */
 int passl_hip_mae_unshuffle_bwd(const void* dout, const int32_t* ids_keep, const int32_t* ids_restore,
                                 void* dx, float* dmask_token, int B, int L, int K, int D, int dtype,
-                                passl_stream_t stream);
+                                float* ws, int64_t ws_floats, passl_stream_t stream);
 /* imgs fp32 NCHW -> out [B*L, p*p*C] in `dtype`, column order (ph, pw, c): the patch-embed conv
  * (mae.py:87-121) as a GEMM, and MAE.patchify's order (mae.py:433-445). */
 int passl_hip_patchify(const float* img, void* out, int B, int C, int H, int W, int p, int dtype,
                        passl_stream_t stream);
 /* forward_loss (mae.py:541-557): pred fp32 [B, L+1, P] (row 0 of every image = cls, ignored);
  * loss[0] = sum_l mask * mean_P (pred - target)^2 / denom, target = patches of img, normalised per
- * patch ((x - mean)/sqrt(var_unbiased + 1e-6)) when norm_pix.  denom = sum(mask). */
+ * patch ((x - mean)/sqrt(var_unbiased + 1e-6)) when norm_pix.  denom = sum(mask).  ws: B * (L + 1) floats (the
+ * per-patch terms, summed in one fixed order). */
 int passl_hip_mae_loss_fwd(const float* img, const float* pred, const float* mask, float* loss, int B,
-                           int C, int H, int W, int p, int norm_pix, float denom,
-                           passl_stream_t stream);
+                           int C, int H, int W, int p, int norm_pix, float denom, float* ws,
+                           int64_t ws_floats, passl_stream_t stream);
 int passl_hip_mae_loss_bwd(const float* img, const float* pred, const float* mask,
                            const float* gscale, float* dpred, int B, int C, int H, int W, int p,
                            int norm_pix, float denom, passl_stream_t stream);
@@ -477,9 +483,16 @@ int passl_hip_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n,
 int passl_hip_embed_fwd(const int64_t* text, const float* table, const float* pos, void* out, int B,
                         int T, int C, int vocab, int dtype, passl_stream_t stream);
 /* its backward: dtable[text[b,t]] += dout[b,t] (scatter-add), dpos[t] += sum_b dout[b,t]; both fp32,
- * ACCUMULATED into.  C <= 2048. */
+ * ACCUMULATED into.  C <= 2048.  Bit-reproducible: the scatter-add accumulates 64-bit FIXED-POINT values (one
+ * power-of-two scale per launch, chosen from max|dout|) with integer atomics — exact and order-independent —
+ * in `acc` (>= passl_hip_embed_bwd_acc_bytes(vocab, C) bytes, a PERSISTENT buffer of the caller that is zero
+ * before the first call and is left zero by every call); the position sums go through slabs in `ws`
+ * (>= passl_hip_embed_bwd_ws_floats(B, T, C) floats, per-call scratch). */
+int64_t passl_hip_embed_bwd_acc_bytes(int vocab, int C);
+int64_t passl_hip_embed_bwd_ws_floats(int B, int T, int C);
 int passl_hip_embed_bwd(const int64_t* text, const void* dout, float* dtable, float* dpos, int B,
-                        int T, int C, int vocab, int dtype, passl_stream_t stream);
+                        int T, int C, int vocab, int dtype, void* acc, int64_t acc_bytes, float* ws,
+                        int64_t ws_floats, passl_stream_t stream);
 /* out[r] = x[idx[r]] for r < n (class-token rows x[:, 0], EOT rows x[i][argmax text[i]]). */
 int passl_hip_gather_rows(const void* x, const int32_t* idx, void* out, int n, int C, int dtype,
                           passl_stream_t stream);
@@ -497,9 +510,11 @@ int64_t passl_hip_clip_logits_ws_floats(int B, int D);
 int passl_hip_clip_logits_fwd(const float* img, const float* txt, float* logit_scale, int B, int D,
                               float clip_lo, float clip_hi, float* ws, float* logits,
                               passl_stream_t stream);
-/* dimg, dtxt [B,D] fully written; dlogit_scale[0] += sum(dlogits .* logits). */
+/* dimg, dtxt [B,D] fully written; dlogit_scale[0] += sum(dlogits .* logits) (<= 256 block partials in
+ * `scratch` (>= 256 floats), added in block order). */
 int passl_hip_clip_logits_bwd(const float* dlogits, const float* logits, const float* ws, int B, int D,
-                              float* dimg, float* dtxt, float* dlogit_scale, passl_stream_t stream);
+                              float* dimg, float* dtxt, float* dlogit_scale, float* scratch,
+                              passl_stream_t stream);
 /* Building blocks of the CROSS-RANK form of the same logits (BASELINE configs[4]: the negatives of
  * every rank; pattern of passl/models/mocov3.py:187-198 — gather the other modality's features, labels
  * arange(B) + B*rank): image_logits = exp(s) * I^_local . T^_all^T  [B][W*B] and the text counterpart.
@@ -519,8 +534,10 @@ int passl_hip_dot_acc(const float* a, const float* b, int64_t n, float* out, flo
                       passl_stream_t stream);
 /* CLIPHead (clip_head.py:24-36) with labels arange(B): out = {CE over the rows of logits (img_loss),
  * CE over its columns (= rows of text_logits; text_loss), their sum (loss)}; lse [2B] = row and
- * column log-sum-exp, saved for the backward. */
-int passl_hip_clip_ce_fwd(const float* logits, int B, float* lse, float* out, passl_stream_t stream);
+ * column log-sum-exp, saved for the backward.  ws: 2 * B floats (per-row / per-column terms, summed in a fixed
+ * order). */
+int passl_hip_clip_ce_fwd(const float* logits, int B, float* lse, float* out, float* ws, int64_t ws_floats,
+                          passl_stream_t stream);
 /* dlogits[i][j] = gloss/B * (softmax_row_i[j] + softmax_col_j[i] - 2 [i == j]); gloss: device scalar. */
 int passl_hip_clip_ce_bwd(const float* logits, const float* lse, const float* gloss, int B,
                           float* dlogits, passl_stream_t stream);
@@ -530,9 +547,10 @@ int passl_hip_clip_ce_bwd(const float* logits, const float* lse, const float* gl
 
 /* scores fp32 [N,C], labels int64 [N] -> lse [N] (row log-sum-exp, saved for the backward),
  * out = {mean cross-entropy, acc1 (%), acc5 (%)}.  Top-k membership by rank counting (ties resolve to
- * the lower index).  A label outside [0,C) makes the loss NaN. */
+ * the lower index).  A label outside [0,C) makes the loss NaN.  ws: 3 * N floats (per-row terms, summed in a
+ * fixed order). */
 int passl_hip_softmax_ce_fwd(const float* scores, const int64_t* labels, int N, int C, float* lse,
-                             float* out, passl_stream_t stream);
+                             float* out, float* ws, int64_t ws_floats, passl_stream_t stream);
 /* dscores[i][j] = gloss/N * (softmax(scores_i)[j] - [j == labels[i]]); gloss: device scalar. */
 int passl_hip_softmax_ce_bwd(const float* scores, const float* lse, const int64_t* labels,
                              const float* gloss, int N, int C, float* dscores, passl_stream_t stream);

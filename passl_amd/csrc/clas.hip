@@ -17,7 +17,7 @@ constexpr int kThreads = 256;
 __global__ void __launch_bounds__(kThreads) softmax_ce_fwd_kernel(const float* __restrict__ s,
                                                                   const int64_t* __restrict__ labels,
                                                                   int N, int C, float* __restrict__ lse,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ terms) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= N) return;
@@ -40,10 +40,20 @@ __global__ void __launch_bounds__(kThreads) softmax_ce_fwd_kernel(const float* _
     const float l = m + __logf(z);
     lse[row] = l;
     const float invN = 1.0f / (float)N;
-    atomicAdd(out + 0, ok ? (l - sl) * invN : NAN);
-    if (ok && cnt < 0.5f) atomicAdd(out + 1, 100.0f * invN);
-    if (ok && cnt < 4.5f) atomicAdd(out + 2, 100.0f * invN);
+    terms[row] = ok ? (l - sl) * invN : NAN;               // [3][N]: loss term, top-1 hit, top-5 hit
+    terms[N + row] = (ok && cnt < 0.5f) ? 100.0f * invN : 0.f;
+    terms[2 * N + row] = (ok && cnt < 4.5f) ? 100.0f * invN : 0.f;
   }
+}
+
+// out[k] = sum_i terms[k][i] in one fixed order (wave k)
+__global__ void __launch_bounds__(192) softmax_ce_finish_kernel(const float* __restrict__ terms, int N,
+                                                                float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float a = 0.f;
+  for (int i = lane; i < N; i += 64) a += terms[(int64_t)w * N + i];
+  a = wave_sum(a);
+  if (lane == 0) out[w] = a;
 }
 
 // ds[i][j] = g/N (exp(s_ij - lse_i) - [j == label_i])
@@ -63,13 +73,16 @@ __global__ void __launch_bounds__(kThreads) softmax_ce_bwd_kernel(const float* _
 
 }  // namespace
 
+// ws: 3 * N floats (per-row loss term and top-1 / top-5 hits, summed in a fixed order)
 extern "C" int passl_hip_softmax_ce_fwd(const float* scores, const int64_t* labels, int N, int C,
-                                        float* lse, float* out, passl_stream_t stream) {
-  if (!scores || !labels || !lse || !out || N <= 0 || C <= 0) return PASSL_EINVAL;
+                                        float* lse, float* out, float* ws, int64_t ws_floats,
+                                        passl_stream_t stream) {
+  if (!scores || !labels || !lse || !out || !ws || N <= 0 || C <= 0 || ws_floats < 3 * (int64_t)N)
+    return PASSL_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(out, 0, 3 * sizeof(float), st) != hipSuccess) return PASSL_ELAUNCH;
   hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, st, scores, labels, N,
-                     C, lse, out);
+                     C, lse, ws);
+  hipLaunchKernelGGL(softmax_ce_finish_kernel, dim3(1), dim3(192), 0, st, ws, N, out);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

@@ -98,25 +98,58 @@ __global__ void __launch_bounds__(kThreads) embed_fwd_kernel(const int64_t* __re
   }
 }
 
-// dE[text[b][t]] += dout[b][t] (fp32 atomics), dpos[t] += sum_b dout[b][t].  grid = (Tn, slabs);
-// a thread owns one 8-column chunk for a strided set of images; partial dpos sums are combined
-// through LDS and flushed with one atomic per column per block.
+// Token-embedding gradient dE[text[b][t]] += dout[b][t]: a scatter-add with arbitrary collisions (every padded
+// position of every caption hits the pad token's row).  Floating-point atomics would make the sum depend on the
+// order in which the hardware serialises them; instead every addend is converted to 64-bit fixed point with ONE
+// power-of-two scale for the whole launch and accumulated with INTEGER atomics — integer addition is associative,
+// so the result is independent of the order, bit-reproducible, and exact (the final fp32 value is the correctly
+// rounded sum).  Scale: 2^(61 - e) with 2^e > max|dout| * rows, so the total cannot overflow; an addend keeps all
+// 24 mantissa bits unless it is more than ~2^37 times smaller than the largest one.
+//   pass 1  embed_absmax_kernel   max|dout| via atomicMax on the float's bit pattern (order-independent)
+//   pass 2  embed_scatter_kernel  fixed-point atomics into acc[vocab][C] (int64), touched[tok] = 1;
+//                                 per-(position, image-slab) column sums of dout into the dpos slabs
+//   pass 3  embed_flush_kernel    dE[tok] += acc[tok] * 2^-(61-e) for touched tokens; acc and touched are cleared
+// acc / touched must be zero on entry and are zero again on return (a persistent workspace of the caller).
 template <typename T>
-__global__ void __launch_bounds__(kThreads) embed_bwd_kernel(const int64_t* __restrict__ text,
-                                                             const T* __restrict__ dout,
-                                                             float* __restrict__ dE,
-                                                             float* __restrict__ dpos, int B, int Tn,
-                                                             int C, int vocab) {
+__global__ void __launch_bounds__(kThreads) embed_absmax_kernel(const T* __restrict__ dout, int64_t nchunks,
+                                                                uint32_t* __restrict__ amax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nchunks; i += (int64_t)gridDim.x * kThreads) {
+    float v[8];
+    ElemTraits<T>::load8(dout + i * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(v[k]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));   // non-negative floats order as uints
+}
+
+__device__ __forceinline__ int embed_scale_exp(uint32_t amax_bits, int64_t rows) {
+  int e;
+  frexpf(__uint_as_float(amax_bits) * (float)rows, &e);      // amax * rows < 2^e
+  return min(61 - e, 120);                                   // (2^s must stay a finite float for tiny gradients)
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) embed_scatter_kernel(const int64_t* __restrict__ text,
+                                                                 const T* __restrict__ dout,
+                                                                 const uint32_t* __restrict__ amax,
+                                                                 unsigned long long* __restrict__ acc,
+                                                                 int32_t* __restrict__ touched,
+                                                                 float* __restrict__ pos_slab, int B, int Tn,
+                                                                 int C, int vocab) {
   extern __shared__ float red[];                       // [rows_par][C]
   const int chunks = C >> 3;
   const int rows_par = kThreads / chunks;
   const int ch = threadIdx.x % chunks, rl = threadIdx.x / chunks;
   const int t = blockIdx.x;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const uint32_t mx = *amax;
+  const float scale = mx ? ldexpf(1.0f, embed_scale_exp(mx, (int64_t)B * Tn)) : 0.f;
+  float accp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (rl < rows_par) {
     // run-length accumulation: captions are zero-padded, so at most positions the ids of consecutive
-    // images repeat (the pad id) — their gradients are summed in registers and flushed once
-    float run[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // images repeat (the pad id) — their gradients are summed (exactly, in fixed point) in registers first
+    long long run[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t run_tok = -1;
     for (int b = blockIdx.y * rows_par + rl; b < B; b += gridDim.y * rows_par) {
       const int64_t row = (int64_t)b * Tn + t;
@@ -124,35 +157,55 @@ __global__ void __launch_bounds__(kThreads) embed_bwd_kernel(const int64_t* __re
       ElemTraits<T>::load8(dout + row * C + ch * 8, v);
       const int64_t tok = text[row];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] += v[k];
+      for (int k = 0; k < 8; ++k) accp[k] += v[k];
       if (tok != run_tok) {
         if (run_tok >= 0 && run_tok < vocab) {
-          float* dst = dE + run_tok * C + ch * 8;
+          unsigned long long* dst = acc + run_tok * C + ch * 8;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) atomicAdd(dst + k, run[k]);
+          for (int k = 0; k < 8; ++k) atomicAdd(dst + k, (unsigned long long)run[k]);
+          if (ch == 0) touched[run_tok] = 1;
         }
         run_tok = tok;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) run[k] = v[k];
+        for (int k = 0; k < 8; ++k) run[k] = (long long)(v[k] * scale);     // power-of-two scale: exact
       } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) run[k] += v[k];
+        for (int k = 0; k < 8; ++k) run[k] += (long long)(v[k] * scale);
       }
     }
     if (run_tok >= 0 && run_tok < vocab) {
-      float* dst = dE + run_tok * C + ch * 8;
+      unsigned long long* dst = acc + run_tok * C + ch * 8;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) atomicAdd(dst + k, run[k]);
+      for (int k = 0; k < 8; ++k) atomicAdd(dst + k, (unsigned long long)run[k]);
+      if (ch == 0) touched[run_tok] = 1;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[rl * C + ch * 8 + k] = acc[k];
+    for (int k = 0; k < 8; ++k) red[rl * C + ch * 8 + k] = accp[k];
   }
   __syncthreads();
+  float* slab = pos_slab + ((int64_t)blockIdx.y * Tn + t) * C;          // [slabs][Tn][C]
   for (int c = threadIdx.x; c < C; c += kThreads) {
     float s = 0.f;
     for (int r = 0; r < rows_par; ++r) s += red[r * C + c];
-    atomicAdd(dpos + (int64_t)t * C + c, s);
+    slab[c] = s;
   }
+}
+
+// one wave per vocabulary row
+__global__ void __launch_bounds__(kThreads) embed_flush_kernel(unsigned long long* __restrict__ acc,
+                                                               int32_t* __restrict__ touched,
+                                                               const uint32_t* __restrict__ amax,
+                                                               float* __restrict__ dE, int vocab, int C,
+                                                               int64_t rows) {
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= vocab || !touched[tok]) return;
+  const double inv = ldexp(1.0, -embed_scale_exp(*amax, rows));
+  for (int c = threadIdx.x & 63; c < C; c += 64) {
+    const int64_t o = (int64_t)tok * C + c;
+    dE[o] += (float)((double)(long long)acc[o] * inv);
+    acc[o] = 0ull;
+  }
+  if ((threadIdx.x & 63) == 0) touched[tok] = 0;
 }
 
 // ------------------------------------------------------------------ row gather / scatter
@@ -340,7 +393,7 @@ __global__ void clip_scale_kernel(float* __restrict__ logit_scale, float* __rest
 // out = {img_loss (rows), text_loss (columns), loss = their sum}, labels = arange(B)
 __global__ void __launch_bounds__(kThreads) clip_ce_kernel(const float* __restrict__ Lm, int B,
                                                            float* __restrict__ stats,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ terms) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nrow_blocks = (B + 3) / 4;
   const float invB = 1.0f / (float)B;
@@ -357,8 +410,7 @@ __global__ void __launch_bounds__(kThreads) clip_ce_kernel(const float* __restri
     if (lane == 0) {
       const float l = m + __logf(z);
       stats[i] = l;
-      atomicAdd(out + 0, (l - r[i]) * invB);
-      atomicAdd(out + 2, (l - r[i]) * invB);
+      terms[i] = (l - r[i]) * invB;
     }
   } else {                                                // columns: one thread per column
     const int j = (blockIdx.x - nrow_blocks) * kThreads + threadIdx.x;
@@ -369,10 +421,21 @@ __global__ void __launch_bounds__(kThreads) clip_ce_kernel(const float* __restri
     for (int i = 0; i < B; ++i) z += __expf(Lm[(int64_t)i * B + j] - m);
     const float l = m + __logf(z);
     stats[B + j] = l;
-    const float d = (l - Lm[(int64_t)j * B + j]) * invB;
-    atomicAdd(out + 1, d);
-    atomicAdd(out + 2, d);
+    terms[B + j] = (l - Lm[(int64_t)j * B + j]) * invB;
   }
+}
+
+// out = {sum terms[0..B), sum terms[B..2B), their sum}, each in one fixed order (wave 0: rows, wave 1: columns)
+__global__ void __launch_bounds__(128) clip_ce_finish_kernel(const float* __restrict__ terms, int B,
+                                                             float* __restrict__ out) {
+  __shared__ float part[2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float a = 0.f;
+  for (int i = lane; i < B; i += 64) a += terms[w * B + i];
+  a = wave_sum(a);
+  if (lane == 0) part[w] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) { out[0] = part[0]; out[1] = part[1]; out[2] = part[0] + part[1]; }
 }
 
 // G[i][j] = g/B (exp(L - lse_row[i]) + exp(L - lse_col[j]) - 2 [i == j])
@@ -388,22 +451,6 @@ __global__ void __launch_bounds__(kThreads) clip_grad_kernel(const float* __rest
     const float l = Lm[e];
     G[e] = k * (__expf(l - stats[i]) + __expf(l - stats[B + j]) - (i == j ? 2.0f : 0.0f));
   }
-}
-
-// dscale += sum_e G[e] * L[e]     (d loss / d logit_scale: dL/ds = L)
-__global__ void __launch_bounds__(kThreads) clip_dscale_kernel(const float* __restrict__ G,
-                                                               const float* __restrict__ Lm,
-                                                               int64_t total,
-                                                               float* __restrict__ dscale) {
-  __shared__ float part[4];
-  float acc = 0.f;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * kThreads)
-    acc += G[e] * Lm[e];
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dscale, part[0] + part[1] + part[2] + part[3]);
 }
 
 // partial[b] = sum over block b's grid-stride elements of a[e] * b[e]  (fixed order inside the block)
@@ -466,23 +513,56 @@ extern "C" int passl_hip_embed_fwd(const int64_t* text, const float* table, cons
   return PASSL_OK;
 }
 
+int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, int accumulate,
+                             hipStream_t st);   // flat.hip
+
+static inline int embed_bwd_slabs(int B, int C) {
+  const int rows_par = kThreads / (C >> 3);
+  int slabs = (B + rows_par * 32 - 1) / (rows_par * 32);  // ~32 images per thread (long pad runs)
+  return slabs < 1 ? 1 : (slabs > 64 ? 64 : slabs);
+}
+
+// bytes of the PERSISTENT workspace (zero on first use, left zero by every call): int64 acc[vocab][C],
+// int32 touched[vocab] (+ padding), uint32 amax
+extern "C" int64_t passl_hip_embed_bwd_acc_bytes(int vocab, int C) {
+  if (vocab <= 0 || C <= 0) return 0;
+  return (int64_t)vocab * C * 8 + (((int64_t)vocab * 4 + 15) / 16) * 16 + 16;
+}
+
+// floats of the per-call scratch (position-gradient slabs)
+extern "C" int64_t passl_hip_embed_bwd_ws_floats(int B, int T_, int C) {
+  if (B <= 0 || T_ <= 0 || C <= 0 || (C & 7) || (C >> 3) > kThreads) return 0;
+  return (int64_t)embed_bwd_slabs(B, C) * T_ * C;
+}
+
 extern "C" int passl_hip_embed_bwd(const int64_t* text, const void* dout, float* dtable, float* dpos,
-                                   int B, int T_, int C, int vocab, int dtype, passl_stream_t stream) {
-  if (!text || !dout || !dtable || !dpos || B <= 0 || T_ <= 0 || C <= 0 || (C & 7) || vocab <= 0 ||
-      !aligned16(dout))
+                                   int B, int T_, int C, int vocab, int dtype, void* acc, int64_t acc_bytes,
+                                   float* ws, int64_t ws_floats, passl_stream_t stream) {
+  if (!text || !dout || !dtable || !dpos || !acc || !ws || B <= 0 || T_ <= 0 || C <= 0 || (C & 7) ||
+      vocab <= 0 || !aligned16(dout) || !aligned16(acc) || !aligned16(ws) || !aligned16(dpos))
     return PASSL_EINVAL;
   const int chunks = C >> 3;
   if (chunks > kThreads) return PASSL_EUNSUPPORTED;       // C <= 2048
+  if (acc_bytes < passl_hip_embed_bwd_acc_bytes(vocab, C) || ws_floats < passl_hip_embed_bwd_ws_floats(B, T_, C))
+    return PASSL_EINVAL;
+  hipStream_t st = as_stream(stream);
   const int rows_par = kThreads / chunks;
-  int slabs = (B + rows_par * 32 - 1) / (rows_par * 32);  // ~32 images per thread (long pad runs)
-  if (slabs < 1) slabs = 1;
-  if (slabs > 64) slabs = 64;
-  CLIP_DISPATCH(dtype, hipLaunchKernelGGL(embed_bwd_kernel<T>, dim3(T_, slabs), dim3(kThreads),
-                                          (size_t)rows_par * C * sizeof(float), as_stream(stream), text,
-                                          reinterpret_cast<const T*>(dout), dtable, dpos, B, T_, C,
-                                          vocab);)
+  const int slabs = embed_bwd_slabs(B, C);
+  unsigned long long* acc64 = reinterpret_cast<unsigned long long*>(acc);
+  int32_t* touched = reinterpret_cast<int32_t*>(acc64 + (int64_t)vocab * C);
+  uint32_t* amax = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(touched) + (((int64_t)vocab * 4 + 15) / 16) * 16);
+  const int64_t nchunks = (int64_t)B * T_ * chunks;
+  if (hipMemsetAsync(amax, 0, sizeof(uint32_t), st) != hipSuccess) return PASSL_ELAUNCH;
+  CLIP_DISPATCH(dtype,
+                hipLaunchKernelGGL(embed_absmax_kernel<T>, dim3(grid_for(nchunks)), dim3(kThreads), 0, st,
+                                   reinterpret_cast<const T*>(dout), nchunks, amax);
+                hipLaunchKernelGGL(embed_scatter_kernel<T>, dim3(T_, slabs), dim3(kThreads),
+                                   (size_t)rows_par * C * sizeof(float), st, text,
+                                   reinterpret_cast<const T*>(dout), amax, acc64, touched, ws, B, T_, C, vocab);)
+  hipLaunchKernelGGL(embed_flush_kernel, dim3((vocab + 3) / 4), dim3(kThreads), 0, st, acc64, touched, amax,
+                     dtable, vocab, C, (int64_t)B * T_);
   PASSL_RETURN_IF_LAUNCH_FAILED();
-  return PASSL_OK;
+  return passl_slab_reduce_launch(ws, dpos, (int64_t)T_ * C, slabs, 1, st);
 }
 
 extern "C" int passl_hip_gather_rows(const void* x, const int32_t* idx, void* out, int n, int C,
@@ -551,19 +631,23 @@ extern "C" int passl_hip_clip_logits_fwd(const float* img, const float* txt, flo
   return PASSL_OK;
 }
 
+// scratch: 256 floats (block partials of d logit_scale = sum dL o L, added in block order)
 extern "C" int passl_hip_clip_logits_bwd(const float* dlogits, const float* logits, const float* ws,
                                          int B, int D, float* dimg, float* dtxt, float* dlogit_scale,
-                                         passl_stream_t stream) {
-  if (!dlogits || !logits || !ws || !dimg || !dtxt || !dlogit_scale || B <= 0 || D <= 0 || (D & 15) ||
-      !aligned16(ws) || !aligned16(dimg) || !aligned16(dtxt))
+                                         float* scratch, passl_stream_t stream) {
+  if (!dlogits || !logits || !ws || !dimg || !dtxt || !dlogit_scale || !scratch || B <= 0 || D <= 0 ||
+      (D & 15) || !aligned16(ws) || !aligned16(dimg) || !aligned16(dtxt))
     return PASSL_EINVAL;
   hipStream_t st = as_stream(stream);
   const float* In = ws;
   const float* Tn = In + (int64_t)B * D;
   const float* inv = Tn + (int64_t)B * D;
   const float* alpha = inv + 2 * (int64_t)B;
-  hipLaunchKernelGGL(clip_dscale_kernel, dim3(grid_for((int64_t)B * B)), dim3(kThreads), 0, st, dlogits,
-                     logits, (int64_t)B * B, dlogit_scale);
+  int dblocks = grid_for((int64_t)B * B);
+  if (dblocks > 256) dblocks = 256;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(dblocks), dim3(kThreads), 0, st, dlogits, logits, (int64_t)B * B,
+                     scratch);
+  hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(1), 0, st, scratch, dblocks, dlogit_scale);
   // d I^ -> dimg, d T^ -> dtxt (then the normalisation backward in place)
   const int tiles = ((B + 15) / 16) * ((D + 15) / 16);
   hipLaunchKernelGGL(gemm_gx_kernel<false>, dim3((tiles + 3) / 4), dim3(kThreads), 0, st, dlogits, Tn,
@@ -576,13 +660,14 @@ extern "C" int passl_hip_clip_logits_bwd(const float* dlogits, const float* logi
   return PASSL_OK;
 }
 
-extern "C" int passl_hip_clip_ce_fwd(const float* logits, int B, float* lse, float* out,
-                                     passl_stream_t stream) {
-  if (!logits || !lse || !out || B <= 0) return PASSL_EINVAL;
+// ws: 2 * B floats (the per-row and per-column loss terms)
+extern "C" int passl_hip_clip_ce_fwd(const float* logits, int B, float* lse, float* out, float* ws,
+                                     int64_t ws_floats, passl_stream_t stream) {
+  if (!logits || !lse || !out || !ws || B <= 0 || ws_floats < 2 * (int64_t)B) return PASSL_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(out, 0, 3 * sizeof(float), st) != hipSuccess) return PASSL_ELAUNCH;
   hipLaunchKernelGGL(clip_ce_kernel, dim3((B + 3) / 4 + (B + kThreads - 1) / kThreads), dim3(kThreads),
-                     0, st, logits, B, lse, out);
+                     0, st, logits, B, lse, ws);
+  hipLaunchKernelGGL(clip_ce_finish_kernel, dim3(1), dim3(128), 0, st, ws, B, out);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

@@ -49,13 +49,12 @@ __device__ __forceinline__ int swz(int row, int slot) {
 
 // One element of a partial tile.  Deterministic forms: a single M-slice owns dW (plain
 // read-modify-write), several slices write their tile into slab `bz` of the workspace (summed in slice
-// order by slab_reduce_kernel afterwards).  Without a workspace the slices fall back to fp32 atomics
-// (order-dependent rounding; kept for callers of the bare C ABI that pass no workspace).
+// order by slab_reduce_kernel afterwards).  There is no atomic form: a multi-slice launch without a workspace
+// is rejected by the host code (PASSL_EINVAL).
 __device__ __forceinline__ void wg_store(const WParams& p, int bz, int oc, int jj, float v) {
   const int64_t o = (int64_t)oc * p.KDIM + jj;
   if (p.ws) p.ws[(int64_t)bz * p.NCOLS * p.KDIM + o] = v;
-  else if (p.nsplits == 1) p.dw[o] += v;
-  else atomicAdd(p.dw + o, v);
+  else p.dw[o] += v;
 }
 
 template <typename T, int BMo, int BNo>
@@ -936,6 +935,7 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
     p.dbg = dbg;
   }
   const int64_t n_out = (int64_t)d->NCOLS * K64;
+  if (splits > 1 && !d->ws) return PASSL_EINVAL;      // partial tiles need their slabs (no fp32 atomics)
   if (splits > 1 && d->ws) {
     if (!aligned16(d->ws) || !aligned16(d->dw) || d->ws_floats < (int64_t)splits * n_out) return PASSL_EINVAL;
     p.ws = d->ws;

@@ -222,8 +222,7 @@ __global__ void __launch_bounds__(kThreads) colsum_kernel(const T* __restrict__ 
     for (int l = 0; l < 8; ++l) s += red[l][threadIdx.x];
     if (mode == 0) out[col] = s;
     else if (mode == 1) out[col] += s;
-    else if (mode == 2) ws[(int64_t)blockIdx.y * C + col] = s;
-    else atomicAdd(out + col, s);
+    else ws[(int64_t)blockIdx.y * C + col] = s;           // mode 2: slab, added in order afterwards
   }
 }
 
@@ -349,10 +348,7 @@ static int colsum_impl(const void* x, float* out, int64_t M, int C, int dtype, b
     if (!aligned16(ws) || !aligned16(out) || ws_floats < (int64_t)slabs * C) return PASSL_EINVAL;
     mode = 2;
   } else {
-    mode = 3;
-    if (!accumulate &&
-        hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, as_stream(stream)) != hipSuccess)
-      return PASSL_ELAUNCH;
+    return PASSL_EINVAL;                                // several row slabs need the workspace (no fp32 atomics)
   }
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3((C + 255) / 256, slabs),
                                            dim3(kThreads), 0, as_stream(stream),

@@ -53,7 +53,9 @@ __global__ void __launch_bounds__(kThreads) layernorm_fwd_kernel(
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma.  The column sums of dy*xhat
 // and dy are kept in registers (a lane owns the same column chunks for every row its wave visits),
-// combined across the 4 waves through LDS and flushed with one atomic per column per block.
+// combined across the 4 waves through LDS and written to slab `blockIdx.x` of the workspace ([nb][2][C]);
+// ln_param_reduce_kernel then adds the slabs in block order into dgamma / dbeta (no atomics: the sums are
+// bit-reproducible from run to run).
 constexpr int kLnMaxChunks = 4;            // C <= 2048
 
 // NCH = number of 512-column chunks a lane owns (C <= 512 * NCH).  A wave handles RPI rows per
@@ -64,8 +66,7 @@ template <typename T, int NCH>
 __global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const T* __restrict__ dres,
-    T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
-    int rows_per_block) {
+    T* __restrict__ dx, float* __restrict__ slab, int M, int C, int rows_per_block) {
   extern __shared__ float col[];            // [4 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_block;
@@ -168,10 +169,31 @@ __global__ void __launch_bounds__(kThreads) layernorm_bwd_kernel(
     }
   }
   __syncthreads();
+  float* mine = slab + (int64_t)blockIdx.x * 2 * C;
   for (int c = threadIdx.x; c < C; c += kThreads) {
-    atomicAdd(dgamma + c, col[c] + col[2 * C + c] + col[4 * C + c] + col[6 * C + c]);
-    atomicAdd(dbeta + c, col[C + c] + col[3 * C + c] + col[5 * C + c] + col[7 * C + c]);
+    mine[c] = col[c] + col[2 * C + c] + col[4 * C + c] + col[6 * C + c];
+    mine[C + c] = col[C + c] + col[3 * C + c] + col[5 * C + c] + col[7 * C + c];
   }
+}
+
+// dgamma[c] += sum_b slab[b][0][c], dbeta[c] += sum_b slab[b][1][c]: 16 columns x 16 slab lanes per block; lane z
+// adds slabs z, z+16, ... in ascending order, the 16 partial sums are combined in lane order.
+__global__ void __launch_bounds__(kThreads) ln_param_reduce_kernel(const float* __restrict__ slab, int nb, int C,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta) {
+  __shared__ float red[16][16];
+  const int cl = threadIdx.x & 15, z = threadIdx.x >> 4;
+  const int c2 = blockIdx.x * 16 + cl;                    // column of the [2C] slab row
+  float a = 0.f;
+  if (c2 < 2 * C)
+    for (int b = z; b < nb; b += 16) a += slab[(int64_t)b * 2 * C + c2];
+  red[z][cl] = a;
+  __syncthreads();
+  if (z != 0 || c2 >= 2 * C) return;
+#pragma unroll
+  for (int l = 1; l < 16; ++l) a += red[l][cl];
+  if (c2 < C) dgamma[c2] += a;
+  else dbeta[c2 - C] += a;
 }
 
 // ------------------------------------------------------------------ GELU (exact erf form)
@@ -264,26 +286,19 @@ __global__ void __launch_bounds__(kThreads) mae_gather_kernel(
   }
 }
 
-// backward of the gather: dx[b, l] = dout[b, 1 + rank] if rank < K else 0 (rank = ids_restore);
-// dcls += sum_b dout[b, 0]
+// backward of the gather: dx[b, l] = dout[b, 1 + rank] if rank < K else 0 (rank = ids_restore)
 template <typename T>
 __global__ void __launch_bounds__(kThreads) mae_gather_bwd_kernel(
     const T* __restrict__ dout, const int32_t* __restrict__ ids_restore, T* __restrict__ dx,
-    float* __restrict__ dcls, int B, int L, int K, int D) {
+    int B, int L, int K, int D) {
   const int cpr = D >> 3;
-  const int64_t total = (int64_t)B * (L + 1) * cpr;
+  const int64_t total = (int64_t)B * L * cpr;
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * kThreads) {
     const int c = (int)(i % cpr) * 8;
     const int64_t tok = i / cpr;
-    const int l = (int)(tok % (L + 1)), b = (int)(tok / (L + 1));
+    const int l = (int)(tok % L), b = (int)(tok / L);
     float v[8];
-    if (l == L) {               // the extra slot handles the cls row of image b
-      ld8(dout + ((int64_t)b * (K + 1)) * D + c, v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(dcls + c + e, v[e]);
-      continue;
-    }
     const int rank = ids_restore[(int64_t)b * L + l];
     if (rank < K) ld8(dout + ((int64_t)b * (K + 1) + 1 + rank) * D + c, v);
     else {
@@ -292,6 +307,25 @@ __global__ void __launch_bounds__(kThreads) mae_gather_bwd_kernel(
     }
     ElemTraits<T>::store8(dx + ((int64_t)b * L + l) * D + c, v);
   }
+}
+
+// dcls[c] += sum_b dout[b, 0, c] (row stride `stride` elements): 32 columns x 8 image lanes per block, lane z adds
+// images z, z+8, ... in ascending order, the 8 partial sums are combined in lane order (no atomics).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cls_grad_kernel(const T* __restrict__ dout, float* __restrict__ dcls,
+                                                            int B, int64_t stride, int D) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, z = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a = 0.f;
+  if (c < D)
+    for (int b = z; b < B; b += 8) a += ElemTraits<T>::ld(dout + (int64_t)b * stride + c);
+  red[z][cl] = a;
+  __syncthreads();
+  if (z != 0 || c >= D) return;
+#pragma unroll
+  for (int l = 1; l < 8; ++l) a += red[l][cl];
+  dcls[c] += a;
 }
 
 // decoder input: out[b,0] = x[b,0] + pos[0]; out[b,1+l] = (r < K ? x[b,1+r] : mask_token) + pos[1+l]
@@ -322,7 +356,8 @@ __global__ void __launch_bounds__(kThreads) mae_unshuffle_kernel(
 // token k sits at position l = ids_keep[b,k]); dmask_token += sum over masked positions.
 // A thread keeps ONE column chunk for all the tokens it visits (block = 32 chunks x 8 token lanes,
 // grid.y = token slabs), so the mask-token gradient is accumulated in registers, reduced over the
-// token lanes in LDS and flushed with one atomic per column per block.
+// token lanes in LDS and written to slab `blockIdx.y` of the workspace ([slabs][D]); the slabs are added in order
+// afterwards (passl_slab_reduce_launch): no atomics.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) mae_unshuffle_bwd_kernel(
     const T* __restrict__ dout, const int32_t* __restrict__ ids_keep,
@@ -360,7 +395,7 @@ __global__ void __launch_bounds__(kThreads) mae_unshuffle_bwd_kernel(
     float s = 0.f;
 #pragma unroll
     for (int l = 0; l < 8; ++l) s += red[l][threadIdx.x];
-    atomicAdd(dmask + col, s);
+    dmask[(int64_t)blockIdx.y * D + col] = s;             // (the workspace slab)
   }
 }
 
@@ -403,6 +438,7 @@ __global__ void __launch_bounds__(kThreads) mae_loss_kernel(
   const float m = t == 0 ? 0.f : mask[(int64_t)b * L + t - 1];
   if (m == 0.f) {
     if (BWD) for (int i = lane; i < P; i += 64) dr[i] = 0.f;
+    else if (lane == 0) out[patch] = 0.f;
     return;
   }
   const int l = t - 1, w_ = l % gw, h_ = l / gw;
@@ -433,8 +469,20 @@ __global__ void __launch_bounds__(kThreads) mae_loss_kernel(
   }
   if (!BWD) {
     acc = wave_sum(acc);
-    if (lane == 0) atomicAdd(out, acc / (float)P * inv_denom);
+    if (lane == 0) out[patch] = acc / (float)P * inv_denom;        // (the per-patch workspace)
   }
+}
+
+// out[0] = sum_i v[i] in ONE fixed order: thread t adds elements t, t+256, ...; wave shuffles; 4 wave sums in order
+__global__ void __launch_bounds__(kThreads) ordered_sum_kernel(const float* __restrict__ v, int64_t n,
+                                                               float* __restrict__ out) {
+  __shared__ float part[4];
+  float a = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += kThreads) a += v[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = part[0] + part[1] + part[2] + part[3];
 }
 
 // ------------------------------------------------------------------ AdamW (flat buffer)
@@ -512,29 +560,42 @@ extern "C" int passl_hip_layernorm_fwd(const void* x, const float* gamma, const 
   return PASSL_OK;
 }
 
+static inline void ln_bwd_blocks(int64_t M, int& rows, int& nb) {
+  // 16..64 rows per block: >= 2 blocks per CU for the short-sequence shapes (CLIP: M = 6400 / 9856)
+  rows = (int)(M / 1024);
+  rows = rows < 16 ? 16 : (rows > 64 ? 64 : rows);
+  nb = (int)((M + rows - 1) / rows);
+}
+
+extern "C" int64_t passl_hip_layernorm_bwd_ws_floats(int64_t M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  int rows, nb;
+  ln_bwd_blocks(M, rows, nb);
+  return (int64_t)nb * 2 * C;
+}
+
 extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma,
                                        const float* mean, const float* rstd, const void* dres,
                                        void* dx, float* dgamma, float* dbeta, int64_t M, int C,
-                                       int dtype, passl_stream_t stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0 || C <= 0 ||
+                                       int dtype, float* ws, int64_t ws_floats, passl_stream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || M <= 0 || C <= 0 ||
       (C & 7) || C > 512 * kLnMaxChunks || !aligned16(dy) || !aligned16(x) || !aligned16(dx) ||
-      !aligned16(gamma) || (dres && !aligned16(dres)))
+      !aligned16(gamma) || (dres && !aligned16(dres)) || ws_floats < passl_hip_layernorm_bwd_ws_floats(M, C))
     return PASSL_EINVAL;
-  // 16..64 rows per block: >= 2 blocks per CU for the short-sequence shapes (CLIP: M = 6400 / 9856);
-  // the per-block dgamma/dbeta atomics (2 C) were measured not to matter at these block counts
-  int rows = (int)(M / 1024);
-  rows = rows < 16 ? 16 : (rows > 64 ? 64 : rows);
-  const int nb = (int)((M + rows - 1) / rows);
+  int rows, nb;
+  ln_bwd_blocks(M, rows, nb);
 #define LN_BWD_LAUNCH(NCH)                                                                          \
   VIT_DISPATCH(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T, NCH>), dim3(nb), dim3(kThreads),  \
                                          8 * C * sizeof(float), as_stream(stream),                  \
                                          reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x), \
                                          gamma, mean, rstd, reinterpret_cast<const T*>(dres),       \
-                                         reinterpret_cast<T*>(dx), dgamma, dbeta, (int)M, C, rows);)
+                                         reinterpret_cast<T*>(dx), ws, (int)M, C, rows);)
   if (C <= 512) { LN_BWD_LAUNCH(1) }
   else if (C <= 1024) { LN_BWD_LAUNCH(2) }
   else { LN_BWD_LAUNCH(4) }
 #undef LN_BWD_LAUNCH
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 15) / 16), dim3(kThreads), 0, as_stream(stream), ws, nb,
+                     C, dgamma, dbeta);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -590,9 +651,11 @@ extern "C" int passl_hip_mae_gather_bwd(const void* dout, const int32_t* ids_res
   if (!dout || !ids_restore || !dx || !dcls || B <= 0 || L <= 0 || K <= 0 || K > L || D <= 0 || (D & 7))
     return PASSL_EINVAL;
   VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_gather_bwd_kernel<T>,
-                                         dim3(grid_for((int64_t)B * (L + 1) * (D >> 3))), dim3(kThreads), 0,
+                                         dim3(grid_for((int64_t)B * L * (D >> 3))), dim3(kThreads), 0,
                                          as_stream(stream), reinterpret_cast<const T*>(dout), ids_restore,
-                                         reinterpret_cast<T*>(dx), dcls, B, L, K, D);)
+                                         reinterpret_cast<T*>(dx), B, L, K, D);
+               hipLaunchKernelGGL(cls_grad_kernel<T>, dim3((D + 31) / 32), dim3(kThreads), 0, as_stream(stream),
+                                  reinterpret_cast<const T*>(dout), dcls, B, (int64_t)(K + 1) * D, D);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -611,23 +674,29 @@ extern "C" int passl_hip_mae_unshuffle(const void* x, const float* mask_token, c
   return PASSL_OK;
 }
 
+int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, int accumulate,
+                             hipStream_t st);   // flat.hip
+
+// workspace: 1024 * D floats cover every shape
 extern "C" int passl_hip_mae_unshuffle_bwd(const void* dout, const int32_t* ids_keep,
                                            const int32_t* ids_restore, void* dx, float* dmask_token,
-                                           int B, int L, int K, int D, int dtype,
-                                           passl_stream_t stream) {
-  if (!dout || !ids_keep || !ids_restore || !dx || !dmask_token || B <= 0 || L <= 0 || K <= 0 ||
-      K > L || D <= 0 || (D & 7))
+                                           int B, int L, int K, int D, int dtype, float* ws,
+                                           int64_t ws_floats, passl_stream_t stream) {
+  if (!dout || !ids_keep || !ids_restore || !dx || !dmask_token || !ws || B <= 0 || L <= 0 || K <= 0 ||
+      K > L || D <= 0 || (D & 7) || !aligned16(ws) || !aligned16(dmask_token))
     return PASSL_EINVAL;
   const int64_t ntok = (int64_t)B * (L + 1);
   int slabs = (int)((ntok + 127) / 128);
   if (slabs > 1024) slabs = 1024;
   const int tpb = (int)((ntok + slabs - 1) / slabs);
+  slabs = (int)((ntok + tpb - 1) / tpb);
+  if (ws_floats < (int64_t)slabs * D) return PASSL_EINVAL;
   VIT_DISPATCH(dtype, hipLaunchKernelGGL(mae_unshuffle_bwd_kernel<T>, dim3((D + 255) / 256, slabs),
                                          dim3(kThreads), 0, as_stream(stream),
                                          reinterpret_cast<const T*>(dout), ids_keep, ids_restore,
-                                         reinterpret_cast<T*>(dx), dmask_token, B, L, K, D, tpb);)
+                                         reinterpret_cast<T*>(dx), ws, B, L, K, D, tpb);)
   PASSL_RETURN_IF_LAUNCH_FAILED();
-  return PASSL_OK;
+  return passl_slab_reduce_launch(ws, dmask_token, D, slabs, 1, as_stream(stream));
 }
 
 extern "C" int passl_hip_patchify(const float* img, void* out, int B, int C, int H, int W, int p,
@@ -641,16 +710,19 @@ extern "C" int passl_hip_patchify(const float* img, void* out, int B, int C, int
   return PASSL_OK;
 }
 
+// workspace: one float per (image, token) row = B * (L + 1)
 extern "C" int passl_hip_mae_loss_fwd(const float* img, const float* pred, const float* mask,
                                       float* loss, int B, int C, int H, int W, int p, int norm_pix,
-                                      float denom, passl_stream_t stream) {
-  if (!img || !pred || !mask || !loss || B <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p) || !(denom > 0.f))
+                                      float denom, float* ws, int64_t ws_floats, passl_stream_t stream) {
+  if (!img || !pred || !mask || !loss || !ws || B <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p) ||
+      !(denom > 0.f))
     return PASSL_EINVAL;
   hipStream_t st = as_stream(stream);
-  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return PASSL_ELAUNCH;
   const int64_t rows = (int64_t)B * ((H / p) * (W / p) + 1);
+  if (ws_floats < rows) return PASSL_EINVAL;
   hipLaunchKernelGGL(mae_loss_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(kThreads), 0, st, img,
-                     pred, mask, nullptr, loss, nullptr, B, C, H, W, p, norm_pix, 1.0f / denom);
+                     pred, mask, nullptr, ws, nullptr, B, C, H, W, p, norm_pix, 1.0f / denom);
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(kThreads), 0, st, ws, rows, loss);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

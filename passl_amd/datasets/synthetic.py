@@ -88,6 +88,17 @@ class ImageNet(object):
             'SyntheticTwoView` for benchmarking/parity runs.')
 
 
+@DATASETS.register()
+class ImageFolder(object):
+    """The v2 configs' dataset (reference passl/data/dataset/imagefolder_dataset.py)."""
+
+    def __init__(self, **kwargs):
+        raise NotImplementedError(
+            'The image-folder dataset + CPU augmentation pipeline of the reference is outside the MI355X hot path '
+            '(SURVEY §2.1 row 9).  Use `-o DataLoader.Train.dataset.name=SyntheticTwoView` for benchmarking / '
+            'parity runs (the remaining dataset keys of the yaml are ignored by the synthetic source).')
+
+
 class SyntheticLoader(object):
     def __init__(self, dataset, batch_size, device, drop_last=True):
         self.dataset = dataset

@@ -9,9 +9,13 @@ new kernels.  Kept from the reference: the attributes the loops read (``accum_st
 ``print_batch_step``, ``save_interval``, ``lr_decay_unit``, ``optimizer``, ``lr_scheduler``, ``model``,
 ``train_dataloader``, ``config``, ``mode``, ``training``, ``output_dir``, ``model_name``), seed + rank
 seeding, ``max_train_step``, data-parallel start-up broadcast.  Not carried over (outside the hot
-path): FP16 GradScaler (bf16 compute needs no loss scaling: ``Global.compute_dtype``), EMA of the
-student weights, VisualDL, export, evaluation loops.
+path): FP16 GradScaler (an ``FP16:`` section — level O1 / O2 with its GradScaler, engine.py:177-210 — selects
+reduced-precision compute, which here is bf16 with fp32 master weights and moments and needs no loss scaling;
+``Global.compute_dtype`` overrides), EMA of the student weights, VisualDL, export, evaluation loops.
+``runtime_info_hub`` (engine.py:346-349) carries epochs / max_steps / total_iterations to the models that read
+them (MoCo-v3's momentum schedule).
 """
+import inspect
 import copy
 import logging
 import random
@@ -25,6 +29,7 @@ from ..hip import config as hip_config
 from ..models import build_model
 from ..solver.builder import LRSCHEDULERS, OPTIMIZERS
 from ..utils.config import AttrDict
+from ..utils.infohub import runtime_info_hub
 from ..utils.registry import build_from_config
 from . import loops
 from .trainer import _init_distributed
@@ -65,6 +70,14 @@ class Engine(object):
 
         assert g['device'] in ['cpu', 'gpu']
         self.device = hip_config.set_device(g['device'])
+        fp16 = config.get('FP16', None)
+        if fp16 is not None:
+            level = fp16.get('level', 'O2')
+            assert level in ['O0', 'O1', 'O2']
+            if not g.get('compute_dtype', None):
+                hip_config.set_compute_dtype('fp32' if level == 'O0' else 'bf16')
+            self.logger.info('FP16 level %s -> %s compute, fp32 master weights; GradScaler settings are not used '
+                             '(bf16 keeps fp32\'s exponent range)', level, 'fp32' if level == 'O0' else 'bf16')
         if g.get('compute_dtype', None):
             hip_config.set_compute_dtype(g['compute_dtype'])
         rank, world = _init_distributed(self.device)
@@ -99,6 +112,11 @@ class Engine(object):
             per_unit = len(self.train_dataloader) if self.lr_decay_unit == 'step' else 1
             if sched_cfg.name == 'CosineAnnealingDecay' and 'T_max' not in sched_cfg:
                 sched_cfg.T_max = g['epochs'] * per_unit        # decay over the whole run
+            # build_lr_scheduler (passl/scheduler/__init__.py:22-23) hands every v2 scheduler the run length
+            accepted = inspect.signature(LRSCHEDULERS.get(sched_cfg.name).__init__).parameters
+            if 'step_each_epoch' in accepted:
+                sched_cfg.update({'epochs': g['epochs'], 'step_each_epoch': len(self.train_dataloader),
+                                  'decay_unit': self.lr_decay_unit})
             self.lr_scheduler = build_from_config(sched_cfg, LRSCHEDULERS)
         name = opt_cfg.pop('name')
         params = list(self.model.parameters())
@@ -123,6 +141,12 @@ class Engine(object):
         train_loop_name = g.get('train_loop')
         self.train_loop = getattr(loops, train_loop_name)(self, epochs=g['epochs'],
                                                           max_train_step=self.max_train_step, val_loop=None)
+        self.init_runtime_info_hub()
+
+    def init_runtime_info_hub(self):
+        runtime_info_hub.epochs = self.train_loop.epochs
+        runtime_info_hub.max_steps = self.train_loop.max_steps
+        runtime_info_hub.total_iterations = self.train_loop.global_step
 
     # ---- engine.py:319-347
     @property

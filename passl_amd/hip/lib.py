@@ -104,7 +104,8 @@ SIGNATURES = {
     'passl_hip_ntxent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p,
                                    c_p, c_p, c_p, c_p]),
     'passl_hip_layernorm_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p]),
-    'passl_hip_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p]),
+    'passl_hip_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p]),
+    'passl_hip_layernorm_bwd_ws_floats': (c_l, [c_l, c_i]),
     'passl_hip_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_attention_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
@@ -112,30 +113,32 @@ SIGNATURES = {
     'passl_hip_quick_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_quick_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_embed_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
-    'passl_hip_embed_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_embed_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p, c_l, c_p]),
+    'passl_hip_embed_bwd_acc_bytes': (c_l, [c_i, c_i]),
+    'passl_hip_embed_bwd_ws_floats': (c_l, [c_i, c_i, c_i]),
     'passl_hip_gather_rows': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'passl_hip_scatter_rows': (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p]),
     'passl_hip_eot_index': (c_i, [c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_clip_logits_ws_floats': (c_l, [c_i, c_i]),
     'passl_hip_clip_logits_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
-    'passl_hip_clip_logits_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'passl_hip_clip_logits_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'passl_hip_clip_scale': (c_i, [c_p, c_p, c_f, c_f, c_p]),
     'passl_hip_gemm_f32_nt': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     'passl_hip_gemm_f32_gx': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     'passl_hip_dot_acc': (c_i, [c_p, c_p, c_l, c_p, c_p, c_p]),
-    'passl_hip_clip_ce_fwd': (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    'passl_hip_clip_ce_fwd': (c_i, [c_p, c_i, c_p, c_p, c_p, c_l, c_p]),
     'passl_hip_clip_ce_bwd': (c_i, [c_p, c_p, c_p, c_i, c_p, c_p]),
     'passl_hip_mae_mask': (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     'passl_hip_mae_gather': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_mae_gather_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_mae_unshuffle': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
-    'passl_hip_mae_unshuffle_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_mae_unshuffle_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_l, c_p]),
     'passl_hip_patchify': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
-    'passl_hip_mae_loss_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    'passl_hip_mae_loss_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p]),
     'passl_hip_mae_loss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'passl_hip_adamw': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
     'passl_hip_adamw_dev': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
-    'passl_hip_softmax_ce_fwd': (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    'passl_hip_softmax_ce_fwd': (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p]),
     'passl_hip_softmax_ce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),
     'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),

@@ -271,16 +271,20 @@ class _BNActFn(Function):
     def backward(ctx, dz):
         y, st, mask = ctx.saved_tensors
         layer = ctx.layer
-        for p in (layer.weight, layer.bias):
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
+        if layer.affine:
+            for p in (layer.weight, layer.bias):
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            gamma, dgamma, dbeta = layer.weight.detach(), layer.weight.grad, layer.bias.grad
+        else:
+            gamma, dgamma, dbeta = layer._const[0], layer._dscratch[0], layer._dscratch[1]
         want_dres = ctx.has_res and (ctx.needs_input_grad[3] or ctx.res_slot is not None)
         # the consumer conv's data-gradient launch may already have masked dz and reduced it
         fused = ctx.link.fused if ctx.link is not None else None
         if ctx.link is not None:
             ctx.link.y = ctx.link.st = ctx.link.mask = ctx.link.fused = None     # drop the references
-        dx, dres = ops.bn_bwd(dz.contiguous(), mask, y, layer.weight.detach(), st[0], st[1],
-                              layer.weight.grad, layer.bias.grad, relu=ctx.relu_mode,
+        dx, dres = ops.bn_bwd(dz.contiguous(), mask, y, gamma, st[0], st[1],
+                              dgamma, dbeta, relu=ctx.relu_mode,
                               want_dres=want_dres, scale=st[2], shift=st[3], fused=fused)
         if ctx.res_slot is not None:
             ctx.res_slot.put(dres)
@@ -302,8 +306,20 @@ class _BatchNormBase(Layer):
         self._momentum, self._epsilon = momentum, epsilon
         self._use_global_stats = use_global_stats
         self.num_features = num_features
-        self.weight = tnn.Parameter(torch.ones(num_features, device=dev))
-        self.bias = tnn.Parameter(torch.zeros(num_features, device=dev))
+        # weight_attr=False / bias_attr=False (both or neither): no gamma / beta (the last BatchNorm of MoCo-v3's
+        # projector and predictor, passl/models/mocov3.py:152-157).  The kernels read constant 1 / 0 vectors and
+        # write the unused d-gamma / d-beta into a scratch pair; neither shows up in parameters() or state_dict().
+        if (weight_attr is False) != (bias_attr is False):
+            raise NotImplementedError('BatchNorm with only one of weight / bias')
+        self.affine = weight_attr is not False
+        if self.affine:
+            self.weight = tnn.Parameter(torch.ones(num_features, device=dev))
+            self.bias = tnn.Parameter(torch.zeros(num_features, device=dev))
+        else:
+            self.weight = self.bias = None
+            self.register_buffer('_const', torch.stack([torch.ones(num_features, device=dev),
+                                                        torch.zeros(num_features, device=dev)]), persistent=False)
+            self.register_buffer('_dscratch', torch.zeros(2, num_features, device=dev), persistent=False)
         self.register_buffer('_mean', torch.zeros(num_features, device=dev))
         self.register_buffer('_variance', torch.ones(num_features, device=dev))
         self._rt = None
@@ -318,14 +334,20 @@ class _BatchNormBase(Layer):
         if rt is not None and rt.arena.bn_affine is not None:
             s, e = rt.bn_slice
             return rt.arena.bn_affine[0][s:e], rt.arena.bn_affine[1][s:e]
-        scale = self.weight.detach() * torch.rsqrt(self._variance + self._epsilon)
-        return scale, self.bias.detach() - self._mean * scale
+        gamma, beta = self.gamma_beta()
+        scale = gamma * torch.rsqrt(self._variance + self._epsilon)
+        return scale, beta - self._mean * scale
+
+    def gamma_beta(self):
+        if self.affine:
+            return self.weight.detach(), self.bias.detach()
+        return self._const[0], self._const[1]
 
     def forward(self, y, residual=None, relu=False, stats=None, res_slot=None):
         """stats: fused statistics from the producing conv's epilogue (Conv2D.forward(...,
         want_stats=True)); res_slot: GradSlot that receives the residual branch's gradient."""
         if self.uses_global_stats():
-            if torch.is_grad_enabled() and (y.requires_grad or self.weight.requires_grad):
+            if torch.is_grad_enabled() and (y.requires_grad or (self.affine and self.weight.requires_grad)):
                 raise NotImplementedError('frozen BatchNorm inside a differentiated graph is not on '
                                           'the MoCo hot path (key encoder runs under no_grad)')
             scale, shift = self.infer_affine()
@@ -333,7 +355,8 @@ class _BatchNormBase(Layer):
         # the output carries a BNLink so that a sole-consumer conv can take over the backward reduction
         box = [None] if (torch.is_grad_enabled() and y.dtype == torch.bfloat16 and
                          config.fused_bn_backward()) else None
-        z = _BNActFn.apply(y, self.weight, self.bias, residual, self, relu, stats, res_slot, box)
+        gamma, beta = (self.weight, self.bias) if self.affine else (self._const[0], self._const[1])
+        z = _BNActFn.apply(y, gamma, beta, residual, self, relu, stats, res_slot, box)
         if box is not None and box[0] is not None:
             z._passl_bn_link = box[0]
         return z
@@ -691,8 +714,11 @@ class EncoderArena:
 
     ALIGN = 8   # elements; keeps every slot 32-byte aligned in fp32 and 16-byte aligned in bf16
 
-    def __init__(self, module, trainable=True, dtype=None):
+    def __init__(self, module, trainable=True, dtype=None, exclude=()):
+        """exclude: sub-layers whose own parameters / statistics live elsewhere (a frozen layer inside a trainable
+        encoder gets a non-trainable arena of its own, e.g. MoCo-v3's patch embedding)."""
         self.module = module
+        skip = {id(m) for m in exclude}
         self.trainable = trainable
         self.dtype = dtype or config.get_compute_dtype()
         self.reducer = None
@@ -700,6 +726,8 @@ class EncoderArena:
         params = []      # (owner, name, kind)
         seen = set()
         for mod in module.modules():
+            if id(mod) in skip:
+                continue
             for name, p in mod._parameters.items():
                 if p is None or id(p) in seen:
                     continue
@@ -708,7 +736,7 @@ class EncoderArena:
                                   and name == 'weight') else \
                     ('linw' if isinstance(mod, Linear) and name == 'weight' else 'vec')
                 params.append((mod, name, kind))
-        stats = [(mod, n) for mod in module.modules() if isinstance(mod, _BatchNormBase)
+        stats = [(mod, n) for mod in module.modules() if isinstance(mod, _BatchNormBase) and id(mod) not in skip
                  for n in ('_mean', '_variance')]
         if not params:
             raise ValueError('EncoderArena over a module without parameters')
@@ -786,7 +814,8 @@ class EncoderArena:
         slot_of.update({(id(m), nm): (o, n) for m, nm, o, n in stat_slots})
         self._bn_eps = 1e-5
         for mod in module.modules():
-            if isinstance(mod, _BatchNormBase):
+            # (a BatchNorm without gamma / beta has no slot to fold from: it keeps the per-layer path)
+            if isinstance(mod, _BatchNormBase) and mod.affine and id(mod) not in skip:
                 Cc = mod.num_features
                 for lst, nm in ((gi, 'weight'), (bi, 'bias'), (mi, '_mean'), (vi, '_variance')):
                     o, _ = slot_of[(id(mod), nm)]

@@ -453,10 +453,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
     Cc = x.shape[-1]
     M = x.numel() // Cc
     dx = torch.empty_like(x)
+    ws = workspace.get(-(-M // 16) * 2 * Cc, x.device)       # >= passl_hip_layernorm_bwd_ws_floats(M, C)
     L.check(_lib().passl_hip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
                                            L.ptr(dres) if dres is not None else None, L.ptr(dx),
-                                           L.ptr(dgamma), L.ptr(dbeta), M, Cc, L.dt(x), L.stream()),
-            'layernorm_bwd')
+                                           L.ptr(dgamma), L.ptr(dbeta), M, Cc, L.dt(x), L.ptr(ws), ws.numel(),
+                                           L.stream()), 'layernorm_bwd')
     return dx
 
 
@@ -528,9 +529,10 @@ def mae_unshuffle(x, mask_token, pos, ids_restore, B, K):
 def mae_unshuffle_bwd(dout, ids_keep, ids_restore, dmask_token, B):
     K, Ln, D = ids_keep.shape[1], ids_restore.shape[1], dout.shape[-1]
     dx = torch.empty(B * (K + 1), D, dtype=dout.dtype, device=dout.device)
+    ws = workspace.get(1024 * D, dout.device)
     L.check(_lib().passl_hip_mae_unshuffle_bwd(L.ptr(dout), L.ptr(ids_keep), L.ptr(ids_restore), L.ptr(dx),
-                                               L.ptr(dmask_token), B, Ln, K, D, L.dt(dout), L.stream()),
-            'mae_unshuffle_bwd')
+                                               L.ptr(dmask_token), B, Ln, K, D, L.dt(dout), L.ptr(ws),
+                                               ws.numel(), L.stream()), 'mae_unshuffle_bwd')
     return dx
 
 
@@ -545,8 +547,10 @@ def patchify(img, p, dtype):
 def mae_loss_fwd(img, pred, mask, p, norm_pix, denom):
     B, Cc, H, W = img.shape
     loss = torch.empty(1, dtype=torch.float32, device=img.device)
+    ws = workspace.get(B * ((H // p) * (W // p) + 1), img.device)
     L.check(_lib().passl_hip_mae_loss_fwd(L.ptr(img), L.ptr(pred), L.ptr(mask), L.ptr(loss), B, Cc, H, W, p,
-                                          1 if norm_pix else 0, denom, L.stream()), 'mae_loss_fwd')
+                                          1 if norm_pix else 0, denom, L.ptr(ws), ws.numel(), L.stream()),
+            'mae_loss_fwd')
     return loss
 
 
@@ -595,11 +599,24 @@ def embed_fwd(text, table, pos, dtype):
     return out
 
 
+_embed_acc = {}
+
+
 def embed_bwd(text, dout, dtable, dpos):
+    """dtable[text] += dout (exact fixed-point scatter-add), dpos += sum_b dout: see include/passl_hip.h."""
     B, T = text.shape
     V, Cc = dtable.shape
-    L.check(_lib().passl_hip_embed_bwd(L.ptr(text), L.ptr(dout), L.ptr(dtable), L.ptr(dpos), B, T, Cc, V,
-                                       L.dt(dout), L.stream()), 'embed_bwd')
+    lib = _lib()
+    # the persistent accumulator of the fixed-point scatter: zero once, every call leaves it zero
+    key = (dout.device.type, dout.device.index, V, Cc)
+    acc = _embed_acc.get(key)
+    if acc is None:
+        acc = torch.zeros(int(lib.passl_hip_embed_bwd_acc_bytes(V, Cc)) // 8, dtype=torch.int64, device=dout.device)
+        _embed_acc[key] = acc
+    ws = workspace.get(int(lib.passl_hip_embed_bwd_ws_floats(B, T, Cc)), dout.device)
+    L.check(lib.passl_hip_embed_bwd(L.ptr(text), L.ptr(dout), L.ptr(dtable), L.ptr(dpos), B, T, Cc, V,
+                                    L.dt(dout), L.ptr(acc), acc.numel() * 8, L.ptr(ws), ws.numel(), L.stream()),
+            'embed_bwd')
 
 
 def gather_rows(x, idx):
@@ -640,8 +657,10 @@ def clip_logits_bwd(dlogits, logits, ws, Dd, dlogit_scale):
     B = logits.shape[0]
     dimg = torch.empty(B, Dd, dtype=torch.float32, device=ws.device)
     dtxt = torch.empty(B, Dd, dtype=torch.float32, device=ws.device)
+    scratch = workspace.get(256, ws.device)
     L.check(_lib().passl_hip_clip_logits_bwd(L.ptr(dlogits), L.ptr(logits), L.ptr(ws), B, Dd, L.ptr(dimg),
-                                             L.ptr(dtxt), L.ptr(dlogit_scale), L.stream()), 'clip_logits_bwd')
+                                             L.ptr(dtxt), L.ptr(dlogit_scale), L.ptr(scratch), L.stream()),
+            'clip_logits_bwd')
     return dimg, dtxt
 
 
@@ -682,7 +701,9 @@ def clip_ce_fwd(logits):
     B = logits.shape[0]
     lse = torch.empty(2 * B, dtype=torch.float32, device=logits.device)
     out = torch.empty(3, dtype=torch.float32, device=logits.device)
-    L.check(_lib().passl_hip_clip_ce_fwd(L.ptr(logits), B, L.ptr(lse), L.ptr(out), L.stream()), 'clip_ce_fwd')
+    ws = workspace.get(2 * B, logits.device)
+    L.check(_lib().passl_hip_clip_ce_fwd(L.ptr(logits), B, L.ptr(lse), L.ptr(out), L.ptr(ws), ws.numel(),
+                                         L.stream()), 'clip_ce_fwd')
     return out, lse
 
 
@@ -699,8 +720,9 @@ def softmax_ce_fwd(scores, labels):
     N, Cc = scores.shape
     lse = torch.empty(N, dtype=torch.float32, device=scores.device)
     out = torch.empty(3, dtype=torch.float32, device=scores.device)
+    ws = workspace.get(3 * N, scores.device)
     L.check(_lib().passl_hip_softmax_ce_fwd(L.ptr(scores), L.ptr(labels), N, Cc, L.ptr(lse), L.ptr(out),
-                                            L.stream()), 'softmax_ce_fwd')
+                                            L.ptr(ws), ws.numel(), L.stream()), 'softmax_ce_fwd')
     return out, lse
 
 

@@ -20,14 +20,7 @@ from ..utils.checkpoint import load_lenient, load_pickle, to_numpy
 __all__ = ['build_model', 'Model']
 
 
-class Model(hnn.Layer):
-    """passl/models/base_model.py:25-40."""
-
-    def load_pretrained(self, path, rank=0, finetune=False):
-        raise Exception('NotImplementedError, you must overwrite load_pretrained method in subclass.')
-
-    def save(self, path, local_rank=0, rank=0):
-        raise Exception('NotImplementedError, you must overwrite save method in subclass.')
+from .base_model import Model          # noqa: E402  (passl/models/base_model.py)
 
 
 class ArchModel(Model):
@@ -95,6 +88,10 @@ def simclr_resnet50(dim=128, T=0.1, multi_rank=False, **kw):
                                     out_channels=dim, with_avg_pool=True),
                           head=dict(name='SimCLRContrastiveHead', temperature=T, return_accuracy=True,
                                     multi_rank=multi_rank), dim=dim, T=T, **kw))
+
+
+from .mocov3 import (MoCoV3ViT, MoCoV3Pretrain, mocov3_vit_base,      # noqa: E402,F401
+                     mocov3_vit_base_pretrain)
 
 
 def build_model(config):

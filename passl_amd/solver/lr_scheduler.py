@@ -103,3 +103,49 @@ class simclrCosineWarmup(LinearWarmup):
         super().__init__(learning_rate=lr_sch, warmup_steps=warmup_steps, start_lr=0.0, end_lr=lr,
                          last_epoch=last_epoch)
         self.update_specified = False
+
+
+@LRSCHEDULERS.register()
+class TimmCosine(LRScheduler):
+    """passl/scheduler/lr_scheduler.py:22-77 (the v2 schedulers; MoCo-v3 / MAE-v2 configs): linear warm-up from
+    ``warmup_start_lr`` over ``warmup_epoch`` epochs, then one cosine period down to ``eta_min``; with
+    ``warmup_prefix`` the cosine is counted from the end of the warm-up over the remaining ``T_max - warmup``
+    units.  ``decay_unit: step`` counts optimizer steps (``epochs * step_each_epoch`` in total).
+
+    As in the reference, the constructor does NOT take the first ``step()`` (it never calls the base class'
+    __init__): until the loop's first ``lr_scheduler.step()`` the value is ``learning_rate`` itself — the very first
+    optimizer step runs at the PEAK rate, the second at ``warmup_start_lr``, and the ramp starts from there."""
+
+    def __init__(self, learning_rate, step_each_epoch, epochs, decay_unit='epoch', eta_min=0.0, warmup_epoch=0,
+                 warmup_start_lr=0.0, warmup_prefix=False, verbose=False, last_epoch=-1, **kwargs):
+        if warmup_epoch >= epochs:
+            warmup_epoch = epochs
+        if not isinstance(learning_rate, (float, int)):
+            raise TypeError('The type of learning rate must be float, but received {}'.format(type(learning_rate)))
+        assert decay_unit in ['step', 'epoch']
+        self.learning_rate = learning_rate
+        self.decay_unit = decay_unit
+        if decay_unit == 'step':
+            self.T_max = epochs * step_each_epoch
+            self.warmup_steps = int(round(warmup_epoch * step_each_epoch))
+        else:
+            self.T_max = epochs
+            self.warmup_steps = warmup_epoch
+        self.eta_min = eta_min
+        self.warmup_start_lr = warmup_start_lr
+        self.warmup_prefix = warmup_prefix
+        self.base_lr = float(learning_rate)
+        self.last_lr = float(learning_rate)
+        self.last_epoch = last_epoch
+        self.verbose = verbose
+
+    def get_lr(self):
+        if self.last_epoch < self.warmup_steps:
+            return float(max(0, self.last_epoch)) * (self.learning_rate - self.warmup_start_lr) / \
+                float(self.warmup_steps) + self.warmup_start_lr
+        last_epoch, T_max = self.last_epoch, self.T_max
+        if self.warmup_prefix:
+            last_epoch = last_epoch - self.warmup_steps
+            T_max = self.T_max - self.warmup_steps
+        cur_steps = last_epoch - (self.T_max * (last_epoch // self.T_max))
+        return self.eta_min + 0.5 * (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * cur_steps / T_max))

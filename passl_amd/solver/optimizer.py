@@ -294,7 +294,16 @@ class AdamW(_DeviceHyper):
 
     def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-08, parameters=None,
                  weight_decay=0.01, lr_ratio=None, apply_decay_param_fun=None, grad_clip=None,
-                 lazy_mode=False, multi_precision=False, name=None):
+                 lazy_mode=False, multi_precision=False, name=None, betas=None, eps=None,
+                 use_master_param=None, exp_avg_force_fp32=None):
+        # v2 spelling (passl/optimizer/adamw.py:24-50, the MoCo-v3 yaml): betas=(b1, b2), eps.  use_master_param /
+        # exp_avg_force_fp32 ask for fp32 master weights and an fp32 first moment next to fp16 parameters: the
+        # flat arena IS fp32 (weights and both moments; the compute-dtype copy is derived from it every step), so
+        # both are always satisfied and the flags are accepted as no-ops.
+        if betas is not None:
+            beta1, beta2 = (float(b) for b in betas)
+        if eps is not None:
+            epsilon = eps
         if apply_decay_param_fun is not None or lr_ratio is not None or grad_clip is not None:
             raise NotImplementedError('per-parameter decay / lr ratios / clipping are not used by the MAE '
                                       'pre-training config and are not built')

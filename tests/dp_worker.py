@@ -69,8 +69,73 @@ OVERRIDES['clipx'] = OVERRIDES['clip']        # + multi_rank: cross-rank InfoNCE
 OVERRIDES['moco_shuffle'] = OVERRIDES['moco']  # + shuffle_bn: the cross-rank batch shuffle of moco.py:107-152
 
 
+def mocov3_run():
+    """Two data-parallel ranks of MoCo-v3 (small ViT) from the golden case's state and inputs
+    (tests/golden/mocov3_small_2rank.npz: the reference's own forward run as rank r of 2): the rank-local loss and
+    gradient norms must equal the reference's — which they only do if the keys are gathered in rank order and row
+    i's positive is column N*rank + i — then two more steps through the overlapped bucketed all-reduce keep the
+    replicas bit-identical."""
+    import numpy as np
+    import mocov3_util as U
+    from oracle import mocov3 as O
+    from passl_amd.core.sync_utils import GradReducer, grad_sync, param_sync
+    from passl_amd.engine.trainer import _init_distributed
+    from passl_amd.hip import config as hip_config
+    dev = hip_config.set_device('gpu')
+    rank, world = _init_distributed(dev)
+    assert world == 2
+    cfg, N = O.SMALL, 4
+    oracle = O.MoCoV3Oracle(cfg, seed=0, max_steps=10, **U.SOLVER)
+    model, opt = U.build_product(cfg, torch.float32, max_steps=10)
+    U.load_oracle_state(model, oracle)
+    param_sync(model)
+    model.train()
+    gen = torch.Generator().manual_seed(777 + rank)
+    x1 = torch.randn(N, 3, 64, 64, generator=gen).cuda()
+    x2 = torch.randn(N, 3, 64, 64, generator=gen).cuda()
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'mocov3_small_2rank.npz'))
+    loss = model([x1, x2])
+    opt.clear_grad()
+    loss.backward()                                   # no reducer yet: the gradients are this rank's own
+    torch.cuda.synchronize()
+    got = float(loss.detach())
+    assert abs(got - float(z['r%d_loss' % rank])) < 2e-5, (rank, got, float(z['r%d_loss' % rank]))
+    ps = dict(model.named_parameters())
+    for key in z.files:
+        if key.startswith('r%d_gradnorm/' % rank) and not key.endswith('norm.bias'):
+            n = key.split('/', 1)[1]
+            g = ps[n].grad.double().norm().item()
+            assert abs(g - float(z[key])) <= 5e-4 * g, (rank, n, g, float(z[key]))
+    grad_sync([{'params': opt._parameter_list}])      # blocking all-reduce (mean), as the reference's loop
+    opt.step()
+    reducer = GradReducer(model.arena_q, opt)
+    losses = [got]
+    for _ in range(2):
+        loss = model([x1, x2])
+        opt.clear_grad()
+        reducer.begin()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    # (the weights: BatchNorm running statistics stay rank-local, as in the reference's DataParallel)
+    nt = model.arena_q.n_train
+    for name, t in (('arena_q', model.arena_q.flat[:nt]), ('arena_k', model.arena_k.flat[:nt])):
+        ref = t.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, t), '%s differs between ranks (max abs diff %.3e)' % (name, float((ref - t).abs().max()))
+    assert model.momentum_encoder._steps == 3
+    dist.barrier()
+    if rank == 0:
+        print('DP-OK mocov3 %.6f losses=%s' % (losses[-1], ','.join('%.9g' % l for l in losses)), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     workload = sys.argv[1]
+    if workload == 'mocov3':
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        return mocov3_run()
     from passl_amd.engine.trainer import Trainer
     from passl_amd.hooks import OptimizerHook, LRSchedulerHook
     from passl_amd.utils.config import get_config

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.passl_hip_abi_version() == 8
+    assert lib.passl_hip_abi_version() == 9
     assert b'invalid' in lib.passl_hip_strerror(-1)
     assert lib.passl_hip_strerror(0) == b'ok'
 
@@ -84,7 +84,8 @@ def test_every_entry_point_rejects_null_arguments(lib):
             'passl_hip_last_igemm_kernel',
             'passl_hip_infonce_workspace_bytes', 'passl_hip_infonce_bwd_workspace_bytes',
             'passl_hip_bn_partial_floats',
-            'passl_hip_clip_logits_ws_floats'}
+            'passl_hip_clip_logits_ws_floats', 'passl_hip_layernorm_bwd_ws_floats',
+            'passl_hip_embed_bwd_acc_bytes', 'passl_hip_embed_bwd_ws_floats'}
     checked = 0
     for name, (res, args) in sorted(L.SIGNATURES.items()):
         if name in skip:
@@ -106,7 +107,12 @@ def test_every_entry_point_rejects_null_arguments(lib):
     p = C.cast(buf, C.c_void_p)
     assert lib.passl_hip_attention_fwd(p, p, p, 1, 300, 1, 64, 0.125, 0, L.F32, None) == -3     # T > 208
     assert lib.passl_hip_attention_fwd(p, p, p, 1, 16, 1, 48, 0.125, 0, L.F32, None) == -3      # head dim
-    assert lib.passl_hip_layernorm_bwd(p, p, p, p, p, None, p, p, p, 4, 4096, L.F32, None) == -1  # C > 2048
+    assert lib.passl_hip_layernorm_bwd(p, p, p, p, p, None, p, p, p, 4, 4096, L.F32, p, 1 << 20, None) == -1  # C > 2048
+    # reductions have no atomic fall-back: the workspace is mandatory, and its size is published
+    assert lib.passl_hip_layernorm_bwd(p, p, p, p, p, None, p, p, p, 64, 16, L.F32, None, 0, None) == -1
+    assert lib.passl_hip_layernorm_bwd_ws_floats(50432, 768) == 1030 * 2 * 768
+    assert lib.passl_hip_embed_bwd_acc_bytes(49408, 512) == 49408 * 512 * 8 + 49408 * 4 + 16
+    assert lib.passl_hip_embed_bwd_ws_floats(256, 77, 512) == 2 * 77 * 512
     assert lib.passl_hip_set_option(b'no_such_option', 1) == -1
 
 

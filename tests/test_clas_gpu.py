@@ -214,3 +214,25 @@ def test_pretrain_checkpoint_extract_linear_probe_chain(tmp_path):
     for k, v in tr.model.backbone.state_dict().items():    # the trunk is frozen
         assert torch.equal(v, w0[k]), k
     assert set(tr.val_results) == {'acc1', 'acc5'} and 0.0 <= tr.val_results['acc1'] <= tr.val_results['acc5'] <= 100.0
+
+
+def test_step_is_bit_reproducible():
+    """The linear-probe step (frozen trunk, trained head; loss and accuracies summed in a fixed order) twice from
+    the same state: bit-identical loss, accuracies and parameters."""
+    ncls = 16
+    ends = []
+    for _ in range(2):
+        oracle = OC.ClasOracle(num_classes=ncls, seed=0, lr=U.LR, momentum=U.MU, frozen_stages=2)
+        model, opt = U.build_product(ncls, torch.bfloat16, frozen_stages=2)
+        U.load_oracle_state(model, oracle)
+        model.train()
+        gen = torch.Generator().manual_seed(909)
+        outs = []
+        for _s in range(3):
+            img = torch.randn(16, 3, 64, 64, generator=gen).to(DEV)
+            lab = torch.randint(0, ncls, (16,), generator=gen).to(DEV)
+            out = U.product_step(model, opt, img, lab)
+            outs.append(torch.cat([out[k].detach().reshape(1).float() for k in ('loss', 'acc1', 'acc5')]))
+        ends.append((torch.cat(outs), torch.cat([p.detach().reshape(-1) for p in model.parameters()])))
+    for a, b in zip(*ends):
+        assert torch.equal(a, b)

@@ -337,3 +337,57 @@ def test_trainer_runs_clip_config_end_to_end(tmp_path):
     assert tr.current_iter == 24
     l1 = float(tr.outputs['loss'].detach())
     assert np.isfinite(l1) and l1 < l0, (l0, l1)           # one cached batch: it must be fitted
+
+
+@pytest.mark.parametrize('multi', [False, True])
+def test_step_is_bit_reproducible(multi):
+    """No floating-point atomics on the CLIP path: the token-embedding scatter-add accumulates exact 64-bit fixed
+    point (integer atomics are order-independent), position / LayerNorm / logit-scale gradients and both
+    cross-entropies are fixed-order reductions.  Two runs from the same state end bit-identical."""
+    cfg = OC.SMALL
+    ends = []
+    for _ in range(2):
+        oracle = OC.CLIPOracle(cfg, seed=0, text_std_cap=U.STD_CAP, **U.SOLVER)
+        model, opt = U.build_product(cfg, torch.bfloat16)
+        model.multi_rank = multi
+        U.load_oracle_state(model, oracle)
+        model.train()
+        gen = torch.Generator().manual_seed(4242)
+        losses = []
+        for _s in range(3):
+            image = torch.randn(16, 3, cfg['image_resolution'], cfg['image_resolution'], generator=gen).to(DEV)
+            text = OC.make_text(gen, 16, cfg['context_length'], cfg['vocab_size']).to(DEV)
+            losses.append(U.product_step(model, opt, image, text)['loss'].detach().clone())
+        ends.append((torch.cat([l.reshape(1) for l in losses]), model.arena_q.flat.clone()))
+    for a, b in zip(*ends):
+        assert torch.equal(a, b)
+
+
+def test_embedding_scatter_is_exact_and_order_independent():
+    """embed_bwd's fixed-point scatter-add: heavy collisions (a pad id at most positions), values spread over 12
+    orders of magnitude — the result equals the fp64 sum rounded to fp32 (to 1 ulp of the row maximum) and is
+    bit-identical when the same work is presented in a different order (images permuted)."""
+    gen = torch.Generator().manual_seed(8)
+    B, T, V, C = 96, 24, 300, 64
+    text = torch.randint(1, V, (B, T), generator=gen)
+    text[:, 10:] = 0
+    text[torch.arange(B), torch.randint(3, 10, (B,), generator=gen)] = V - 1
+    dout = torch.randn(B * T, C, generator=gen) * torch.pow(10.0, torch.randint(-9, 3, (B * T, 1), generator=gen).float())
+    for dtype in (torch.float32, torch.bfloat16):
+        d = dout.to(dtype)
+        dE = torch.zeros(V, C, device=DEV)
+        dpos = torch.zeros(T, C, device=DEV)
+        ops.embed_bwd(text.to(DEV), d.to(DEV), dE, dpos)
+        ref = torch.zeros(V, C, dtype=torch.float64).index_add_(0, text.reshape(-1), d.double())
+        err = (dE.cpu().double() - ref).abs().max(dim=1).values
+        assert bool((err <= 2.0 ** -23 * ref.abs().max()).all()), float(err.max())
+        refp = d.double().reshape(B, T, C).sum(0)
+        assert float((dpos.cpu().double() - refp).abs().max()) <= 1e-5 * float(refp.abs().max())
+        perm = torch.randperm(B, generator=gen)
+        dE2 = torch.zeros(V, C, device=DEV)
+        dpos2 = torch.zeros(T, C, device=DEV)
+        ops.embed_bwd(text[perm].to(DEV), d.reshape(B, T, C)[perm].reshape(B * T, C).to(DEV), dE2, dpos2)
+        assert torch.equal(dE, dE2)            # integer accumulation: independent of the order of the addends
+        # accumulate semantics and a clean accumulator for the next call
+        ops.embed_bwd(text.to(DEV), d.to(DEV), dE, dpos)
+        assert float((dE.cpu().double() - 2 * ref).abs().max()) <= 2.0 ** -22 * float(ref.abs().max())

@@ -43,6 +43,12 @@ def _run_worker(workload, nproc, env_extra, launcher=True):
     return line
 
 
+def test_two_ranks_mocov3_cross_rank_keys():
+    """MoCo-v3's gathered keys and rank-offset labels (reference passl/models/mocov3.py:161-183) against the
+    reference's own two-rank forward (tests/golden/mocov3_small_2rank.npz) — see dp_worker.mocov3_run."""
+    _run_worker('mocov3', 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0'))
+
+
 def test_two_ranks_shuffle_bn_is_output_neutral():
     """MoCo's cross-rank batch shuffle (reference passl_v110/modeling/architectures/moco.py:107-152): all-gather
     the key view, a permutation drawn on rank 0 and broadcast, every rank encodes its slice of the permuted batch,

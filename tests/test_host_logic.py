@@ -626,3 +626,81 @@ def test_v2_engine_runs_the_named_loop(tmp_path):
             M.build_model(dict(name='no_such_model'))
     finally:
         del M.dummy_v2
+
+
+def test_timm_cosine_schedule_known_answers():
+    """passl/scheduler/lr_scheduler.py:22-77 with the MoCo-v3 yaml's settings: no step() in the constructor (the
+    first optimizer step runs at the peak rate: reference behaviour), linear warm-up over warmup_epoch epochs of
+    steps, then a cosine over the REMAINING steps (warmup_prefix)."""
+    from passl_amd.solver.lr_scheduler import TimmCosine
+    s = TimmCosine(learning_rate=0.0024, step_each_epoch=10, epochs=30, decay_unit='step', eta_min=0.0,
+                   warmup_epoch=4, warmup_start_lr=0.0, warmup_prefix=True)
+    assert s.T_max == 300 and s.warmup_steps == 40 and s.last_epoch == -1
+    assert s() == 0.0024                                  # before the first step(): the base rate
+    s.step()
+    assert s.last_epoch == 0 and s() == 0.0
+    for _ in range(10):
+        s.step()
+    assert abs(s() - 0.0024 * 10 / 40) < 1e-15
+    for _ in range(30):
+        s.step()
+    assert s.last_epoch == 40 and abs(s() - 0.0024) < 1e-15              # end of the warm-up = start of the cosine
+    for _ in range(130):
+        s.step()
+    assert abs(s() - 0.5 * 0.0024 * (1 + math.cos(math.pi * 130 / 260))) < 1e-15
+    for _ in range(130):
+        s.step()
+    assert s.last_epoch == 300 and abs(s()) < 1e-15
+    # epoch unit, no prefix: the cosine is counted from 0 over T_max
+    e = TimmCosine(learning_rate=1.0, step_each_epoch=10, epochs=20, decay_unit='epoch', warmup_epoch=5)
+    e.step(10)
+    assert abs(e() - 0.5 * (1 + math.cos(math.pi * 10 / 20))) < 1e-15
+    sd = s.state_dict()
+    t = TimmCosine(learning_rate=0.0024, step_each_epoch=10, epochs=30, decay_unit='step', warmup_epoch=4)
+    t.set_state_dict(sd)
+    assert t.last_epoch == 300
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/tasks/ssl/mocov3'), reason='reference tree not present')
+def test_v2_engine_builds_from_the_reference_mocov3_yaml_unchanged():
+    """tasks/ssl/mocov3/configs/mocov3_vit_base_patch16_224_pt_in1k_4n32c_dp_fp16o1.yaml read as it is (only `-o`
+    overrides: device, the dataset class — there is no ImageNet here — and a smaller run): Engine builds the ViT-B
+    MoCo-v3 model through passl.models.build_model, AdamW from `betas / eps / use_master_param /
+    exp_avg_force_fp32`, TimmCosine from the run length, the FP16 section selects bf16 compute, and
+    runtime_info_hub carries max_steps to the momentum schedule."""
+    from passl_amd.engine.engine import Engine
+    from passl_amd.hip import config as hip_config
+    from passl_amd.utils.infohub import runtime_info_hub
+    yaml_path = '/root/reference/tasks/ssl/mocov3/configs/mocov3_vit_base_patch16_224_pt_in1k_4n32c_dp_fp16o1.yaml'
+    prev = hip_config.get_compute_dtype()
+    try:
+        cfg = get_config(yaml_path, ['Global.device=cpu', 'Global.epochs=50',
+                                     'DataLoader.Train.dataset.name=SyntheticTwoView',
+                                     'DataLoader.Train.sampler.batch_size=2'])
+        cfg.DataLoader.Train.dataset.num_samples = 40          # (not a key of the yaml: `-o` cannot add it)
+        cfg.DataLoader.Train.dataset.image_size = 224
+        eng = Engine(cfg, mode='train')
+        assert hip_config.get_compute_dtype() == torch.bfloat16
+        m = eng.model
+        assert type(m).__name__ == 'MoCoV3Pretrain' and m.T == 0.2 and m.momentum_encoder.momentum == 0.99
+        n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+        # ViT-B without its (frozen) patch embedding and fixed position table, + projector + predictor
+        vit = 768 + 12 * (2 * 768 * 2 + 768 * 2304 + 2304 + 768 * 768 + 768 + 2 * 768 * 3072 + 3072 + 768) + 2 * 768
+        proj = 768 * 4096 + 2 * 4096 + 4096 * 4096 + 2 * 4096 + 4096 * 256
+        pred = 256 * 4096 + 2 * 4096 + 4096 * 256
+        assert n_train == vit + proj + pred == m.arena_q.n_train - sum(
+            (-n) % 8 for _o, n in m.arena_q.param_slices)
+        opt = eng.optimizer
+        assert type(opt).__name__ == 'AdamW' and (opt._b1, opt._b2, opt._eps, opt._wd) == (0.9, 0.999, 1e-8, 0.1)
+        assert opt._arenas == [m.arena_q]
+        sch = eng.lr_scheduler
+        assert type(sch).__name__ == 'TimmCosine' and sch.T_max == 50 * 20 and sch.warmup_steps == 40 * 20
+        assert sch.warmup_prefix is True and eng.lr_decay_unit == 'step' and opt.get_lr() == 0.0024
+        assert runtime_info_hub.max_steps == 1000 and runtime_info_hub.epochs == 50
+        assert abs(m.momentum_encoder.current_momentum(500) - 0.99 * 0.5) < 1e-12
+        assert type(eng.train_loop).__name__ == 'ContrastiveLearningTrainingEpochLoop'
+        sd = m.state_dict()
+        assert 'momentum_encoder.model.0.blocks.11.mlp.fc2.weight' in sd and 'predictor.4._variance' in sd
+        assert 'base_encoder.head.7.weight' not in sd and tuple(sd['base_encoder.pos_embed'].shape) == (1, 197, 768)
+    finally:
+        hip_config.set_compute_dtype(prev)

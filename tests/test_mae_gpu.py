@@ -297,3 +297,23 @@ def test_trainer_runs_mae_config_end_to_end(tmp_path):
     assert tr.current_iter == 24
     l1 = float(tr.outputs['loss'].detach())
     assert np.isfinite(l1) and l1 < l0, (l0, l1)           # one cached batch: it must be fitted
+
+
+def test_step_is_bit_reproducible():
+    """No floating-point atomics on the MAE path (LayerNorm d-gamma / d-beta, class- and mask-token gradients and
+    the masked-patch loss are fixed-order slab reductions): two runs from the same state end bit-identical."""
+    ends = []
+    for _ in range(2):
+        oracle = M.MAEOracle(dict(SMALL, norm_pix_loss=True), seed=0, **U.SOLVER)
+        model, opt = U.build_product(SMALL, torch.bfloat16, True)
+        U.load_oracle_state(model, oracle)
+        model.train()
+        gen = torch.Generator().manual_seed(31)
+        losses = []
+        for _s in range(3):
+            x = torch.randn(16, 3, 64, 64, generator=gen).to(DEV)
+            noise = torch.rand(16, 16, generator=gen).to(DEV)
+            losses.append(U.product_step(model, opt, x, noise)['loss'].detach().clone())
+        ends.append((torch.cat([l.reshape(1) for l in losses]), model.arena_q.flat.clone()))
+    for a, b in zip(*ends):
+        assert torch.equal(a, b)

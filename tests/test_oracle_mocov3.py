@@ -1,0 +1,181 @@
+"""CPU tests that pin the MoCo-v3 oracle (oracle/mocov3.py): against golden vectors produced by running the
+reference's own v2 sources (tests/golden/make_golden_mocov3.py: passl/models/mocov3.py + vision_transformer.py +
+utils/averaged_model.py under the paddle shim), live against those sources when /root/reference is present, and
+known answers for the fixed position embedding and the cosine momentum."""
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mocov3 as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+SOLVER = dict(lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.1)
+WATCH = ['base_encoder.cls_token', 'base_encoder.blocks.0.attn.qkv.weight', 'base_encoder.blocks.1.mlp.fc2.bias',
+         'base_encoder.blocks.1.norm2.weight', 'base_encoder.norm.bias', 'base_encoder.head.0.weight',
+         'base_encoder.head.4.bias', 'base_encoder.head.6.weight', 'predictor.0.weight', 'predictor.1.weight',
+         'predictor.3.weight']
+WATCH_MOM = ['base_encoder.patch_embed.proj.weight', 'base_encoder.blocks.0.attn.qkv.weight',
+             'base_encoder.head.6.weight', 'predictor.3.weight', 'base_encoder.head.7._mean',
+             'predictor.1._variance']
+
+
+def _against(name, cfg, N, steps, max_steps):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    o = O.MoCoV3Oracle(cfg, seed=0, max_steps=max_steps, **SOLVER)
+    gen = torch.Generator().manual_seed(777)
+    S = cfg['img_size']
+    for s in range(steps):
+        x1 = torch.randn(N, 3, S, S, generator=gen)
+        x2 = torch.randn(N, 3, S, S, generator=gen)
+        out = o.train_step(x1, x2)
+        pre = 's%d_' % s
+        # step 0 pins the algorithm to fp32 rounding; later steps start from parameters that AdamW's first, sign-like
+        # updates moved by +-lr on rounding-level gradient differences (both this run and the reference's sit ~1e-5
+        # from the fp64 trajectory stored beside it)
+        amp = 10.0 ** s             # ... and the tiny BatchNorm batches amplify that ~10x per step
+        ltol, gtol = (5e-6, 2e-4) if s == 0 else (1e-4 * amp / 10, 5e-3 * amp / 10)
+        assert abs(float(out['loss']) - float(z[pre + 'loss'])) < ltol, (s, float(out['loss']), float(z[pre + 'loss']))
+        assert abs(float(out['loss']) - float(z[pre + 'f64_loss'])) < ltol
+        assert o.steps == int(z[pre + 'ema_steps'])
+        for n in WATCH:
+            g = out['grads'][n].double().norm().item()
+            if n == 'base_encoder.norm.bias':
+                # feeds a bias-free Linear + BatchNorm: its gradient is analytically zero (rounding noise in both
+                # runs), AdamW normalises that noise to +-lr steps, and the BatchNorm removes whatever shift results
+                assert g < 1e-4 and float(z[pre + 'gradnorm/' + n]) < 1e-4
+                continue
+            assert abs(g - float(z[pre + 'gradnorm/' + n])) <= gtol * g, (s, n)
+            assert abs(o.st[n].double().norm().item() - float(z[pre + 'pnorm/' + n])) < 5e-5 * amp, (s, n)
+        for n in WATCH_MOM:
+            v = o.mom[n].double().norm().item()
+            assert abs(v - float(z[pre + 'mom_pnorm/' + n])) < 2e-5 * amp * max(v, 1.0), (s, n)
+
+
+def test_oracle_matches_golden_small():
+    _against('mocov3_small', O.SMALL, 8, 3, 10)
+
+
+def test_oracle_matches_golden_vit_b_first_step():
+    _against('mocov3_vit_b', O.VIT_B, 4, 1, 100)
+
+
+def test_oracle_two_rank_labels_match_golden():
+    """Rank r's positives are columns N*r .. N*r+N-1 of the gathered keys (reference mocov3.py:176-183)."""
+    z = np.load(os.path.join(GOLDEN, 'mocov3_small_2rank.npz'))
+    cfg, N = O.SMALL, 4
+    xs = []
+    for r in range(2):
+        gen = torch.Generator().manual_seed(777 + r)
+        xs.append((torch.randn(N, 3, 64, 64, generator=gen), torch.randn(N, 3, 64, 64, generator=gen)))
+    keys = []
+    for r in range(2):                                  # the keys carry no gradient: harvest them first
+        o = O.MoCoV3Oracle(cfg, seed=0, max_steps=10, **SOLVER)
+        out = o.forward_backward(*xs[r])
+        keys.append((out['k1'], out['k2']))
+    for r in range(2):
+        o = O.MoCoV3Oracle(cfg, seed=0, max_steps=10, **SOLVER)
+
+        def gather(k, r=r):
+            i = 0 if torch.equal(k, keys[r][0]) else 1
+            assert torch.equal(k, keys[r][i])
+            return torch.cat([keys[0][i], keys[1][i]], dim=0)
+        out = o.forward_backward(*xs[r], k_gather=gather, rank=r)
+        assert abs(float(out['loss']) - float(z['r%d_loss' % r])) < 5e-6
+        for n in WATCH:
+            g = out['grads'][n].double().norm().item()
+            if n == 'base_encoder.norm.bias':
+                continue
+            assert abs(g - float(z['r%d_gradnorm/%s' % (r, n)])) <= 2e-4 * g, (r, n)
+
+
+def test_position_embedding_known_answers():
+    """mocov3.py:69-91: token (i, j) of the h x w grid, flattened i*w + j by the reference's forward, gets
+    [sin(j*omega), cos(j*omega), sin(i*omega), cos(i*omega)]?  No: meshgrid(arange(w), arange(h)) in 'ij' order makes
+    grid_w vary along the FIRST axis, so flat index t carries (w = t // h, h = t % h)."""
+    D, h, w = 16, 3, 3
+    pe = O.sincos_position_embedding(D, h, w)
+    assert pe.shape == (1, 1 + h * w, D) and float(pe[0, 0].abs().max()) == 0.0
+    omega = [1.0 / 10000 ** (k / 4.0) for k in range(4)]
+    for t in (0, 1, 5, 8):
+        gw, gh = t // h, t % h
+        want = [math.sin(gw * o) for o in omega] + [math.cos(gw * o) for o in omega] + \
+               [math.sin(gh * o) for o in omega] + [math.cos(gh * o) for o in omega]
+        np.testing.assert_allclose(pe[0, 1 + t].numpy(), np.array(want, dtype=np.float32), atol=1e-6)
+
+
+def test_cosine_momentum_known_answers():
+    """averaged_model.py:176-188 with momentum 0.99, end 0: the first call copies, call t >= 1 lerps with
+    m_t = 0.99 * (cos(pi t / T) + 1) / 2; the BatchNorm statistics (Paddle parameters) are averaged like the weights."""
+    o = O.MoCoV3Oracle(O.SMALL, seed=2, max_steps=8)
+    k = 'predictor.3.weight'
+    o.st[k] = o.st[k] + 1.0
+    o.update_momentum_encoder()
+    assert o.steps == 1 and torch.equal(o.mom[k], o.st[k])
+    before = o.mom[k].clone()
+    o.st[k] = o.st[k] + 2.0
+    o.st['predictor.1._mean'] = o.st['predictor.1._mean'] + 3.0
+    m = o.ema_momentum()
+    assert abs(m - 0.99 * (math.cos(math.pi / 8) + 1) / 2) < 1e-12
+    o.update_momentum_encoder()
+    torch.testing.assert_close(o.mom[k], before * (1 - m) + o.st[k] * m)
+    torch.testing.assert_close(o.mom['predictor.1._mean'], o.st['predictor.1._mean'] - 3.0 * (1 - m))
+    o.steps = 8
+    assert abs(o.ema_momentum()) < 1e-12                 # the momentum encoder is frozen at the end of training
+
+
+def test_frozen_patch_embedding_and_position_embedding():
+    o = O.MoCoV3Oracle(O.SMALL, seed=0, max_steps=10, **SOLVER)
+    g = torch.Generator().manual_seed(1)
+    before = {k: o.st[k].clone() for k in O.FROZEN}
+    out = o.train_step(torch.randn(4, 3, 64, 64, generator=g), torch.randn(4, 3, 64, 64, generator=g))
+    assert not (set(out['grads']) & set(O.FROZEN))
+    for k in O.FROZEN:
+        assert torch.equal(o.st[k], before[k])
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/passl/models'), reason='reference tree not present (GPU box)')
+def test_oracle_matches_reference_sources_live():
+    code = r'''
+import sys, torch
+sys.path.insert(0, 'tests/golden')
+from oracle import ref_runner_v2
+import make_golden_mocov3 as G
+from oracle.mocov3 import MoCoV3Oracle
+ns = ref_runner_v2.load()
+cfg = dict(img_size=48, patch_size=8, embed_dim=64, depth=1, num_heads=2, mlp_ratio=4.0, dim=32, mlp_dim=96)
+o = MoCoV3Oracle(cfg, seed=4, max_steps=5)
+m = G.build_reference(ns, cfg, 0.2, 0.99, 5)
+G.load_state(m, o)
+m.train()
+g = torch.Generator().manual_seed(3)
+for step in range(2):
+    x1 = torch.randn(6, 3, 48, 48, generator=g); x2 = torch.randn(6, 3, 48, 48, generator=g)
+    for p in m.parameters():
+        p.grad = None
+    loss = m([x1, x2])
+    loss.backward()
+    r = o.forward_backward(x1, x2)
+    assert abs(float(loss.detach()) - float(r['loss'])) < 3e-6, (float(loss), float(r['loss']))
+    ps = dict(m.named_parameters())
+    assert ps['base_encoder.pos_embed'].grad is None and ps['base_encoder.patch_embed.proj.weight'].grad is None
+    for n, gr in r['grads'].items():
+        assert (ps[n].grad - gr).abs().max().item() <= 3e-5 * max(gr.abs().max().item(), 1.0), n
+    sd = m.state_dict()
+    for k, v in o.mom.items():
+        assert (sd[G.ref_key(k, True)] - v).abs().max().item() < 2e-5 * max(1.0, v.abs().max().item()), k
+    # a plain SGD nudge so that the second step's momentum update really lerps; the restatement restarts from the
+    # reference's state (teacher forcing: rounding differences of step 1 are not amplified into step 2)
+    with torch.no_grad():
+        for n, gr in r['grads'].items():
+            ps[n].sub_(1e-3 * ps[n].grad)
+    G.pull_state(m, o)
+print('LIVE-OK')
+'''
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'LIVE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
