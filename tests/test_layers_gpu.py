@@ -298,3 +298,159 @@ def test_r50_layers_teacher_forced_bf16(geometry):
     finally:
         ops.conv_igemm = real_conv
     rep.finish()
+
+
+# ======================================================================================== ViT block
+def _rb(t):
+    """Round to bfloat16 (RNE), keep as fp64 for the next exact evaluation."""
+    return t.float().bfloat16().double()
+
+
+def _vit_block_oracle(B, T, D, H, seed, quick_gelu=False):
+    """One pre-norm transformer block (reference passl/models/vision_transformer.py:159-249 = passl_v110/
+    modeling/backbones/mae.py:61-189) evaluated OP BY OP in fp64 from bfloat16-valued inputs, the result of every
+    op rounded to bfloat16 where the product stores bf16 (the input of the next op is that rounded tensor):
+    forward tensors and, from a bfloat16-valued output gradient, every op's input gradient (rounded likewise) and
+    parameter gradients (fp64).  Weights: Xavier-uniform fp32 masters; the GEMM operands are their bf16 roundings."""
+    gen = torch.Generator().manual_seed(seed)
+    hid, dh = 4 * D, D // H
+
+    def xav(i, o):
+        return ((torch.rand(i, o, generator=gen) * 2 - 1) * math.sqrt(6.0 / (i + o)))
+    P = {'norm1.weight': 1 + 0.1 * torch.randn(D, generator=gen), 'norm1.bias': 0.1 * torch.randn(D, generator=gen),
+         'attn.qkv.weight': xav(D, 3 * D), 'attn.qkv.bias': 0.02 * torch.randn(3 * D, generator=gen),
+         'attn.proj.weight': xav(D, D), 'attn.proj.bias': 0.02 * torch.randn(D, generator=gen),
+         'norm2.weight': 1 + 0.1 * torch.randn(D, generator=gen), 'norm2.bias': 0.1 * torch.randn(D, generator=gen),
+         'mlp.fc1.weight': xav(D, hid), 'mlp.fc1.bias': 0.02 * torch.randn(hid, generator=gen),
+         'mlp.fc2.weight': xav(hid, D), 'mlp.fc2.bias': 0.02 * torch.randn(D, generator=gen)}
+    rec, grads = {}, {}
+    x0 = _rb(torch.randn(B * T, D, generator=gen) * 1.5)
+    dx2 = _rb(torch.randn(B * T, D, generator=gen) * 1e-3)
+
+    def leaf(t):
+        return t.detach().clone().requires_grad_(True)
+
+    def op(name, fn, inputs, dout, params=()):
+        """Evaluate fn on leaf copies of `inputs` (bf16-valued fp64) and the fp64 params; returns the bf16-rounded
+        output.  With `dout` (bf16-valued): input gradients (rounded) and parameter gradients (fp64)."""
+        ins = [leaf(t) for t in inputs]
+        ps = [leaf(P[k].double()) for k in params]
+        out = fn(*ins, *ps)
+        rec[name + '.in'] = [t.detach() for t in inputs]
+        rec[name + '.out'] = _rb(out.detach())
+        if dout is not None:
+            out.backward(dout)
+            rec[name + '.dout'] = dout
+            rec[name + '.din'] = [_rb(t.grad) for t in ins]
+            for k, p in zip(params, ps):
+                grads[k] = p.grad.clone()
+        return rec[name + '.out']
+
+    def ln(x, g, b):
+        return torch.nn.functional.layer_norm(x, (D,), g, b, 1e-6)
+
+    def lin(x, w, b, res=None):
+        y = x @ w
+        return y + b if res is None else y + b + res
+
+    def attn(qkv):
+        q, k, v = [qkv.reshape(B, T, 3, H, dh)[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+        a = torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, dim=-1)
+        return (a @ v).permute(0, 2, 1, 3).reshape(B * T, D)
+
+    def act(x):
+        return x * torch.sigmoid(1.702 * x) if quick_gelu else torch.nn.functional.gelu(x)
+
+    # the GEMM kernels read the bf16 rounding of the fp32 master weights
+    Pm = dict(P)
+    for k in ('attn.qkv.weight', 'attn.proj.weight', 'mlp.fc1.weight', 'mlp.fc2.weight'):
+        P[k] = _rb(P[k]).float()
+    # ---- forward (outputs recorded), then backward op by op in reverse with the recorded inputs
+    fwd = {}
+    fwd['h1'] = op('norm1', ln, [x0], None, ('norm1.weight', 'norm1.bias'))
+    fwd['qkv'] = op('qkv', lin, [fwd['h1']], None, ('attn.qkv.weight', 'attn.qkv.bias'))
+    fwd['a'] = op('attn', attn, [fwd['qkv']], None)
+    fwd['x1'] = op('proj', lambda a, r, w, b: lin(a, w, b, r), [fwd['a'], x0], None,
+                   ('attn.proj.weight', 'attn.proj.bias'))
+    fwd['h2'] = op('norm2', ln, [fwd['x1']], None, ('norm2.weight', 'norm2.bias'))
+    fwd['f1'] = op('fc1', lin, [fwd['h2']], None, ('mlp.fc1.weight', 'mlp.fc1.bias'))
+    fwd['g'] = op('act', act, [fwd['f1']], None)
+    fwd['x2'] = op('fc2', lambda g_, r, w, b: lin(g_, w, b, r), [fwd['g'], fwd['x1']], None,
+                   ('mlp.fc2.weight', 'mlp.fc2.bias'))
+    op('fc2', lambda g_, r, w, b: lin(g_, w, b, r), [fwd['g'], fwd['x1']], dx2, ('mlp.fc2.weight', 'mlp.fc2.bias'))
+    dg, dres2 = rec['fc2.din']
+    op('act', act, [fwd['f1']], dg)
+    op('fc1', lin, [fwd['h2']], rec['act.din'][0], ('mlp.fc1.weight', 'mlp.fc1.bias'))
+    # norm2 is a residual fork: dx1 = LN-backward(dh2) + the skip branch's gradient, added in ONE kernel
+    op('norm2', ln, [fwd['x1']], rec['fc1.din'][0], ('norm2.weight', 'norm2.bias'))
+    rec['norm2.fork_din'] = _rb(rec['norm2.din'][0] + dres2)
+    op('proj', lambda a, r, w, b: lin(a, w, b, r), [fwd['a'], x0], rec['norm2.fork_din'],
+       ('attn.proj.weight', 'attn.proj.bias'))
+    da, dres1 = rec['proj.din']
+    op('attn', attn, [fwd['qkv']], da)
+    op('qkv', lin, [fwd['h1']], rec['attn.din'][0], ('attn.qkv.weight', 'attn.qkv.bias'))
+    op('norm1', ln, [x0], rec['qkv.din'][0], ('norm1.weight', 'norm1.bias'))
+    rec['norm1.fork_din'] = _rb(rec['norm1.din'][0] + dres1)
+    return Pm, rec, grads, x0, dx2
+
+
+@pytest.mark.parametrize('geometry', ['mae_encoder', 'clip_b16'])
+def test_vit_block_teacher_forced_bf16(geometry):
+    """Every kernel of a ViT-B block (LayerNorm, Linear + bias (+ residual) epilogues, fused attention, GELU /
+    QuickGELU) forward and backward, each fed the ORACLE's bfloat16 input / output gradient of that op and held to
+    the R50 layers' bound: max|d| <= 2 bf16 ulp of the tensor's largest magnitude, mean|d| <= 1/2 ulp; fp32
+    parameter gradients relative to their largest magnitude.  mae_encoder: 50 tokens (MAE's visible set + class
+    token), exact GELU; clip_b16: 197 tokens, QuickGELU."""
+    from passl_amd.modeling.backbones import mae as MB
+    from passl_amd.modeling.backbones import vision_transformer as VB
+    quick = geometry == 'clip_b16'
+    B, T, D, H = (6, 50, 768, 12) if not quick else (3, 197, 768, 12)
+    Pm, rec, grads, x0, dx2 = _vit_block_oracle(B, T, D, H, seed=17, quick_gelu=quick)
+    hip_config.set_device('gpu')
+    hip_config.set_compute_dtype(torch.bfloat16)
+    if quick:
+        blk = VB.Block(dim=D, num_heads=H, mlp_ratio=4.0, qkv_bias=True, epsilon=1e-6)
+    else:
+        from functools import partial
+        blk = MB.Block(D, H, 4.0, qkv_bias=True, norm_layer=partial(nn.LayerNorm, epsilon=1e-6))
+    arena = nn.EncoderArena(blk, trainable=True)
+    missing, unexpected = blk.load_state_dict({k: v.float() for k, v in Pm.items()}, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    arena.refresh()
+    rep = Report('vit_block_%s' % geometry)
+
+    def dev(t):
+        return t.float().to(DEV).to(torch.bfloat16)
+
+    def run(name, call, n_in, param_keys=(), fork_res=None):
+        """Forward with the oracle's inputs, backward with the oracle's output gradient."""
+        arena.clear_grad()
+        ins = [dev(t).requires_grad_(True) for t in rec[name + '.in'][:n_in]]
+        out = call(*ins)
+        rep.bf16(name + ' fwd', out, rec[name + '.out'])
+        out.backward(dev(rec[name + '.dout']))
+        torch.cuda.synchronize()
+        for i, t in enumerate(ins):
+            ref = rec[name + '.din'][i]
+            rep.bf16('%s d-input %d' % (name, i), t.grad, ref)
+        ps = dict(blk.named_parameters())
+        for k in param_keys:
+            rep.f32('%s d %s' % (name, k), ps[k].grad, grads[k], 1e-5)
+
+    attn = blk.attn
+    run('norm1', lambda x: blk.norm1(x), 1, ('norm1.weight', 'norm1.bias'))
+    run('qkv', lambda h: attn.qkv(h), 1, ('attn.qkv.weight', 'attn.qkv.bias'))
+    run('attn', lambda q: nn.attention(q, B, T, attn.num_heads, attn.head_dim, attn.scale), 1)
+    run('proj', lambda a, r: attn.proj(a, residual=r), 2, ('attn.proj.weight', 'attn.proj.bias'))
+    run('norm2', lambda x: blk.norm2(x), 1, ('norm2.weight', 'norm2.bias'))
+    run('fc1', lambda h: blk.mlp.fc1(h), 1, ('mlp.fc1.weight', 'mlp.fc1.bias'))
+    run('act', lambda f: blk.mlp.act(f), 1)
+    run('fc2', lambda g, r: blk.mlp.fc2(g, residual=r), 2, ('mlp.fc2.weight', 'mlp.fc2.bias'))
+    # the residual forks: LayerNorm backward + skip gradient in one kernel (nn.LayerNorm.fork)
+    for name, norm, dres in (('norm2', blk.norm2, rec['fc2.din'][1]), ('norm1', blk.norm1, rec['proj.din'][1])):
+        arena.clear_grad()
+        x = dev(rec[name + '.in'][0]).requires_grad_(True)
+        h, xr = norm.fork(x)
+        torch.autograd.backward([h, xr], [dev(rec[name + '.dout']), dev(dres)])
+        rep.bf16(name + ' fork d-input', x.grad, rec[name + '.fork_din'])
+    rep.finish()
