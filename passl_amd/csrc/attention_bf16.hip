@@ -15,6 +15,7 @@
 //     receives channel i of the 4 rows) — no transposed copy of V / K / dO / Q is ever made.
 // Softmax statistics, exp, delta and all accumulators are fp32; P and dS are rounded to bf16 only
 // as MFMA operands.  8x fewer MFMA issue slots than the exact-fp32 kernels.
+#include <stdlib.h>
 #include "common.h"
 
 namespace abf {
@@ -35,11 +36,11 @@ __device__ __forceinline__ int64_t qkv_off(int b, int t, int which, int h, int T
 }
 
 // rows [0, Tn) of a strided bf16 matrix -> LDS [Tpad][DH + 8]; rows >= Tn are zero
-template <int DH>
+template <int DH, int NTH>
 __device__ __forceinline__ void stage(const bf16_t* __restrict__ base, int64_t rs, int Tn, int Tpad,
                                       bf16_t* lds) {
   constexpr int P = DH + 8, CH = DH / 8;
-  for (int i = threadIdx.x; i < Tpad * CH; i += kThreads) {
+  for (int i = threadIdx.x; i < Tpad * CH; i += NTH) {
     const int r = i / CH, c = (i % CH) * 8;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (r < Tn) v = *reinterpret_cast<const uint4*>(base + (int64_t)r * rs + c);
@@ -100,8 +101,8 @@ __device__ __forceinline__ void accum_pair(const float (&c0)[4], const float (&c
 }
 
 // ------------------------------------------------------------------ forward
-template <int DH>
-__global__ void __launch_bounds__(kThreads) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
+template <int DH, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                  bf16_t* __restrict__ out,
                                                                  float* __restrict__ lse, int Tn, int H,
                                                                  float scale, int causal) {
@@ -112,12 +113,12 @@ __global__ void __launch_bounds__(kThreads) attn_fwd_bf16_kernel(const bf16_t* _
   bf16_t* Ks = smem;
   bf16_t* Vs = smem + Tpad * P;
   const int64_t rs = (int64_t)3 * H * DH;
-  stage<DH>(qkv + qkv_off<DH>(b, 0, 1, h, Tn, H), rs, Tn, Tpad, Ks);
-  stage<DH>(qkv + qkv_off<DH>(b, 0, 2, h, Tn, H), rs, Tn, Tpad, Vs);
+  stage<DH, NW * 64>(qkv + qkv_off<DH>(b, 0, 1, h, Tn, H), rs, Tn, Tpad, Ks);
+  stage<DH, NW * 64>(qkv + qkv_off<DH>(b, 0, 2, h, Tn, H), rs, Tn, Tpad, Vs);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  for (int rb = wave; rb < nt; rb += 4) {
+  for (int rb = wave; rb < nt; rb += NW) {
     const int row = rb * 16 + l15;
     bf16x8_t q[DH / 32];
     glb_frags<DH>(qkv + qkv_off<DH>(b, row < Tn ? row : 0, 0, h, Tn, H), row < Tn, l4, q);
@@ -179,8 +180,8 @@ __global__ void __launch_bounds__(kThreads) attn_fwd_bf16_kernel(const bf16_t* _
 }
 
 // ------------------------------------------------------------------ backward, sweep 1: dQ
-template <int DH>
-__global__ void __launch_bounds__(kThreads) attn_bwd_q_bf16_kernel(
+template <int DH, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_q_bf16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int Tn, int H, float scale, int causal) {
   constexpr int P = DH + 8;
@@ -190,12 +191,12 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_q_bf16_kernel(
   bf16_t* Ks = smem;
   bf16_t* Vs = smem + Tpad * P;
   const int64_t rs = (int64_t)3 * H * DH;
-  stage<DH>(qkv + qkv_off<DH>(b, 0, 1, h, Tn, H), rs, Tn, Tpad, Ks);
-  stage<DH>(qkv + qkv_off<DH>(b, 0, 2, h, Tn, H), rs, Tn, Tpad, Vs);
+  stage<DH, NW * 64>(qkv + qkv_off<DH>(b, 0, 1, h, Tn, H), rs, Tn, Tpad, Ks);
+  stage<DH, NW * 64>(qkv + qkv_off<DH>(b, 0, 2, h, Tn, H), rs, Tn, Tpad, Vs);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  for (int rb = wave; rb < nt; rb += 4) {
+  for (int rb = wave; rb < nt; rb += NW) {
     const int row = rb * 16 + l15;
     const bool rv = row < Tn;
     const int rr = rv ? row : 0;
@@ -250,8 +251,8 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_q_bf16_kernel(
 }
 
 // ------------------------------------------------------------------ backward, sweep 2: dK, dV
-template <int DH>
-__global__ void __launch_bounds__(kThreads) attn_bwd_kv_bf16_kernel(
+template <int DH, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_kv_bf16_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int Tn, int H, float scale, int causal) {
   constexpr int P = DH + 8;
@@ -262,10 +263,10 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_kv_bf16_kernel(
   bf16_t* Ds = smem + Tpad * P;                                    // dO
   float* Ls = reinterpret_cast<float*>(smem + 2 * Tpad * P);       // lse[Tpad]
   float* Dl = Ls + Tpad;                                           // delta[Tpad]
-  stage<DH>(qkv + qkv_off<DH>(b, 0, 0, h, Tn, H), (int64_t)3 * H * DH, Tn, Tpad, Qs);
-  stage<DH>(dout + (((int64_t)b * Tn) * H + h) * DH, (int64_t)H * DH, Tn, Tpad, Ds);
+  stage<DH, NW * 64>(qkv + qkv_off<DH>(b, 0, 0, h, Tn, H), (int64_t)3 * H * DH, Tn, Tpad, Qs);
+  stage<DH, NW * 64>(dout + (((int64_t)b * Tn) * H + h) * DH, (int64_t)H * DH, Tn, Tpad, Ds);
   __syncthreads();
-  for (int t = threadIdx.x; t < Tpad; t += kThreads) {
+  for (int t = threadIdx.x; t < Tpad; t += NW * 64) {
     float d = 0.f, l = 0.f;
     if (t < Tn) {
       const bf16_t* op = out + (((int64_t)b * Tn + t) * H + h) * DH;
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_kv_bf16_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int ntp = Tpad >> 4;                                      // even
-  for (int cb = wave; cb < nt; cb += 4) {
+  for (int cb = wave; cb < nt; cb += NW) {
     const int col = cb * 16 + l15;
     const bool cv = col < Tn;
     bf16x8_t kown[DH / 32], vown[DH / 32];
@@ -327,24 +328,37 @@ __global__ void __launch_bounds__(kThreads) attn_bwd_kv_bf16_kernel(
 
 constexpr int max_lds(int DH) { return 2 * 224 * (DH + 8) * 2 + 2 * 224 * 4; }
 
-template <int DH>
+// PASSL_ATTN_WAVES=4 / 8 forces the workgroup size (A/B runs); default: 8 waves from 8 row tiles on
+inline bool eight_waves(int Tn, bool backward) {
+  static const int forced = [] { const char* e = getenv("PASSL_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+  if (forced == 4) return false;
+  if (forced == 8) return true;
+  // measured (scratch/bench_attn.py): the forward gains from 8 waves at every benchmark shape (faster staging even
+  // when half the waves have no row tile), the backward only from 8 row tiles on
+  return backward ? (Tn + 15) / 16 >= 8 : true;
+}
+
+// NW = waves per workgroup: a head with >= 8 row tiles (T > 112) gets 8 waves — its K / V staging (64 KB at
+// T = 197, d = 64) allows only 2 workgroups per CU, and 8 waves per CU cannot hide the global-load latency of the
+// per-tile query fragments; shorter sequences keep 4 (more workgroups per CU fit anyway).
+template <int DH, int NW>
 int launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, float scale, int causal,
                hipStream_t st) {
   const int Tpad = (Tn + 31) / 32 * 32;
   const int ldsb = 2 * Tpad * (DH + 8) * 2;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(DH));
     attr = true;
   }
-  hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH>), dim3(B * H), dim3(kThreads), ldsb, st,
+  hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NW>), dim3(B * H), dim3(NW * 64), ldsb, st,
                      reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<bf16_t*>(out), lse, Tn, H,
                      scale, causal);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
-template <int DH>
+template <int DH, int NW>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
                int Tn, int H, float scale, int causal, hipStream_t st) {
   const int Tpad = (Tn + 31) / 32 * 32;
@@ -352,18 +366,18 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
   const int lds2 = lds1 + 2 * Tpad * 4;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_bf16_kernel<DH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_bf16_kernel<DH, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(DH));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_bf16_kernel<DH>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_bf16_kernel<DH, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, max_lds(DH));
     attr = true;
   }
-  hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<DH>), dim3(B * H), dim3(kThreads), lds1, st,
+  hipLaunchKernelGGL((attn_bwd_q_bf16_kernel<DH, NW>), dim3(B * H), dim3(NW * 64), lds1, st,
                      reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<const bf16_t*>(out),
                      reinterpret_cast<const bf16_t*>(dout), lse, reinterpret_cast<bf16_t*>(dqkv), Tn, H,
                      scale, causal);
   if (hipGetLastError() != hipSuccess) return PASSL_ELAUNCH;
-  hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<DH>), dim3(B * H), dim3(kThreads), lds2, st,
+  hipLaunchKernelGGL((attn_bwd_kv_bf16_kernel<DH, NW>), dim3(B * H), dim3(NW * 64), lds2, st,
                      reinterpret_cast<const bf16_t*>(qkv), reinterpret_cast<const bf16_t*>(out),
                      reinterpret_cast<const bf16_t*>(dout), lse, reinterpret_cast<bf16_t*>(dqkv), Tn, H,
                      scale, causal);
@@ -375,12 +389,20 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 // entry points used by attention.hip (shapes already validated there); 16-byte aligned rows required
 int passl_attn_bf16_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, int DH, float scale,
                         int causal, hipStream_t st) {
-  return DH == 64 ? abf::launch_fwd<64>(qkv, out, lse, B, Tn, H, scale, causal, st)
-                  : abf::launch_fwd<32>(qkv, out, lse, B, Tn, H, scale, causal, st);
+  const bool wide = abf::eight_waves(Tn, false);
+  if (DH == 64)
+    return wide ? abf::launch_fwd<64, 8>(qkv, out, lse, B, Tn, H, scale, causal, st)
+                : abf::launch_fwd<64, 4>(qkv, out, lse, B, Tn, H, scale, causal, st);
+  return wide ? abf::launch_fwd<32, 8>(qkv, out, lse, B, Tn, H, scale, causal, st)
+              : abf::launch_fwd<32, 4>(qkv, out, lse, B, Tn, H, scale, causal, st);
 }
 
 int passl_attn_bf16_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                         int B, int Tn, int H, int DH, float scale, int causal, hipStream_t st) {
-  return DH == 64 ? abf::launch_bwd<64>(qkv, out, dout, lse, dqkv, B, Tn, H, scale, causal, st)
-                  : abf::launch_bwd<32>(qkv, out, dout, lse, dqkv, B, Tn, H, scale, causal, st);
+  const bool wide = abf::eight_waves(Tn, true);
+  if (DH == 64)
+    return wide ? abf::launch_bwd<64, 8>(qkv, out, dout, lse, dqkv, B, Tn, H, scale, causal, st)
+                : abf::launch_bwd<64, 4>(qkv, out, dout, lse, dqkv, B, Tn, H, scale, causal, st);
+  return wide ? abf::launch_bwd<32, 8>(qkv, out, dout, lse, dqkv, B, Tn, H, scale, causal, st)
+              : abf::launch_bwd<32, 4>(qkv, out, dout, lse, dqkv, B, Tn, H, scale, causal, st);
 }
