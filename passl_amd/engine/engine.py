@@ -64,6 +64,7 @@ class Engine(object):
         assert isinstance(self.accum_steps, int) and self.accum_steps > 0, \
             'accum_steps must be int dtype and greater than 0'
         self.max_train_step = g.get('max_train_step', None)
+        self.checkpoint = g.get('checkpoint', None)           # resume prefix (engine.py:82)
         assert self.max_train_step is None or (isinstance(self.max_train_step, int) and self.max_train_step > 0), \
             'max_train_step must be int dtype and greater than 0'
         self.logger = logging.getLogger('passl')

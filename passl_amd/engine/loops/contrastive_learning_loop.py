@@ -11,6 +11,7 @@ import collections
 import torch
 
 from ...core.sync_utils import grad_sync
+from ...models import Model
 from .loop import TrainingEpochLoop
 
 
@@ -31,7 +32,6 @@ class ContrastiveLearningTrainingEpochLoop(TrainingEpochLoop):
             sub = [b[idx * step:(idx + 1) * step] for b in batch]
             # v2 models take the sub-batch as ONE list argument (contrastive_learning_loop.py:52);
             # v110 architectures (mode='train') take the views positionally
-            from ...models import Model
             loss_dict = self.trainer.model(sub) if isinstance(self.trainer.model, Model) \
                 else self.trainer.model(*sub)
             if torch.is_tensor(loss_dict):

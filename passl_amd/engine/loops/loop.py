@@ -39,6 +39,7 @@ class TrainingEpochLoop(object):
     # ---- loop.py:207-252
     def run(self):
         assert self.trainer.mode == 'train' and self.trainer.training is True
+        self.resume()
         self.total_batch_idx = len(self.trainer.train_dataloader)
         for epoch_id in range(self.start_eopch + 1, self.epochs + 1):
             self.cur_epoch_id = epoch_id
@@ -108,6 +109,50 @@ class TrainingEpochLoop(object):
             ', '.join('{}: {:.5f}'.format(k, m.avg) for k, m in self.time_info.items()),
             self.batch_size * world / cost, datetime.timedelta(seconds=int(eta))))
 
+    # ---- loop.py:317-340 over passl/utils/io.py:115-170
     def save_checkpoint(self):
-        out = os.path.join(self.trainer.output_dir, self.trainer.model_name, 'epoch_{}'.format(self.cur_epoch_id))
-        self.trainer.model.save(out, rank=self.trainer.config['Global'].get('rank', 0))
+        """<output_dir>/<model_name>/epoch_N.{pdparams,pdopt,pdstates} and the same three under ``latest``:
+        model (``Model.save``), optimizer + lr-scheduler state, and {epoch, global_step, timestamp} — the set
+        ``resume`` needs to continue a run."""
+        import pickle
+        from ...utils.checkpoint import to_numpy
+        rank = self.trainer.config['Global'].get('rank', 0)
+        model_dir = os.path.join(self.trainer.output_dir, self.trainer.model_name)
+        prefixes = [os.path.join(model_dir, 'epoch_{}'.format(self.cur_epoch_id)), os.path.join(model_dir, 'latest')]
+        for prefix in prefixes:
+            self.trainer.model.save(prefix, rank=rank)
+        if rank != 0:
+            return
+        os.makedirs(model_dir, exist_ok=True)
+        opt_state = to_numpy(self.trainer.optimizer.state_dict())
+        metric_info = {'epoch': self.cur_epoch_id, 'global_step': self.global_step,
+                       'timestamp': time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(time.time()))}
+        for prefix in prefixes:
+            with open(prefix + '.pdopt', 'wb') as f:
+                pickle.dump(opt_state, f, protocol=2)
+            with open(prefix + '.pdstates', 'wb') as f:
+                pickle.dump(metric_info, f, protocol=2)
+        logger.info('Already save epoch_{} model in {}'.format(self.cur_epoch_id, model_dir))
+
+    # ---- loop.py:358-375 over passl/utils/io.py:52-96
+    def resume(self):
+        """``Global.checkpoint`` (a path prefix without extension): model, optimizer / lr-scheduler state and the
+        epoch / step counters of a previous run; training continues with epoch ``epoch + 1``."""
+        ckpt = getattr(self.trainer, 'checkpoint', None)
+        if ckpt is None:
+            return
+        from ...utils.checkpoint import load_pickle
+        assert isinstance(ckpt, str), 'checkpoint type is not available. Please use `string`.'
+        rank = self.trainer.config['Global'].get('rank', 0)
+        self.trainer.model.load_pretrained(ckpt, rank=rank, finetune=False)
+        opt_path = ckpt + '.pdopt'
+        assert os.path.exists(opt_path), 'Optimizer checkpoint path {} does not exists.'.format(opt_path)
+        opt_state = load_pickle(opt_path)
+        self.trainer.optimizer.set_state_dict(opt_state)
+        if os.path.exists(ckpt + '.pdstates'):
+            metric_info = load_pickle(ckpt + '.pdstates')
+            if 'global_step' in metric_info:
+                self.global_step = int(metric_info['global_step'])
+            if 'epoch' in metric_info:
+                self.start_eopch = int(metric_info['epoch'])
+        logger.info('Finish load checkpoint from {}'.format(ckpt))

@@ -87,7 +87,7 @@ class LogHook(Hook):
                 trainer.logs[k].update(float(v))
         if self.by_epoch and self.every_n_inner_iters(trainer, self.interval):
             self.print_log(trainer)
-        elif self._hits(trainer.current_iter, self.interval):
+        elif self.every_n_iters(trainer, self.interval):
             # iteration-based runs print nothing here (as the reference), but the queue is still
             # drained every `interval` iterations so it cannot grow for a whole epoch
             self._flush(trainer)

@@ -157,7 +157,11 @@ def _register_dummies():
             return float(self.lr())
 
         def state_dict(self):
-            return {}
+            return {'LR_Scheduler': self.lr.state_dict()} if hasattr(self.lr, 'state_dict') else {}
+
+        def set_state_dict(self, sd):
+            if 'LR_Scheduler' in sd:
+                self.lr.set_state_dict(sd['LR_Scheduler'])
 
 
 def test_trainer_loop_hooks_and_checkpoint(tmp_path):
@@ -613,7 +617,8 @@ def test_v2_engine_runs_the_named_loop(tmp_path):
         eng.train()
         assert eng.global_step == 6 and eng.cur_epoch_id == 2 and eng.lr_scheduler.last_epoch == 6
         assert not torch.equal(w0, eng.model.inner.fc.weight)
-        assert len(eng.model.saved) == 2                  # save_interval 1 -> one file per epoch
+        # save_interval 1 -> epoch_N and `latest` every epoch
+        assert [os.path.basename(q) for q in eng.model.saved] == ['epoch_1', 'latest', 'epoch_2', 'latest']
         # each optimizer step saw accum_steps micro-batches of 2 samples
         assert len(eng.model.inner.calls) == 12
         # max_train_step ends the run early
@@ -624,6 +629,71 @@ def test_v2_engine_runs_the_named_loop(tmp_path):
         assert eng2.global_step == 4
         with pytest.raises(AttributeError):
             M.build_model(dict(name='no_such_model'))
+    finally:
+        del M.dummy_v2
+
+
+def test_v2_checkpoint_set_and_resume(tmp_path):
+    """save_checkpoint writes epoch_N.{pdparams (Model.save), pdopt, pdstates} and `latest.*` (reference
+    passl/utils/io.py:115-170); Global.checkpoint resumes model, optimizer / lr-scheduler state and the epoch /
+    step counters (loop.py:358-375): a run stopped after epoch 1 and resumed ends where the uninterrupted run ends."""
+    import pickle
+    _register_dummies()
+    import passl_amd.models as M
+    from passl_amd.engine.engine import Engine
+    from passl_amd.modeling.architectures.builder import MODELS
+    from passl_amd.solver.lr_scheduler import LRScheduler
+
+    class DummyV2(M.Model):
+        def __init__(self, dim=4):
+            super().__init__()
+            self.inner = MODELS.get('DummySSL')(dim)
+
+        def forward(self, inputs):
+            return self.inner(*inputs)
+
+        def save(self, path, local_rank=0, rank=0):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path + '.pdparams', 'wb') as f:
+                pickle.dump({k: v.detach().numpy() for k, v in self.state_dict().items()}, f)
+
+        def load_pretrained(self, path, rank=0, finetune=False):
+            with open(path + '.pdparams', 'rb') as f:
+                self.load_state_dict({k: torch.as_tensor(v) for k, v in pickle.load(f).items()})
+    M.dummy_v2 = lambda **kw: DummyV2(**kw)
+    try:
+        def make(out, epochs, checkpoint=None):
+            cfg = get_config(os.path.join(ROOT, 'configs/v2/moco_v2_resnet50_pt_synthetic.yaml'),
+                             ['Global.device=cpu', 'Global.epochs=%d' % epochs, 'Global.save_interval=1',
+                              'Global.print_batch_step=100', 'Global.output_dir=%s' % out, 'Global.seed=3',
+                              'DataLoader.Train.sampler.batch_size=4', 'DataLoader.Train.dataset.num_samples=12',
+                              'DataLoader.Train.dataset.image_size=8'])
+            cfg.Model = AttrDict(name='dummy_v2', dim=4)
+            cfg.Optimizer = AttrDict(name='PlainSGD')
+            cfg.LRScheduler.T_max = 6                      # the schedule of the WHOLE (2-epoch) run in every arm
+            cfg.Global.checkpoint = checkpoint
+            eng = Engine(cfg, mode='train')
+            eng.optimizer._parameter_list = eng.optimizer.params
+            return eng
+        full = make(tmp_path / 'full', 2)
+        full.train()
+        first = make(tmp_path / 'part', 1)
+        first.train()
+        d = tmp_path / 'part' / 'dummy_v2'
+        for stem in ('epoch_1', 'latest'):
+            for ext in ('.pdparams', '.pdopt', '.pdstates'):
+                assert (d / (stem + ext)).exists(), stem + ext
+        with open(d / 'latest.pdstates', 'rb') as f:
+            st = pickle.load(f)
+        assert st['epoch'] == 1 and st['global_step'] == 3 and 'timestamp' in st
+        with open(d / 'latest.pdopt', 'rb') as f:
+            assert pickle.load(f)['LR_Scheduler']['last_epoch'] == 3
+        second = make(tmp_path / 'part', 2, checkpoint=str(d / 'latest'))
+        second.train()
+        assert second.train_loop.start_eopch == 1 and second.global_step == 6 and second.cur_epoch_id == 2
+        assert second.lr_scheduler.last_epoch == full.lr_scheduler.last_epoch == 6
+        assert isinstance(second.lr_scheduler, LRScheduler)
+        assert torch.equal(second.model.inner.fc.weight, full.model.inner.fc.weight)
     finally:
         del M.dummy_v2
 
