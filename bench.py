@@ -35,7 +35,7 @@ FLOP_PER_SAMPLE = 32.77e9      # 2*[(3+1)*(4.0871+0.00446) + 2*0.00
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured streaming ceiling)
-PMC_TRAFFIC_FILE = os.path.join('profiles', 'r02_pmc_traffic.json')
+PMC_TRAFFIC_FILE = os.path.join('profiles', 'r03_pmc_traffic.json')
 
 # workload -> (config, default per-GPU batch, algorithmic FLOP per sample, metric text, workload text)
 WORKLOADS = {
@@ -151,7 +151,7 @@ def pmc_traffic(args):
     src = ('%s (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + WRITE_SIZE; '
            'not measured by this run)' % PMC_TRAFFIC_FILE)
     out = {}
-    for k in ('ring', 'igemm', 'wgrad'):
+    for k in ('ring', 'g8p', 'igemm', 'wgrad'):
         if k in z.get('classes', {}):
             out[k] = {'hbm_bytes_per_launch': z['classes'][k]['hbm_bytes_per_launch'], 'source': src}
     return out
@@ -162,6 +162,9 @@ def main():
     # multi-process GPU work on this stack needs dmabuf IPC (RCCL across ranks); set here too, not only in
     # self_launch: the driver starts the ranks with torch.distributed.run itself
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # cached-but-unused blocks are returned before the pool grows past 70 % of the device (read by the allocator at
+    # its first allocation; hip/config.py additionally caps the pool at PASSL_MEMORY_FRACTION = 0.85)
+    os.environ.setdefault('PYTORCH_HIP_ALLOC_CONF', 'garbage_collection_threshold:0.7')
     if args.dp_buckets:
         os.environ['PASSL_DP_BUCKETS'] = str(args.dp_buckets)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -63,6 +63,7 @@ def main():
                                                       for k in ks) / max(n, 1)),
                     'kernels': sorted(ks)}
         classes = {'ring': klass(lambda k: 'igemm_ring_kernel' in k),
+                   'g8p': klass(lambda k: 'igemm_8p_kernel' in k),
                    'igemm': klass(lambda k: k.startswith('igemm_kernel')),
                    'wgrad': klass(lambda k: 'wgrad' in k)}
         json.dump({'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 '
