@@ -162,9 +162,6 @@ def main():
     # multi-process GPU work on this stack needs dmabuf IPC (RCCL across ranks); set here too, not only in
     # self_launch: the driver starts the ranks with torch.distributed.run itself
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    # cached-but-unused blocks are returned before the pool grows past 70 % of the device (read by the allocator at
-    # its first allocation; hip/config.py additionally caps the pool at PASSL_MEMORY_FRACTION = 0.85)
-    os.environ.setdefault('PYTORCH_HIP_ALLOC_CONF', 'garbage_collection_threshold:0.7')
     if args.dp_buckets:
         os.environ['PASSL_DP_BUCKETS'] = str(args.dp_buckets)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -37,13 +37,16 @@ _capped = set()
 
 
 def _cap_memory(device):
-    """Keep torch's caching allocator below PASSL_MEMORY_FRACTION (default 0.85) of the device: the rest stays
-    free for RCCL's communicator buffers and the driver on a data-parallel node (a SimCLR bs-512 run used to
-    RESERVE 242 of 288 GB for 155 GB of live tensors: one workspace allocation away from an out-of-memory retry).
-    With the cap the allocator returns cached blocks and retries before it fails."""
+    """Keep torch's caching allocator below PASSL_MEMORY_FRACTION (default 0.9 = 259 GB) of the device: the rest
+    (29 GB) stays free for RCCL's communicator buffers and the driver on a data-parallel node.  The largest
+    benchmarked configuration (SimCLR bs 512: 155 GB of live tensors) settles at 241-253 GB of cached blocks; with the
+    cap a pool that wants more returns cached blocks and retries instead of taking the last free page.  Measured
+    alternatives (profiles/r03_allocator_cap.txt): a 0.85 cap forces exactly that retry every step (273 -> 762
+    ms/step), a garbage-collection threshold of 0.7 keeps 177 GB reserved but every collection is a
+    device-synchronising free (351 ms/step), expandable segments change nothing on this build."""
     if not torch.cuda.is_available() or device.index in _capped:
         return
-    frac = float(os.environ.get('PASSL_MEMORY_FRACTION', '0.85'))
+    frac = float(os.environ.get('PASSL_MEMORY_FRACTION', '0.9'))
     if 0.0 < frac < 1.0:
         torch.cuda.set_per_process_memory_fraction(frac, device)
     _capped.add(device.index)
