@@ -4,13 +4,15 @@ contrastive_head.py:21-78.
 ``fused(q, k, queue)`` is the hot-path entry used by MoCo.train_iter: one HIP kernel computes the
 positive logit, the 65 536 negative logits, the online log-sum-exp and the rank of the positive
 without materialising the [N, K+1] logits (passl_amd/csrc/head.hip).  ``forward(pos, neg)`` keeps
-the reference's call signature for callers that already hold logits; it is not on the hot path.
+the reference's call signature for callers that already hold logits; it is not on the hot path: the
+materialised [N, 1 + K] logits go through the row cross-entropy / rank-counting kernel of the linear probe
+(csrc/clas.hip) — the only torch ops are the concatenation and the 1/T scale of its input.
 """
 import torch
-import torch.nn.functional as F
 
 from ...hip import nn
 from .builder import HEADS
+from .clas_head import _SoftmaxCEFn
 
 
 @HEADS.register()
@@ -32,19 +34,10 @@ class ContrastiveHead(nn.Layer):
     def forward(self, pos, neg):
         """Compatibility entry (materialised logits): pos [N,1], neg [N,K]."""
         N = pos.shape[0]
-        logits = torch.cat((pos, neg), dim=1) / self.temperature
+        logits = (torch.cat((pos, neg), dim=1) / self.temperature).float()
         labels = torch.zeros((N,), dtype=torch.int64, device=logits.device)
-        outputs = dict(loss=F.cross_entropy(logits, labels).reshape(1))
+        loss, acc1, acc5 = _SoftmaxCEFn.apply(logits, labels)
+        outputs = dict(loss=loss)
         if self.return_accuracy:
-            acc1, acc5 = accuracy(logits, labels, topk=(1, 5))
             outputs['acc1'], outputs['acc5'] = acc1, acc5
         return outputs
-
-
-def accuracy(output, target, topk=(1,)):
-    with torch.no_grad():
-        maxk = max(topk)
-        batch_size = target.shape[0]
-        _, pred = output.topk(maxk, 1, True, True)
-        correct = (pred.t() == target.reshape(1, -1)).float()
-        return [correct[:k].reshape(-1).sum(0, keepdim=True) * 100.0 / batch_size for k in topk]

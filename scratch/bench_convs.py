@@ -6,6 +6,12 @@ from passl_amd.hip import ops, plan as P
 from passl_amd.hip.packer import WeightPacker
 
 DEV = 'cuda'
+# PASSL_OPTS="igemm_ring_bk=32,igemm_8p=0": library options for A/B runs
+for kv in filter(None, os.environ.get('PASSL_OPTS', '').split(',')):
+    k, v = kv.split('=')
+    from passl_amd.hip import lib as _L
+    rc = _L.load().passl_hip_set_option(k.encode(), int(v))
+    assert rc == 0, (k, v, rc)
 N = int(os.environ.get('BATCH', 256))
 dtype = torch.bfloat16 if os.environ.get('DTYPE', 'bf16') == 'bf16' else torch.float32
 # (cin, cout, k, stride, pad, H, count per forward pass)

@@ -512,3 +512,33 @@ def test_step_graph_replay_is_bit_identical(dtype):
     for key in ('losses', 'q', 'k', 'queue'):
         assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), key
     assert float(a['losses'][0, 0]) != float(a['losses'][-1, 0])
+
+
+def test_contrastive_head_forward_with_materialised_logits():
+    """ContrastiveHead.forward(pos, neg) (reference contrastive_head.py:37-78: cat, / T, CrossEntropy, top-1/5):
+    the compatibility entry runs the row cross-entropy / rank kernel and agrees with torch and with the fused
+    hot-path entry on the same q, k, queue."""
+    import torch.nn.functional as F
+    from passl_amd.modeling.heads import ContrastiveHead
+    gen = torch.Generator().manual_seed(9)
+    N, D, K, T = 32, 128, 512, 0.2
+    q = F.normalize(torch.randn(N, D, generator=gen), dim=1).to(DEV).requires_grad_(True)
+    k = F.normalize(torch.randn(N, D, generator=gen), dim=1).to(DEV)
+    queue = F.normalize(torch.randn(D, K, generator=gen), dim=0).to(DEV)
+    head = ContrastiveHead(temperature=T)
+    pos = (q * k).sum(1, keepdim=True)
+    neg = q @ queue
+    out = head(pos, neg)
+    logits = torch.cat([pos, neg], 1).detach().double().cpu() / T
+    ref = F.cross_entropy(logits, torch.zeros(N, dtype=torch.long))
+    assert abs(float(out['loss']) - float(ref)) < 1e-5
+    rank = (logits[:, 1:] > logits[:, :1]).sum(1)
+    assert abs(float(out['acc1']) - 100.0 * float((rank < 1).float().mean())) < 1e-4
+    assert abs(float(out['acc5']) - 100.0 * float((rank < 5).float().mean())) < 1e-4
+    out['loss'].backward()
+    qg = q.grad.clone()
+    q2 = q.detach().clone().requires_grad_(True)
+    fused = head.fused(q2, k, queue)
+    fused['loss'].backward()
+    assert abs(float(fused['loss']) - float(out['loss'])) < 1e-5
+    assert float((q2.grad - qg).abs().max()) < 1e-5 * float(qg.abs().max()) + 1e-7
