@@ -326,6 +326,14 @@ int passl_hip_l2norm_fwd(const float* x, float* y, float* norm, int N, int D, fl
 /* dx = (dy - y*(y.dy)) / norm ; written as fp32 (dtype F32) or bf16. */
 int passl_hip_l2norm_bwd(const float* dy, const float* y, const float* norm, void* dx, int N,
                          int D, int dtype, passl_stream_t stream);
+/* SimSiam's criterion (reference passl/models/simsiam.py:69,93: nn.CosineSimilarity(axis=1) of the predictor output
+ * against the stop-gradient projector output, negated and averaged): loss[0] = -(1/N) sum_i a_i.b_i / max(|a_i||b_i|,
+ * eps); a, b fp32 [N,D]; stats [N,4] is saved for the backward.  The mean is one fixed-order sum. */
+int passl_hip_cosine_loss_fwd(const float* a, const float* b, int N, int D, float eps, float* stats, float* loss,
+                              passl_stream_t stream);
+/* da [N,D] = gloss[0] * d loss / d a  (b is a constant); gloss: device scalar. */
+int passl_hip_cosine_loss_bwd(const float* a, const float* b, const float* stats, const float* gloss, int N, int D,
+                              float* da, passl_stream_t stream);
 
 /* Fused InfoNCE forward (moco.py:178-180 + heads/contrastive_head.py:47-78):
  *   l_pos[i] = q[i].k[i];  l_neg[i][j] = q[i].queue[:,j];  logits = [l_pos | l_neg]/T

@@ -462,6 +462,21 @@ def install():
     amp.auto_cast = lambda *a, **k: _ctx.nullcontext()
     nn.Identity = type('Identity', (torch.nn.Identity, Layer), {})
     nn.Tanh = type('Tanh', (torch.nn.Tanh, Layer), {})
+
+    class CosineSimilarity(Layer):
+        """paddle.nn.CosineSimilarity(axis, eps=1e-8) = F.cosine_similarity: sum(x1*x2) / max(|x1|*|x2|, eps)
+        [Paddle-semantics: paddle/nn/functional/common.py cosine_similarity]."""
+
+        def __init__(self, axis=1, eps=1e-8):
+            super().__init__()
+            self._axis, self._eps = axis, eps
+
+        def forward(self, x1, x2):
+            w12 = (x1 * x2).sum(self._axis)
+            w1 = (x1 * x1).sum(self._axis)
+            w2 = (x2 * x2).sum(self._axis)
+            return w12 / (w1 * w2).sqrt().clamp_min(self._eps)
+    nn.CosineSimilarity = CosineSimilarity
     Layer.named_sublayers = lambda self, prefix='', include_self=False: (
         (n, m) for n, m in self.named_modules(prefix=prefix) if include_self or m is not self)
     paddle.get_default_dtype = lambda: torch.get_default_dtype()

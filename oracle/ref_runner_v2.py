@@ -59,3 +59,27 @@ def load():
     m3 = imp('passl.models.mocov3')
     return types.SimpleNamespace(mocov3=m3, runtime_info_hub=hub.runtime_info_hub,
                                  vit=sys.modules['passl.models.vision_transformer'])
+
+
+def load_simsiam():
+    """-> namespace(simsiam module).  passl/models/resnet.py subclasses ``paddle.vision.models.resnet.ResNet`` — a
+    class of the Paddle wheel (2.4 line), not of the reference tree.  The tree carries its own copy of that class
+    (passl_v110/modeling/backbones/resnetimagenet.py, used by the v110 models): the v2 sources are executed against
+    THAT copy, adapted to the wheel's constructor signature (width / groups accepted at their defaults only)."""
+    ns = load()
+    from . import paddle_shim
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'passl_ref_resnetimagenet', os.path.join(REF_ROOT, 'passl_v110', 'modeling', 'backbones', 'resnetimagenet.py'))
+    rin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rin)
+
+    class PDResNet(rin.ResNet):
+        def __init__(self, block, depth=50, width=64, num_classes=1000, with_pool=True, groups=1):
+            assert width == 64 and groups == 1, 'only the plain ResNet of the vendored copy'
+            super().__init__(block, depth, num_classes=num_classes, with_pool=with_pool)
+    shadow = types.SimpleNamespace(ResNet=PDResNet, BasicBlock=rin.BasicBlock, BottleneckBlock=rin.BottleneckBlock)
+    paddle_shim.bind_vision_resnet(shadow)
+    importlib.import_module('passl.models.resnet')
+    ns.simsiam = importlib.import_module('passl.models.simsiam')
+    return ns

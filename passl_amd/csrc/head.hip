@@ -313,6 +313,63 @@ __global__ void __launch_bounds__(kThreads) l2norm_bwd_kernel(const float* __res
   }
 }
 
+
+// ------------------------------------------------------------------ SimSiam: negative cosine similarity
+// reference passl/models/simsiam.py:69,93: loss = -mean_i cos(a_i, b_i), cos = a.b / max(|a||b|, eps), b constant
+// (stop-gradient).  One wave per row; stats[i] = {cos, |a|^2, max(|a||b|, eps), clamped?}; the mean is one ordered
+// sum (no atomics).
+__global__ void __launch_bounds__(kThreads) cosine_rows_kernel(const float* __restrict__ a,
+                                                               const float* __restrict__ b, int N, int Dd,
+                                                               float eps, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float d = 0.f, na = 0.f, nb = 0.f;
+  for (int c = lane; c < Dd; c += 64) {
+    const float x = a[(int64_t)row * Dd + c], y = b[(int64_t)row * Dd + c];
+    d += x * y; na += x * x; nb += y * y;
+  }
+  d = wave_sum(d); na = wave_sum(na); nb = wave_sum(nb);
+  if (lane == 0) {
+    const float den = sqrtf(na * nb);
+    const float dc = fmaxf(den, eps);
+    stats[row * 4 + 0] = d / dc;
+    stats[row * 4 + 1] = na;
+    stats[row * 4 + 2] = dc;
+    stats[row * 4 + 3] = den > eps ? 1.f : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) cosine_mean_kernel(const float* __restrict__ stats, int N,
+                                                               float* __restrict__ loss) {
+  __shared__ float part[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < N; i += kThreads) s += stats[i * 4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = -(part[0] + part[1] + part[2] + part[3]) / (float)N;
+}
+
+// da = -g/N * d cos / d a;   d cos / d a = b/den - cos * a/|a|^2  (den > eps)  |  b/eps  (clamped)
+__global__ void __launch_bounds__(kThreads) cosine_bwd_kernel(const float* __restrict__ a,
+                                                              const float* __restrict__ b,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gloss, int N, int Dd,
+                                                              float* __restrict__ da) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float cs = stats[row * 4 + 0], na = stats[row * 4 + 1], dc = stats[row * 4 + 2];
+  const bool live = stats[row * 4 + 3] != 0.f;
+  const float k = -(*gloss) / (float)N;
+  const float kb = k / dc, ka = live ? k * cs / na : 0.f;
+  for (int c = lane; c < Dd; c += 64) {
+    const int64_t o = (int64_t)row * Dd + c;
+    da[o] = kb * b[o] - ka * a[o];
+  }
+}
+
 }  // namespace
 
 int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, int accumulate,
@@ -402,6 +459,25 @@ extern "C" int passl_hip_enqueue_dev(float* queue, const float* keys, int Dd, in
                      Dd, K, 0, (const int64_t*)ptr, B);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(64), 0, as_stream(stream), ptr, B, K);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_cosine_loss_fwd(const float* a, const float* b, int N, int Dd, float eps, float* stats,
+                                         float* loss, passl_stream_t stream) {
+  if (!a || !b || !stats || !loss || N <= 0 || Dd <= 0 || !(eps > 0.f)) return PASSL_EINVAL;
+  hipLaunchKernelGGL(cosine_rows_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, as_stream(stream), a, b, N, Dd,
+                     eps, stats);
+  hipLaunchKernelGGL(cosine_mean_kernel, dim3(1), dim3(kThreads), 0, as_stream(stream), stats, N, loss);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_cosine_loss_bwd(const float* a, const float* b, const float* stats, const float* gloss,
+                                         int N, int Dd, float* da, passl_stream_t stream) {
+  if (!a || !b || !stats || !gloss || !da || N <= 0 || Dd <= 0) return PASSL_EINVAL;
+  hipLaunchKernelGGL(cosine_bwd_kernel, dim3((N + 3) / 4), dim3(kThreads), 0, as_stream(stream), a, b, stats,
+                     gloss, N, Dd, da);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

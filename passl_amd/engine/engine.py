@@ -50,6 +50,82 @@ class _ListBatchLoader(object):
             yield [list(views), None]
 
 
+class _Schedulers(object):
+    """Several schedules stepped as one (the default schedule + those of parameter groups:
+    Optimizer.lr_step, passl/optimizer/optimizer.py:216-222)."""
+
+    def __init__(self, scheds):
+        self.scheds = list(scheds)
+
+    def step(self, epoch=None):
+        for s_ in self.scheds:
+            s_.step(epoch)
+
+    def __call__(self):
+        return self.scheds[0]()
+
+    def __getattr__(self, name):
+        return getattr(self.scheds[0], name)
+
+    def state_dict(self):
+        return {'sched_%d' % i: s_.state_dict() for i, s_ in enumerate(self.scheds)}
+
+    def set_state_dict(self, sd):
+        for i, s_ in enumerate(self.scheds):
+            s_.set_state_dict(sd['sched_%d' % i])
+
+
+class OptimizerGroup(object):
+    """One flat-arena optimizer per parameter group (each group must cover whole arenas: the model puts the
+    groups of its task yaml into separate arenas), behind the optimizer API the loops use."""
+
+    def __init__(self, klass, key, groups, default_lr, common, build_scheduler):
+        self.optimizers, self.names, self.schedulers = [], [], []
+        for c, plist in groups:
+            kw = dict(common)
+            lr = default_lr
+            if isinstance(c.get('lr', None), dict):
+                lr = build_scheduler(c['lr'])
+                self.schedulers.append(lr)
+            elif c.get('lr', None) is not None:
+                lr = float(c['lr'])
+            for k in ('weight_decay', 'momentum'):
+                if k in c:
+                    kw[k] = c[k]
+            self.optimizers.append(klass(lr, **kw, **{key: plist}))
+            self.names.append(c['name'])
+        self._parameter_list = [p for o in self.optimizers for p in o._parameter_list]
+
+    @property
+    def grad_scale(self):
+        return self.optimizers[0].grad_scale
+
+    @grad_scale.setter
+    def grad_scale(self, v):
+        for o in self.optimizers:
+            o.grad_scale = v
+
+    def get_lr(self, group_id=0):
+        return self.optimizers[group_id].get_lr()
+
+    def step(self):
+        for o in self.optimizers:
+            o.step()
+
+    def clear_grad(self, set_to_zero=True):
+        for o in self.optimizers:
+            o.clear_grad()
+
+    clear_gradients = clear_grad
+
+    def state_dict(self):
+        return {'group_%d' % i: o.state_dict() for i, o in enumerate(self.optimizers)}
+
+    def set_state_dict(self, sd):
+        for i, o in enumerate(self.optimizers):
+            o.set_state_dict(sd['group_%d' % i])
+
+
 class Engine(object):
     def __init__(self, config, mode='train'):
         assert mode in ['train', 'eval', 'export']
@@ -108,22 +184,33 @@ class Engine(object):
         self.lr_scheduler = None
         sched_cfg = config.get('LRScheduler', None)
         if sched_cfg is not None:
-            sched_cfg = AttrDict(copy.deepcopy(dict(sched_cfg)))
-            self.lr_decay_unit = sched_cfg.pop('decay_unit', 'step')
-            per_unit = len(self.train_dataloader) if self.lr_decay_unit == 'step' else 1
-            if sched_cfg.name == 'CosineAnnealingDecay' and 'T_max' not in sched_cfg:
-                sched_cfg.T_max = g['epochs'] * per_unit        # decay over the whole run
-            # build_lr_scheduler (passl/scheduler/__init__.py:22-23) hands every v2 scheduler the run length
-            accepted = inspect.signature(LRSCHEDULERS.get(sched_cfg.name).__init__).parameters
-            if 'step_each_epoch' in accepted:
-                sched_cfg.update({'epochs': g['epochs'], 'step_each_epoch': len(self.train_dataloader),
-                                  'decay_unit': self.lr_decay_unit})
-            self.lr_scheduler = build_from_config(sched_cfg, LRSCHEDULERS)
+            self.lr_decay_unit = sched_cfg.get('decay_unit', 'step')
+            self.lr_scheduler = self._build_scheduler(dict(sched_cfg), g)
         name = opt_cfg.pop('name')
-        params = list(self.model.parameters())
-        lr = self.lr_scheduler if self.lr_scheduler is not None else opt_cfg.pop('learning_rate')
-        kw = {'parameter_list' if 'Lars' in name else 'parameters': params}
-        self.optimizer = OPTIMIZERS.get(name)(lr, **opt_cfg, **kw)
+        # build_optimizer (passl/optimizer/__init__.py:124-212): `lr` inside the Optimizer block is the default
+        # schedule (a float or a scheduler config, its decay_unit reset to lr_decay_unit); `param_groups` split the
+        # trainable parameters by name (re.match(group name, parameter name), first match wins, the rest is
+        # 'default') and may carry their own `lr`
+        lr_cfg = opt_cfg.pop('lr', None)
+        if isinstance(lr_cfg, dict):
+            self.lr_scheduler = self._build_scheduler(dict(lr_cfg, decay_unit=self.lr_decay_unit), g)
+        groups_cfg = opt_cfg.pop('param_groups', None)
+        if self.lr_scheduler is not None:
+            lr = self.lr_scheduler
+        elif isinstance(lr_cfg, (int, float)):
+            lr = float(lr_cfg)
+        else:
+            lr = opt_cfg.pop('learning_rate')
+        klass = OPTIMIZERS.get(name)
+        key = 'parameter_list' if 'Lars' in name else 'parameters'
+        if groups_cfg:
+            self.optimizer = OptimizerGroup(klass, key, self._group_params(groups_cfg), lr, opt_cfg,
+                                            lambda c: self._build_scheduler(dict(c, decay_unit=self.lr_decay_unit), g))
+            if self.optimizer.schedulers:
+                self.lr_scheduler = _Schedulers([s_ for s_ in [self.lr_scheduler] if s_ is not None] +
+                                                self.optimizer.schedulers)
+        else:
+            self.optimizer = klass(lr, **opt_cfg, **{key: list(self.model.parameters())})
 
         if g.get('pretrained_model', None) is not None:
             assert isinstance(g['pretrained_model'], str), 'pretrained_model type is not available. Please use `string`.'
@@ -143,6 +230,39 @@ class Engine(object):
         self.train_loop = getattr(loops, train_loop_name)(self, epochs=g['epochs'],
                                                           max_train_step=self.max_train_step, val_loop=None)
         self.init_runtime_info_hub()
+
+    def _build_scheduler(self, sched_cfg, g):
+        """build_lr_scheduler (passl/scheduler/__init__.py:22-36): every v2 scheduler is handed the run length."""
+        sched_cfg = AttrDict(copy.deepcopy(dict(sched_cfg)))
+        unit = sched_cfg.pop('decay_unit', self.lr_decay_unit)
+        per_unit = len(self.train_dataloader) if unit == 'step' else 1
+        if sched_cfg.name == 'CosineAnnealingDecay' and 'T_max' not in sched_cfg:
+            sched_cfg.T_max = g['epochs'] * per_unit        # decay over the whole run
+        accepted = inspect.signature(LRSCHEDULERS.get(sched_cfg.name).__init__).parameters
+        if 'step_each_epoch' in accepted:
+            sched_cfg.update({'epochs': g['epochs'], 'step_each_epoch': len(self.train_dataloader), 'decay_unit': unit})
+        return build_from_config(sched_cfg, LRSCHEDULERS)
+
+    def _group_params(self, groups_cfg):
+        """group_params (passl/optimizer/__init__.py:68-113) -> [(group config, [parameters])] in config order,
+        'default' last."""
+        import re
+        groups = [(dict(c), []) for c in groups_cfg]
+        default = []
+        for pname, p in self.model.named_parameters():
+            if not p.requires_grad:
+                continue
+            for c, plist in groups:
+                if re.compile(c.get('regular_exp', c['name'])).match(pname):
+                    plist.append(p)
+                    break
+            else:
+                default.append(p)
+        if default:
+            groups.append(({'name': 'default'}, default))
+        for c, plist in groups:
+            self.logger.info('%s-params length: %d', c['name'], len(plist))
+        return groups
 
     def init_runtime_info_hub(self):
         runtime_info_hub.epochs = self.train_loop.epochs

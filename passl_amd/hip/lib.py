@@ -138,6 +138,8 @@ SIGNATURES = {
     'passl_hip_mae_loss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     'passl_hip_adamw': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
     'passl_hip_adamw_dev': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_f, c_f, c_f, c_p]),
+    'passl_hip_cosine_loss_fwd': (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p]),
+    'passl_hip_cosine_loss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_softmax_ce_fwd': (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p]),
     'passl_hip_softmax_ce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),

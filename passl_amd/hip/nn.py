@@ -460,7 +460,7 @@ class _LinearFn(Function):
                 ops.conv_wgrad(pl.wd, x, dy, rt.dw)
         else:
             ops.conv_wgrad(pl.wd, x, dy, rt.dw)
-        if layer.bias is not None:
+        if layer.bias is not None and layer.bias.requires_grad:
             ops.colsum_into(dy, layer.bias.grad, accumulate=True)     # straight into the arena's gradient
         rt.arena.grad_ready(rt.indices)
         # y = x W + b + residual: the residual branch's gradient is dy itself
@@ -714,11 +714,14 @@ class EncoderArena:
 
     ALIGN = 8   # elements; keeps every slot 32-byte aligned in fp32 and 16-byte aligned in bf16
 
-    def __init__(self, module, trainable=True, dtype=None, exclude=()):
+    def __init__(self, module, trainable=True, dtype=None, exclude=(), exclude_params=()):
         """exclude: sub-layers whose own parameters / statistics live elsewhere (a frozen layer inside a trainable
-        encoder gets a non-trainable arena of its own, e.g. MoCo-v3's patch embedding)."""
+        encoder gets a non-trainable arena of its own, e.g. MoCo-v3's patch embedding).  exclude_params: single
+        parameters that stay ordinary tensors outside the arena (SimSiam's projector bias whose gradient is
+        switched off, passl/models/simsiam.py:61)."""
         self.module = module
         skip = {id(m) for m in exclude}
+        skip_p = {id(q) for q in exclude_params}
         self.trainable = trainable
         self.dtype = dtype or config.get_compute_dtype()
         self.reducer = None
@@ -729,7 +732,7 @@ class EncoderArena:
             if id(mod) in skip:
                 continue
             for name, p in mod._parameters.items():
-                if p is None or id(p) in seen:
+                if p is None or id(p) in seen or id(p) in skip_p:
                     continue
                 seen.add(id(p))
                 kind = 'conv' if ((isinstance(mod, Conv2D) or getattr(mod, 'krsc_weight', False))

@@ -312,6 +312,24 @@ def l2norm_bwd(dy, y, norm, out_dtype):
     return dx
 
 
+def cosine_loss_fwd(a, b, eps=1e-8):
+    """-> loss [1] = -mean_i cos(a_i, b_i), stats [N,4] (for the backward)."""
+    N, Dd = a.shape
+    stats = torch.empty(N, 4, dtype=torch.float32, device=a.device)
+    loss = torch.empty(1, dtype=torch.float32, device=a.device)
+    L.check(_lib().passl_hip_cosine_loss_fwd(L.ptr(a), L.ptr(b), N, Dd, eps, L.ptr(stats), L.ptr(loss), L.stream()),
+            'cosine_loss_fwd')
+    return loss, stats
+
+
+def cosine_loss_bwd(a, b, stats, gloss):
+    N, Dd = a.shape
+    da = torch.empty_like(a)
+    L.check(_lib().passl_hip_cosine_loss_bwd(L.ptr(a), L.ptr(b), L.ptr(stats), L.ptr(gloss), N, Dd, L.ptr(da),
+                                             L.stream()), 'cosine_loss_bwd')
+    return da
+
+
 def infonce_fwd(q, k, queue, T, want_logits=False):
     """Returns out[3] (loss, acc1, acc5), row_lse[N], logits[N,K+1] or None."""
     N, Dd = q.shape

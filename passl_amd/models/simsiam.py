@@ -1,0 +1,127 @@
+"""SimSiam (ResNet-50) pre-training on the MI355X HIP path — reference passl/models/simsiam.py.
+
+Constructor arguments, factory name, sub-layer / state_dict names and the ``model([x1, x2]) -> loss`` contract are the
+reference's: ``SimSiamPretain`` :36-95 (``encoder`` = v2 ResNet whose ``fc`` becomes the 3-layer projector
+[Linear(no bias) - BatchNorm1D - ReLU] x 2 - the original fc - BatchNorm1D(no gamma / beta), the original fc's bias
+kept but without gradient; ``predictor`` = Linear(no bias) - BatchNorm1D - ReLU - Linear), factory :152-163.
+
+Execution: the trunk is the MoCo hot path's (implicit-GEMM convs with fused BatchNorm statistics, fused BatchNorm
+backward in the data-gradient epilogues, weight gradients on the side stream); each view is its own pass (BatchNorm
+statistics are per view, as in the reference); MLPs = GEMM kernel with fp32 output -> BatchNorm1D on fp32 rows -> ReLU
+(SimCLR-neck pattern); the criterion is one fused kernel pair (passl.loss.simsiam).  Parameter groups of the task
+yaml (``encoder`` on the schedule, ``predictor`` at a fixed rate) map to two EncoderArenas = two flat optimizer
+launches.  The reference converts every BatchNorm to SyncBatchNorm when world_size > 1 (:160-162): cross-rank
+BatchNorm statistics are not built here, so a data-parallel SimSiam run raises instead of silently training with
+per-rank statistics.
+"""
+import os
+import pickle
+from functools import partial
+
+import torch
+import torch.nn as tnn
+
+from ..core.sync_utils import collectives_active
+from ..hip import config
+from ..hip import nn as hnn
+from ..hip.nn import EncoderArena
+from ..loss.simsiam import neg_cosine_similarity
+from ..utils.checkpoint import load_lenient, load_pickle, to_numpy
+from .base_model import Model
+from ..modeling.backbones.resnet import ResNet as _Trunk
+from .resnet import BottleneckBlock, ResNet
+
+__all__ = ['SimSiamPretain', 'simsiam_resnet50_pretrain']
+
+
+class _MLP(tnn.Sequential):
+    """Linear -> (BatchNorm1D -> (ReLU)) chains with the reference's Sequential indices as sub-layer names; Linears
+    write fp32, BatchNorm works on fp32 rows, the next Linear reads the compute-dtype cast."""
+
+    def forward(self, x):
+        dt = config.get_compute_dtype()
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            x = lin(hnn.to_compute(x, dt), out_f32=True)
+            i += 1
+            if i < len(mods) and isinstance(mods[i], hnn._BatchNormBase):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], hnn.ReLU)
+                x = mods[i](x, relu=relu)
+                i += 2 if relu else 1
+        return x
+
+
+class SimSiamPretain(Model):
+    """Build a SimSiam Pretrain model."""
+
+    def __init__(self, base_encoder, dim=2048, pred_dim=512):
+        super().__init__()
+        # create the encoder; num_classes is the output fc dimension, zero-initialize last BNs
+        self.encoder = base_encoder(class_num=dim, zero_init_residual=True)
+        # build a 3-layer projector
+        fc = self.encoder.fc
+        prev_dim = fc.weight.shape[1]
+        self.encoder.fc = _MLP(hnn.Linear(prev_dim, prev_dim, bias_attr=False), hnn.BatchNorm1D(prev_dim), hnn.ReLU(),
+                               hnn.Linear(prev_dim, prev_dim, bias_attr=False), hnn.BatchNorm1D(prev_dim), hnn.ReLU(),
+                               fc, hnn.BatchNorm1D(dim, weight_attr=False, bias_attr=False))
+        self.encoder.fc[6].bias.requires_grad_(False)        # hack: not use bias as it is followed by BN
+        # build a 2-layer predictor
+        self.predictor = _MLP(hnn.Linear(dim, pred_dim, bias_attr=False), hnn.BatchNorm1D(pred_dim), hnn.ReLU(),
+                              hnn.Linear(pred_dim, dim))
+        self.arena_q = EncoderArena(self.encoder, trainable=True, exclude_params=[self.encoder.fc[6].bias])
+        self.arena_p = EncoderArena(self.predictor, trainable=True)
+
+    # -- state plumbing
+    def sync_runtime_state(self):
+        self.arena_q.refresh()
+        self.arena_p.refresh()
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.sync_runtime_state()
+        return r
+
+    # -- reference API
+    def _view(self, x):
+        y = _Trunk.forward(self.encoder, x)                  # trunk + average pool (NHWC [N, 1, 1, 2048])
+        z = self.encoder.fc(y.reshape(y.shape[0], -1))
+        return z, self.predictor(z)
+
+    def forward(self, inputs):
+        assert isinstance(inputs, (list, tuple))
+        x1, x2 = inputs[0], inputs[1]
+        self.arena_q.refresh()                   # compute-dtype operands from the fp32 masters (after the update)
+        self.arena_p.refresh()
+        z1, p1 = self._view(x1)                  # compute features for one view: NxC
+        z2, p2 = self._view(x2)
+        return (neg_cosine_similarity(p1, z2) + neg_cosine_similarity(p2, z1)) * 0.5
+
+    def load_pretrained(self, path, rank=0, finetune=False):
+        if not os.path.exists(path + '.pdparams'):
+            raise ValueError('Model pretrain path {} does not exists.'.format(path))
+        load_lenient(self, load_pickle(path + '.pdparams'), what='pretrained model')
+        self.sync_runtime_state()
+
+    def save(self, path, local_rank=0, rank=0):
+        """<path>.pdparams = the whole state; <path>_encoder.pdparams = the trunk without the projector, prefix
+        removed (simsiam.py:113-126)."""
+        if rank != 0:
+            return
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        sd = to_numpy(dict(self.state_dict()))
+        with open(path + '.pdparams', 'wb') as f:
+            pickle.dump(sd, f, protocol=2)
+        enc = {k[len('encoder.'):]: v for k, v in sd.items() if k.startswith('encoder') and not k.startswith('encoder.fc')}
+        with open(path + '_encoder.pdparams', 'wb') as f:
+            pickle.dump(enc, f, protocol=2)
+
+
+def simsiam_resnet50_pretrain(**kwargs):
+    if collectives_active():
+        raise NotImplementedError(
+            'data-parallel SimSiam converts every BatchNorm to SyncBatchNorm (reference simsiam.py:160-162): '
+            'cross-rank BatchNorm statistics are not built on this path — run it on one GPU')
+    encoder = partial(ResNet, block=BottleneckBlock, depth=50)
+    return SimSiamPretain(base_encoder=encoder, dim=2048, pred_dim=512, **kwargs)

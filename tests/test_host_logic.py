@@ -774,3 +774,42 @@ def test_v2_engine_builds_from_the_reference_mocov3_yaml_unchanged():
         assert 'base_encoder.head.7.weight' not in sd and tuple(sd['base_encoder.pos_embed'].shape) == (1, 197, 768)
     finally:
         hip_config.set_compute_dtype(prev)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/tasks/ssl/simsiam'), reason='reference tree not present')
+def test_v2_engine_builds_from_the_reference_simsiam_yaml_unchanged():
+    """tasks/ssl/simsiam/configs/simsiam_resnet50_pt_in1k_1n8c_dp_fp32.yaml read as it is (`-o` overrides: device,
+    dataset class, a smaller run): Engine builds SimSiam through passl.models.build_model; the schedule sits INSIDE
+    the Optimizer block (`lr:` = TimmCosine, stepped per epoch: lr_decay_unit) and `param_groups` split the
+    trainable parameters by name into the encoder group (schedule) and the predictor group (fixed 0.1) — one flat
+    optimizer per group; FP16 level O0 selects fp32 compute."""
+    from passl_amd.engine.engine import Engine, OptimizerGroup
+    from passl_amd.hip import config as hip_config
+    yaml_path = '/root/reference/tasks/ssl/simsiam/configs/simsiam_resnet50_pt_in1k_1n8c_dp_fp32.yaml'
+    prev = hip_config.get_compute_dtype()
+    try:
+        cfg = get_config(yaml_path, ['Global.device=cpu', 'Global.epochs=10',
+                                     'DataLoader.Train.dataset.name=SyntheticTwoView',
+                                     'DataLoader.Train.sampler.batch_size=2'])
+        cfg.DataLoader.Train.dataset.num_samples = 8
+        cfg.DataLoader.Train.dataset.image_size = 32
+        eng = Engine(cfg, mode='train')
+        assert hip_config.get_compute_dtype() == torch.float32
+        m, opt = eng.model, eng.optimizer
+        assert type(m).__name__ == 'SimSiamPretain' and isinstance(opt, OptimizerGroup)
+        assert opt.names == ['encoder', 'predictor']
+        enc, pred = opt.optimizers
+        assert enc._arenas == [m.arena_q] and pred._arenas == [m.arena_p]
+        assert (enc._momentum, enc._wd, pred._wd) == (0.9, 1e-4, 1e-4)
+        assert eng.lr_decay_unit == 'epoch' and type(eng.lr_scheduler).__name__ == 'TimmCosine'
+        assert eng.lr_scheduler.T_max == 10 and eng.lr_scheduler.last_epoch == 0
+        assert opt.get_lr(0) == 0.1 and opt.get_lr(1) == 0.1
+        eng.lr_scheduler.step(5)
+        assert abs(opt.get_lr(0) - 0.05) < 1e-12 and opt.get_lr(1) == 0.1        # the predictor's rate is fixed
+        ps = dict(m.named_parameters())
+        assert not ps['encoder.fc.6.bias'].requires_grad and ps['encoder.fc.6.weight'].requires_grad
+        sd = m.state_dict()
+        assert 'encoder.fc.7._mean' in sd and 'encoder.fc.7.weight' not in sd and 'predictor.3.bias' in sd
+        assert float(sd['encoder.layer3.2.bn3.weight'].abs().max()) == 0.0           # zero_init_residual
+    finally:
+        hip_config.set_compute_dtype(prev)

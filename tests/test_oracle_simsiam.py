@@ -1,0 +1,112 @@
+"""CPU tests that pin the SimSiam oracle (oracle/simsiam.py): against golden vectors produced by running the
+reference's own v2 sources (tests/golden/make_golden_simsiam.py: passl/models/simsiam.py + resnet.py over the tree's
+copy of the paddle.vision ResNet), live against those sources when /root/reference is present, and known answers for
+the loss and the two-group momentum update."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import simsiam as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+SOLVER = dict(lr=2e-4, predictor_lr=5e-4, momentum=0.9, weight_decay=1e-4)
+
+
+def _against(name, max_steps):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    N, size, steps, zero = [int(v) for v in z['meta']]
+    o = S.SimSiamOracle(seed=0, zero_init_residual=bool(zero), **SOLVER)
+    gen = torch.Generator().manual_seed(777)
+    watch = [k[len('s0_gradnorm/'):] for k in z.files if k.startswith('s0_gradnorm/')]
+    stats = [k[len('s0_stat/'):] for k in z.files if k.startswith('s0_stat/')]
+    for s in range(min(steps, max_steps)):
+        x1 = torch.randn(N, 3, size, size, generator=gen)
+        x2 = torch.randn(N, 3, size, size, generator=gen)
+        out = o.train_step(x1, x2)
+        pre = 's%d_' % s
+        amp = 10.0 ** s                    # later steps start from parameters that already differ by rounding
+        assert abs(float(out['loss']) - float(z[pre + 'loss'])) < 2e-6 * amp, (s, float(out['loss']), float(z[pre + 'loss']))
+        np.testing.assert_allclose(out['z1'][:, :8].numpy(), z[pre + 'z1_head'], atol=2e-4 * amp)
+        np.testing.assert_allclose(out['p1'][:, :8].numpy(), z[pre + 'p1_head'], atol=2e-4 * amp)
+        for n in watch:
+            g = out['grads'][n].double().norm().item()
+            ref = float(z[pre + 'gradnorm/' + n])
+            assert abs(g - ref) <= 2e-3 * amp * max(ref, 1e-12) + 1e-9, (s, n, g, ref)
+            assert abs(o.st[n].double().norm().item() - float(z[pre + 'pnorm/' + n])) < 1e-4 * amp, (s, n)
+        for n in stats:
+            np.testing.assert_allclose(o.st[n][:8].double().numpy(), z[pre + 'stat/' + n], rtol=1e-4 * amp, atol=1e-5 * amp)
+
+
+def test_oracle_matches_golden_small():
+    _against('simsiam_r50_small', 2)
+
+
+def test_oracle_matches_golden_zero_init_first_step():
+    _against('simsiam_r50_zero_init', 1)
+
+
+def test_zero_init_residual_and_frozen_bias():
+    """resnet.py:66-73: gamma of the last BatchNorm of every residual branch starts at 0 — the branch's convs get
+    no gradient in the first step, its gamma does; simsiam.py:61: the projector's last bias never moves."""
+    o = S.SimSiamOracle(seed=1, **SOLVER)
+    assert all(float(v.abs().max()) == 0.0 for k, v in o.st.items() if k.endswith('.bn3.weight'))
+    g = torch.Generator().manual_seed(2)
+    b0 = o.st['encoder.fc.6.bias'].clone()
+    out = o.train_step(torch.randn(4, 3, 32, 32, generator=g), torch.randn(4, 3, 32, 32, generator=g))
+    assert 'encoder.fc.6.bias' not in out['grads'] and torch.equal(o.st['encoder.fc.6.bias'], b0)
+    assert float(out['grads']['encoder.layer1.0.conv3.weight'].abs().max()) == 0.0
+    assert float(out['grads']['encoder.layer1.0.bn3.weight'].abs().max()) > 0.0
+
+
+def test_loss_and_parameter_groups_known_answers():
+    a = torch.tensor([[3.0, 4.0], [1.0, 0.0]])
+    b = torch.tensor([[3.0, 4.0], [0.0, 2.0]])
+    assert torch.allclose(S.cosine(a, b), torch.tensor([1.0, 0.0]))
+    assert float(S.cosine(torch.zeros(1, 2), torch.ones(1, 2))) == 0.0          # |a||b| clamped at 1e-8
+    o = S.SimSiamOracle(seed=0, lr=0.5, predictor_lr=0.1, momentum=0.9, weight_decay=0.0)
+    ke, kp = 'encoder.fc.0.weight', 'predictor.0.weight'
+    pe, pp = o.st[ke].clone(), o.st[kp].clone()
+    grads = {ke: torch.ones_like(pe), kp: torch.ones_like(pp)}
+    o.apply_momentum(grads)
+    assert torch.allclose(o.st[ke], pe - 0.5) and torch.allclose(o.st[kp], pp - 0.1)
+    o.apply_momentum(grads)                               # v = 0.9 * 1 + 1
+    assert torch.allclose(o.st[ke], pe - 0.5 - 0.5 * 1.9) and torch.allclose(o.st[kp], pp - 0.1 - 0.1 * 1.9)
+    assert S.group_of('predictor.3.bias') == 'predictor' and S.group_of('encoder.fc.6.weight') == 'encoder'
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/passl/models'), reason='reference tree not present (GPU box)')
+def test_oracle_matches_reference_sources_live():
+    code = r'''
+import sys, torch
+sys.path.insert(0, 'tests/golden')
+from oracle import ref_runner_v2
+import make_golden_simsiam as G
+from oracle.simsiam import SimSiamOracle
+ns = ref_runner_v2.load_simsiam()
+o = SimSiamOracle(seed=4, zero_init_residual=False)
+m = ns.simsiam.simsiam_resnet50_pretrain()
+G.load_state(m, o)
+m.train()
+g = torch.Generator().manual_seed(3)
+x1 = torch.randn(6, 3, 32, 32, generator=g); x2 = torch.randn(6, 3, 32, 32, generator=g)
+loss = m([x1, x2])
+loss.backward()
+r = o.forward_backward(x1, x2)
+assert abs(float(loss.detach()) - float(r['loss'])) < 1e-6, (float(loss), float(r['loss']))
+ps = dict(m.named_parameters())
+assert ps['encoder.fc.6.bias'].grad is None
+for n, gr in r['grads'].items():
+    assert (ps[n].grad - gr).abs().max().item() <= 2e-4 * max(gr.abs().max().item(), 1e-6), (n, (ps[n].grad - gr).abs().max().item(), gr.abs().max().item())
+sd = m.state_dict()
+for k, v in o.st.items():
+    if k.endswith('._mean') or k.endswith('._variance'):
+        assert (sd[k] - v).abs().max().item() < 1e-5 * max(1.0, v.abs().max().item()), k
+print('LIVE-OK')
+'''
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'LIVE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
