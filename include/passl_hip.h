@@ -286,6 +286,22 @@ int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int64_t M, int 
                               const float* gamma, const float* mean, const float* invstd,
                               float* dgamma, float* dbeta, float* coef /* [3][C] */,
                               passl_stream_t stream);
+/* Cross-rank (Sync) BatchNorm — reference passl/models/simsiam.py:160-162 (nn.SyncBatchNorm.convert_sync_batchnorm
+ * under data parallelism): statistics over the batches of ALL ranks.  Forward: bn_moments folds this rank's slab to
+ * fp64 {mean[C], M2[C], n[C]} (mom: 3*C doubles); the caller all-gathers them (rank order) and bn_finalize_moments
+ * combines them with Chan's update and produces what bn_finalize produces (running statistics from the GLOBAL batch).
+ * Backward: bn_bwd_sums folds the slab to fp64 {sum g, sum g*xhat} (2*C doubles), all-gathered; bn_bwd_finalize_sums
+ * accumulates THIS rank's sums into dgamma / dbeta and writes the apply coefficients from the totals and the global
+ * row count.  The collectives are the caller's (torch.distributed): the library never communicates. */
+int passl_hip_bn_moments(const float* partial, int nblocks, int64_t M, int C, int rows_per_block, double* mom,
+                         passl_stream_t stream);
+int passl_hip_bn_finalize_moments(const double* mom_all, int world, int C, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                  float* invstd, float* scale, float* shift, passl_stream_t stream);
+int passl_hip_bn_bwd_sums(const float* partial, int nblocks, int64_t M, int C, double* sums, passl_stream_t stream);
+int passl_hip_bn_bwd_finalize_sums(const double* sums_all, int world, int rank, int64_t M_total, int C,
+                                   const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                                   float* dbeta, float* coef, passl_stream_t stream);
 int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* coef,
                            const float* scale, const float* shift, void* dx, void* dres, int64_t M,
                            int C, int relu, int dtype, passl_stream_t stream);

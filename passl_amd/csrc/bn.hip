@@ -276,6 +276,93 @@ __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
   coef[2 * C + c] = (float)Cc;
 }
 
+// ------------------------------------------------------------------ cross-rank (Sync) BatchNorm pieces
+// SyncBatchNorm (reference passl/models/simsiam.py:160-162: nn.SyncBatchNorm.convert_sync_batchnorm under data
+// parallelism) = BatchNorm over the batches of ALL ranks.  Each rank folds its slab to fp64 moments
+// {mean, M2 = sum (x - mean)^2, n}; the moments of all ranks are gathered (3 C doubles per rank) and combined in RANK
+// ORDER with Chan's update (deterministic, no cancellation); backward the same way with {sum g, sum g xhat}.
+__global__ void __launch_bounds__(kFinThreads) bn_moments_kernel(
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block,
+    const double* __restrict__ scratch, int nseg, double* __restrict__ mom) {
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  double t1, t2;
+  float g0;
+  slab_totals<true>(partial, nblocks, C, M, rows_per_block, scratch, nseg, c, t1, t2, g0);
+  if (threadIdx.x >= 8 || c >= C) return;
+  const double dm = t1 / (double)M;
+  double m2 = t2 - t1 * dm;                          // sum (x - mean)^2, centred on a sample value first
+  if (m2 < 0.0) m2 = 0.0;
+  mom[c] = (double)g0 + dm;
+  mom[C + c] = m2;
+  mom[2 * C + c] = (double)M;
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_moments_kernel(
+    const double* __restrict__ mom_all, int world, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+    float eps, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+    float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const double* m = mom_all + (int64_t)r * 3 * C;
+    const double nb = m[2 * C + c], mb = m[c], qb = m[C + c];
+    if (nb <= 0.0) continue;
+    const double nn = n + nb, d = mb - mu;
+    m2 += qb + d * d * n * nb / nn;
+    mu += d * nb / nn;
+    n = nn;
+  }
+  const double var = n > 0.0 ? m2 / n : 0.0;         // biased
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mu * sc;
+  if (rmean) {
+    rmean[c] = momentum * rmean[c] + (1.0f - momentum) * (float)mu;
+    rvar[c] = momentum * rvar[c] + (1.0f - momentum) * (float)var;
+  }
+}
+
+__global__ void __launch_bounds__(kFinThreads) bn_bwd_sums_kernel(
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, const double* __restrict__ scratch,
+    int nseg, double* __restrict__ sums) {
+  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+  double sg, sgx;
+  float unused;
+  slab_totals<false>(partial, nblocks, C, M, 0, scratch, nseg, c, sg, sgx, unused);
+  if (threadIdx.x >= 8 || c >= C) return;
+  sums[c] = sg;
+  sums[C + c] = sgx;
+}
+
+// dgamma / dbeta accumulate THIS rank's sums (the data-parallel reducer averages parameter gradients afterwards);
+// the input-gradient coefficients use the totals over all ranks and the global row count
+__global__ void __launch_bounds__(256) bn_bwd_finalize_sums_kernel(
+    const double* __restrict__ sums_all, int world, int rank, double m_total, int C,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double sg = 0.0, sgx = 0.0;
+  for (int r = 0; r < world; ++r) {
+    sg += sums_all[(int64_t)r * 2 * C + c];
+    sgx += sums_all[(int64_t)r * 2 * C + C + c];
+  }
+  dbeta[c] += (float)sums_all[(int64_t)rank * 2 * C + c];
+  dgamma[c] += (float)sums_all[(int64_t)rank * 2 * C + C + c];
+  const double gi = (double)gamma[c] * (double)invstd[c];
+  const double inv_m = 1.0 / m_total;
+  const double B = -gi * (double)invstd[c] * sgx * inv_m;
+  const double Cc = -gi * sg * inv_m - B * (double)mean[c];
+  coef[c] = (float)gi;
+  coef[C + c] = (float)B;
+  coef[2 * C + c] = (float)Cc;
+}
+
 // z = relu?(x*scale + shift + res)
 template <typename T>
 __global__ void __launch_bounds__(kThreads) bn_apply_kernel(const T* __restrict__ x,
@@ -614,6 +701,70 @@ extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int6
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
                      partial, nblocks, M, C, scratch, nseg, gamma, mean, invstd, dgamma, dbeta, coef);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+// ---- cross-rank BatchNorm (see the kernels above): mom / sums are caller-owned fp64 buffers
+extern "C" int passl_hip_bn_moments(const float* partial, int nblocks, int64_t M, int C, int rows_per_block,
+                                    double* mom, passl_stream_t stream) {
+  if (!partial || !mom || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || rows_per_block <= 0 ||
+      (int64_t)nblocks * rows_per_block < M || (reinterpret_cast<uintptr_t>(partial) & 7))
+    return PASSL_EINVAL;
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, &seg_rows);
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 3);
+  if (nseg > 1) {
+    hipLaunchKernelGGL(bn_combine_kernel<true>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                       partial, nblocks, M, C, rows_per_block, seg_rows, scratch);
+    PASSL_RETURN_IF_LAUNCH_FAILED();
+  }
+  hipLaunchKernelGGL(bn_moments_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, rows_per_block, scratch, nseg, mom);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_finalize_moments(const double* mom_all, int world, int C, const float* gamma,
+                                             const float* beta, float* running_mean, float* running_var,
+                                             float momentum, float eps, float* mean, float* invstd,
+                                             float* scale, float* shift, passl_stream_t stream) {
+  if (!mom_all || !gamma || !beta || !mean || !invstd || !scale || !shift || world <= 0 || C <= 0 ||
+      (running_mean && !running_var))
+    return PASSL_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_moments_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), mom_all,
+                     world, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_bwd_sums(const float* partial, int nblocks, int64_t M, int C, double* sums,
+                                     passl_stream_t stream) {
+  if (!partial || !sums || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 ||
+      (reinterpret_cast<uintptr_t>(partial) & 7))
+    return PASSL_EINVAL;
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, &seg_rows);
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 2);
+  if (nseg > 1) {
+    hipLaunchKernelGGL(bn_combine_kernel<false>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                       partial, nblocks, M, C, 0, seg_rows, scratch);
+    PASSL_RETURN_IF_LAUNCH_FAILED();
+  }
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, scratch, nseg, sums);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_bn_bwd_finalize_sums(const double* sums_all, int world, int rank, int64_t M_total, int C,
+                                              const float* gamma, const float* mean, const float* invstd,
+                                              float* dgamma, float* dbeta, float* coef, passl_stream_t stream) {
+  if (!sums_all || !gamma || !mean || !invstd || !dgamma || !dbeta || !coef || world <= 0 || rank < 0 ||
+      rank >= world || M_total <= 0 || C <= 0)
+    return PASSL_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_sums_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums_all,
+                     world, rank, (double)M_total, C, gamma, mean, invstd, dgamma, dbeta, coef);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

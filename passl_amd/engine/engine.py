@@ -223,8 +223,14 @@ class Engine(object):
                 'If you want to use data parallel you should set data_parallel=True'
             arch = getattr(self.model, 'arch', self.model)
             param_sync(arch)
-            self.grad_reducer = GradReducer(arch.arena_q if hasattr(arch, 'arena_q') else arch.arena,
-                                            self.optimizer)
+            arenas = arch.trainable_arenas() if hasattr(arch, 'trainable_arenas') else None
+            if arenas is not None and len(arenas) > 1:
+                # several trainable arenas (parameter groups): the loop's blocking grad_sync reduces each flat
+                # gradient buffer after backward (reference behaviour); the overlapped reducer handles one arena
+                self.grad_reducer = None
+            else:
+                self.grad_reducer = GradReducer(arch.arena_q if hasattr(arch, 'arena_q') else arch.arena,
+                                                self.optimizer)
 
         train_loop_name = g.get('train_loop')
         self.train_loop = getattr(loops, train_loop_name)(self, epochs=g['epochs'],

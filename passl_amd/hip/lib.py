@@ -79,6 +79,10 @@ SIGNATURES = {
     'passl_hip_bn_bwd_reduce': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i,
                                       c_i, c_p]),
     'passl_hip_bn_bwd_finalize': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'passl_hip_bn_moments': (c_i, [c_p, c_i, c_l, c_i, c_i, c_p, c_p]),
+    'passl_hip_bn_finalize_moments': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    'passl_hip_bn_bwd_sums': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p]),
+    'passl_hip_bn_bwd_finalize_sums': (c_i, [c_p, c_i, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'passl_hip_bn_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i,
                                      c_p]),
     'passl_hip_maxpool3x3s2_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -249,14 +249,30 @@ class Conv2D(Layer):
 
 
 # =============================================================================== batch norm
+def _collectives_active():
+    from ..core.sync_utils import collectives_active
+    return collectives_active()
+
+
+def convert_sync_batchnorm(module):
+    """paddle.nn.SyncBatchNorm.convert_sync_batchnorm: every BatchNorm of `module` computes its training statistics
+    over the batches of ALL data-parallel ranks from now on (no-op without a process group)."""
+    for m in module.modules():
+        if isinstance(m, _BatchNormBase):
+            m._sync = True
+    return module
+
+
 class _BNActFn(Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, residual, layer, relu, partial, res_slot, link_box):
         has_res = residual is not None
+        # SyncBatchNorm (convert_sync_batchnorm): statistics over every rank's batch when a process group is up
+        ctx.sync = bool(getattr(layer, '_sync', False)) and _collectives_active()
         z, st, mask = ops.bn_train_fwd(y, gamma.detach(), beta.detach(), layer._mean,
                                        layer._variance, residual, relu, layer._momentum,
                                        layer._epsilon, partial=partial,
-                                       want_mask=relu and has_res)
+                                       want_mask=relu and has_res, sync=ctx.sync)
         # ReLU mask for the backward: recomputed from y (no residual) or the bit mask (residual):
         # the output z is never re-read by this layer's backward.
         ctx.relu_mode = 0 if not relu else (3 if has_res else 2)
@@ -285,7 +301,7 @@ class _BNActFn(Function):
             ctx.link.y = ctx.link.st = ctx.link.mask = ctx.link.fused = None     # drop the references
         dx, dres = ops.bn_bwd(dz.contiguous(), mask, y, gamma, st[0], st[1],
                               dgamma, dbeta, relu=ctx.relu_mode,
-                              want_dres=want_dres, scale=st[2], shift=st[3], fused=fused)
+                              want_dres=want_dres, scale=st[2], shift=st[3], fused=fused, sync=ctx.sync)
         if ctx.res_slot is not None:
             ctx.res_slot.put(dres)
             dres = None

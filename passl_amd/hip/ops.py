@@ -154,11 +154,22 @@ def bn_partial_floats(nblocks, Cch, shifted):
     return nblocks * Cch * (3 if shifted else 2) + 16 * Cch * 4
 
 
+def _gather_doubles(t):
+    """all_gather of a small fp64 device tensor in rank order -> [world, *t.shape]."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)            # (concatenation along dim 0: the form every backend accepts)
+    return out.view((world,) + tuple(t.shape))
+
+
 def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum=0.9, eps=1e-5,
-                 partial=None, want_mask=False):
+                 partial=None, want_mask=False, sync=False):
     """x: [..., C] NHWC rows.  Returns z, stats[4,C] (mean, invstd, scale, shift), relu bit mask
     (or None); updates rmean/rvar in place.  `partial` = (slab, tiles) of fused statistics a conv
-    epilogue already wrote (conv_stats_buffer); without it a stats pass over x is launched."""
+    epilogue already wrote (conv_stats_buffer); without it a stats pass over x is launched.
+    `sync`: statistics over the batches of every rank (SyncBatchNorm): this rank's slab is folded to fp64
+    moments, the moments are all-gathered and combined in rank order (csrc/bn.hip)."""
     Cch = x.shape[-1]
     M = x.numel() // Cch
     dev = x.device
@@ -173,15 +184,24 @@ def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum
     else:
         partial, nb = partial
         rpb = 128
-    L.check(lib.passl_hip_bn_finalize(L.ptr(partial), nb, M, Cch, rpb, L.ptr(gamma), L.ptr(beta),
-                                      L.ptr(rmean), L.ptr(rvar), momentum, eps,
-                                      L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
-                                      L.ptr(stats[3]), st), 'bn_finalize')
+    if sync:
+        mom = torch.empty(3, Cch, dtype=torch.float64, device=dev)
+        L.check(lib.passl_hip_bn_moments(L.ptr(partial), nb, M, Cch, rpb, L.ptr(mom), st), 'bn_moments')
+        mom_all = _gather_doubles(mom)
+        L.check(lib.passl_hip_bn_finalize_moments(L.ptr(mom_all), mom_all.shape[0], Cch, L.ptr(gamma), L.ptr(beta),
+                                                  L.ptr(rmean), L.ptr(rvar), momentum, eps, L.ptr(stats[0]),
+                                                  L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.stream()),
+                'bn_finalize_moments')
+    else:
+        L.check(lib.passl_hip_bn_finalize(L.ptr(partial), nb, M, Cch, rpb, L.ptr(gamma), L.ptr(beta),
+                                          L.ptr(rmean), L.ptr(rvar), momentum, eps,
+                                          L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
+                                          L.ptr(stats[3]), st), 'bn_finalize')
     z = torch.empty_like(x)
     mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (want_mask and relu) \
         else None
     L.check(lib.passl_hip_bn_apply(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(residual),
-                                   L.ptr(z), L.ptr(mask), M, Cch, 1 if relu else 0, dtc, st),
+                                   L.ptr(z), L.ptr(mask), M, Cch, 1 if relu else 0, dtc, L.stream()),
             'bn_apply')
     return z, stats, mask
 
@@ -198,7 +218,7 @@ def bn_apply(x, scale, shift, residual=None, relu=False):
 
 
 def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=False,
-           scale=None, shift=None, fused=None):
+           scale=None, shift=None, fused=None, sync=False):
     """Returns dx (and dres).  dgamma/dbeta (fp32 [C]) are accumulated into.
     `relu`: False/0 none, True/1 mask = z > 0, 2 mask recomputed from x*scale+shift (z unused),
     3 `z` is the bit mask written by the forward's bn_apply.
@@ -221,16 +241,26 @@ def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=Fa
         L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), zp, L.ptr(x), L.ptr(mean), L.ptr(invstd),
                                             L.ptr(scale), L.ptr(shift), L.ptr(partial), M, Cch, nb, r,
                                             dtc, st), 'bn_bwd_reduce')
-    L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(mean),
-                                          L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
-                                          st), 'bn_bwd_finalize')
+    if sync:         # SyncBatchNorm: {sum g, sum g*xhat} of every rank, row count of the global batch
+        import torch.distributed as dist
+        sums = torch.empty(2, Cch, dtype=torch.float64, device=dev)
+        L.check(lib.passl_hip_bn_bwd_sums(L.ptr(partial), nb, M, Cch, L.ptr(sums), st), 'bn_bwd_sums')
+        sums_all = _gather_doubles(sums)
+        L.check(lib.passl_hip_bn_bwd_finalize_sums(L.ptr(sums_all), sums_all.shape[0], dist.get_rank(),
+                                                   M * sums_all.shape[0], Cch, L.ptr(gamma), L.ptr(mean),
+                                                   L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
+                                                   L.stream()), 'bn_bwd_finalize_sums')
+    else:
+        L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(mean),
+                                              L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
+                                              st), 'bn_bwd_finalize')
     dx = torch.empty_like(x)
     if fused is not None:
         dres_out, dres = None, (dz if want_dres else None)
     else:
         dres_out = dres = torch.empty_like(x) if want_dres else None
     L.check(lib.passl_hip_bn_bwd_apply(L.ptr(dz), zp, L.ptr(x), L.ptr(coef), L.ptr(scale),
-                                       L.ptr(shift), L.ptr(dx), L.ptr(dres_out), M, Cch, r, dtc, st),
+                                       L.ptr(shift), L.ptr(dx), L.ptr(dres_out), M, Cch, r, dtc, L.stream()),
             'bn_bwd_apply')
     return dx, dres
 

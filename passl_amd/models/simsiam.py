@@ -10,9 +10,10 @@ backward in the data-gradient epilogues, weight gradients on the side stream); e
 statistics are per view, as in the reference); MLPs = GEMM kernel with fp32 output -> BatchNorm1D on fp32 rows -> ReLU
 (SimCLR-neck pattern); the criterion is one fused kernel pair (passl.loss.simsiam).  Parameter groups of the task
 yaml (``encoder`` on the schedule, ``predictor`` at a fixed rate) map to two EncoderArenas = two flat optimizer
-launches.  The reference converts every BatchNorm to SyncBatchNorm when world_size > 1 (:160-162): cross-rank
-BatchNorm statistics are not built here, so a data-parallel SimSiam run raises instead of silently training with
-per-rank statistics.
+launches.  The reference converts every BatchNorm to SyncBatchNorm when world_size > 1 (:160-162): here the
+BatchNorm layers then fold their slabs to fp64 moments, all-gather them (3 C doubles per layer and rank) and combine
+them in rank order (csrc/bn.hip: bn_moments / bn_finalize_moments, bn_bwd_sums / bn_bwd_finalize_sums) — a two-rank run
+equals the one-rank run on the concatenated batch (tests/test_dp_gpu.py).
 """
 import os
 import pickle
@@ -74,6 +75,9 @@ class SimSiamPretain(Model):
         self.arena_p = EncoderArena(self.predictor, trainable=True)
 
     # -- state plumbing
+    def trainable_arenas(self):
+        return [self.arena_q, self.arena_p]
+
     def sync_runtime_state(self):
         self.arena_q.refresh()
         self.arena_p.refresh()
@@ -119,9 +123,9 @@ class SimSiamPretain(Model):
 
 
 def simsiam_resnet50_pretrain(**kwargs):
-    if collectives_active():
-        raise NotImplementedError(
-            'data-parallel SimSiam converts every BatchNorm to SyncBatchNorm (reference simsiam.py:160-162): '
-            'cross-rank BatchNorm statistics are not built on this path — run it on one GPU')
     encoder = partial(ResNet, block=BottleneckBlock, depth=50)
-    return SimSiamPretain(base_encoder=encoder, dim=2048, pred_dim=512, **kwargs)
+    model = SimSiamPretain(base_encoder=encoder, dim=2048, pred_dim=512, **kwargs)
+    # Apply SyncBN (simsiam.py:160-162)
+    if collectives_active():
+        hnn.convert_sync_batchnorm(model)
+    return model

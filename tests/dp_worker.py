@@ -131,8 +131,76 @@ def mocov3_run():
     dist.destroy_process_group()
 
 
+def simsiam_run():
+    """Two data-parallel ranks of SimSiam with SyncBatchNorm (reference passl/models/simsiam.py:160-162): every
+    BatchNorm normalises over BOTH ranks' batches, so the run must equal the ONE-process step on the concatenated
+    batch — loss (mean of the rank losses), averaged gradients, updated parameters and running statistics are
+    compared with the fp64 restatement on [x_rank0 ; x_rank1], and the replicas must end bit-identical, statistics
+    included."""
+    import simsiam_util as U
+    from oracle import simsiam as S
+    from passl_amd.core.sync_utils import grad_sync, param_sync
+    from passl_amd.engine.trainer import _init_distributed
+    from passl_amd.hip import config as hip_config, nn as hnn
+    dev = hip_config.set_device('gpu')
+    rank, world = _init_distributed(dev)
+    assert world == 2
+    N, size = 8, 64
+    oracle = S.SimSiamOracle(seed=0, zero_init_residual=False, dtype=torch.float64, **U.SOLVER)
+    model, opt = U.build_product(torch.float32)
+    assert all(m._sync for m in model.modules() if isinstance(m, hnn._BatchNormBase))       # converted by the factory
+    U.load_oracle_state(model, oracle)
+    param_sync(model)
+    model.train()
+    xs = []
+    for r in range(2):
+        gen = torch.Generator().manual_seed(777 + r)
+        xs.append((torch.randn(N, 3, size, size, generator=gen), torch.randn(N, 3, size, size, generator=gen)))
+    loss = model([xs[rank][0].cuda(), xs[rank][1].cuda()])
+    opt.clear_grad()
+    loss.backward()
+    grad_sync([{'params': [p for p in model.parameters() if p.requires_grad]}])      # mean over ranks
+    lall = loss.detach().clone()
+    dist.all_reduce(lall)
+    torch.cuda.synchronize()
+    ps = dict(model.named_parameters())
+    if rank == 0:
+        x1 = torch.cat([xs[0][0], xs[1][0]]).double()
+        x2 = torch.cat([xs[0][1], xs[1][1]]).double()
+        ref = oracle.forward_backward(x1, x2)
+        o32 = S.SimSiamOracle(seed=0, zero_init_residual=False, **U.SOLVER)
+        r32 = o32.forward_backward(x1.float(), x2.float())
+        got = float(lall) / 2
+        assert abs(got - float(ref['loss'])) < max(3e-6, 6 * abs(float(r32['loss']) - float(ref['loss']))), (got, float(ref['loss']))
+        worst = 0.0
+        for n, g in ref['grads'].items():
+            a, b = ps[n].grad.double().cpu().reshape(-1), g.reshape(-1)
+            err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            e32 = float((r32['grads'][n].double().reshape(-1) - b).norm() / b.norm().clamp_min(1e-30))
+            assert err <= max(5e-4, 8 * e32), (n, err, e32)
+            worst = max(worst, err)
+        sd = model.state_dict()
+        for k, v in oracle.st.items():          # running statistics of the GLOBAL batch (advanced twice)
+            if S.is_stat(k):
+                e = float(((sd[k].cpu().double() - v).abs() / v.abs().clamp_min(0.1)).max())
+                assert e < 2e-3, (k, e)
+    opt.step()
+    torch.cuda.synchronize()
+    for name, t in (('arena_q', model.arena_q.flat), ('arena_p', model.arena_p.flat)):
+        ref_t = t.clone()
+        dist.broadcast(ref_t, src=0)
+        assert torch.equal(ref_t, t), '%s differs between ranks (max abs diff %.3e)' % (name, float((ref_t - t).abs().max()))
+    dist.barrier()
+    if rank == 0:
+        print('DP-OK simsiam %.6f worst-grad-l2=%.3e' % (got, worst), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     workload = sys.argv[1]
+    if workload == 'simsiam':
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        return simsiam_run()
     if workload == 'mocov3':
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         return mocov3_run()

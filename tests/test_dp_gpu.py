@@ -49,6 +49,12 @@ def test_two_ranks_mocov3_cross_rank_keys():
     _run_worker('mocov3', 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0'))
 
 
+def test_two_ranks_simsiam_sync_batchnorm_equals_one_rank_on_the_joint_batch():
+    """SyncBatchNorm (reference passl/models/simsiam.py:160-162): cross-rank BatchNorm statistics, forward and
+    backward — see dp_worker.simsiam_run."""
+    _run_worker('simsiam', 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0'))
+
+
 def test_two_ranks_shuffle_bn_is_output_neutral():
     """MoCo's cross-rank batch shuffle (reference passl_v110/modeling/architectures/moco.py:107-152): all-gather
     the key view, a permutation drawn on rank 0 and broadcast, every rank encodes its slice of the permuted batch,
