@@ -902,6 +902,51 @@ class EncoderArena:
         self.packer.run(self.flat)
         self.update_bn_affine()
 
+    # ---- the same update in pieces (MoCo's key pipeline): parameters first, then the running statistics of one
+    # group of BatchNorm layers at a time (each group's statistics and folded affine are contiguous: module order)
+    @torch.no_grad()
+    def ema_params_from(self, other, m):
+        n = self.n_train
+        ops.ema_update(self.flat[:n], other.flat[:n], m, self.lp[:n] if self.lp is not None else None)
+        self.packer.run(self.flat)
+
+    def bn_groups(self, groups):
+        """groups: lists of sub-layers (in module order, together covering every BatchNorm of the arena) ->
+        [(stat range in flat, affine range, index tensors)] for ema_stats_from."""
+        out, pos = [], 0
+        bns = [m for m in self.module.modules() if isinstance(m, _BatchNormBase) and m.affine]
+        stat_start = {}
+        off = self.n_train
+
+        def aligned(n):
+            return (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        for mod in [m for m in self.module.modules() if isinstance(m, _BatchNormBase)]:
+            stat_start[id(mod)] = off
+            off += 2 * aligned(mod.num_features)
+        assert off == self.total
+        done = 0
+        for g in groups:
+            mods = [m for sub in g for m in sub.modules() if isinstance(m, _BatchNormBase)]
+            assert mods == bns[done:done + len(mods)], 'BatchNorm groups must follow the module order'
+            s0 = stat_start[id(mods[0])]
+            s1 = stat_start[id(mods[-1])] + 2 * aligned(mods[-1].num_features)
+            a0 = mods[0]._rt.bn_slice[0]
+            a1 = (mods[-1]._rt.bn_slice[1] + 7) // 8 * 8
+            out.append(((s0, s1), (a0, a1), tuple(t[a0:a1].contiguous() for t in self._bn_idx)))
+            done += len(mods)
+        assert done == len(bns)
+        return out
+
+    @torch.no_grad()
+    def ema_stats_from(self, other, m, group):
+        (s0, s1), (a0, a1), idx = group
+        ops.ema_update(self.flat[s0:s1], other.flat[s0:s1], m, None)
+        if self.bn_affine is None:
+            n = self._bn_idx[0].numel()
+            self.bn_affine = (torch.empty(n, dtype=torch.float32, device=self.flat.device),
+                              torch.empty(n, dtype=torch.float32, device=self.flat.device))
+        ops.bn_fold(self.flat, idx, self._bn_eps, self.bn_affine[0][a0:a1], self.bn_affine[1][a0:a1])
+
     def _refresh_if_on_device(self):
         # Building a model on the host is allowed (config / registry / checkpoint tooling);
         # *running* it is not: refresh() and every layer raise on host tensors.

@@ -7,8 +7,9 @@ launch hangs off that chain without feeding it:
 
   * weight gradients: dW of a layer needs (x, dy) and is consumed by the optimizer only.
 
-(MoCo's key path is NOT hoisted: its EMA covers the BatchNorm running statistics the query forward has
-just updated, moco.py:82-90 — a true dependency.)  Side work is issued on ONE side stream per device,
+(MoCo's key path is not hoisted as a whole: its EMA covers the BatchNorm running statistics the query forward has
+just updated, moco.py:82-90 — a true dependency, but a LAYER-WISE one: the key encoder runs on a stream of its own
+one trunk stage behind the query forward, see key_stream and architectures/moco.py:_train_iter_overlapped.)  Side work is issued on ONE side stream per device,
 so that its workgroups fill the CUs next to the main chain's (different bottlenecks share a CU:
 LDS-heavy GEMM workgroups + register-light streaming workgroups) instead of extending the chain.  Ordering: the side stream waits for an event recorded on
 the main stream at the hand-off point (its inputs are complete), and the main stream waits
@@ -69,6 +70,19 @@ def fork_stream(device):
     s = _fork_streams.get(key)
     if s is None:
         s = _fork_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+_key_streams = {}
+
+
+def key_stream(device):
+    """Stream of MoCo's key-encoder forward (architectures/moco.py:_KeyPipeline): it runs one trunk stage behind
+    the query forward and must not queue behind the side stream's forked downsample branches."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _key_streams.get(key)
+    if s is None:
+        s = _key_streams[key] = torch.cuda.Stream(device=device)
     return s
 
 

@@ -17,11 +17,13 @@ because a key encoder with frozen-statistics BN is per-sample independent, so sh
 output; ``shuffle_bn=True`` restores the collective pattern.  (2) the EMA is one launch over a flat
 buffer instead of 269 ``paddle.assign`` calls.  (3) encoders keep their state in EncoderArenas.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from ...core.sync_utils import collectives_active
-from ...hip import nn, ops
+from ...hip import nn, ops, streams
 from ...hip.nn import EncoderArena
 from ...modules import freeze_batchnorm_statictis
 from ..backbones import build_backbone
@@ -69,6 +71,7 @@ class MoCo(nn.Layer):
         self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.int64, device=dev))
         self._ptr = 0     # host mirror of queue_ptr: no device->host sync in the step
         self._enqueued = 0
+        self._key_groups = None       # BatchNorm groups of the key pipeline (built on first use)
 
     # -- state ------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -127,18 +130,79 @@ class MoCo(nn.Layer):
         idx_this = idx_unshuffle.view(x_gather.shape[0] // bs, -1)[rank]
         return x_gather[idx_this]
 
+    # -- key path under the query forward ---------------------------------------------------
+    def _key_overlap(self, img):
+        """May the key encoder run on its own stream, one trunk stage behind the query forward?"""
+        if self._key_groups is None:
+            bb = self.encoder_k[0]
+            ok = all(hasattr(bb, n) for n in ('frozen_stage', 'layer1', 'layer4')) and \
+                os.environ.get('PASSL_KEY_OVERLAP', '1') != '0'
+            self._key_groups = False
+            if ok:
+                groups = [[bb.bn1, bb.layer1], [bb.layer2], [bb.layer3], [bb.layer4]]
+                try:
+                    self._key_groups = self.arena_k.bn_groups(groups)
+                except AssertionError:
+                    self._key_groups = False          # a neck with BatchNorm layers, an unusual trunk: keep the plain path
+        return bool(self._key_groups) and not self.shuffle_bn and streams.enabled(img) and \
+            not torch.cuda.is_current_stream_capturing()
+
+    def _train_iter_overlapped(self, img_q, img_k):
+        """Same arithmetic as train_iter's plain path, different schedule.  The momentum update
+        (moco.py:82-90) couples the key encoder to THIS step's query forward only through the BatchNorm running
+        statistics, layer by layer: the key encoder's stage s needs the statistics the query forward's stage s has
+        just written.  So the parameter part of the update runs before the query forward, and each stage of the
+        key encoder (statistics part of the update for that stage, folded affine, fused inference convs) is issued
+        on the key stream right after the query encoder's same stage was enqueued — it executes under the query
+        encoder's next stages (MFMA-bound fused convs next to the query path's HBM-bound BatchNorm passes)."""
+        dev = img_q.device
+        main, key = torch.cuda.current_stream(dev), streams.key_stream(dev)
+        bb_q, bb_k = self.encoder_q[0], self.encoder_k[0]
+        with torch.no_grad():
+            self.arena_k.ema_params_from(self.arena_q, self.m)
+        state = {'y': img_k, 'hold': [img_k]}      # (a staged input lives in the SIDE stream's pool: keep it until the join)
+
+        def stage_done(i):
+            ev = main.record_event()                 # the query stage's statistics are final
+            with torch.no_grad(), torch.cuda.stream(key):
+                key.wait_event(ev)
+                self.arena_k.ema_stats_from(self.arena_q, self.m, self._key_groups[i])
+                state['y'] = bb_k.frozen_stage(i, state['y'], allow_fork=False)
+        bb_q._stage_done = stage_done
+        try:
+            q = self.encoder_q(img_q)               # queries: NxC (fp32)
+        finally:
+            bb_q._stage_done = None
+        q = nn.normalize(q, axis=1)
+        with torch.no_grad(), torch.cuda.stream(key):
+            k = self.encoder_k[1](state['y'])
+            k = nn.normalize(k, axis=1)
+        main.wait_stream(key)
+        state.clear()                                # (inputs / activations of the key path: released after the join)
+        return q, k
+
     # -- moco.py:154-185 --------------------------------------------------------------------
     def train_iter(self, *inputs, **kwargs):
         img_q, img_k = inputs
         self.arena_q.refresh()                      # compute-dtype copies of the updated weights
+        if self._key_overlap(img_q):
+            if hasattr(self.encoder_k[0], 'stage_input'):
+                img_k = self.encoder_k[0].stage_input(img_k)
+            q, k = self._train_iter_overlapped(img_q, img_k)
+            with torch.no_grad():
+                queue_snapshot = self.queue.clone()     # `self.queue.clone().detach()`, moco.py:180
+            outputs = self.head.fused(q, k, queue_snapshot)
+            self._dequeue_and_enqueue(k)
+            return outputs
         if not self.shuffle_bn and hasattr(self.encoder_k[0], 'stage_input'):
             # the key view's layout conversion does not depend on the EMA: side stream, under the query forward
             img_k = self.encoder_k[0].stage_input(img_k)
 
         q = self.encoder_q(img_q)                   # queries: NxC (fp32)
         q = nn.normalize(q, axis=1)
-        # NOTE: the key path cannot be hoisted next to the query forward: the EMA covers the BatchNorm
-        # running statistics that the query forward has just updated (moco.py:82-90, SURVEY §3.1 note A)
+        # plain schedule (side stream off, shuffle_bn, graph capture): the whole momentum update after the query
+        # forward — it covers the BatchNorm running statistics that forward has just updated (moco.py:82-90,
+        # SURVEY §3.1 note A) — then the key forward
         with torch.no_grad():
             self._momentum_update_key_encoder()
             if self.shuffle_bn:

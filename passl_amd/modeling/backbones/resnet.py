@@ -87,9 +87,12 @@ class BottleneckBlock(nn.Layer):
             return self.bn3(out, residual=identity, relu=True, stats=st3)
         return self.bn3(out, residual=x, relu=True, stats=st3, res_slot=slot)   # out += identity; relu
 
-    def forward_frozen(self, x):
-        """Same block with running-stat BN folded into the conv epilogues (3-4 kernels)."""
-        fork = self.downsample is not None and streams.enabled(x) and config.fork_downsample()
+    def forward_frozen(self, x, allow_fork=True):
+        """Same block with running-stat BN folded into the conv epilogues (3-4 kernels).  allow_fork=False: the
+        caller runs on a stream of its own (MoCo's key pipeline): the side stream's memory hand-off is ordered
+        against the MAIN stream only (hip/streams.py), so a branch forked from a third stream could see its output
+        recycled under it."""
+        fork = allow_fork and self.downsample is not None and streams.enabled(x) and config.fork_downsample()
         x_ready = torch.cuda.current_stream(x.device).record_event() if fork else None
         out = self.conv1.infer(x, self.bn1, relu=True)
         out = self.conv2.infer(out, self.bn2, relu=True)
@@ -230,6 +233,28 @@ class ResNet(nn.Layer):
             xp, H, W = self._stem_input(x)
         return _StagedInput(xp, H, W, side.record_event())
 
+    @torch.no_grad()
+    def frozen_stage(self, i, x, allow_fork=True):
+        """Stage i of the fused inference path on the CURRENT stream: 0 = stem conv (+ max-pool) + layer1 from the
+        image batch (or its staged form), 1..3 = layer2..4 from the previous stage's output; the average pool
+        follows stage 3.  forward() of a fully frozen trunk is these four calls in a row."""
+        if i == 0:
+            if isinstance(x, _StagedInput):
+                xp, H, W = x.xp, x.H, x.W
+                torch.cuda.current_stream(xp.device).wait_event(x.ready)
+            else:
+                xp, H, W = self._stem_input(x)
+            y = self.conv1.infer(xp, self.bn1, relu=True, hw=(H, W))
+            if self.stem_pool:
+                y = self.maxpool(y)
+        else:
+            y = x
+        for blk in (self.layer1, self.layer2, self.layer3, self.layer4)[i]:
+            y = blk.forward_frozen(y, allow_fork)
+        if i == 3 and self.with_pool:
+            y = self.avgpool(y)
+        return y
+
     def forward(self, x):
         """x: [N,3,H,W] fp32 (reference layout) -> [N,H/32,W/32,2048] NHWC in the compute dtype."""
         if isinstance(x, _StagedInput):
@@ -258,9 +283,16 @@ class ResNet(nn.Layer):
             y = self.bn1(y, relu=True, stats=st)
             if self.stem_pool:
                 y = self.maxpool(y)
-        for stage in stages[max(n_frozen, 0):]:
+        # stage_done(i): called on the host right after stage i (0 = stem + layer1, 1..3 = layer2..4) was enqueued
+        # (MoCo's key pipeline issues the key encoder's same stage from there)
+        stage_done = getattr(self, '_stage_done', None)
+        for si, stage in enumerate(stages):
+            if si < max(n_frozen, 0):
+                continue
             for blk in stage:
                 y = blk(y)
+            if stage_done is not None:
+                stage_done(si)
         if self.with_pool:
             y = self.avgpool(y)
         return y
