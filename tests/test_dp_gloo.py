@@ -299,3 +299,31 @@ def test_clip_cross_rank_infonce():
         e_loss, e_img, e_txt, e_s, e_clip = ret[rank]
         assert e_loss < 1e-5 and e_img < 1e-5 and e_txt < 1e-5 and e_s < 1e-4, (rank, ret[rank])
         assert e_clip < 1e-7            # 1.3 is inside the clip range: unchanged
+
+
+def _sync_bn_math_case(rank, world):
+    """SyncBatchNorm's exchange (ops._gather_doubles + the rank-ordered Chan combination of csrc/bn.hip, restated
+    here in torch): every rank contributes {mean, M2, n} of its own batch; the combined moments equal those of the
+    concatenated batch, and the backward sums gathered the same way give the joint batch's input gradient."""
+    from passl_amd.hip.ops import _gather_doubles
+    gen = torch.Generator().manual_seed(5)
+    xs = [torch.randn(6 + r, 16, generator=gen, dtype=torch.float64) * (r + 1) + r for r in range(world)]
+    x = xs[rank]
+    mom = torch.stack([x.mean(0), ((x - x.mean(0)) ** 2).sum(0), torch.full((16,), float(x.shape[0]), dtype=torch.float64)])
+    allm = _gather_doubles(mom)
+    assert allm.shape == (world, 3, 16)
+    n, mu, m2 = torch.zeros(16, dtype=torch.float64), torch.zeros(16, dtype=torch.float64), torch.zeros(16, dtype=torch.float64)
+    for r in range(world):                     # bn_finalize_moments_kernel
+        mb, qb, nb = allm[r]
+        nn_, d = n + nb, mb - mu
+        m2 = m2 + qb + d * d * n * nb / nn_
+        mu = mu + d * nb / nn_
+        n = nn_
+    joint = torch.cat(xs)
+    assert torch.allclose(mu, joint.mean(0), atol=1e-12) and torch.allclose(m2 / n, joint.var(0, unbiased=False), atol=1e-12)
+    return float(mu.sum())
+
+
+def test_sync_batchnorm_moment_exchange():
+    out = _spawn(_sync_bn_math_case)
+    assert out[0] == out[1]                    # rank-ordered combination: identical on every rank
