@@ -135,13 +135,12 @@ class MoCo(nn.Layer):
         """May the key encoder run on its own stream, one trunk stage behind the query forward?"""
         if self._key_groups is None:
             bb = self.encoder_k[0]
-            ok = all(hasattr(bb, n) for n in ('frozen_stage', 'layer1', 'layer4')) and \
+            ok = all(hasattr(bb, n) for n in ('frozen_unit', 'units')) and \
                 os.environ.get('PASSL_KEY_OVERLAP', '1') != '0'
             self._key_groups = False
             if ok:
-                groups = [[bb.bn1, bb.layer1], [bb.layer2], [bb.layer3], [bb.layer4]]
                 try:
-                    self._key_groups = self.arena_k.bn_groups(groups)
+                    self._key_groups = self.arena_k.bn_groups(bb.units())
                 except AssertionError:
                     self._key_groups = False          # a neck with BatchNorm layers, an unusual trunk: keep the plain path
         return bool(self._key_groups) and not self.shuffle_bn and streams.enabled(img) and \
@@ -150,11 +149,12 @@ class MoCo(nn.Layer):
     def _train_iter_overlapped(self, img_q, img_k):
         """Same arithmetic as train_iter's plain path, different schedule.  The momentum update
         (moco.py:82-90) couples the key encoder to THIS step's query forward only through the BatchNorm running
-        statistics, layer by layer: the key encoder's stage s needs the statistics the query forward's stage s has
-        just written.  So the parameter part of the update runs before the query forward, and each stage of the
-        key encoder (statistics part of the update for that stage, folded affine, fused inference convs) is issued
-        on the key stream right after the query encoder's same stage was enqueued — it executes under the query
-        encoder's next stages (MFMA-bound fused convs next to the query path's HBM-bound BatchNorm passes)."""
+        statistics, layer by layer: the key encoder's unit u (ResNet.units(): one bottleneck) needs the statistics
+        the query forward's unit u has just written.  So the parameter part of the update runs before the query
+        forward, and each unit of the key encoder (statistics part of the update for that unit, folded affine, fused
+        inference convs) is issued on the key stream right after the query encoder's same unit was enqueued — it
+        executes under the query encoder's next units (MFMA-bound fused convs next to the query path's HBM-bound
+        BatchNorm passes); only the last bottleneck and the neck remain behind the query forward."""
         dev = img_q.device
         main, key = torch.cuda.current_stream(dev), streams.key_stream(dev)
         bb_q, bb_k = self.encoder_q[0], self.encoder_k[0]
@@ -162,17 +162,17 @@ class MoCo(nn.Layer):
             self.arena_k.ema_params_from(self.arena_q, self.m)
         state = {'y': img_k, 'hold': [img_k]}      # (a staged input lives in the SIDE stream's pool: keep it until the join)
 
-        def stage_done(i):
-            ev = main.record_event()                 # the query stage's statistics are final
+        def unit_done(u):
+            ev = main.record_event()                 # the query unit's statistics are final
             with torch.no_grad(), torch.cuda.stream(key):
                 key.wait_event(ev)
-                self.arena_k.ema_stats_from(self.arena_q, self.m, self._key_groups[i])
-                state['y'] = bb_k.frozen_stage(i, state['y'], allow_fork=False)
-        bb_q._stage_done = stage_done
+                self.arena_k.ema_stats_from(self.arena_q, self.m, self._key_groups[u])
+                state['y'] = bb_k.frozen_unit(u, state['y'], allow_fork=False)
+        bb_q._unit_done = unit_done
         try:
             q = self.encoder_q(img_q)               # queries: NxC (fp32)
         finally:
-            bb_q._stage_done = None
+            bb_q._unit_done = None
         q = nn.normalize(q, axis=1)
         with torch.no_grad(), torch.cuda.stream(key):
             k = self.encoder_k[1](state['y'])

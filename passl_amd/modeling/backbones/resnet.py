@@ -233,12 +233,19 @@ class ResNet(nn.Layer):
             xp, H, W = self._stem_input(x)
         return _StagedInput(xp, H, W, side.record_event())
 
+    def units(self):
+        """The trunk as a list of pipeline units: unit 0 = stem conv + BatchNorm (+ max-pool) + the first bottleneck,
+        then one bottleneck per unit (16 units for depth 50).  -> [[sub-layers of unit u]]"""
+        blocks = [b for st in (self.layer1, self.layer2, self.layer3, self.layer4) for b in st]
+        return [[self.bn1, blocks[0]]] + [[b] for b in blocks[1:]]
+
     @torch.no_grad()
-    def frozen_stage(self, i, x, allow_fork=True):
-        """Stage i of the fused inference path on the CURRENT stream: 0 = stem conv (+ max-pool) + layer1 from the
-        image batch (or its staged form), 1..3 = layer2..4 from the previous stage's output; the average pool
-        follows stage 3.  forward() of a fully frozen trunk is these four calls in a row."""
-        if i == 0:
+    def frozen_unit(self, u, x, allow_fork=True):
+        """Unit u of the fused inference path on the CURRENT stream (see units()): unit 0 takes the image batch (or
+        its staged form), every other unit the previous unit's output; the average pool follows the last unit.
+        forward() of a fully frozen trunk is these calls in a row."""
+        blocks = [b for st in (self.layer1, self.layer2, self.layer3, self.layer4) for b in st]
+        if u == 0:
             if isinstance(x, _StagedInput):
                 xp, H, W = x.xp, x.H, x.W
                 torch.cuda.current_stream(xp.device).wait_event(x.ready)
@@ -249,9 +256,8 @@ class ResNet(nn.Layer):
                 y = self.maxpool(y)
         else:
             y = x
-        for blk in (self.layer1, self.layer2, self.layer3, self.layer4)[i]:
-            y = blk.forward_frozen(y, allow_fork)
-        if i == 3 and self.with_pool:
+        y = blocks[u].forward_frozen(y, allow_fork)
+        if u == len(blocks) - 1 and self.with_pool:
             y = self.avgpool(y)
         return y
 
@@ -283,16 +289,17 @@ class ResNet(nn.Layer):
             y = self.bn1(y, relu=True, stats=st)
             if self.stem_pool:
                 y = self.maxpool(y)
-        # stage_done(i): called on the host right after stage i (0 = stem + layer1, 1..3 = layer2..4) was enqueued
-        # (MoCo's key pipeline issues the key encoder's same stage from there)
-        stage_done = getattr(self, '_stage_done', None)
+        # unit_done(u): called on the host right after unit u (units(): stem + first bottleneck, then one bottleneck
+        # each) was enqueued — MoCo's key pipeline issues the key encoder's same unit from there
+        unit_done = getattr(self, '_unit_done', None)
+        u = 0
         for si, stage in enumerate(stages):
-            if si < max(n_frozen, 0):
-                continue
             for blk in stage:
-                y = blk(y)
-            if stage_done is not None:
-                stage_done(si)
+                if si >= max(n_frozen, 0):
+                    y = blk(y)
+                    if unit_done is not None:
+                        unit_done(u)
+                u += 1
         if self.with_pool:
             y = self.avgpool(y)
         return y

@@ -37,8 +37,8 @@ with torch.no_grad():
     bb, neck = model.encoder_k[0], model.encoder_k[1]
     k_ref = neck(bb(xk))
     y = xk
-    for i in range(4):
-        y = bb.frozen_stage(i, y)
+    for i in range(len(bb.units())):
+        y = bb.frozen_unit(i, y)
     k_st = neck(y)
     torch.cuda.synchronize()
     print('staged-vs-forward on one stream: max abs diff %.3e' % float((k_ref - k_st).abs().max()))
@@ -51,8 +51,8 @@ with torch.no_grad():
     with torch.cuda.stream(key):
         key.wait_event(ev)
         y = xs
-        for i in range(4):
-            y = bb.frozen_stage(i, y)
+        for i in range(len(bb.units())):
+            y = bb.frozen_unit(i, y)
         k_key = neck(y)
     main.wait_stream(key)
     torch.cuda.synchronize()
