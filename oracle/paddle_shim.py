@@ -74,6 +74,24 @@ def _install_tensor_patches():
                             lambda s, v: s.requires_grad_(bool(v)) if s.is_leaf else None)
     _T.cuda = lambda self, *a, **k: self
     _T.astype = lambda self, dt: self.to(_dtype(dt))
+    # v2 optimizers (passl/optimizer/*.py): state is keyed by Parameter.name; dense gradients only
+    import itertools
+    _uid = itertools.count()
+
+    def _get_name(self):
+        if '_pd_name' not in self.__dict__:
+            self.__dict__['_pd_name'] = 'generated_tensor_%d' % next(_uid)
+        return self.__dict__['_pd_name']
+    _T.name = property(_get_name, lambda self, v: self.__dict__.__setitem__('_pd_name', v))
+    _T.is_selected_rows = lambda self: False
+
+    def clear_gradient(self, set_to_zero=True):
+        if self.grad is not None:
+            if set_to_zero:
+                self.grad.zero_()
+            else:
+                self.grad = None
+    _T.clear_gradient = clear_gradient
     _T._paddle_shim = True
 
 
@@ -528,6 +546,83 @@ def install():
     dl = mod('paddle.utils.download')
     utils.download = dl
     dl.get_weights_path_from_url = lambda *a, **k: None
+
+    # ---- v2 solver / loss / metric sources (passl/optimizer, passl/scheduler, passl/loss, passl/metric)
+    paddle.norm = lambda x, p=2, axis=None: x.norm(p=p) if axis is None else x.norm(p=p, axis=axis)
+    paddle.zeros_like = lambda x, dtype=None: torch.zeros_like(x, dtype=None if dtype is None else _dtype(dtype))
+    paddle.add_n = lambda xs: sum(xs[1:], xs[0]) if isinstance(xs, (list, tuple)) else xs
+
+    def cross_entropy(input, label, soft_label=False, axis=-1, reduction='mean'):
+        """paddle.nn.functional.cross_entropy, hard labels ([N] or [N, 1]) or soft labels, mean over rows
+        [Paddle-semantics]."""
+        lsm = torch.log_softmax(input, dim=axis)
+        if soft_label:
+            loss = -(label * lsm).sum(dim=axis)
+        else:
+            loss = -lsm.gather(axis, label.reshape(-1, 1).long()).reshape(-1)
+        return loss.mean() if reduction == 'mean' else (loss.sum() if reduction == 'sum' else loss)
+    F.cross_entropy = cross_entropy
+    F.label_smooth = lambda label, epsilon=0.1: (1.0 - epsilon) * label + epsilon / label.shape[-1]
+
+    opt = mod('paddle.optimizer')
+    paddle.optimizer = opt
+    lr_mod = mod('paddle.optimizer.lr')
+    opt.lr = lr_mod
+
+    class LRScheduler(object):
+        """paddle.optimizer.lr.LRScheduler (python/paddle/optimizer/lr.py, 2.4 line) [Paddle-semantics]: the
+        constructor takes the first step(); step() advances last_epoch by one, step(epoch) sets it; last_lr caches
+        get_lr() (or _get_closed_form_lr() for an explicit epoch); __call__ returns the cached value."""
+
+        def __init__(self, learning_rate=0.1, last_epoch=-1, verbose=False):
+            if not isinstance(learning_rate, (float, int)):
+                raise TypeError('The type of learning rate must be float, but received {}'.format(
+                    type(learning_rate)))
+            self.base_lr = float(learning_rate)
+            self.last_lr = float(learning_rate)
+            self.last_epoch = last_epoch
+            self.verbose = verbose
+            self._var_name = None
+            self.step()
+
+        def __call__(self):
+            return self.last_lr
+
+        def step(self, epoch=None):
+            if epoch is None:
+                self.last_epoch += 1
+                self.last_lr = self.get_lr()
+            else:
+                self.last_epoch = epoch
+                if hasattr(self, '_get_closed_form_lr'):
+                    self.last_lr = self._get_closed_form_lr()
+                else:
+                    self.last_lr = self.get_lr()
+
+        def get_lr(self):
+            raise NotImplementedError
+    lr_mod.LRScheduler = LRScheduler
+
+    class MultiStepDecay(LRScheduler):
+        """paddle.optimizer.lr.MultiStepDecay: base_lr * gamma^(milestones passed) [Paddle-semantics]."""
+
+        def __init__(self, learning_rate, milestones, gamma=0.1, last_epoch=-1, verbose=False):
+            self.milestones, self.gamma = list(milestones), gamma
+            super().__init__(learning_rate, last_epoch, verbose)
+
+        def get_lr(self):
+            return self.base_lr * self.gamma ** sum(1 for m in self.milestones if self.last_epoch >= m)
+    lr_mod.MultiStepDecay = MultiStepDecay
+
+    metric = mod('paddle.metric')
+    paddle.metric = metric
+
+    def metric_accuracy(input, label, k=1):
+        """paddle.metric.accuracy: fraction of rows whose label is among the k largest scores (ties: lower index
+        first, as top_k) [Paddle-semantics]."""
+        top = input.topk(k, dim=1).indices
+        return (top == label.reshape(-1, 1)).any(dim=1).float().mean()
+    metric.accuracy = metric_accuracy
 
     vision = mod('paddle.vision')
     paddle.vision = vision

@@ -83,3 +83,66 @@ def load_simsiam():
     importlib.import_module('passl.models.resnet')
     ns.simsiam = importlib.import_module('passl.models.simsiam')
     return ns
+
+
+def _exec_init(name):
+    """Run a reference package's own __init__.py inside its pre-seeded package object (relative imports resolve
+    through ``__path__``)."""
+    m = sys.modules[name]
+    fn = os.path.join(m.__path__[0], '__init__.py')
+    with open(fn) as f:
+        exec(compile(f.read(), fn, 'exec'), m.__dict__)
+    return m
+
+
+def load_solver(ns=None):
+    """Adds the v2 solver / loss / metric sources to the namespace: passl/optimizer/{optimizer,momentum,
+    momentum_larc}.py (pure-Python update rules: executed as they are), passl/scheduler/lr_scheduler.py (TimmCosine over
+    the shim's statement of paddle.optimizer.lr.LRScheduler), passl/loss (CombinedLoss / CELoss) and passl/metric
+    (CombinedMetrics / TopkAcc over paddle.metric.accuracy).  AdamW is NOT loadable: its update is the Paddle kernel
+    ``_C_ops.adamw``."""
+    ns = ns or load()
+    import paddle
+    if not hasattr(paddle, '_legacy_C_ops'):
+        c_ops = types.ModuleType('paddle._legacy_C_ops')       # imported by momentum.py, used only on sparse paths
+        sys.modules['paddle._legacy_C_ops'] = c_ops
+        paddle._legacy_C_ops = c_ops
+    base = os.path.join(REF_ROOT, 'passl')
+    for sub in ('optimizer', 'scheduler', 'loss', 'metric'):
+        if 'passl.' + sub not in sys.modules:
+            _pkg('passl.' + sub, os.path.join(base, sub))
+    imp = importlib.import_module
+    imp('passl.optimizer.optimizer')
+    ns.momentum = imp('passl.optimizer.momentum')
+    ns.momentum_larc = imp('passl.optimizer.momentum_larc')
+    ns.lr_scheduler = imp('passl.scheduler.lr_scheduler')
+    ns.loss = _exec_init('passl.loss')
+    ns.metric = _exec_init('passl.metric')
+    return ns
+
+
+def load_loops(ns):
+    """Adds the v2 loops (passl/engine/loops/{loop,classification_loop}.py) — driven by a stand-in trainer object that
+    carries the attributes the loops read (see tests/golden/make_golden_linprobe_v2.py).  Replaced by empty stand-ins:
+    passl.utils.io (paddle.save / load plumbing), passl.utils.profiler, passl.core (grad_sync / param_sync: one rank)."""
+    base = os.path.join(REF_ROOT, 'passl')
+    for sub in ('engine', 'engine/loops'):
+        name = 'passl.' + sub.replace('/', '.')
+        if name not in sys.modules:
+            _pkg(name, os.path.join(base, sub))
+    lg = sys.modules['passl.utils.logger']
+    lg.dict_format = lambda d, float_placeholders='{:.5f}': ', '.join(
+        '{}: {}'.format(k, getattr(v, 'avg', v)) for k, v in d.items())
+    lg.scaler = lambda *a, **k: None
+    for name in ('passl.utils.io', 'passl.utils.profiler'):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        setattr(sys.modules['passl.utils'], name.rsplit('.', 1)[1], m)
+    core = types.ModuleType('passl.core')
+    core.grad_sync = lambda param_groups, **k: None
+    core.param_sync = lambda *a, **k: None
+    sys.modules['passl.core'] = core
+    sys.modules['passl'].core = core
+    importlib.import_module('passl.engine.loops.loop')
+    ns.classification_loop = importlib.import_module('passl.engine.loops.classification_loop')
+    return ns

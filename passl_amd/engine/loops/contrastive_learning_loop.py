@@ -58,5 +58,5 @@ class ContrastiveLearningTrainingEpochLoop(TrainingEpochLoop):
         if getattr(self.trainer, 'lr_decay_unit', 'step') == 'step':
             sched = getattr(self.trainer, 'lr_scheduler', None)
             if sched is not None:
-                sched.step()
+                sched.step(self.global_step)          # optimizer.lr_step(self.global_step), loop.py:86-87
         return None, loss_dict

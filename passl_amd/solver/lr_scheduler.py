@@ -112,9 +112,16 @@ class TimmCosine(LRScheduler):
     ``warmup_prefix`` the cosine is counted from the end of the warm-up over the remaining ``T_max - warmup``
     units.  ``decay_unit: step`` counts optimizer steps (``epochs * step_each_epoch`` in total).
 
-    As in the reference, the constructor does NOT take the first ``step()`` (it never calls the base class'
-    __init__): until the loop's first ``lr_scheduler.step()`` the value is ``learning_rate`` itself — the very first
-    optimizer step runs at the PEAK rate, the second at ``warmup_start_lr``, and the ramp starts from there."""
+    Two reference behaviours that differ from paddle.optimizer.lr's own classes, both kept:
+      * the constructor never calls the base class' __init__, so it does NOT take the first ``step()``:
+        ``last_epoch`` stays at the yaml's value (-1 by default);
+      * the v2 optimizers do not read the cached ``last_lr``: passl/optimizer/optimizer.py:117-120 (``_get_lr``)
+        evaluates ``get_lr()`` at the CURRENT ``last_epoch`` on every step.  ``__call__`` does the same here.
+    With the loop's ``lr_step(global_step)`` after every optimizer step (contrastive_learning_loop.py:86-87,
+    classification_loop.py:97-98) optimizer step n >= 2 runs at ``get_lr(n - 1)`` and step 1 at ``get_lr(-1)``:
+    ``warmup_start_lr`` when there is a warm-up (MoCo-v3: the first step moves nothing).  Without a warm-up
+    ``get_lr(-1)`` takes the warm-up branch (-1 < 0) and divides by ``warmup_steps = 0`` — in the reference too —
+    which is why the recipes without one (SimSiam, the linear probes) set ``last_epoch: 0``."""
 
     def __init__(self, learning_rate, step_each_epoch, epochs, decay_unit='epoch', eta_min=0.0, warmup_epoch=0,
                  warmup_start_lr=0.0, warmup_prefix=False, verbose=False, last_epoch=-1, **kwargs):
@@ -149,3 +156,6 @@ class TimmCosine(LRScheduler):
             T_max = self.T_max - self.warmup_steps
         cur_steps = last_epoch - (self.T_max * (last_epoch // self.T_max))
         return self.eta_min + 0.5 * (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * cur_steps / T_max))
+
+    def __call__(self):
+        return self.get_lr()

@@ -232,10 +232,15 @@ def test_v2_train_one_step_facade():
     loop = ContrastiveLearningTrainingEpochLoop(tr, epochs=1)
     batch = [[torch.randn(4, 3, 8, 8), torch.randn(4, 3, 8, 8)], torch.zeros(4)]
     w0 = model.fc.weight.detach().clone()
+    loop.global_step += 1                 # advanced by train_one_epoch (loop.py:282), not by the step itself
     out, loss_dict = loop.train_one_step(batch)
     assert out is None and 'loss' in loss_dict
-    assert loop.global_step == 0          # advanced by train_one_epoch (loop.py:282), not by the step itself
+    assert loop.global_step == 1
+    # optimizer.lr_step(self.global_step) (contrastive_learning_loop.py:86-87): the schedule is SET to the step count
     assert not torch.equal(w0, model.fc.weight) and sched.last_epoch == 1
+    loop.global_step = 7
+    loop.train_one_step(batch)
+    assert sched.last_epoch == 7
 
 
 # ------------------------------------------------------------------ SimCLR row (host side)
@@ -699,14 +704,16 @@ def test_v2_checkpoint_set_and_resume(tmp_path):
 
 
 def test_timm_cosine_schedule_known_answers():
-    """passl/scheduler/lr_scheduler.py:22-77 with the MoCo-v3 yaml's settings: no step() in the constructor (the
-    first optimizer step runs at the peak rate: reference behaviour), linear warm-up over warmup_epoch epochs of
-    steps, then a cosine over the REMAINING steps (warmup_prefix)."""
+    """passl/scheduler/lr_scheduler.py:22-77 with the MoCo-v3 yaml's settings: no step() in the constructor, and the
+    value an optimizer sees is get_lr() at the current last_epoch (passl/optimizer/optimizer.py:117-120) — the first
+    optimizer step runs at get_lr(-1) = warmup_start_lr; linear warm-up over warmup_epoch epochs of steps, then a
+    cosine over the REMAINING steps (warmup_prefix).  Pinned by the reference's own class:
+    tests/test_oracle_linprobe_v2.py + tests/golden/make_golden_linprobe_v2.py."""
     from passl_amd.solver.lr_scheduler import TimmCosine
     s = TimmCosine(learning_rate=0.0024, step_each_epoch=10, epochs=30, decay_unit='step', eta_min=0.0,
                    warmup_epoch=4, warmup_start_lr=0.0, warmup_prefix=True)
     assert s.T_max == 300 and s.warmup_steps == 40 and s.last_epoch == -1
-    assert s() == 0.0024                                  # before the first step(): the base rate
+    assert s() == 0.0 and s.last_lr == 0.0024             # get_lr(-1) = warmup_start_lr; the cached value is not read
     s.step()
     assert s.last_epoch == 0 and s() == 0.0
     for _ in range(10):
@@ -765,7 +772,8 @@ def test_v2_engine_builds_from_the_reference_mocov3_yaml_unchanged():
         assert opt._arenas == [m.arena_q]
         sch = eng.lr_scheduler
         assert type(sch).__name__ == 'TimmCosine' and sch.T_max == 50 * 20 and sch.warmup_steps == 40 * 20
-        assert sch.warmup_prefix is True and eng.lr_decay_unit == 'step' and opt.get_lr() == 0.0024
+        assert sch.warmup_prefix is True and eng.lr_decay_unit == 'step' and opt.get_lr() == 0.0 \
+            and sch.base_lr == 0.0024
         assert runtime_info_hub.max_steps == 1000 and runtime_info_hub.epochs == 50
         assert abs(m.momentum_encoder.current_momentum(500) - 0.99 * 0.5) < 1e-12
         assert type(eng.train_loop).__name__ == 'ContrastiveLearningTrainingEpochLoop'
