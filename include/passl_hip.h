@@ -117,6 +117,19 @@ int passl_hip_lars_momentum_dev(float* p, const float* g, float* v, const int64_
                                 const float* seg_wd, int n_seg, float* norms, const float* hyper, float mu,
                                 float lars_coeff, float epsilon, float grad_scale, passl_stream_t stream);
 
+/* MomentumLARC over the same segmented flat buffer and workspace (blk_*, seg_wd, norms as above), lr = hyper[0]:
+ *   if |p_s| != 0 and |g_s| != 0:  a = trust_coefficient*|p_s| / (|g_s| + |p_s|*wd_s + epsilon)
+ *                                  (clip != 0: a = min(a / lr, 1));   g' = a*(g*grad_scale + wd_s*p)
+ *   else                        :  g' = g*grad_scale                 (no weight decay)
+ *   v = mu*v + g';   p = p - lr*v
+ * Replaces passl/optimizer/momentum_larc.py:56-111 (MomentumLARC.step: a Python loop of per-tensor norm / scale /
+ * copy ops), the optimizer of tasks/ssl/simsiam/configs/simsiam_resnet50_lp_in1k_1n8c_dp_fp32.yaml. */
+int passl_hip_larc_momentum_dev(float* p, const float* g, float* v, const int64_t* blk_off,
+                                const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
+                                const float* seg_wd, int n_seg, float* norms, const float* hyper, float mu,
+                                float trust_coefficient, float epsilon, int clip, float grad_scale,
+                                passl_stream_t stream);
+
 /* dst_bf16[i] = bf16(src[i]) (round-to-nearest-even). */
 int passl_hip_cast_f32_to_bf16(const float* src, void* dst, int64_t n, passl_stream_t stream);
 

@@ -237,6 +237,49 @@ __global__ void __launch_bounds__(kThreads) lars_update_kernel(
   }
 }
 
+// MomentumLARC (passl/optimizer/momentum_larc.py:56-111), per parameter tensor:
+//   if |p| != 0 and |g| != 0:  a = trust*|p| / (|g| + |p|*wd + eps)  [clip: a = min(a / lr, 1)],  g' = a*(g + wd*p)
+//   else                     :  g' = g  (no weight decay)
+//   v = mu*v + g';   p -= lr*v
+__global__ void __launch_bounds__(kThreads) larc_update_kernel(
+    float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v,
+    const int64_t* __restrict__ blk_off, const int32_t* __restrict__ blk_len,
+    const int32_t* __restrict__ blk_seg, const float* __restrict__ seg_wd,
+    const float* __restrict__ norms, const float* __restrict__ hyper, float mu, float trust,
+    float eps, int clip, float gs) {
+  const float lr = hyper[0];
+  const int seg = blk_seg[blockIdx.x];
+  const float pn = sqrtf(norms[2 * seg]), gn = sqrtf(norms[2 * seg + 1]);
+  float a = 1.f, wd = 0.f;
+  if (pn != 0.f && gn != 0.f) {
+    wd = seg_wd[seg];
+    a = trust * pn / (gn + pn * wd + eps);
+    if (clip) a = fminf(a / lr, 1.f);
+  }
+  const int64_t off = blk_off[blockIdx.x];
+  const int len = blk_len[blockIdx.x];
+  for (int i = threadIdx.x * 4; i < len; i += kThreads * 4) {
+    if (i + 4 <= len) {
+      float4 pv = *reinterpret_cast<float4*>(p + off + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + off + i);
+      float4 vv = *reinterpret_cast<float4*>(v + off + i);
+      vv.x = mu * vv.x + a * (gv.x * gs + wd * pv.x);
+      vv.y = mu * vv.y + a * (gv.y * gs + wd * pv.y);
+      vv.z = mu * vv.z + a * (gv.z * gs + wd * pv.z);
+      vv.w = mu * vv.w + a * (gv.w * gs + wd * pv.w);
+      pv.x -= lr * vv.x; pv.y -= lr * vv.y; pv.z -= lr * vv.z; pv.w -= lr * vv.w;
+      *reinterpret_cast<float4*>(v + off + i) = vv;
+      *reinterpret_cast<float4*>(p + off + i) = pv;
+    } else {
+      for (int e = i; e < len; ++e) {
+        const float vv = mu * v[off + e] + a * (g[off + e] * gs + wd * p[off + e]);
+        v[off + e] = vv;
+        p[off + e] -= lr * vv;
+      }
+    }
+  }
+}
+
 // One block = up to 1024 consecutive destination elements of one job.
 template <typename T>
 __global__ void __launch_bounds__(kThreads) pack_kernel(const float* __restrict__ src,
@@ -469,4 +512,27 @@ extern "C" int passl_hip_lars_momentum_dev(float* p, const float* g, float* v, c
   if (!hyper) return PASSL_EINVAL;
   return lars_impl(p, g, v, blk_off, blk_len, blk_seg, n_blocks, seg_wd, n_seg, norms, 0.f, hyper, mu, lars_coeff,
                    epsilon, grad_scale, stream);
+}
+
+extern "C" int passl_hip_larc_momentum_dev(float* p, const float* g, float* v, const int64_t* blk_off,
+                                           const int32_t* blk_len, const int32_t* blk_seg, int n_blocks,
+                                           const float* seg_wd, int n_seg, float* norms, const float* hyper,
+                                           float mu, float trust_coefficient, float epsilon, int clip,
+                                           float grad_scale, passl_stream_t stream) {
+  if (!p || !g || !v || !blk_off || !blk_len || !blk_seg || !seg_wd || !norms || !hyper || n_blocks < 0 ||
+      n_seg <= 0 || !aligned16(p) || !aligned16(g) || !aligned16(v))
+    return PASSL_EINVAL;
+  if (n_blocks == 0) return PASSL_OK;
+  hipStream_t st = as_stream(stream);
+  float* partial = norms + 2 * (size_t)n_seg;          // as passl_hip_lars_momentum: same workspace layout
+  hipLaunchKernelGGL(lars_norm_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, blk_off, blk_len,
+                     grad_scale, partial);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(lars_seg_reduce_kernel, dim3(n_seg), dim3(kThreads), 0, st, partial, blk_seg,
+                     (int)n_blocks, norms);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  hipLaunchKernelGGL(larc_update_kernel, dim3(n_blocks), dim3(kThreads), 0, st, p, g, v, blk_off,
+                     blk_len, blk_seg, seg_wd, norms, hyper, mu, trust_coefficient, epsilon, clip, grad_scale);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
 }

@@ -108,6 +108,8 @@ class SyntheticLoader(object):
         rank = int(os.environ.get('RANK', 0))
         per_rank = len(dataset) // world
         self._len = per_rank // self.batch_size if drop_last else -(-per_rank // self.batch_size)
+        # drop_last False: the last batch holds the remaining rows only (evaluation loaders of the v2 recipes)
+        self._tail = 0 if drop_last else per_rank % self.batch_size
         gen = torch.Generator().manual_seed(dataset.seed + rank)
         s = dataset.image_size
         self._cache = []
@@ -123,5 +125,9 @@ class SyntheticLoader(object):
         return max(self._len, 1)
 
     def __iter__(self):
-        for i in range(len(self)):
-            yield self._cache[i % len(self._cache)]
+        n = len(self)
+        for i in range(n):
+            b = self._cache[i % len(self._cache)]
+            if self._tail and i == n - 1 and self._len > 0:
+                b = tuple(t[:self._tail] for t in b)
+            yield b

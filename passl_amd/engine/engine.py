@@ -11,7 +11,10 @@ new kernels.  Kept from the reference: the attributes the loops read (``accum_st
 seeding, ``max_train_step``, data-parallel start-up broadcast.  Not carried over (outside the hot
 path): FP16 GradScaler (an ``FP16:`` section — level O1 / O2 with its GradScaler, engine.py:177-210 — selects
 reduced-precision compute, which here is bf16 with fp32 master weights and moments and needs no loss scaling;
-``Global.compute_dtype`` overrides), EMA of the student weights, VisualDL, export, evaluation loops.
+``Global.compute_dtype`` overrides), EMA of the student weights, VisualDL, export.
+``task_type: Classification`` (the linear-probe recipes of tasks/ssl/{simsiam,mocov3}): ``Loss`` / ``Metric`` blocks
+(engine.py:142-177), the ``DataLoader.Eval`` loader and ``Global.validate_loop`` when ``eval_during_train`` or
+``mode='eval'`` (engine.py:135-141, 301-306), ``Engine.eval()`` (engine.py:361-367).
 ``runtime_info_hub`` (engine.py:346-349) carries epochs / max_steps / total_iterations to the models that read
 them (MoCo-v3's momentum schedule).
 """
@@ -35,6 +38,15 @@ from . import loops
 from .trainer import _init_distributed
 
 
+def _plain(x):
+    """AttrDict / list config nodes -> plain dicts and lists (the loss / metric builders pop from them)."""
+    if isinstance(x, dict):
+        return {k: _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    return x
+
+
 class _ListBatchLoader(object):
     """Adapts the v110 loader (yields the views as a tuple) to the v2 batch convention
     ``[views, label]`` (contrastive_learning_loop.py:69 drops ``batch[-1]`` = the label)."""
@@ -48,6 +60,22 @@ class _ListBatchLoader(object):
     def __iter__(self):
         for views in self.inner:
             yield [list(views), None]
+
+
+class _LabeledBatchLoader(object):
+    """(image, label) batches of the synthetic labeled source as the v2 classification loops take them:
+    ``batch[0]`` = data, ``batch[1]`` = label (classification_loop.py:52-53); ``dataset`` for the sample count."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.dataset = inner.dataset
+
+    def __len__(self):
+        return len(self.inner)
+
+    def __iter__(self):
+        for img, label in self.inner:
+            yield [img, label]
 
 
 class _Schedulers(object):
@@ -129,9 +157,11 @@ class OptimizerGroup(object):
 class Engine(object):
     def __init__(self, config, mode='train'):
         assert mode in ['train', 'eval', 'export']
-        if mode != 'train':
-            raise NotImplementedError('Engine(mode=%r): evaluation / export loops are outside the hot path' % mode)
+        if mode == 'export':
+            raise NotImplementedError('Engine(mode=%r): export (paddle.jit inference model) is outside the hot path' % mode)
         self.mode = mode
+        self.training = False
+        self.validating = False
         self.config = config
         g = config['Global']
         self.print_batch_step = g.get('print_batch_step', 10)
@@ -169,15 +199,77 @@ class Engine(object):
             random.seed(seed)
 
         from ..datasets import build_dataloader
-        dl = config['DataLoader']['Train']
-        inner, _mix = build_dataloader(AttrDict(dataset=dl['dataset'], sampler=dl.get('sampler', {}),
-                                                loader=dl.get('loader', {})), self.device)
-        self.train_dataloader = _ListBatchLoader(inner)
+        classification = g.get('task_type', None) == 'Classification' or \
+            str(g.get('train_loop', '')).startswith('Classification')
+        eval_wanted = mode == 'eval' or (mode == 'train' and g.get('eval_during_train', False))
+
+        def loader(block):
+            inner, _mix = build_dataloader(AttrDict(dataset=block['dataset'], sampler=block.get('sampler', {}),
+                                                    loader=block.get('loader', {})), self.device)
+            return _LabeledBatchLoader(inner) if classification else _ListBatchLoader(inner)
+        self.train_dataloader = loader(config['DataLoader']['Train']) if mode == 'train' else None
+        self.eval_dataloader = None
+        if eval_wanted and config['DataLoader'].get('Eval', None) is not None:
+            self.eval_dataloader = loader(config['DataLoader']['Eval'])
+
+        # build loss / metric (engine.py:142-177)
+        from ..loss import build_loss
+        from ..metric import build_metrics
+        self.train_loss_func = self.eval_loss_func = self.train_metric_func = self.eval_metric_func = None
+        loss_cfg, metric_cfg = config.get('Loss', None), config.get('Metric', None)
+        if loss_cfg is not None:
+            if mode == 'train' and loss_cfg.get('Train', None) is not None:
+                self.train_loss_func = build_loss(_plain(loss_cfg['Train']))
+            if eval_wanted and loss_cfg.get('Eval', None) is not None:
+                self.eval_loss_func = build_loss(_plain(loss_cfg['Eval']))
+        if metric_cfg is not None:
+            if mode == 'train' and metric_cfg.get('Train', None) is not None:
+                self.train_metric_func = build_metrics(_plain(metric_cfg['Train']))
+            if eval_wanted and metric_cfg.get('Eval', None) is not None:
+                self.eval_metric_func = build_metrics(_plain(metric_cfg['Eval']))
 
         self.model = build_model(config['Model'])
         n_parameters = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
         self.logger.info('Number of Parameters is {:.2f}M.'.format(n_parameters / 1e6))
 
+        self.optimizer = self.lr_scheduler = None
+        self.lr_decay_unit = 'step'
+        if mode == 'train':
+            self._build_optimizer(config, g)
+
+        if g.get('pretrained_model', None) is not None:
+            assert isinstance(g['pretrained_model'], str), 'pretrained_model type is not available. Please use `string`.'
+            self.model.load_pretrained(g['pretrained_model'], rank, g.get('finetune', False))
+
+        self.grad_reducer = None
+        if (g['distributed'] or collectives_active()) and mode == 'train':
+            assert config.get('DistributedStrategy', None) is not None
+            assert config['DistributedStrategy'].get('data_parallel', False) is True, \
+                'If you want to use data parallel you should set data_parallel=True'
+            arch = getattr(self.model, 'arch', self.model)
+            param_sync(arch)
+            arenas = arch.trainable_arenas() if hasattr(arch, 'trainable_arenas') else None
+            if arenas is not None and len(arenas) > 1:
+                # several trainable arenas (parameter groups): the loop's blocking grad_sync reduces each flat
+                # gradient buffer after backward (reference behaviour); the overlapped reducer handles one arena
+                self.grad_reducer = None
+            else:
+                self.grad_reducer = GradReducer(arch.arena_q if hasattr(arch, 'arena_q') else arch.arena,
+                                                self.optimizer)
+
+        # build train_loop and eval_loop (engine.py:301-316)
+        self.validate_loop = None
+        if g.get('validate_loop', None) is not None and self.eval_dataloader is not None:
+            self.validate_loop = getattr(loops, g['validate_loop'])(self)
+        self.train_loop = None
+        if mode == 'train':
+            self.train_loop = getattr(loops, g.get('train_loop'))(self, epochs=g['epochs'],
+                                                                  max_train_step=self.max_train_step,
+                                                                  val_loop=self.validate_loop)
+            self.init_runtime_info_hub()
+
+    def _build_optimizer(self, config, g):
+        """engine.py:212-236 over build_lr_scheduler / build_optimizer."""
         assert config.get('Optimizer', None) is not None, 'Optimizer must be defined in config.'
         opt_cfg = copy.deepcopy(dict(config['Optimizer']))
         self.lr_decay_unit = opt_cfg.pop('lr_decay_unit', None) or 'step'
@@ -211,31 +303,6 @@ class Engine(object):
                                                 self.optimizer.schedulers)
         else:
             self.optimizer = klass(lr, **opt_cfg, **{key: list(self.model.parameters())})
-
-        if g.get('pretrained_model', None) is not None:
-            assert isinstance(g['pretrained_model'], str), 'pretrained_model type is not available. Please use `string`.'
-            self.model.load_pretrained(g['pretrained_model'], rank, g.get('finetune', False))
-
-        self.grad_reducer = None
-        if g['distributed'] or collectives_active():
-            assert config.get('DistributedStrategy', None) is not None
-            assert config['DistributedStrategy'].get('data_parallel', False) is True, \
-                'If you want to use data parallel you should set data_parallel=True'
-            arch = getattr(self.model, 'arch', self.model)
-            param_sync(arch)
-            arenas = arch.trainable_arenas() if hasattr(arch, 'trainable_arenas') else None
-            if arenas is not None and len(arenas) > 1:
-                # several trainable arenas (parameter groups): the loop's blocking grad_sync reduces each flat
-                # gradient buffer after backward (reference behaviour); the overlapped reducer handles one arena
-                self.grad_reducer = None
-            else:
-                self.grad_reducer = GradReducer(arch.arena_q if hasattr(arch, 'arena_q') else arch.arena,
-                                                self.optimizer)
-
-        train_loop_name = g.get('train_loop')
-        self.train_loop = getattr(loops, train_loop_name)(self, epochs=g['epochs'],
-                                                          max_train_step=self.max_train_step, val_loop=None)
-        self.init_runtime_info_hub()
 
     def _build_scheduler(self, sched_cfg, g):
         """build_lr_scheduler (passl/scheduler/__init__.py:22-36): every v2 scheduler is handed the run length."""
@@ -278,15 +345,15 @@ class Engine(object):
     # ---- engine.py:319-347
     @property
     def cur_epoch_id(self):
-        return self.train_loop.cur_epoch_id
+        return self.train_loop.cur_epoch_id if self.train_loop is not None else 0
 
     @property
     def global_step(self):
-        return self.train_loop.global_step
+        return self.train_loop.global_step if self.train_loop is not None else 0
 
     @property
     def epochs(self):
-        return self.train_loop.epochs
+        return self.train_loop.epochs if self.train_loop is not None else 0
 
     @property
     def model_name(self):
@@ -301,3 +368,14 @@ class Engine(object):
         self.training = True
         self.model.train()
         self.train_loop.run()
+
+    # ---- engine.py:361-367
+    def eval(self):
+        assert self.mode in ['train', 'eval']
+        if self.validate_loop is None:
+            raise RuntimeError('Engine.eval() needs Global.validate_loop and a DataLoader.Eval block')
+        self.model.eval()
+        self.validating = True
+        eval_result = self.validate_loop.run()
+        self.model.train()
+        return eval_result

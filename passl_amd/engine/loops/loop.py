@@ -2,7 +2,9 @@
 passl/engine/loops/loop.py:141-311 (``run`` -> ``train_one_epoch`` -> ``train_one_step``; global step
 counter, ``max_train_step`` early stop, timers reset after 5 warm-up iterations, ``ips`` =
 batch_size * world_size / batch_cost in the log line, lr stepping per epoch when
-``lr_decay_unit == 'epoch'``, checkpoint every ``save_interval`` epochs).
+``lr_decay_unit == 'epoch'``, checkpoint every ``save_interval`` epochs; with a validation loop:
+``_should_check_val`` (loop.py:51-64) after an epoch / every ``eval_interval`` units, then a checkpoint that also
+carries the metric, plus a ``best`` copy when the ``metric`` entry improved).
 
 Differences by design: losses are kept as device tensors and only converted when a line is printed
 (the reference calls ``.item()`` every iteration = one device->host sync per step, loop.py:85);
@@ -52,9 +54,31 @@ class TrainingEpochLoop(object):
             self.output_info.clear()
             if stop:
                 break
-            if epoch_id % self.trainer.save_interval == 0 or epoch_id == self.epochs:
+            to_save = epoch_id % self.trainer.save_interval == 0 or epoch_id == self.epochs
+            if self._should_check_val():
+                self.trainer.validating = True
+                self.val_loop.run()
+                self.trainer.training = True
+                self.trainer.model.train()
+                to_save = True
+                best = self.val_loop.best_model_metric
+                if best is not None and 'metric' in best:
+                    logger.info('[Eval][Epoch {}][best metric: {}]'.format(self.cur_epoch_id, best['metric']))
+            if to_save or (self.val_loop is not None and self.val_loop.best_model_to_save):
                 self.save_checkpoint()
         self.trainer.training = False
+
+    def _should_check_val(self):
+        """loop.py:51-64."""
+        if self.val_loop is None:
+            return False
+        g = self.trainer.config['Global']
+        if not g.get('eval_during_train', False):
+            return False
+        interval = g.get('eval_interval', 1)
+        if g.get('eval_unit', 'epoch') == 'epoch':
+            return self.cur_epoch_id % interval == 0
+        return self.global_step % interval == 0
 
     # ---- loop.py:255-308
     def train_one_epoch(self):
@@ -119,14 +143,21 @@ class TrainingEpochLoop(object):
         rank = self.trainer.config['Global'].get('rank', 0)
         model_dir = os.path.join(self.trainer.output_dir, self.trainer.model_name)
         prefixes = [os.path.join(model_dir, 'epoch_{}'.format(self.cur_epoch_id)), os.path.join(model_dir, 'latest')]
+        metric_info = {}
+        if self.val_loop is not None:
+            if self.val_loop.best_model_to_save:
+                prefixes.append(os.path.join(model_dir, 'best'))          # io.save_checkpoint(is_best=True)
+                metric_info = dict(self.val_loop.best_model_metric)
+            elif self.val_loop.latest_model_metric is not None:
+                metric_info = dict(self.val_loop.latest_model_metric)
         for prefix in prefixes:
             self.trainer.model.save(prefix, rank=rank)
         if rank != 0:
             return
         os.makedirs(model_dir, exist_ok=True)
         opt_state = to_numpy(self.trainer.optimizer.state_dict())
-        metric_info = {'epoch': self.cur_epoch_id, 'global_step': self.global_step,
-                       'timestamp': time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(time.time()))}
+        metric_info.update({'epoch': self.cur_epoch_id, 'global_step': self.global_step,
+                            'timestamp': time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(time.time()))})
         for prefix in prefixes:
             with open(prefix + '.pdopt', 'wb') as f:
                 pickle.dump(opt_state, f, protocol=2)

@@ -104,6 +104,8 @@ SIGNATURES = {
                                       c_f, c_f, c_f, c_p]),
     'passl_hip_lars_momentum_dev': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_f,
                                           c_f, c_f, c_f, c_p]),
+    'passl_hip_larc_momentum_dev': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_f,
+                                          c_f, c_f, c_i, c_f, c_p]),
     'passl_hip_ntxent_fwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p]),
     'passl_hip_ntxent_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p,
                                    c_p, c_p, c_p, c_p]),

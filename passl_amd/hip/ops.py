@@ -484,6 +484,17 @@ def lars_momentum_dev(p, g, v, table, hyper, mu, coeff, eps, grad_scale=1.0):
                                                coeff, eps, grad_scale, L.stream()), 'lars_momentum_dev')
 
 
+def larc_momentum_dev(p, g, v, table, hyper, mu, trust, eps, clip, grad_scale=1.0):
+    """MomentumLARC over the flat arena (include/passl_hip.h), lr = hyper[0] on the device; same table as LARS."""
+    assert table['norms'].numel() >= 2 * (table['seg_wd'].numel() + table['blk_off'].numel())
+    L.check(_lib().passl_hip_larc_momentum_dev(L.ptr(p), L.ptr(g), L.ptr(v), L.ptr(table['blk_off']),
+                                               L.ptr(table['blk_len']), L.ptr(table['blk_seg']),
+                                               table['blk_off'].numel(), L.ptr(table['seg_wd']),
+                                               table['seg_wd'].numel(), L.ptr(table['norms']), L.ptr(hyper), mu,
+                                               trust, eps, int(bool(clip)), grad_scale, L.stream()),
+            'larc_momentum_dev')
+
+
 # ------------------------------------------------------------------ ViT / MAE
 def layernorm_fwd(x, gamma, beta, eps):
     Cc = x.shape[-1]

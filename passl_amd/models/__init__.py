@@ -90,10 +90,11 @@ def simclr_resnet50(dim=128, T=0.1, multi_rank=False, **kw):
                                     multi_rank=multi_rank), dim=dim, T=T, **kw))
 
 
-from .mocov3 import (MoCoV3ViT, MoCoV3Pretrain, mocov3_vit_base,      # noqa: E402,F401
-                     mocov3_vit_base_pretrain)
+from .mocov3 import (MoCoV3ViT, MoCoV3LinearProbe, MoCoV3Pretrain, mocov3_vit_base,      # noqa: E402,F401
+                     mocov3_vit_base_linearprobe, mocov3_vit_base_pretrain)
 from .resnet import ResNet, resnet50                                   # noqa: E402,F401
-from .simsiam import SimSiamPretain, simsiam_resnet50_pretrain         # noqa: E402,F401
+from .simsiam import (SimSiamPretain, SimSiamLinearProbe, simsiam_resnet50_pretrain,      # noqa: E402,F401
+                      simsiam_resnet50_linearprobe)
 
 
 def build_model(config):

@@ -42,7 +42,8 @@ from ..utils.infohub import runtime_info_hub
 from .base_model import Model
 from .utils.averaged_model import CosineEMA
 
-__all__ = ['MoCoV3ViT', 'MoCoV3Pretrain', 'mocov3_vit_base', 'mocov3_vit_base_pretrain']
+__all__ = ['MoCoV3ViT', 'MoCoV3LinearProbe', 'MoCoV3Pretrain', 'mocov3_vit_base', 'mocov3_vit_base_linearprobe',
+           'mocov3_vit_base_pretrain']
 
 
 def build_2d_sincos_position_embedding(embed_dim, h, w, temperature=10000.):
@@ -162,6 +163,63 @@ class MoCoV3ViT(hnn.Layer):
     def forward(self, x):
         x = self.forward_features(x)
         return x if self.head is None else self.head(x)
+
+
+class MoCoV3LinearProbe(MoCoV3ViT, Model):
+    """mocov3.py:94-109: a MoCoV3ViT whose every parameter but ``head.weight`` / ``head.bias`` is frozen; the head
+    starts at Normal(0, 0.01) / zero bias.  ``load_pretrained`` (VisionTransformer.load_pretrained,
+    vision_transformer.py:365-381, finetune=False) takes the ``<prefix>_base_encoder.pdparams`` file
+    ``MoCoV3Pretrain.save`` writes (backbone keys without prefix, no head).
+
+    Execution: the frozen encoder lives in a NON-trainable arena and runs under no_grad (nothing is kept for
+    backward); the head is the only trainable arena — one GEMM with fp32 scores."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        # freeze all layers but the last fc
+        for name, param in self.named_parameters():
+            if name not in ['head.weight', 'head.bias']:
+                param.requires_grad_(False)
+        # optimize only the linear classifier
+        parameters = [p for p in self.parameters() if p.requires_grad]
+        assert len(parameters) == 2  # weight, bias
+        with torch.no_grad():
+            self.head.weight.copy_(torch.randn(self.head.weight.shape) * 0.01)
+            self.head.bias.zero_()
+        frozen = [self.patch_embed, self.blocks, self.norm]
+        self.arena_k = EncoderArena(tnn.ModuleList(frozen), trainable=False)
+        self.arena_q = EncoderArena(self.head, trainable=True)
+
+    def sync_runtime_state(self):
+        self.arena_k.refresh()
+        self.arena_q.refresh()
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.sync_runtime_state()
+        return r
+
+    def load_pretrained(self, path, rank=0, finetune=False):
+        if not os.path.exists(path + '.pdparams'):
+            raise ValueError('Model pretrain path {} does not exists.'.format(path))
+        if finetune:
+            raise NotImplementedError('finetune=True (head removal + position-embedding interpolation) belongs to the '
+                                      'fine-tuning recipe')
+        load_lenient(self, load_pickle(path + '.pdparams'), what='pretrained model')
+        self.sync_runtime_state()
+
+    def save(self, path, local_rank=0, rank=0):
+        if rank != 0:
+            return
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        with open(path + '.pdparams', 'wb') as f:
+            pickle.dump(to_numpy(dict(self.state_dict())), f, protocol=2)
+
+    def forward(self, x):
+        self.arena_q.refresh()
+        with torch.no_grad():
+            feats = self.forward_features(x)
+        return self.head(feats, out_f32=True)
 
 
 class _KeyLogitsFn(Function):
@@ -290,6 +348,11 @@ class MoCoV3Pretrain(Model):
 def mocov3_vit_base(**kwargs):
     return MoCoV3ViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
                      norm_layer=partial(hnn.LayerNorm, epsilon=1e-6), **kwargs)
+
+
+def mocov3_vit_base_linearprobe(**kwargs):
+    return MoCoV3LinearProbe(patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(hnn.LayerNorm, epsilon=1e-6), **kwargs)
 
 
 def mocov3_vit_base_pretrain(**kwargs):

@@ -32,7 +32,7 @@ from .base_model import Model
 from ..modeling.backbones.resnet import ResNet as _Trunk
 from .resnet import BottleneckBlock, ResNet
 
-__all__ = ['SimSiamPretain', 'simsiam_resnet50_pretrain']
+__all__ = ['SimSiamPretain', 'SimSiamLinearProbe', 'simsiam_resnet50_pretrain', 'simsiam_resnet50_linearprobe']
 
 
 class _MLP(tnn.Sequential):
@@ -122,6 +122,51 @@ class SimSiamPretain(Model):
             pickle.dump(enc, f, protocol=2)
 
 
+class SimSiamLinearProbe(ResNet):
+    """simsiam.py:128-147: a v2 ResNet whose every parameter but ``fc.weight`` / ``fc.bias`` is frozen and whose every
+    BatchNorm uses its running statistics also in train mode (``_use_global_stats``); the classifier starts at
+    Normal(0, 0.01) / zero bias.  ``load_pretrained`` takes the ``<prefix>_encoder.pdparams`` file ``SimSiamPretain.save``
+    writes (trunk keys without the ``encoder.`` prefix; the absent ``fc`` keeps its initialisation).
+
+    Execution: the frozen trunk lives in a NON-trainable arena and runs the fused inference path (BatchNorm + ReLU +
+    residual folded into the conv epilogues: one kernel per conv, nothing kept for backward); the classifier is the
+    only trainable arena — one GEMM with fp32 scores forward, its weight / bias gradients backward."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        # freeze all layers but the last fc
+        self.frozen_stages = 4
+        self._freeze_stages()
+        # optimize only the linear classifier
+        parameters = [p for p in self.parameters() if p.requires_grad]
+        assert len(parameters) == 2  # weight, bias
+        with torch.no_grad():
+            self.fc.weight.copy_(torch.randn(self.fc.weight.shape) * 0.01)
+            self.fc.bias.zero_()
+        self.arena_k = EncoderArena(tnn.ModuleList(self.frozen_modules()), trainable=False)   # (name as in MoCo)
+        self.arena_k.update_bn_affine()
+        self.arena_q = EncoderArena(self.fc, trainable=True)       # what the optimizer / reducer see
+
+    def sync_runtime_state(self):
+        """After weights were written from outside (checkpoint / pre-trained trunk)."""
+        self.arena_k.refresh()
+        self.arena_k.update_bn_affine()
+        self.arena_q.refresh()
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.sync_runtime_state()
+        return r
+
+    def load_pretrained(self, path, rank=0, finetune=False):
+        super().load_pretrained(path, rank=rank, finetune=finetune)
+        self.sync_runtime_state()
+
+    def forward(self, x):
+        self.arena_q.refresh()                  # compute-dtype classifier operands from the fp32 masters
+        return super().forward(x)
+
+
 def simsiam_resnet50_pretrain(**kwargs):
     encoder = partial(ResNet, block=BottleneckBlock, depth=50)
     model = SimSiamPretain(base_encoder=encoder, dim=2048, pred_dim=512, **kwargs)
@@ -129,3 +174,7 @@ def simsiam_resnet50_pretrain(**kwargs):
     if collectives_active():
         hnn.convert_sync_batchnorm(model)
     return model
+
+
+def simsiam_resnet50_linearprobe(**kwargs):
+    return SimSiamLinearProbe(block=BottleneckBlock, depth=50, **kwargs)

@@ -283,6 +283,35 @@ class LarsMomentumOptimizer(_DeviceHyper):
 
 
 @OPTIMIZERS.register()
+class MomentumLARC(LarsMomentumOptimizer):
+    """passl/optimizer/momentum_larc.py:25-111 (the optimizer of the SimSiam linear-probe recipe,
+    tasks/ssl/simsiam/configs/simsiam_resnet50_lp_in1k_1n8c_dp_fp32.yaml) as the multi-tensor LARS machinery with the
+    LARC update (passl_hip_larc_momentum_dev).  Rule per parameter tensor:
+        if |p| != 0 and |g| != 0:  a = trust_coefficient |p| / (|g| + |p| wd + eps)   [clip: a = min(a / lr, 1)]
+                                   g = a (g + wd p)
+        v = mu v + g;  p -= lr v          (a zero-norm tensor takes its raw gradient, without weight decay)
+    Unlike LARS the learning rate multiplies the velocity, not the gradient: a schedule rescales the whole history.
+    ``use_master_param``: parameters are fp32 masters here anyway."""
+    type = 'momentum_larc'
+
+    def __init__(self, learning_rate=0.0, momentum=0.9, weight_decay=0.0, trust_coefficient=0.02, clip=True,
+                 eps=1e-8, use_master_param=True, grad_clip=None, parameters=None, lr_func=None, **args):
+        if grad_clip is not None or lr_func is not None:
+            raise NotImplementedError('grad_clip / lr_func are not used by the linear-probe recipes')
+        super().__init__(learning_rate, momentum, lars_coeff=trust_coefficient, lars_weight_decay=weight_decay,
+                         parameter_list=parameters, epsilon=eps)
+        self._clip = bool(clip)
+
+    @torch.no_grad()
+    def step(self):
+        hyper = self._hyper_for_step()
+        for a, v, t in zip(self._arenas, self._velocity, self._tables):
+            _grads_complete(a)
+            ops.larc_momentum_dev(a.flat[:a.n_train], a.grads, v, t, hyper, self._momentum, self._coeff,
+                                  self._eps, self._clip, self.grad_scale * self._rescale)
+
+
+@OPTIMIZERS.register()
 class AdamW(_DeviceHyper):
     """paddle.optimizer.AdamW (registered by the reference at passl_v110/solver/optimizer.py:22) as ONE
     launch over the flat arena.  adamw op  [Paddle-semantics]:

@@ -196,8 +196,77 @@ def simsiam_run():
     dist.destroy_process_group()
 
 
+def lp_run():
+    """Two data-parallel ranks of the SimSiam linear-probe recipe through the v2 Engine (param_sync at start-up,
+    the classifier arena's gradient all-reduce, MomentumLARC on identical averaged gradients, the evaluation pass with
+    gathered scores / labels): the run must equal the ONE-process restatement on the concatenated batches — updated
+    classifier and the evaluation metric — and the replicas must end bit-identical."""
+    from oracle import linprobe_v2 as L
+    from passl_amd.engine.engine import Engine
+    from passl_amd.utils.config import get_config
+    classes, bs, size = 40, 8, 64
+    cfg = get_config(os.path.join(ROOT, 'configs', 'v2', 'simsiam_resnet50_lp_synthetic.yaml'),
+                     ['Global.epochs=1', 'Global.print_batch_step=1', 'Global.output_dir=%s' % os.environ['PASSL_DP_OUT'],
+                      'Model.class_num=%d' % classes, 'DataLoader.Train.dataset.num_classes=%d' % classes,
+                      'DataLoader.Eval.dataset.num_classes=%d' % classes,
+                      'DataLoader.Train.dataset.num_samples=%d' % (2 * 2 * bs),
+                      'DataLoader.Train.dataset.image_size=%d' % size,
+                      'DataLoader.Train.sampler.batch_size=%d' % bs, 'DataLoader.Eval.dataset.num_samples=24',
+                      'DataLoader.Eval.dataset.image_size=%d' % size, 'DataLoader.Eval.sampler.batch_size=%d' % bs])
+    cfg.DataLoader.Train.dataset.num_batches_cached = 2
+    cfg.DataLoader.Eval.dataset.num_batches_cached = 2
+    eng = Engine(cfg, mode='train')
+    rank, world = cfg['Global']['rank'], cfg['Global']['world_size']
+    assert world == 2 and eng.grad_reducer is not None
+    oracle = L.LinearProbeOracle('simsiam', class_num=classes, seed=0, optimizer='MomentumLARC', lr=1.6, momentum=0.9,
+                                 weight_decay=0.0, trust_coefficient=0.001, clip=False)
+    missing, unexpected = eng.model.load_state_dict({k: v.float() for k, v in oracle.st.items()}, strict=False)
+    assert not missing and not unexpected
+    eng.train()
+    torch.cuda.synchronize()
+
+    def batches(part, seed, n):
+        ds = getattr(eng, part).inner.dataset
+        out = []
+        for r in range(world):
+            gen = torch.Generator().manual_seed(seed + r)
+            out.append([ds.make_batch(gen, bs) for _ in range(n)])
+        return out
+    if rank == 0:
+        tr = batches('train_dataloader', 1234, 2)
+        for s in range(2):
+            oracle.train_step(torch.cat([tr[0][s][0], tr[1][s][0]]), torch.cat([tr[0][s][1], tr[1][s][1]]))
+        for n, ref in (('fc.weight', oracle.st['fc.weight']), ('fc.bias', oracle.st['fc.bias'])):
+            got = dict(eng.model.named_parameters())[n].detach().cpu().double()
+            err = float((got - ref.double()).norm() / ref.double().norm())
+            assert err < 2e-4, (n, err)
+        ev = batches('eval_dataloader', 4321, 2)
+        rows = []
+        for r in range(world):
+            rows.append((ev[r][0][0], ev[r][0][1]))
+            rows.append((ev[r][1][0][:4], ev[r][1][1][:4]))        # 12 rows per rank: the last batch holds 4
+        ref = oracle.evaluate(rows)
+        got = eng.validate_loop.latest_model_metric
+        assert abs(got['top1'] - ref['top1']) < 1e-6 and abs(got['top5'] - ref['top5']) < 1e-6, (got, ref)
+    t = eng.model.arena_q.flat
+    ref_t = t.clone()
+    dist.broadcast(ref_t, src=0)
+    assert torch.equal(ref_t, t), 'classifier differs between ranks'
+    m = torch.tensor([eng.validate_loop.latest_model_metric['top1']], dtype=torch.float64, device=t.device)
+    m0 = m.clone()
+    dist.broadcast(m0, src=0)
+    assert torch.equal(m, m0), 'evaluation metric differs between ranks'
+    dist.barrier()
+    if rank == 0:
+        print('DP-OK lp %.6f' % eng.validate_loop.latest_model_metric['loss'], flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     workload = sys.argv[1]
+    if workload == 'lp':
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        return lp_run()
     if workload == 'simsiam':
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         return simsiam_run()

@@ -327,3 +327,49 @@ def _sync_bn_math_case(rank, world):
 def test_sync_batchnorm_moment_exchange():
     out = _spawn(_sync_bn_math_case)
     assert out[0] == out[1]                    # rank-ordered combination: identical on every rank
+
+
+def _eval_gather_case(rank, world):
+    """ClassificationEvaluationLoop over two ranks: 21 samples, batch 4 per rank -> 3 batches per rank = 24 rows with
+    3 repeats in the last global batch (DistributedBatchSampler pads by wrapping around); scores and labels of every
+    batch are gathered and the repeats dropped, so the metric is over exactly the 21 samples
+    (classification_loop.py:196-222)."""
+    import torch.nn.functional as F
+    from passl_amd.engine.loops import ClassificationEvaluationLoop
+    total, bs = 21, 4
+    gen = torch.Generator().manual_seed(11)
+    xs, ys = torch.randn(total, 6, generator=gen), torch.randint(0, 5, (total,), generator=gen)
+    W = torch.randn(6, 5, generator=gen)
+    # global batch b = rows [b*8, b*8+8): rank r takes [b*8 + r*4, b*8 + r*4 + 4), indices wrap around at the end
+    idx = [[(b * bs * world + rank * bs + i) % total for i in range(bs)] for b in range(3)]
+
+    class Loader(list):
+        dataset = range(total)
+
+    loader = Loader([[xs[i], ys[i]] for i in idx])
+    model = torch.nn.Linear(6, 5, bias=False)
+    with torch.no_grad():
+        model.weight.copy_(W.t())
+
+    def loss_func(out, label):
+        v = F.cross_entropy(out, label)
+        return {'CELoss': v, 'loss': v}
+
+    def metric_func(out, label):
+        a = (out.argmax(1) == label).float().mean()
+        return {'top1': a, 'metric': a}
+    tr = SimpleNamespace(model=model, eval_loss_func=loss_func, eval_metric_func=metric_func, eval_dataloader=loader,
+                         mode='eval', validating=True, cur_epoch_id=0)
+    res = ClassificationEvaluationLoop(tr).run()
+    want = float(((xs @ W).argmax(1) == ys).float().mean())
+    local = torch.cat([xs[i] for i in idx]), torch.cat([ys[i] for i in idx])
+    return res['top1'], want, res['loss'], float(F.cross_entropy(local[0] @ W, local[1]))
+
+
+def test_evaluation_loop_gathers_scores_and_drops_the_sampler_repeats():
+    out = _spawn(_eval_gather_case)
+    for rank in (0, 1):
+        top1, want, loss, local_loss = out[rank]
+        assert abs(top1 - want) < 1e-6, (rank, top1, want)              # the metric is global and exact
+        assert abs(loss - local_loss) < 1e-6                           # the loss average is per rank (as the reference)
+    assert out[0][0] == out[1][0]

@@ -49,6 +49,11 @@ def test_two_ranks_mocov3_cross_rank_keys():
     _run_worker('mocov3', 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0'))
 
 
+def test_two_ranks_linear_probe_engine_equals_one_rank_on_the_joint_batches(tmp_path):
+    """The v2 linear-probe recipe under data parallelism through Engine.train() — see dp_worker.lp_run."""
+    _run_worker('lp', 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0', PASSL_DP_OUT=str(tmp_path)))
+
+
 def test_two_ranks_simsiam_sync_batchnorm_equals_one_rank_on_the_joint_batch():
     """SyncBatchNorm (reference passl/models/simsiam.py:160-162): cross-rank BatchNorm statistics, forward and
     backward — see dp_worker.simsiam_run."""

@@ -243,6 +243,99 @@ def test_v2_train_one_step_facade():
     assert sched.last_epoch == 7
 
 
+def test_v2_classification_loops_host_logic(tmp_path):
+    """ClassificationTrainingEpochLoop / ClassificationEvaluationLoop (passl/engine/loops/classification_loop.py) on a
+    torch-CPU stand-in: micro-batch accumulation equals the full batch, the schedule is set to the step count, the
+    train metric joins the logged entries, the evaluation pass weights every batch by its rows (uneven last batch),
+    the best metric is tracked, validation after every epoch writes epoch / latest / best checkpoints."""
+    _register_dummies()
+    import torch.nn.functional as F
+    from types import SimpleNamespace
+    from passl_amd.engine.loops import ClassificationEvaluationLoop, ClassificationTrainingEpochLoop
+    from passl_amd.solver.builder import OPTIMIZERS
+    from passl_amd.solver.lr_scheduler import TimmCosine
+
+    class Probe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(6, 5)
+
+        def forward(self, x):
+            return self.fc(x)
+
+        def save(self, path, local_rank=0, rank=0):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save(self.state_dict(), path + '.pdparams')
+
+    def loss_func(out, label):
+        v = F.cross_entropy(out, label)
+        return {'CELoss': v, 'loss': v}
+
+    def metric_func(out, label):
+        a = (out.argmax(1) == label).float().mean()
+        return {'top1': a, 'metric': a}
+
+    class Loader(list):
+        @property
+        def dataset(self):
+            return range(sum(b[0].shape[0] for b in self))
+
+    gen = torch.Generator().manual_seed(0)
+    train = Loader([[torch.randn(8, 6, generator=gen), torch.randint(0, 5, (8,), generator=gen)] for _ in range(3)])
+    ev = Loader([[torch.randn(n, 6, generator=gen), torch.randint(0, 5, (n,), generator=gen)] for n in (8, 8, 3)])
+
+    def make(accum):
+        torch.manual_seed(1)
+        model = Probe()
+        sched = TimmCosine(learning_rate=0.5, step_each_epoch=3, epochs=2, decay_unit='step', last_epoch=0)
+        opt = OPTIMIZERS.get('PlainSGD')(sched, parameters=model.parameters())
+        opt._parameter_list = opt.params
+        tr = SimpleNamespace(model=model, optimizer=opt, lr_scheduler=sched, lr_decay_unit='step', accum_steps=accum,
+                             train_loss_func=loss_func, eval_loss_func=loss_func, train_metric_func=metric_func,
+                             eval_metric_func=metric_func, train_dataloader=train, eval_dataloader=ev,
+                             print_batch_step=1, save_interval=5, mode='train', training=True, validating=False,
+                             checkpoint=None, output_dir=str(tmp_path / ('accum%d' % accum)), model_name='probe',
+                             config={'Global': {'eval_during_train': True, 'eval_interval': 1, 'eval_unit': 'epoch',
+                                                'world_size': 1}})
+        val = ClassificationEvaluationLoop(tr)
+        loop = ClassificationTrainingEpochLoop(tr, epochs=2, val_loop=val)
+        tr.cur_epoch_id = 0
+        return tr, loop, val
+
+    tr1, loop1, val1 = make(1)
+    loop1.global_step = 1
+    out, ld = loop1.train_one_step(train[0])
+    assert out.shape == (8, 5) and set(ld) == {'CELoss', 'loss', 'top1', 'metric'} and tr1.lr_scheduler.last_epoch == 1
+    tr2, loop2, _ = make(2)
+    loop2.global_step = 1
+    out2, ld2 = loop2.train_one_step(train[0])
+    assert torch.allclose(out, out2) and abs(float(ld['loss']) - float(ld2['loss'])) < 1e-6
+    assert torch.allclose(tr1.model.fc.weight, tr2.model.fc.weight, atol=1e-6)
+    # evaluation: row-weighted averages over 8 + 8 + 3 rows
+    tr1.validating = True
+    res = val1.run()
+    with torch.no_grad():
+        xs, ys = torch.cat([b[0] for b in ev]), torch.cat([b[1] for b in ev])
+        logits = tr1.model(xs)
+        assert abs(res['loss'] - float(F.cross_entropy(logits, ys))) < 1e-6
+        assert abs(res['top1'] - float((logits.argmax(1) == ys).float().mean())) < 1e-6
+    assert val1.best_model_to_save and val1.best_model_metric == res and tr1.validating is False
+    val1.latest_model_metric = dict(res, metric=res['metric'] - 0.1)
+    val1.reset_state()
+    val1.update_best_model_metric_info()
+    assert not val1.best_model_to_save and val1.best_model_metric == res            # a worse pass keeps the best
+    # the whole run: validation after each epoch, checkpoints with the metric
+    tr, loop, val = make(1)
+    loop.run()
+    assert loop.global_step == 6 and tr.lr_scheduler.last_epoch == 6 and tr.training is False
+    d = os.path.join(tr.output_dir, 'probe')
+    for stem in ('epoch_1', 'epoch_2', 'latest', 'best'):
+        assert os.path.exists(os.path.join(d, stem + '.pdstates')), os.listdir(d)
+    from passl_amd.utils.checkpoint import load_pickle
+    st = load_pickle(os.path.join(d, 'latest.pdstates'))
+    assert st['epoch'] == 2 and st['global_step'] == 6 and 'top1' in st and 'loss' in st
+
+
 # ------------------------------------------------------------------ SimCLR row (host side)
 REF_SIMCLR_CFG = '/root/reference/configs/simclr/simclr_r50_IM.yaml'
 
@@ -819,5 +912,58 @@ def test_v2_engine_builds_from_the_reference_simsiam_yaml_unchanged():
         sd = m.state_dict()
         assert 'encoder.fc.7._mean' in sd and 'encoder.fc.7.weight' not in sd and 'predictor.3.bias' in sd
         assert float(sd['encoder.layer3.2.bn3.weight'].abs().max()) == 0.0           # zero_init_residual
+    finally:
+        hip_config.set_compute_dtype(prev)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/tasks/ssl/simsiam'), reason='reference tree not present')
+@pytest.mark.parametrize('yaml_path, model, opt_name, lr, compute', [
+    ('/root/reference/tasks/ssl/simsiam/configs/simsiam_resnet50_lp_in1k_1n8c_dp_fp32.yaml',
+     'SimSiamLinearProbe', 'MomentumLARC', 1.6, torch.float32),
+    ('/root/reference/tasks/ssl/mocov3/configs/mocov3_vit_base_patch16_224_lp_in1k_1n8c_dp_fp16o1.yaml',
+     'MoCoV3LinearProbe', 'Momentum', 12.0, torch.bfloat16)])
+def test_v2_engine_builds_from_the_reference_linear_probe_yamls_unchanged(yaml_path, model, opt_name, lr, compute):
+    """The linear-probe recipes of tasks/ssl/{simsiam,mocov3} read as they are (`-o`: device, dataset class, no
+    pre-trained file, a smaller run): task_type Classification -> ClassificationTrainingEpochLoop +
+    ClassificationEvaluationLoop, Loss / Metric blocks -> CombinedLoss(CELoss) / CombinedMetrics(TopkAcc), the
+    probe model with ONLY its classifier trainable, the optimizer of the yaml over that one arena, TimmCosine per
+    epoch starting at the base rate (last_epoch: 0), train and evaluation loaders."""
+    from passl_amd.engine.engine import Engine
+    from passl_amd.hip import config as hip_config
+    prev = hip_config.get_compute_dtype()
+    try:
+        cfg = get_config(yaml_path, ['Global.device=cpu', 'Global.epochs=9', 'Global.pretrained_model=None',
+                                     'DataLoader.Train.dataset.name=SyntheticLabeled',
+                                     'DataLoader.Eval.dataset.name=SyntheticLabeled',
+                                     'DataLoader.Train.sampler.batch_size=4', 'DataLoader.Eval.sampler.batch_size=4'])
+        for part in ('Train', 'Eval'):
+            cfg.DataLoader[part].dataset.num_samples = 10      # (not keys of the yaml: `-o` cannot add them)
+            cfg.DataLoader[part].dataset.image_size = 32 if 'simsiam' in yaml_path else 224
+        eng = Engine(cfg, mode='train')
+        assert hip_config.get_compute_dtype() == compute
+        m, opt = eng.model, eng.optimizer
+        assert type(m).__name__ == model and type(opt).__name__ == opt_name
+        trainable = [n for n, p in m.named_parameters() if p.requires_grad]
+        head = 'fc' if 'simsiam' in yaml_path else 'head'
+        assert trainable == [head + '.weight', head + '.bias'] and opt._arenas == [m.arena_q]
+        assert m.arena_q.n_train == (2048 if head == 'fc' else 768) * 1000 + 1000
+        assert eng.lr_decay_unit == 'epoch' and type(eng.lr_scheduler).__name__ == 'TimmCosine'
+        assert eng.lr_scheduler.T_max == 9 and eng.lr_scheduler.last_epoch == 0 and opt.get_lr() == lr
+        eng.lr_scheduler.step(3)
+        assert abs(opt.get_lr() - 0.5 * lr * (1 + math.cos(math.pi * 3 / 9))) < 1e-12
+        if opt_name == 'MomentumLARC':
+            assert (opt._momentum, opt._wd, opt._coeff, opt._clip, opt._eps) == (0.9, 0.0, 0.001, False, 1e-8)
+        else:
+            assert (opt._momentum, opt._wd) == (0.9, 0.0)
+        assert type(eng.train_loop).__name__ == 'ClassificationTrainingEpochLoop'
+        assert type(eng.validate_loop).__name__ == 'ClassificationEvaluationLoop' and eng.train_loop.val_loop is eng.validate_loop
+        assert type(eng.train_loss_func.loss_func[0]).__name__ == 'CELoss' and eng.train_loss_func.loss_weight == [1.0]
+        assert eng.eval_metric_func.metric_func_list[0].topk == [1, 5]
+        # train: 10 samples / 4 with drop_last False -> 3 batches, the last one with 2 rows; [data, label] batches
+        sizes = [(b[0].shape[0], b[1].shape[0]) for b in eng.eval_dataloader]
+        assert sizes == [(4, 4), (4, 4), (2, 2)] and len(eng.eval_dataloader.dataset) == 10
+        sd = m.state_dict()
+        assert (head + '.weight') in sd and abs(float(sd[head + '.weight'].std()) - 0.01) < 1e-3
+        assert float(sd[head + '.bias'].abs().max()) == 0.0
     finally:
         hip_config.set_compute_dtype(prev)
