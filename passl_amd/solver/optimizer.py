@@ -96,11 +96,13 @@ class Momentum(_DeviceHyper):
 
     def __init__(self, learning_rate=0.001, momentum=0.9, parameters=None, use_nesterov=False,
                  weight_decay=None, grad_clip=None, multi_precision=False, rescale_grad=1.0,
-                 name=None):
+                 name=None, use_master_param=None, lr_func=None):
+        # v2 spelling (passl/optimizer/momentum.py:25-45): use_master_param asks for fp32 masters next to fp16
+        # parameters — the arena's parameters ARE fp32 masters; lr_func (LRCallable groups) is not used by the recipes
         if use_nesterov:
             raise NotImplementedError('nesterov momentum is not used on the MoCo path')
-        if grad_clip is not None:
-            raise NotImplementedError('grad_clip is not used on the MoCo path')
+        if grad_clip is not None or lr_func is not None:
+            raise NotImplementedError('grad_clip / lr_func are not used on the MoCo path')
         self._learning_rate = learning_rate
         self._momentum = float(momentum)
         self._wd = float(weight_decay) if weight_decay else 0.0

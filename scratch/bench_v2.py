@@ -19,10 +19,12 @@ eng.model.train()
 batch_data = next(iter(eng.train_dataloader))
 loop = eng.train_loop
 for _ in range(6):
+    loop.global_step += 1
     loop.train_one_step(batch_data)
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(steps):
+    loop.global_step += 1
     _o, ld = loop.train_one_step(batch_data)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps

@@ -391,6 +391,7 @@ def test_v2_train_one_step_on_hip_moco(accum):
         xk = torch.randn(N, 3, 64, 64, generator=gen)
         p0 = {n: oracle.q[n].detach().clone() for n in ('0.conv1.weight', '0.layer4.2.conv3.weight', '1.mlp.2.weight')}
         ref = oracle.train_step_accum(xq, xk, accum)
+        loop.global_step += 1                  # train_one_epoch advances it before the step (loop.py:282)
         out, loss_dict = loop.train_one_step([[xq.to(DEV), xk.to(DEV)], None])
         assert out is None
         assert abs(float(loss_dict['loss']) - float(ref['loss'])) < (1e-3 if s == 0 else 2e-2)
