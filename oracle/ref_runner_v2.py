@@ -95,16 +95,43 @@ def _exec_init(name):
     return m
 
 
+def _adamw_op(p, grad, lr, m, v, beta1_pow, beta2_pow, master, p_out, m_out, v_out, b1_out, b2_out, master_out, *attrs):
+    """The Paddle `adamw` op as passl/optimizer/adamw.py:124-137 calls it (a STATEMENT of the kernel, not reference code
+    [Paddle-semantics]: paddle/phi/kernels/funcs/adam_functors.h + adamw_kernel): in place on p / m / v,
+        p *= 1 - lr*coeff (with_decay);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+        p -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps*sqrt(1-b2^t))
+    with b^t = the beta-pow INPUTS.  What IS executed from the reference around it: the per-parameter state, the step
+    count, beta^step, the learning rate read (`_get_lr`), with_decay / coeff / multi_precision plumbing."""
+    import torch
+    a = dict(zip(attrs[0::2], attrs[1::2]))
+    b1, b2, eps = a['beta1'], a['beta2'], a['epsilon']
+    lr_ = float(lr) * a.get('lr_ratio', 1.0)
+    b1p, b2p = float(beta1_pow), float(beta2_pow)
+    tgt = master if master is not None else p
+    with torch.no_grad():
+        g = grad.to(tgt.dtype)
+        if a.get('with_decay', False):
+            tgt.mul_(1.0 - lr_ * a['coeff'])
+        m.mul_(b1).add_(g.to(m.dtype), alpha=1 - b1)
+        v.mul_(b2).add_((g * g).to(v.dtype), alpha=1 - b2)
+        corr2 = (1.0 - b2p) ** 0.5
+        tgt.sub_(lr_ * corr2 / (1.0 - b1p) * m.to(tgt.dtype) / (v.sqrt().to(tgt.dtype) + eps * corr2))
+        if master is not None:
+            p.copy_(master.to(p.dtype))
+    return p, m, v, beta1_pow, beta2_pow, master
+
+
 def load_solver(ns=None):
     """Adds the v2 solver / loss / metric sources to the namespace: passl/optimizer/{optimizer,momentum,
     momentum_larc}.py (pure-Python update rules: executed as they are), passl/scheduler/lr_scheduler.py (TimmCosine over
     the shim's statement of paddle.optimizer.lr.LRScheduler), passl/loss (CombinedLoss / CELoss) and passl/metric
-    (CombinedMetrics / TopkAcc over paddle.metric.accuracy).  AdamW is NOT loadable: its update is the Paddle kernel
-    ``_C_ops.adamw``."""
+    (CombinedMetrics / TopkAcc over paddle.metric.accuracy).  passl/optimizer/adamw.py is loaded too, but its update is
+    the Paddle kernel ``_C_ops.adamw``: that one call is answered by ``_adamw_op`` (a statement of the kernel)."""
     ns = ns or load()
     import paddle
     if not hasattr(paddle, '_legacy_C_ops'):
         c_ops = types.ModuleType('paddle._legacy_C_ops')       # imported by momentum.py, used only on sparse paths
+        c_ops.adamw = _adamw_op
         sys.modules['paddle._legacy_C_ops'] = c_ops
         paddle._legacy_C_ops = c_ops
     base = os.path.join(REF_ROOT, 'passl')
@@ -115,9 +142,44 @@ def load_solver(ns=None):
     imp('passl.optimizer.optimizer')
     ns.momentum = imp('passl.optimizer.momentum')
     ns.momentum_larc = imp('passl.optimizer.momentum_larc')
+    ns.adamw = imp('passl.optimizer.adamw')              # python wrapper executed; the op itself is _adamw_op
     ns.lr_scheduler = imp('passl.scheduler.lr_scheduler')
     ns.loss = _exec_init('passl.loss')
     ns.metric = _exec_init('passl.metric')
+    return ns
+
+
+def _core_stub():
+    """passl.core as a package object whose __init__ is bypassed (it imports the fused-parameter machinery over
+    paddle.fluid): grad_sync / param_sync are one-rank no-ops, sub-modules (grad_clip) import from the tree."""
+    core = sys.modules.get('passl.core')
+    if core is None:
+        core = _pkg('passl.core', os.path.join(REF_ROOT, 'passl', 'core'))
+        core.grad_sync = lambda param_groups, **k: None
+        core.param_sync = lambda *a, **k: None
+        sys.modules['passl'].core = core
+    return core
+
+
+def load_optimizer_builder(ns):
+    """Adds passl/optimizer/__init__.py itself (build_optimizer, group_params, build_group_lr_scheduler) and
+    passl/scheduler/__init__.py (build_lr_scheduler).  Stand-ins: passl.core.param_fuse (tensor fusion is skipped off
+    the GPU anyway: `'gpu' not in paddle.get_device()`), paddle.optimizer.adam (imported by adan.py)."""
+    import paddle
+    _core_stub()
+    pf = types.ModuleType('passl.core.param_fuse')
+    pf.get_fused_params = lambda params: params
+    sys.modules['passl.core.param_fuse'] = pf
+    sys.modules['passl.core'].param_fuse = pf
+    paddle.get_device = lambda: 'cpu'
+    adam = types.ModuleType('paddle.optimizer.adam')
+    sys.modules['paddle.optimizer.adam'] = adam
+    paddle.optimizer.adam = adam
+    base = os.path.join(REF_ROOT, 'passl')
+    if 'passl.optimizer.utils' not in sys.modules:
+        _pkg('passl.optimizer.utils', os.path.join(base, 'optimizer', 'utils'))
+    ns.scheduler = _exec_init('passl.scheduler')
+    ns.optimizer = _exec_init('passl.optimizer')
     return ns
 
 
@@ -138,11 +200,7 @@ def load_loops(ns):
         m = types.ModuleType(name)
         sys.modules[name] = m
         setattr(sys.modules['passl.utils'], name.rsplit('.', 1)[1], m)
-    core = types.ModuleType('passl.core')
-    core.grad_sync = lambda param_groups, **k: None
-    core.param_sync = lambda *a, **k: None
-    sys.modules['passl.core'] = core
-    sys.modules['passl'].core = core
+    core = _core_stub()
     importlib.import_module('passl.engine.loops.loop')
     ns.classification_loop = importlib.import_module('passl.engine.loops.classification_loop')
     return ns

@@ -110,3 +110,66 @@ print('LIVE-OK')
 '''
     r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and 'LIVE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/passl/optimizer'), reason='reference tree not present (GPU box)')
+def test_reference_build_optimizer_and_loop_step_match_the_two_group_restatement():
+    """The task yaml's Optimizer block through the reference's OWN build_optimizer (passl/optimizer/__init__.py:
+    group_params by name, a scheduler copy per group, the predictor group's fixed rate), Momentum.step and
+    ContrastiveLearningTrainingEpochLoop.train_one_step (forward, backward, step, clear_grad, lr_step), executed under
+    the shim — against SimSiamOracle.train_step with the same two rates: group membership, two steps of parameters,
+    and the rates after lr_step."""
+    code = r'''
+import sys, copy, types, importlib, torch, yaml
+sys.path.insert(0, 'tests/golden')
+from oracle import ref_runner_v2 as R
+import make_golden_simsiam as G
+from oracle.simsiam import SimSiamOracle, trainable_keys, group_of
+ns = R.load_optimizer_builder(R.load_loops(R.load_solver(R.load_simsiam())))
+cl = importlib.import_module('passl.engine.loops.contrastive_learning_loop')
+cfg = yaml.safe_load(open('/root/reference/tasks/ssl/simsiam/configs/simsiam_resnet50_pt_in1k_1n8c_dp_fp32.yaml'))
+opt_cfg = cfg['Optimizer']
+opt_cfg['weight_decay'] = float(opt_cfg['weight_decay'])
+opt_cfg['lr']['learning_rate'] = 2e-3                 # small rates: a random-init step at 0.1 is chaotic in fp32
+opt_cfg['param_groups'][1]['lr'] = 5e-3
+unit = opt_cfg.pop('lr_decay_unit')
+o = SimSiamOracle(seed=4, zero_init_residual=False, lr=2e-3, predictor_lr=5e-3, momentum=0.9, weight_decay=1e-4)
+m = ns.simsiam.simsiam_resnet50_pretrain()
+G.load_state(m, o)
+opt = ns.optimizer.build_optimizer(opt_cfg, None, m, 10, 5, unit)
+names = {id(p): n for n, p in m.named_parameters()}
+groups = {g['name']: sorted(names[id(p)] for p in g['params']) for g in opt.param_groups}
+want = {'encoder': sorted(k for k in trainable_keys(o.st) if group_of(k) == 'encoder'),
+        'predictor': sorted(k for k in trainable_keys(o.st) if group_of(k) == 'predictor')}
+assert groups == want, {k: set(groups[k]) ^ set(want[k]) for k in want}
+assert opt.get_lr(0) == 2e-3 and opt.get_lr(1) == 5e-3 and unit == 'epoch'
+
+class Scaler:
+    def scale(self, x): return x
+    def step(self, op): op.step()
+    def update(self): pass
+tr = types.SimpleNamespace(model=m, optimizer=opt, scaler=Scaler(), accum_steps=1, fp16=False, fp16_level='O0',
+                           fp16_custom_white_list=None, fp16_custom_black_list=None, lr_decay_unit=unit,
+                           print_batch_step=1, enabled_ema=False)
+loop = cl.ContrastiveLearningTrainingEpochLoop(tr, epochs=10)
+m.train()
+g = torch.Generator().manual_seed(3)
+for s in range(2):
+    x1, x2 = torch.randn(8, 3, 64, 64, generator=g), torch.randn(8, 3, 64, 64, generator=g)
+    loop.global_step += 1
+    _, ld = loop.train_one_step([[x1, x2], None])
+    ref = o.train_step(x1, x2)
+    assert abs(float(ld['loss']) - float(ref['loss'])) < 2e-5 * 10 ** s, (s, float(ld['loss']), float(ref['loss']))
+    sd = m.state_dict()
+    worst = 0.0
+    for k in trainable_keys(o.st):
+        a, b = sd[k].double().reshape(-1), o.st[k].double().reshape(-1)
+        worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-12)))
+    assert worst < 2e-5 * 20 ** s, (s, worst)
+assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in m.parameters())      # clear_grad
+opt.lr_step(5)                                         # loop.py:224-225 after an epoch: lr_step(cur_epoch_id)
+assert abs(opt.get_lr(0) - 1e-3) < 1e-15 and opt.get_lr(1) == 5e-3
+print('LIVE-OK')
+'''
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and 'LIVE-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
