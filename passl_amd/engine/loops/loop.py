@@ -164,6 +164,30 @@ class TrainingEpochLoop(object):
             with open(prefix + '.pdstates', 'wb') as f:
                 pickle.dump(metric_info, f, protocol=2)
         logger.info('Already save epoch_{} model in {}'.format(self.cur_epoch_id, model_dir))
+        self._prune_checkpoints(model_dir)
+
+    def _prune_checkpoints(self, model_dir):
+        """passl/utils/io.py:172-201: ``Global.max_num_latest_checkpoint`` = N >= 0 keeps the N most recent ``epoch_*``
+        checkpoints (ordered by the timestamp stored in their .pdstates; 0 — the task yamls' value — keeps none:
+        only ``latest`` / ``best`` survive); absent or negative keeps all.  As in the reference the files removed are
+        <prefix>.{pdparams,pdopt,pdstates}; the encoder-only exports a model's ``save`` writes next to them stay."""
+        import glob
+        from ...utils.checkpoint import load_pickle
+        keep = self.trainer.config['Global'].get('max_num_latest_checkpoint', -1)
+        if keep is None or keep < 0:
+            return
+        timestamp_to_path = {}
+        for path in glob.glob(os.path.join(model_dir, '*.pdstates')):
+            if any(p in path for p in ('best', 'latest')):
+                continue
+            timestamp_to_path[load_pickle(path)['timestamp']] = path[:-len('.pdstates')]
+        timestamps = sorted(timestamp_to_path)
+        for ts in (timestamps[:-keep] if keep > 0 else timestamps):
+            for ext in ('.pdparams', '.pdopt', '.pdstates'):
+                try:
+                    os.remove(timestamp_to_path[ts] + ext)
+                except OSError:
+                    pass
 
     # ---- loop.py:358-375 over passl/utils/io.py:52-96
     def resume(self):

@@ -334,6 +334,22 @@ def test_v2_classification_loops_host_logic(tmp_path):
     from passl_amd.utils.checkpoint import load_pickle
     st = load_pickle(os.path.join(d, 'latest.pdstates'))
     assert st['epoch'] == 2 and st['global_step'] == 6 and 'top1' in st and 'loss' in st
+    # Global.max_num_latest_checkpoint (passl/utils/io.py:172-201): 0 — the task yamls' value — keeps no epoch_*
+    # checkpoint (latest / best survive); N keeps the N most recent by their stored timestamp
+    import pickle
+    for i, ts in ((1, '2024-01-01 00:00:01'), (2, '2024-01-01 00:00:02')):
+        meta = load_pickle(os.path.join(d, 'epoch_%d.pdstates' % i))
+        meta['timestamp'] = ts
+        with open(os.path.join(d, 'epoch_%d.pdstates' % i), 'wb') as f:
+            pickle.dump(meta, f, protocol=2)
+    tr.config['Global']['max_num_latest_checkpoint'] = 1
+    loop._prune_checkpoints(d)
+    left = sorted(os.listdir(d))
+    assert 'epoch_2.pdstates' in left and 'epoch_2.pdparams' in left and not any(n.startswith('epoch_1.') for n in left)
+    tr.config['Global']['max_num_latest_checkpoint'] = 0
+    loop._prune_checkpoints(d)
+    left = sorted(os.listdir(d))
+    assert not any(n.startswith('epoch_') for n in left) and 'latest.pdparams' in left and 'best.pdstates' in left
 
 
 # ------------------------------------------------------------------ SimCLR row (host side)
