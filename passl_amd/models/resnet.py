@@ -7,8 +7,11 @@ downsample.{0,1} / fc``.
 The trunk IS the hot path's trunk (passl_amd/modeling/backbones/resnet.py: NHWC implicit-GEMM convs with fused
 BatchNorm statistics, streaming BatchNorm kernels, fused max-pool); this class adds the average pool -> flatten -> fc
 tail (fc = the GEMM kernel with a bias epilogue and fp32 output).  Bottleneck blocks, width 64, groups 1 only."""
+import math
 import os
 import pickle
+
+import torch
 
 from ..hip import nn as hnn
 from ..modeling.backbones.resnet import BottleneckBlock, ResNet as _Trunk
@@ -16,6 +19,18 @@ from ..utils.checkpoint import load_lenient, load_pickle, to_numpy
 from .base_model import Model
 
 __all__ = ['ResNet', 'BottleneckBlock', 'resnet50']
+
+
+@torch.no_grad()
+def paddle_default_linear_init_(lin):
+    """paddle.nn.Linear without a weight_attr: the framework default initializer = Xavier uniform over [in, out]
+    (U(-a, a), a = sqrt(6 / (in + out))), zero bias  [Paddle-semantics] — hip.nn.Linear leaves its weight unset for
+    the model's own init rule to fill, and the v2 ResNet fc / SimSiam MLPs have none of their own."""
+    a = math.sqrt(6.0 / float(lin.in_features + lin.out_features))
+    lin.weight.copy_((torch.rand(lin.weight.shape) * 2 - 1) * a)
+    if lin.bias is not None:
+        lin.bias.zero_()
+    return lin
 
 
 class ResNet(_Trunk, Model):
@@ -30,7 +45,7 @@ class ResNet(_Trunk, Model):
         _Trunk.__init__(self, depth, num_classes=0, with_pool=with_pool, zero_init_residual=zero_init_residual)
         self.class_num = class_num
         if class_num > 0:
-            self.fc = hnn.Linear(512 * BottleneckBlock.expansion, class_num)
+            self.fc = paddle_default_linear_init_(hnn.Linear(512 * BottleneckBlock.expansion, class_num))
 
     def forward(self, x):
         y = _Trunk.forward(self, x)                      # NHWC; [N, 1, 1, 2048] behind the pool

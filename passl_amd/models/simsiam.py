@@ -30,7 +30,7 @@ from ..loss.simsiam import neg_cosine_similarity
 from ..utils.checkpoint import load_lenient, load_pickle, to_numpy
 from .base_model import Model
 from ..modeling.backbones.resnet import ResNet as _Trunk
-from .resnet import BottleneckBlock, ResNet
+from .resnet import BottleneckBlock, ResNet, paddle_default_linear_init_
 
 __all__ = ['SimSiamPretain', 'SimSiamLinearProbe', 'simsiam_resnet50_pretrain', 'simsiam_resnet50_linearprobe']
 
@@ -71,6 +71,10 @@ class SimSiamPretain(Model):
         # build a 2-layer predictor
         self.predictor = _MLP(hnn.Linear(dim, pred_dim, bias_attr=False), hnn.BatchNorm1D(pred_dim), hnn.ReLU(),
                               hnn.Linear(pred_dim, dim))
+        for mlp in (self.encoder.fc, self.predictor):       # nn.Linear's framework default (the original fc has it already)
+            for layer in mlp:
+                if isinstance(layer, hnn.Linear) and layer is not fc:
+                    paddle_default_linear_init_(layer)
         self.arena_q = EncoderArena(self.encoder, trainable=True, exclude_params=[self.encoder.fc[6].bias])
         self.arena_p = EncoderArena(self.predictor, trainable=True)
 

@@ -983,3 +983,39 @@ def test_v2_engine_builds_from_the_reference_linear_probe_yamls_unchanged(yaml_p
         assert float(sd[head + '.bias'].abs().max()) == 0.0
     finally:
         hip_config.set_compute_dtype(prev)
+
+
+def test_no_model_leaves_a_parameter_uninitialised(monkeypatch):
+    """hip.nn.Linear / Conv2D allocate their weights with torch.empty and leave the values to the model's init rule
+    (the reference's layers draw a framework default first).  With torch.empty poisoned to NaN every parameter and
+    buffer of every buildable model must come out finite — the v2 ResNet fc and the SimSiam MLPs, which have no init
+    rule of their own in the reference, take Paddle's nn.Linear default (Xavier uniform, zero bias)."""
+    from passl_amd.hip import config as hip_config
+    from passl_amd.models import build_model
+    from passl_amd.modeling.architectures import build_model as build_v110
+    hip_config.set_device('cpu')
+    real_empty = torch.empty
+
+    def poisoned(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_floating_point():
+            t.fill_(float('nan'))
+        return t
+    monkeypatch.setattr(torch, 'empty', poisoned)
+    torch.manual_seed(0)
+    built = []
+    for cfg in (dict(name='simsiam_resnet50_pretrain'), dict(name='simsiam_resnet50_linearprobe', class_num=16),
+                dict(name='mocov3_vit_base_pretrain'), dict(name='mocov3_vit_base_linearprobe', class_num=16),
+                dict(name='moco_v2_resnet50', K=256), dict(name='simclr_resnet50')):
+        built.append((cfg['name'], build_model(cfg)))
+    for path in ('configs/mae/mae_vit_b_synthetic.yaml', 'configs/clip/vit-b-32_synthetic.yaml',
+                 'configs/moco/moco_clas_r50_synthetic.yaml'):
+        cfg = get_config(os.path.join(ROOT, path), [])
+        built.append((path, build_v110(cfg.model)))
+    for name, m in built:
+        bad = [n for n, t in list(m.named_parameters()) + list(m.named_buffers())
+               if t.is_floating_point() and not bool(torch.isfinite(t).all())]
+        assert not bad, (name, bad[:8])
+    sim = dict(built)['simsiam_resnet50_pretrain']
+    w = sim.encoder.fc[0].weight
+    assert abs(float(w.abs().max()) - math.sqrt(6.0 / 4096)) < 1e-4 and float(sim.predictor[3].bias.abs().max()) == 0.0
