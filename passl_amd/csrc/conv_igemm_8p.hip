@@ -70,7 +70,13 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 typedef std::integral_constant<int, 0> I0;
 typedef std::integral_constant<int, 1> I1;
 
-template <bool DIRECT>
+// DENSE (compile-time): the operand is a plain [M, C] matrix (Linear / 1x1 stride-1 convolution) — the filter-tap
+// walk, the per-tap bounds checks and the image decomposition of a row drop out of the instruction stream and of the
+// scalar register file (the general form keeps ~20 more scalars live and spills 69 of them to lanes:
+// profiles/r03_kernel_resources.txt).  Same arithmetic, same order, same bits.  Opt-in until measured on the GPU
+// (passl_hip_set_option("igemm_8p_dense", 1) / PASSL_IGEMM_8P_DENSE=1): the default launches are the two
+// instantiations with DENSE = false, unchanged.
+template <bool DIRECT, bool DENSE = false>
 __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int64_t* rowoff = reinterpret_cast<int64_t*>(smem + LDS_TILES);     // staged epilogue only
@@ -81,7 +87,7 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int opq = p.OP * p.OQ;
+  const int opq = DENSE ? 1 : p.OP * p.OQ;
   const int nk = p.KDIM / BK;
 
   // ---- tiles of this workgroup: virtual ids bid, bid + grid, ... through the XCD-aware map (bijective for
@@ -109,8 +115,8 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
   int r1 = 0, s1 = 0, c1 = 0;       // next K-tile of the A1 stream
   auto set_geometry = [&](int m0, int n0) __attribute__((always_inline)) {
     // A beyond 2 GB: the descriptor starts at the first image (dense: row) of this tile (see the ring kernel)
-    const int nb = p.dense ? 0 : fdiv(m0 < p.M ? m0 : p.M - 1, p.d_opq);
-    const int64_t a_off0 = p.dense ? (int64_t)m0 * (p.C * 2) : (int64_t)nb * p.a_sn2;
+    const int nb = (DENSE || p.dense) ? 0 : fdiv(m0 < p.M ? m0 : p.M - 1, p.d_opq);
+    const int64_t a_off0 = (DENSE || p.dense) ? (int64_t)m0 * (p.C * 2) : (int64_t)nb * p.a_sn2;
     const int64_t a_left = p.a_total - a_off0;
     rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a) + a_off0, 0,
                                              (uint32_t)(a_left < 0x7ffffff0ll ? a_left : 0x7ffffff0ll), 0x00020000);
@@ -124,9 +130,9 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
       const int mc = valid ? m : p.M - 1;
       uint32_t ab;
       int ih = 0, iw = 0;
-      if (p.dense) {                      // wave-uniform
+      if (DENSE || p.dense) {             // wave-uniform
         ab = (uint32_t)(mc - m0) * (uint32_t)(p.C * 2) + chunk;
-      } else {
+      } else if constexpr (!DENSE) {
         const int n = fdiv(mc, p.d_opq);
         const int rem = mc - n * opq;
         const int op = fdiv(rem, p.d_oq);
@@ -135,9 +141,13 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
         iw = oq * p.sw - p.pw;
         ab = (uint32_t)(n - nb) * (uint32_t)p.a_sn2 + (uint32_t)(ih * p.a_sh2) + (uint32_t)(iw * p.a_sw2) + chunk;
       }
-      a_base[x] = valid ? ab : 0u;
-      ih0[x] = valid ? ih : -(1 << 28);       // fails every tap's bounds check: the DMA reads zeros
-      iw0[x] = valid ? iw : 0;
+      if constexpr (DENSE) {
+        a_base[x] = valid ? ab : kOOB;        // rows past M read zeros
+      } else {
+        a_base[x] = valid ? ab : 0u;
+        ih0[x] = valid ? ih : -(1 << 28);     // fails every tap's bounds check: the DMA reads zeros
+        iw0[x] = valid ? iw : 0;
+      }
       const int col = n0 + (x >> 1) * 128 + hrow;
       b_off[x] = col < p.NCOLS ? (uint32_t)col * (uint32_t)(p.KDIM * 2) + chunk : kOOB;
     }
@@ -153,9 +163,9 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
       const int m = cm0 + tid;
       int64_t off = -1;
       if (m < p.M) {
-        if (p.dense) {
+        if (DENSE || p.dense) {
           off = (int64_t)m * p.NCOLS;
-        } else {
+        } else if constexpr (!DENSE) {
           const int n = fdiv(m, p.d_opq);
           const int rem = m - n * opq;
           const int op = fdiv(rem, p.d_oq);
@@ -171,18 +181,25 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
   // the (r, s, c0) taps on its own
   auto issue_a = [&](auto PB, auto H, int& tr, int& ts, int& tc) __attribute__((always_inline)) {
     constexpr int PB_ = decltype(PB)::value, H_ = decltype(H)::value;
-    const uint32_t tap = (uint32_t)(tr * p.a_sh2 + ts * p.a_sw2 + tc * 2);
+    const uint32_t tap = DENSE ? (uint32_t)(tc * 2) : (uint32_t)(tr * p.a_sh2 + ts * p.a_sw2 + tc * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int x = H_ * 2 + i;
-      const bool ok = (uint32_t)(ih0[x] + tr) < (uint32_t)p.IH && (uint32_t)(iw0[x] + ts) < (uint32_t)p.IW;
-      const uint32_t off = ok ? a_base[x] + tap : kOOB;
+      uint32_t off;
+      if constexpr (DENSE) {
+        off = a_base[x] == kOOB ? kOOB : a_base[x] + tap;
+      } else {
+        const bool ok = (uint32_t)(ih0[x] + tr) < (uint32_t)p.IH && (uint32_t)(iw0[x] + ts) < (uint32_t)p.IW;
+        off = ok ? a_base[x] + tap : kOOB;
+      }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rs_a, (__attribute__((address_space(3))) void*)(smem + A_REGION + PB_ * BUF + H_ * HALF + (i * 8 + wave) * 1024),
           16, off, 0, 0, 0);
     }
-    tc += BK;
-    if (tc == p.C) { tc = 0; if (++ts == p.S) { ts = 0; ++tr; } }
+    tc += BK;                     // (DENSE: one tap — every stream issues exactly nk K-tiles between two set_geometry)
+    if constexpr (!DENSE) {
+      if (tc == p.C) { tc = 0; if (++ts == p.S) { ts = 0; ++tr; } }
+    }
   };
   auto issue_b = [&](auto PB, auto H, int t) __attribute__((always_inline)) {
     constexpr int PB_ = decltype(PB)::value, H_ = decltype(H)::value;
@@ -288,9 +305,9 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
         const int m = m0 + h * 128 + wr * 64 + i * 16 + l15;
         const int mc = m < p.M ? m : p.M - 1;
         int64_t o;
-        if (p.dense) {
+        if (DENSE || p.dense) {
           o = (int64_t)mc * p.NCOLS;
-        } else {
+        } else if constexpr (!DENSE) {
           const int n = fdiv(mc, p.d_opq);
           const int rem = mc - n * opq;
           const int op = fdiv(rem, p.d_oq);
@@ -474,17 +491,17 @@ __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
   }
 }
 
-template <bool DIRECT>
+template <bool DIRECT, bool DENSE = false>
 static int launch(const Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_8p_kernel<DIRECT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_8p_kernel<DIRECT, DENSE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
   // persistent form: one workgroup per CU (a multiple of 8 so that a workgroup's tiles stay on one XCD's range)
   const int grid = DIRECT && p.ntiles > 256 ? 256 : p.ntiles;
-  hipLaunchKernelGGL(igemm_8p_kernel<DIRECT>, dim3(grid), dim3(kThreads), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((igemm_8p_kernel<DIRECT, DENSE>), dim3(grid), dim3(kThreads), LDS_BYTES, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
@@ -498,7 +515,7 @@ static int launch(const Params& p, hipStream_t st) {
 // a tile (the staged 8-phase form's is larger: nothing else runs on the CU while a tile is stored; the persistent
 // form — igemm_8p_direct, default on — hides most of it: te_direct).
 static int g_8p_mode = -1, g_8p_min_nk = 8, g_8p_tk = 145, g_8p_te = 1000, g_8p_ted = 900, g_8p_rtk = 112,
-           g_8p_rte = 420, g_8p_margin = 100, g_8p_direct = 1;
+           g_8p_rte = 420, g_8p_margin = 100, g_8p_direct = 1, g_8p_dense = -1;
 
 int passl_igemm_8p_option(const char* name, int value) {
   if (!strcmp(name, "igemm_8p")) {
@@ -507,6 +524,7 @@ int passl_igemm_8p_option(const char* name, int value) {
     return PASSL_OK;
   }
   if (!strcmp(name, "igemm_8p_direct")) { g_8p_direct = value != 0; return PASSL_OK; }
+  if (!strcmp(name, "igemm_8p_dense")) { g_8p_dense = value != 0; return PASSL_OK; }
   int* slot = !strcmp(name, "igemm_8p_min_nk") ? &g_8p_min_nk : !strcmp(name, "igemm_8p_tk") ? &g_8p_tk :
               !strcmp(name, "igemm_8p_te") ? &g_8p_te : !strcmp(name, "igemm_8p_te_direct") ? &g_8p_ted : !strcmp(name, "igemm_8p_ring_tk") ? &g_8p_rtk :
               !strcmp(name, "igemm_8p_ring_te") ? &g_8p_rte : !strcmp(name, "igemm_8p_margin") ? &g_8p_margin : nullptr;
@@ -540,5 +558,11 @@ int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st) {
     const double timer = (rr < 1.0 ? 1.0 : rr) * ((double)nk * g_8p_rtk + g_8p_rte);
     if (time8 * g_8p_margin >= timer * 100.0) return PASSL_EUNSUPPORTED;
   }
+  if (g_8p_dense < 0) {
+    const char* e = getenv("PASSL_IGEMM_8P_DENSE");
+    g_8p_dense = e ? atoi(e) != 0 : 0;
+  }
+  // the matrix-operand specialisation (opt-in): persistent form only — the ViT Linears' launches
+  if (g_8p_dense && direct && p.dense) return g8::launch<true, true>(p, st);
   return direct ? g8::launch<true>(p, st) : g8::launch<false>(p, st);
 }

@@ -1,0 +1,91 @@
+"""(prepared in r03 without GPU time left; FIRST GPU call of the next round)  The matrix-operand specialisation of
+the persistent 8-phase kernel (`igemm_8p_kernel<true, true>`, opt-in: passl_hip_set_option("igemm_8p_dense", 1)) vs
+the general persistent form on the ViT Linear shapes: bit-exactness of every output (forward with bias / GELU-less
+epilogue, residual epilogue, data gradient) incl. ragged M / N tiles and repeated launches, then timing.
+Compile-time evidence: profiles/r03_kernel_resources.txt (SGPR spills 69 -> 26, VGPRs 241 -> 232, 7797 -> 5754
+instructions, lane reads in the K loop 183 -> 51).
+    python scratch/ab_8p_dense.py [--quick]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch
+
+from passl_amd.hip import config, lib as L
+from passl_amd.hip import nn as hnn
+from passl_amd.hip.nn import EncoderArena
+
+lib = L.load()
+DEV = 'cuda'
+QUICK = '--quick' in sys.argv
+config.set_device('gpu')
+config.set_compute_dtype(torch.bfloat16)
+
+
+def dense(v):
+    assert lib.passl_hip_set_option(b'igemm_8p_dense', v) == 0
+
+
+def timed(fn, iters=30):
+    for _ in range(5):
+        fn()
+    s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def case(M, K, N, residual=False):
+    torch.manual_seed(M + K + N)
+    lin = hnn.Linear(K, N).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(K, N) * 0.05)
+        lin.bias.copy_(torch.randn(N) * 0.1)
+    arena = EncoderArena(lin, trainable=True)
+    arena.refresh()
+    x = (torch.randn(M, K, device=DEV) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    res = (torch.randn(M, N, device=DEV)).to(torch.bfloat16) if residual else None
+    dy = (torch.randn(M, N, device=DEV) * 0.1).to(torch.bfloat16)
+
+    def run():
+        x.grad = None
+        y = lin(x, residual=res)
+        y.backward(dy)
+        return y.detach().clone(), x.grad.detach().clone()
+    outs = {}
+    kern = {}
+    for v in (0, 1):
+        dense(v)
+        reps = [run() for _ in range(3 if QUICK else 6)]
+        kern[v] = lib.passl_hip_last_igemm_kernel()
+        for r in reps[1:]:
+            assert torch.equal(r[0].view(torch.int16), reps[0][0].view(torch.int16)), 'run-to-run (y) v=%d' % v
+            assert torch.equal(r[1].view(torch.int16), reps[0][1].view(torch.int16)), 'run-to-run (dx) v=%d' % v
+        outs[v] = reps[0]
+    same_y = torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    same_dx = torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    t = {}
+    with torch.no_grad():
+        xd = x.detach()
+        for v in (0, 1):
+            dense(v)
+            t[v] = timed(lambda: lin(xd, residual=res))
+    flops = 2.0 * M * K * N
+    print('M %6d K %5d N %5d %s  y %s dx %s   fwd %7.1f us (%5.0f TF) -> dense %7.1f us (%5.0f TF)  x%.3f  [kernel ids %s]'
+          % (M, K, N, 'res' if residual else '   ', 'EXACT' if same_y else 'DIFF ', 'EXACT' if same_dx else 'DIFF ',
+             t[0], flops / t[0] / 1e6, t[1], flops / t[1] / 1e6, t[0] / t[1], kern), flush=True)
+    dense(0)
+    return same_y and same_dx
+
+
+ok = True
+shapes = [(50432, 768, 2304, False), (50432, 768, 768, True), (50432, 768, 3072, False), (50432, 3072, 768, True),
+          (12800, 768, 2304, False), (12800, 3072, 768, True), (50432, 512, 2048, False), (50432, 2048, 512, True),
+          (25216, 768, 768, False), (50000, 768, 1000, False), (12801, 768, 2304, False)]
+for s in (shapes[:4] if QUICK else shapes):
+    ok = case(*s) and ok
+print('ALL EXACT' if ok else 'MISMATCH')
+sys.exit(0 if ok else 1)
