@@ -206,6 +206,8 @@ class TrainingEpochLoop(object):
         self.trainer.optimizer.set_state_dict(opt_state)
         if os.path.exists(ckpt + '.pdstates'):
             metric_info = load_pickle(ckpt + '.pdstates')
+            if self.val_loop is not None and 'metric' in metric_info:
+                self.val_loop.best_model_metric = dict(metric_info)       # loop.py:370-371: the bar a new best must pass
             if 'global_step' in metric_info:
                 self.global_step = int(metric_info['global_step'])
             if 'epoch' in metric_info:

@@ -342,6 +342,12 @@ def test_v2_classification_loops_host_logic(tmp_path):
         meta['timestamp'] = ts
         with open(os.path.join(d, 'epoch_%d.pdstates' % i), 'wb') as f:
             pickle.dump(meta, f, protocol=2)
+    # resume (loop.py:358-375): counters and the stored metric — the bar a later evaluation must pass to become 'best'
+    tr3, loop3, val3 = make(1)
+    tr3.checkpoint = os.path.join(d, 'latest')
+    tr3.model.load_pretrained = lambda path, rank=0, finetune=False: tr3.model.load_state_dict(torch.load(path + '.pdparams'))
+    loop3.resume()
+    assert loop3.start_eopch == 2 and loop3.global_step == 6 and val3.best_model_metric['metric'] == st['metric']
     tr.config['Global']['max_num_latest_checkpoint'] = 1
     loop._prune_checkpoints(d)
     left = sorted(os.listdir(d))
