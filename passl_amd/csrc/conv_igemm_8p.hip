@@ -562,7 +562,8 @@ int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st) {
     const char* e = getenv("PASSL_IGEMM_8P_DENSE");
     g_8p_dense = e ? atoi(e) != 0 : 0;
   }
-  // the matrix-operand specialisation (opt-in): persistent form only — the ViT Linears' launches
-  if (g_8p_dense && direct && p.dense) return g8::launch<true, true>(p, st);
+  // the matrix-operand specialisation (opt-in): the ViT Linears' launches (persistent form) and the 1x1 stride-1
+  // convolutions with fused statistics (staged form)
+  if (g_8p_dense && p.dense) return direct ? g8::launch<true, true>(p, st) : g8::launch<false, true>(p, st);
   return direct ? g8::launch<true>(p, st) : g8::launch<false>(p, st);
 }

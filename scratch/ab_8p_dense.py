@@ -81,7 +81,33 @@ def case(M, K, N, residual=False):
     return same_y and same_dx
 
 
+def conv_case(cin, cout, H, N):
+    """1x1 stride-1 convolution with the fused BatchNorm statistics (staged form, igemm_8p_kernel<false, true>)."""
+    torch.manual_seed(cin + cout)
+    conv = hnn.Conv2D(cin, cout, 1, bias_attr=False).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape) * 0.05)
+    arena = EncoderArena(conv, trainable=True)
+    arena.refresh()
+    x = (torch.randn(N, H, H, cin, device=DEV) * 0.5).to(torch.bfloat16)
+    outs, t = {}, {}
+    with torch.no_grad():
+        for v in (0, 1):
+            dense(v)
+            y, st = conv(x, hw=(H, H), want_stats=True)
+            outs[v] = (y.clone(), st[0].clone() if st is not None else None)
+            t[v] = timed(lambda: conv(x, hw=(H, H), want_stats=True))
+    same = torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and (
+        outs[0][1] is None or torch.equal(outs[0][1], outs[1][1]))
+    print('conv 1x1 %4d -> %4d @%2d N %3d stats   %s   %7.1f us -> dense %7.1f us  x%.3f' % (
+        cin, cout, H, N, 'EXACT' if same else 'DIFF ', t[0], t[1], t[0] / t[1]), flush=True)
+    dense(0)
+    return same
+
+
 ok = True
+for c in ((1024, 256, 14, 256), (256, 1024, 14, 256), (2048, 512, 7, 256), (512, 2048, 7, 256)):
+    ok = conv_case(*c) and ok
 shapes = [(50432, 768, 2304, False), (50432, 768, 768, True), (50432, 768, 3072, False), (50432, 3072, 768, True),
           (12800, 768, 2304, False), (12800, 3072, 768, True), (50432, 512, 2048, False), (50432, 2048, 512, True),
           (25216, 768, 768, False), (50000, 768, 1000, False), (12801, 768, 2304, False)]
