@@ -1025,3 +1025,38 @@ def test_no_model_leaves_a_parameter_uninitialised(monkeypatch):
     sim = dict(built)['simsiam_resnet50_pretrain']
     w = sim.encoder.fc[0].weight
     assert abs(float(w.abs().max()) - math.sqrt(6.0 / 4096)) < 1e-4 and float(sim.predictor[3].bias.abs().max()) == 0.0
+
+
+def test_trace_timeline_tool_on_a_synthetic_trace(tmp_path):
+    """tools/trace_timeline.py (per-stream view of a rocprofv3 --kernel-trace csv): busy time per stream, time with
+    k kernels in flight, kernels running alone, idle gaps — on a hand-made two-stream trace with known answers."""
+    import subprocess
+    import sys
+    rows = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name",'
+            '"Correlation_Id","Start_Timestamp","End_Timestamp","LDS_Block_Size","Scratch_Size","VGPR_Count",'
+            '"Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y","Workgroup_Size_Z","Grid_Size_X",'
+            '"Grid_Size_Y","Grid_Size_Z"']
+
+    def k(stream, name, t0, t1, grid=256 * 1024):
+        rows.append('"KERNEL_DISPATCH","Agent 2",1,%d,1,1,1,"%s",1,%d,%d,0,0,8,0,16,256,1,1,%d,1,1'
+                    % (stream, name, t0, t1, grid))
+    # two identical steps of 1 ms: main stream conv 0-600 us, side stream wgrad 200-500 us, a small finalize alone
+    # 700-750 us, then the marker 900-1000 us; 100 us + 150 us idle per step
+    for s in range(3):
+        o = s * 1_000_000
+        k(0, 'void conv_kernel<1>(int)', o + 0, o + 600_000)
+        k(1, 'void wgrad_kernel(int)', o + 200_000, o + 500_000)
+        k(0, 'void bn_finalize_kernel(int)', o + 700_000, o + 750_000, grid=8 * 256)
+        k(0, 'void sgd_kernel(float*)', o + 900_000, o + 1_000_000)
+    path = tmp_path / 'trace.csv'
+    path.write_text('\n'.join(rows) + '\n')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_timeline.py'), str(path), '2'],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert 'window: 2 steps, 1.000 ms per step, 4 kernels per step' in out
+    assert 'stream 0    busy 0.750 ms per step' in out and 'stream 1    busy 0.300 ms per step' in out
+    assert '0 kernels in flight: 0.250 ms per step' in out and '2 kernels in flight: 0.300 ms per step' in out
+    assert '1 kernels in flight: 0.450 ms per step' in out
+    line = [l for l in out.splitlines() if 'bn_finalize_kernel' in l and '[' in l][0]
+    assert '0.050 [0.050]' in line                       # runs alone, and with fewer than 256 workgroups
