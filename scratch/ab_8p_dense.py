@@ -18,15 +18,17 @@ from passl_amd.hip.nn import EncoderArena
 lib = L.load()
 DEV = 'cuda'
 QUICK = '--quick' in sys.argv
+TINY = '--tiny' in sys.argv
 config.set_device('gpu')
 config.set_compute_dtype(torch.bfloat16)
 
 
 def dense(v):
+    """0 off, 1 persistent form, 2 also the staged form."""
     assert lib.passl_hip_set_option(b'igemm_8p_dense', v) == 0
 
 
-def timed(fn, iters=30):
+def timed(fn, iters=10 if '--tiny' in sys.argv else 30):
     for _ in range(5):
         fn()
     s, e = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -59,7 +61,7 @@ def case(M, K, N, residual=False):
     kern = {}
     for v in (0, 1):
         dense(v)
-        reps = [run() for _ in range(3 if QUICK else 6)]
+        reps = [run() for _ in range(2 if TINY else 3 if QUICK else 6)]
         kern[v] = lib.passl_hip_last_igemm_kernel()
         for r in reps[1:]:
             assert torch.equal(r[0].view(torch.int16), reps[0][0].view(torch.int16)), 'run-to-run (y) v=%d' % v
@@ -91,27 +93,34 @@ def conv_case(cin, cout, H, N):
     arena.refresh()
     x = (torch.randn(N, H, H, cin, device=DEV) * 0.5).to(torch.bfloat16)
     outs, t = {}, {}
+    bn = hnn.BatchNorm2D(cout).to(DEV)
     with torch.no_grad():
-        for v in (0, 1):
+        for v in (0, 2):
             dense(v)
             y, st = conv(x, hw=(H, H), want_stats=True)
-            outs[v] = (y.clone(), st[0].clone() if st is not None else None)
+            # the statistics are compared through what consumes them (the slab buffer is torch.empty: rows a launch
+            # does not write hold stale memory — the r03 run compared the raw slab and reported DIFF without saying
+            # whether y or the slab differed)
+            z = bn(y, relu=True, stats=st)
+            outs[v] = (y.clone(), z.clone(), bn._mean.clone() if hasattr(bn, '_mean') else None)
             t[v] = timed(lambda: conv(x, hw=(H, H), want_stats=True))
-    same = torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16)) and (
-        outs[0][1] is None or torch.equal(outs[0][1], outs[1][1]))
-    print('conv 1x1 %4d -> %4d @%2d N %3d stats   %s   %7.1f us -> dense %7.1f us  x%.3f' % (
-        cin, cout, H, N, 'EXACT' if same else 'DIFF ', t[0], t[1], t[0] / t[1]), flush=True)
+    same_y = torch.equal(outs[0][0].view(torch.int16), outs[2][0].view(torch.int16))
+    same_z = torch.equal(outs[0][1].view(torch.int16), outs[2][1].view(torch.int16))
+    same = same_y and same_z
+    print('conv 1x1 %4d -> %4d @%2d N %3d stats   y %s  bn(y) %s   %7.1f us -> dense %7.1f us  x%.3f' % (
+        cin, cout, H, N, 'EXACT' if same_y else 'DIFF ', 'EXACT' if same_z else 'DIFF ', t[0], t[2], t[0] / t[2]),
+        flush=True)
     dense(0)
     return same
 
 
 ok = True
-for c in ((1024, 256, 14, 256), (256, 1024, 14, 256), (2048, 512, 7, 256), (512, 2048, 7, 256)):
+for c in ((1024, 256, 14, 256), (256, 1024, 14, 256), (2048, 512, 7, 256), (512, 2048, 7, 256))[:1 if TINY else 4]:
     ok = conv_case(*c) and ok
 shapes = [(50432, 768, 2304, False), (50432, 768, 768, True), (50432, 768, 3072, False), (50432, 3072, 768, True),
           (12800, 768, 2304, False), (12800, 3072, 768, True), (50432, 512, 2048, False), (50432, 2048, 512, True),
           (25216, 768, 768, False), (50000, 768, 1000, False), (12801, 768, 2304, False)]
-for s in (shapes[:4] if QUICK else shapes):
+for s in (shapes[:2] if TINY else shapes[:4] if QUICK else shapes):
     ok = case(*s) and ok
 print('ALL EXACT' if ok else 'MISMATCH')
 sys.exit(0 if ok else 1)

@@ -121,9 +121,9 @@ def test_tuning_options_validate_their_values(lib):
     names are refused (no launch involved: runs without a GPU)."""
     ok = [(b'bn_stream_unroll', 0), (b'bn_stream_unroll', 2), (b'bn_stream_unroll', 8), (b'bn_stream_unroll', 4),
           (b'stem_kernel', 0), (b'stem_kernel', 1), (b'igemm_ring_bm', 256), (b'igemm_ring_bm', 128),
-          (b'igemm_ring_min_nk', 8), (b'igemm_8p_dense', 1), (b'igemm_8p_dense', 0)]
+          (b'igemm_ring_min_nk', 8), (b'igemm_8p_dense', 1), (b'igemm_8p_dense', 2), (b'igemm_8p_dense', 0)]
     for name, v in ok:
         assert lib.passl_hip_set_option(name, v) == 0, (name, v)
-    bad = [(b'bn_stream_unroll', 3), (b'igemm_ring_bm', 7), (b'no_such_option', 1)]
+    bad = [(b'bn_stream_unroll', 3), (b'igemm_ring_bm', 7), (b'igemm_8p_dense', 3), (b'no_such_option', 1)]
     for name, v in bad:
         assert lib.passl_hip_set_option(name, v) != 0, (name, v)
