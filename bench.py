@@ -86,6 +86,9 @@ def parse():
     ap.add_argument('--graph', action='store_true',
                     help='replay the captured HIP graph of the step (passl_amd/hip/graph.py) instead of launching '
                          'it kernel by kernel from Python; same as PASSL_GRAPH=1')
+    ap.add_argument('--eager', action='store_true',
+                    help='launch every kernel of the step from Python (same as PASSL_PLAN=0): the default replays '
+                         'the recorded native step plan (passl_amd/hip/replay.py)')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='skip the instrumented loop (use under rocprofv3)')
     ap.add_argument('--dp-buckets', type=int, default=0,
@@ -157,6 +160,21 @@ def pmc_traffic(args):
     return out
 
 
+def step_launch(trainer):
+    """How the timed steps were issued."""
+    sg = trainer.step_graph
+    if sg is None or not sg.captured:
+        why = getattr(sg, 'failed', None)
+        return 'eager (one launch per kernel from the host)' + (' — step plan refused: %s' % why if why else '')
+    if type(sg).__name__ == 'StepPlan':
+        i = sg.info
+        return ('native step plan (passl_amd/hip/replay.py: forward + backward + optimizer recorded once = %d kernel '
+                'launches, %d event records, %d stream waits on %d streams, %d segment(s); %d replays in this process)'
+                % (i['kernels'], i['event_records'], i['stream_waits'], i['streams'], i['segments'], sg.replays))
+    return ('HIP graph replay (forward + backward + optimizer captured once, %d replays in this process)'
+            % sg.replays)
+
+
 def main():
     args = parse()
     # multi-process GPU work on this stack needs dmabuf IPC (RCCL across ranks); set here too, not only in
@@ -201,6 +219,8 @@ def main():
     cfg.timestamp = ''
     if args.graph:
         cfg.hip_graph = True
+    if args.eager:
+        cfg.step_plan = False
     trainer = Trainer(cfg)
     trainer.mode = 'train'
     trainer.model.train()
@@ -223,6 +243,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # a native step plan (hip/replay.py) runs a few eager steps and then records one before it replays: with a very
+    # short --warmup those preparatory steps continue here, still outside the timed region
+    extra_warm = 0
+    sg = trainer.step_graph
+    while sg is not None and getattr(sg, 'enabled', False) and not sg.captured and \
+            getattr(sg, 'failed', None) is None and extra_warm < 8:
+        step()
+        extra_warm += 1
 
     # ---- 1. timed loop: product path only
     barrier()
@@ -319,10 +347,7 @@ def main():
                        'timed_region': 'product path only (full hook bus); kernel instrumentation runs '
                                        'in a separate loop afterwards',
                        'host_enqueue_ms_per_step': round(1000 * host_elapsed / args.steps, 3),
-                       'step_launch': ('HIP graph replay (forward + backward + optimizer captured once, %d replays '
-                                       'in this process)' % trainer.step_graph.replays)
-                       if (trainer.step_graph is not None and trainer.step_graph.captured)
-                       else 'eager (one launch per kernel from the host)'},
+                       'step_launch': step_launch(trainer), 'extra_untimed_steps': extra_warm},
             'step_flop_roofline': {
                 'algorithmic_gflop_per_sample': flop_per_sample / 1e9,
                 'achieved_tflops_per_gpu': round(ips / world * flop_per_sample / 1e12, 2),

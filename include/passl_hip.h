@@ -592,6 +592,45 @@ int passl_hip_softmax_ce_fwd(const float* scores, const int64_t* labels, int N, 
 int passl_hip_softmax_ce_bwd(const float* scores, const float* lse, const int64_t* labels,
                              const float* gloss, int N, int C, float* dscores, passl_stream_t stream);
 
+/* ---------------------------------------------------------------- native step plans
+ * Reference: the iteration of passl_v110/engine/trainer.py:287-337 (model forward, then OptimizerHook:
+ * clear_grad -> backward -> step, hooks/optimizer_hook.py:25-50) is ~1 400 launches here, each of which the
+ * reference-side host code (Python) would issue one by one.  A plan is that launch list recorded ONCE while a
+ * step executes normally, and replayed from one call per segment:
+ *   create -> record_begin -> [the step runs: every kernel this library launches, on any thread, is appended
+ *   with its stream and a copy of its arguments; the host reports its cross-stream edges with event_record /
+ *   stream_wait and closes a segment with cut wherever something that is not a library launch must happen in
+ *   between, e.g. a collective] -> record_end -> replay(segment) ... -> destroy.
+ * Contract of a replay: every pointer a recorded launch carried must still be valid and mean the same thing
+ * (the host keeps the recorded step's allocations in a private pool and step-varying scalars in device memory);
+ * streams are the recorded ones.  One plan records at a time per process; a plan records once.
+ * event_record returns the id (>= 0) of a plan-owned event = "everything enqueued on `stream` up to here";
+ * while recording nothing is enqueued for it (the executing step orders itself with the caller's own events).
+ * plan_info(what): 0 segments, 1 kernel launches, 2 event records, 3 stream waits, 4 memsets, 5 argument bytes,
+ * 6 replays so far, 7 distinct streams. */
+typedef struct passl_plan passl_plan_t;
+int passl_hip_plan_create(passl_plan_t** out);
+int passl_hip_plan_destroy(passl_plan_t* plan);
+int passl_hip_plan_record_begin(passl_plan_t* plan);
+int passl_hip_plan_cut(passl_plan_t* plan);                 /* -> index of the segment that starts here */
+int passl_hip_plan_record_end(passl_plan_t* plan);
+int passl_hip_plan_event_record(passl_plan_t* plan, passl_stream_t stream);
+int passl_hip_plan_stream_wait(passl_plan_t* plan, passl_stream_t stream, int event_id);
+int passl_hip_plan_replay(passl_plan_t* plan, int segment);
+int64_t passl_hip_plan_info(passl_plan_t* plan, int what);
+
+/* The step's remaining framework launches as library kernels, so that a recorded step holds library launches
+ * only (reference call sites: `clear_grad()` optimizer_hook.py:31; `self.queue.clone().detach()` moco.py:180;
+ * the implicit dtype casts Paddle inserts around fp32 heads; the stem filter's padded gradient):
+ *   fill_zero: p[0:bytes] = 0                      copy_bytes: dst[0:bytes] = src[0:bytes] (no overlap)
+ *   cast_bf16_to_f32: dst[i] = float(src[i])       (both 16-byte aligned)
+ *   unpad_add: dst[row][r][s][c] += src[row][r][s][c], s < dst_S, c < dst_C; src rows are [R][src_S][src_C] */
+int passl_hip_fill_zero(void* p, int64_t bytes, passl_stream_t stream);
+int passl_hip_copy_bytes(void* dst, const void* src, int64_t bytes, passl_stream_t stream);
+int passl_hip_cast_bf16_to_f32(const void* src, float* dst, int64_t n, passl_stream_t stream);
+int passl_hip_unpad_add(const float* src, float* dst, int64_t rows, int R, int dst_S, int dst_C, int src_S,
+                        int src_C, passl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,11 +105,21 @@ class GradReducer(object):
             from ..hip import streams
             cur = torch.cuda.current_stream(self.grads.device)
             if self._home is not None and cur != self._home:
-                cur.wait_stream(self._home)
+                streams.wait_stream(cur, self._home)
             streams.join(self.grads.device)
         if self.world > 1 or self._forced:
-            self._handles.append(dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM,
-                                                 group=self.group, async_op=True))
+            from ..hip.replay import host_call
+            grads, group = self.grads, self.group
+
+            def collective():
+                # a live call also when the step is replayed from a native plan (hip/replay.py: the plan is cut here).
+                # At a replay it runs on the thread and stream that drive the step, not on the autograd node's: order
+                # that stream behind the streams that may hold this bucket's producers first.
+                if grads.is_cuda:
+                    from ..hip import streams
+                    streams.join(grads.device)
+                self._handles.append(dist.all_reduce(grads[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            host_call(collective)
 
     def mark_ready(self, index):
         if not self._active or index in self._ready:
@@ -132,17 +142,22 @@ class GradReducer(object):
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        timed = self.measure and self.grads.is_cuda and self._handles
-        if timed:
-            t0 = torch.cuda.Event(enable_timing=True)
-            t0.record()
-        for h in self._handles:
-            h.wait()
-        if timed:
-            t1 = torch.cuda.Event(enable_timing=True)
-            t1.record()
-            self._exposed.append((t0, t1))
-        self._handles = []
+        from ..hip.replay import host_call
+
+        def wait_all():
+            timed = self.measure and self.grads.is_cuda and self._handles
+            if timed:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record()
+            for h in self._handles:
+                h.wait()
+            if timed:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record()
+                self._exposed.append((t0, t1))
+            self._handles = []
+        if self._handles or self.world > 1 or self._forced:
+            host_call(wait_all)                 # (live at every replay of a recorded step: see _launch)
         self._active = False
 
     def exposed_ms(self):

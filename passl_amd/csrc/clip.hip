@@ -552,7 +552,7 @@ extern "C" int passl_hip_embed_bwd(const int64_t* text, const void* dout, float*
   int32_t* touched = reinterpret_cast<int32_t*>(acc64 + (int64_t)vocab * C);
   uint32_t* amax = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(touched) + (((int64_t)vocab * 4 + 15) / 16) * 16);
   const int64_t nchunks = (int64_t)B * T_ * chunks;
-  if (hipMemsetAsync(amax, 0, sizeof(uint32_t), st) != hipSuccess) return PASSL_ELAUNCH;
+  if (passl_rec::memset_async(amax, 0, sizeof(uint32_t), st) != hipSuccess) return PASSL_ELAUNCH;
   CLIP_DISPATCH(dtype,
                 hipLaunchKernelGGL(embed_absmax_kernel<T>, dim3(grid_for(nchunks)), dim3(kThreads), 0, st,
                                    reinterpret_cast<const T*>(dout), nchunks, amax);
@@ -586,7 +586,7 @@ extern "C" int passl_hip_scatter_rows(const void* dout, const int32_t* idx, void
   hipStream_t st = as_stream(stream);
   const size_t esz = dtype == PASSL_BF16 ? 2 : 4;
   if (dtype != PASSL_BF16 && dtype != PASSL_F32) return PASSL_EUNSUPPORTED;
-  if (hipMemsetAsync(dx, 0, (size_t)rows_total * C * esz, st) != hipSuccess) return PASSL_ELAUNCH;
+  if (passl_rec::memset_async(dx, 0, (size_t)rows_total * C * esz, st) != hipSuccess) return PASSL_ELAUNCH;
   CLIP_DISPATCH(dtype, hipLaunchKernelGGL(scatter_rows_kernel<T>,
                                           dim3(grid_for((int64_t)n * (C / ElemTraits<T>::VEC))),
                                           dim3(kThreads), 0, st, reinterpret_cast<const T*>(dout), idx,

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/passl_hip.h"
+#include "plan.h"     // re-defines hipLaunchKernelGGL: launches are visible to a recording step plan
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;

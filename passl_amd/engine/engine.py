@@ -93,6 +93,10 @@ class _Schedulers(object):
         return self.scheds[0]()
 
     def __getattr__(self, name):
+        # (only called for names the instance does not have: `scheds` itself is missing while copy / pickle rebuild
+        # the object — forwarding then would recurse until RecursionError)
+        if name == 'scheds' or name.startswith('__'):
+            raise AttributeError(name)
         return getattr(self.scheds[0], name)
 
     def state_dict(self):
@@ -295,6 +299,17 @@ class Engine(object):
             lr = opt_cfg.pop('learning_rate')
         klass = OPTIMIZERS.get(name)
         key = 'parameter_list' if 'Lars' in name else 'parameters'
+        # keys of the reference's Optimizer block (passl/optimizer/__init__.py:124-212) that the flat-arena optimizers
+        # do not implement: say so by name instead of a TypeError from the constructor.  `tensor_fusion` asks Paddle to
+        # fuse parameter storage — the arena IS fused storage, nothing to do.
+        opt_cfg.pop('tensor_fusion', None)
+        if opt_cfg.get('grad_clip', None) is None:
+            opt_cfg.pop('grad_clip', None)
+        for k in ('grad_clip', 'no_weight_decay_name', 'layer_decay'):
+            if opt_cfg.get(k, None) not in (None, [], ''):
+                raise NotImplementedError('Optimizer.%s is not built on the HIP path (pre-training recipes of '
+                                          'tasks/ssl do not use it)' % k)
+            opt_cfg.pop(k, None)
         if groups_cfg:
             self.optimizer = OptimizerGroup(klass, key, self._group_params(groups_cfg), lr, opt_cfg,
                                             lambda c: self._build_scheduler(dict(c, decay_unit=self.lr_decay_unit), g))

@@ -45,6 +45,10 @@ class TrainingEpochLoop(object):
         self.total_batch_idx = len(self.trainer.train_dataloader)
         for epoch_id in range(self.start_eopch + 1, self.epochs + 1):
             self.cur_epoch_id = epoch_id
+            if self.val_loop is not None:
+                # loop.py:200-202 (reset_state, every epoch): a `best` found by an earlier epoch's evaluation must
+                # not tag THIS epoch's (unevaluated) weights when eval_interval > 1 or eval_unit is 'step'
+                self.val_loop.best_model_to_save = False
             stop = self.train_one_epoch()
             if self.trainer.lr_decay_unit == 'epoch' and self.trainer.lr_scheduler is not None:
                 self.trainer.lr_scheduler.step(self.cur_epoch_id)
@@ -176,16 +180,28 @@ class TrainingEpochLoop(object):
         keep = self.trainer.config['Global'].get('max_num_latest_checkpoint', -1)
         if keep is None or keep < 0:
             return
-        timestamp_to_path = {}
+        # (the reference matches 'best' / 'latest' anywhere in the PATH and keys the files by a one-second timestamp
+        # string: an output_dir called 'latest_run' switches pruning off and two checkpoints of the same second
+        # collide.  Here: the file's own name decides, and the order is (epoch in the name, stored timestamp, mtime).)
+        entries = []
         for path in glob.glob(os.path.join(model_dir, '*.pdstates')):
-            if any(p in path for p in ('best', 'latest')):
+            stem = os.path.basename(path)[:-len('.pdstates')]
+            if stem in ('best', 'latest') or not stem.startswith('epoch_'):
                 continue
-            timestamp_to_path[load_pickle(path)['timestamp']] = path[:-len('.pdstates')]
-        timestamps = sorted(timestamp_to_path)
-        for ts in (timestamps[:-keep] if keep > 0 else timestamps):
+            try:
+                epoch = int(stem[len('epoch_'):])
+            except ValueError:
+                epoch = -1
+            try:
+                ts = load_pickle(path).get('timestamp', '')
+            except Exception:
+                ts = ''
+            entries.append(((epoch, ts, os.path.getmtime(path)), path[:-len('.pdstates')]))
+        entries.sort()
+        for _key, prefix in (entries[:-keep] if keep > 0 else entries):
             for ext in ('.pdparams', '.pdopt', '.pdstates'):
                 try:
-                    os.remove(timestamp_to_path[ts] + ext)
+                    os.remove(prefix + ext)
                 except OSError:
                     pass
 

@@ -169,27 +169,31 @@ class Trainer:
         for hook in self.hooks:
             getattr(hook, fn_name)(self)
 
-    # ---- the step as one HIP graph (hip/graph.py) -----------------------------------------------------------
+    # ---- the step as a native launch plan (hip/replay.py) or one HIP graph (hip/graph.py) ---------------------
     def _build_step_graph(self):
-        """Forward + OptimizerHook's clear_grad / backward / step captured once and replayed — opt-in: cfg
-        ``hip_graph: True`` or ``PASSL_GRAPH=1`` (``PASSL_GRAPH=0`` always keeps the eager step).  Measured on this
-        ROCm build (profiles/r03_graph_vs_eager.txt): replay is bit-identical and takes the host off the step
-        (~1 ms instead of 15-17 ms of Python per step), but it does not shorten the step — hipGraphLaunch feeds the
-        command processor no faster than the eager launches do once the GPU is the bottleneck — and the training
-        forward must give up its forked downsample branches while capturing (-3 % on MoCo).  Not used where a captured
-        step cannot be replayed faithfully: host tensors, collectives over gloo (host-staged), MoCo's shuffle-BN
-        (a fresh host-visible permutation every step), models that draw random numbers inside the step (MAE's
-        masking noise), a custom OptimizerHook."""
+        """Forward + OptimizerHook's clear_grad / backward / step recorded once and replayed.
+
+        Default for models that opt in (``graph_safe``; MoCo): the NATIVE STEP PLAN (hip/replay.py) — the library's own
+        launch list of the step, replayed from C on the recorded streams, forked branches and the key pipeline
+        included; cfg ``step_plan: False`` or ``PASSL_PLAN=0`` keeps the eager step.  The HIP graph of round 3 stays
+        available (cfg ``hip_graph: True`` / ``PASSL_GRAPH=1``; profiles/r03_graph_vs_eager.txt: bit-identical but no
+        faster on this ROCm, and it cannot hold the forked branches).  Neither is used where a recorded step cannot be
+        replayed faithfully: host tensors, MoCo's shuffle-BN (a fresh host-visible permutation every step), models
+        that draw random numbers inside the step (MAE's masking noise), a custom OptimizerHook; the graph also not with
+        collectives over gloo (host-staged) — a plan keeps collectives as live calls between its segments."""
         from ..hip.graph import StepGraph
+        from ..hip.replay import StepPlan
         from ..hooks import OptimizerHook
         self._step_done = False
         opt_hooks = [h for h in self.hooks if isinstance(h, OptimizerHook)]
-        want = bool(self.cfg.get('hip_graph', os.environ.get('PASSL_GRAPH', '0') == '1'))
-        ok = (self.device.type == 'cuda' and want and len(opt_hooks) == 1 and
+        want_graph = bool(self.cfg.get('hip_graph', os.environ.get('PASSL_GRAPH', '0') == '1'))
+        want_plan = bool(self.cfg.get('step_plan', os.environ.get('PASSL_PLAN', '1') != '0')) and not want_graph
+        ok = (self.device.type == 'cuda' and (want_graph or want_plan) and len(opt_hooks) == 1 and
               type(opt_hooks[0]) is OptimizerHook and hasattr(self.optimizer, 'push_hyper') and
               not getattr(self.model, 'shuffle_bn', False) and
-              getattr(self.model, 'graph_safe', True) and
-              (not dist.is_initialized() or dist.get_backend() == 'nccl'))
+              getattr(self.model, 'graph_safe', False))
+        if ok and want_graph:
+            ok = not dist.is_initialized() or dist.get_backend() == 'nccl'
         if not ok:
             return None
         hook = opt_hooks[0]
@@ -200,8 +204,11 @@ class Trainer:
             hook.optimize(self)
             return self.outputs
         replay_hooks = [self.model.on_graph_replay] if hasattr(self.model, 'on_graph_replay') else []
-        return StepGraph(full_step, optimizers=[self.optimizer], replay_hooks=replay_hooks,
-                         warmup=int(self.cfg.get('hip_graph_warmup', 3)))
+        if want_graph:
+            return StepGraph(full_step, optimizers=[self.optimizer], replay_hooks=replay_hooks,
+                             warmup=int(self.cfg.get('hip_graph_warmup', 3)))
+        return StepPlan(full_step, optimizers=[self.optimizer], replay_hooks=replay_hooks,
+                        warmup=int(self.cfg.get('step_plan_warmup', 3)))
 
     def train_step(self, data):
         """The body of one iteration between the ``train_iter_begin`` and ``train_iter_end`` hook calls: the

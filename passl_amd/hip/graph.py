@@ -56,14 +56,18 @@ class StepGraph(object):
         for i, (d, s) in enumerate(zip(data, self.static_in)):
             if not torch.is_tensor(d):
                 continue
-            key = (d.data_ptr(), d._version, tuple(d.shape))
-            if self._src[i] == key:
-                continue                        # the same, unmodified resident tensor as last time
+            src = self._src[i]
+            if src is not None and src[0] is d and src[1] == d._version:
+                # the SAME tensor object (held by a strong reference, so its address cannot have been recycled for
+                # another batch) and nobody wrote to it since: the resident synthetic batch.  (An address / version /
+                # shape key is not an identity: a fresh batch from a real loader often lands on the freed address of
+                # the previous one with version 0 — round-3 advisor finding.)
+                continue
             if tuple(d.shape) != tuple(s.shape) or d.dtype != s.dtype:
                 raise RuntimeError('StepGraph: input %d changed shape / dtype (%s %s -> %s %s); a captured step is '
                                    'shape-specialised' % (i, tuple(s.shape), s.dtype, tuple(d.shape), d.dtype))
             s.copy_(d, non_blocking=True)
-            self._src[i] = key
+            self._src[i] = (d, d._version)
 
     def _outputs(self):
         return {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in self.static_out.items()}
@@ -73,7 +77,7 @@ class StepGraph(object):
         torch.cuda.synchronize(dev)
         torch.cuda.empty_cache()                # the warm-up steps' cached blocks go back: the graph owns its pool
         self.static_in = [d.clone() if torch.is_tensor(d) else d for d in data]
-        self._src = [(d.data_ptr(), d._version, tuple(d.shape)) if torch.is_tensor(d) else None for d in data]
+        self._src = [(d, d._version) if torch.is_tensor(d) else None for d in data]
         for o in self.optimizers:
             o.push_hyper()                      # outside the graph: stream-ordered in front of the launch
         streams.reset()                         # no eager-time stream may be pulled into the capture

@@ -148,6 +148,19 @@ SIGNATURES = {
     'passl_hip_cosine_loss_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
     'passl_hip_softmax_ce_fwd': (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_l, c_p]),
     'passl_hip_softmax_ce_bwd': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p]),
+    'passl_hip_plan_create': (c_i, [C.POINTER(c_p)]),
+    'passl_hip_plan_destroy': (c_i, [c_p]),
+    'passl_hip_plan_record_begin': (c_i, [c_p]),
+    'passl_hip_plan_cut': (c_i, [c_p]),
+    'passl_hip_plan_record_end': (c_i, [c_p]),
+    'passl_hip_plan_event_record': (c_i, [c_p, c_p]),
+    'passl_hip_plan_stream_wait': (c_i, [c_p, c_p, c_i]),
+    'passl_hip_plan_replay': (c_i, [c_p, c_i]),
+    'passl_hip_plan_info': (c_l, [c_p, c_i]),
+    'passl_hip_fill_zero': (c_i, [c_p, c_l, c_p]),
+    'passl_hip_copy_bytes': (c_i, [c_p, c_p, c_l, c_p]),
+    'passl_hip_cast_bf16_to_f32': (c_i, [c_p, c_p, c_l, c_p]),
+    'passl_hip_unpad_add': (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_prof_enable': (c_i, [c_i]),
     'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),
     'passl_hip_prof_collect_work': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

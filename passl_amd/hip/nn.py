@@ -73,7 +73,7 @@ class GradSlot:
         self.grad = g
         # the two ends may run on different streams (a downsample branch on the side stream,
         # hip/streams.py): the taker waits for the producer's launches
-        self.ready = torch.cuda.current_stream(g.device).record_event() if g.is_cuda else None
+        self.ready = streams.record_event(torch.cuda.current_stream(g.device)) if g.is_cuda else None
 
     def take(self):
         if not self.armed:
@@ -86,7 +86,7 @@ class GradSlot:
             # g may come from the side stream's pool (a forked downsample branch): ordered by the event; its
             # block is recycled behind later side-stream work only, all of which waits on main-stream events
             # recorded after this launch (hip/streams.py, "Memory") — no record_stream
-            torch.cuda.current_stream(g.device).wait_event(self.ready)
+            streams.wait_event(torch.cuda.current_stream(g.device), self.ready)
             self.ready = None
         return g
 
@@ -134,11 +134,12 @@ class _ConvFn(Function):
         layer, pl = ctx.layer, ctx.pl
         rt = layer._rt
         g = layer.geom
+        streams.autograd_node_entry(dy.device)
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
             N = x.shape[0]
-            alloc = torch.zeros if pl.dgrad_zero else torch.empty
+            alloc = ops.zeros if pl.dgrad_zero else torch.empty
             dx = alloc(N, ctx.hw[0], ctx.hw[1], g.cin, dtype=dy.dtype, device=dy.device)
             extra = ctx.add_slot.take() if ctx.add_slot is not None else None
             if extra is not None and (len(pl.dds) != 1 or pl.dgrad_zero):
@@ -166,9 +167,11 @@ class _ConvFn(Function):
                 dx = None
         def wgrad():
             if layer.is_stem:
-                tmp = torch.zeros(g.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dy.device)
+                # the stem filter is padded to [K][7][8 taps][4 channels] for the kernel; its gradient goes back into
+                # the dense [K][7][7][3] slot of the flat gradient buffer
+                tmp = ops.zeros(g.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dy.device)
                 ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), tmp)
-                rt.dw.view(g.cout, 7, 7, 3).add_(tmp.view(g.cout, 7, 8, 4)[:, :, :7, :3])
+                ops.unpad_add(tmp, rt.dw, g.cout, 7, 7, 3, P.STEM_ROW // 4, 4)
             else:
                 ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
         if ctx.side:
@@ -287,10 +290,11 @@ class _BNActFn(Function):
     def backward(ctx, dz):
         y, st, mask = ctx.saved_tensors
         layer = ctx.layer
+        streams.autograd_node_entry(dz.device)
         if layer.affine:
             for p in (layer.weight, layer.bias):
                 if p.grad is None:
-                    p.grad = torch.zeros_like(p)
+                    p.grad = ops.zeros_like(p)
             gamma, dgamma, dbeta = layer.weight.detach(), layer.weight.grad, layer.bias.grad
         else:
             gamma, dgamma, dbeta = layer._const[0], layer._dscratch[0], layer._dscratch[1]
@@ -463,7 +467,7 @@ class _LinearFn(Function):
         rt = layer._rt
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
-            dy = dy.to(x.dtype)
+            dy = ops.cast_to(dy, x.dtype)
         if ctx.relu:
             dy = ops.relu_bwd(dy, y)
         dx = None
@@ -524,7 +528,7 @@ class _ToComputeFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        return dy.float()
+        return ops.cast_f32(dy)
 
 
 def to_compute(x, dtype):
@@ -977,7 +981,10 @@ class EncoderArena:
 
     def clear_grad(self):
         if self.grads is not None:
-            self.grads.zero_()
+            if self.grads.is_cuda:
+                ops.fill_zero(self.grads)        # (a library launch: part of a recorded step plan)
+            else:
+                self.grads.zero_()
 
     def param_grad_ready(self, *params):
         """grad_ready for raw parameters (class / position embeddings, tokens, logit_scale ...) whose

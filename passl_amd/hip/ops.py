@@ -40,6 +40,81 @@ class _Workspace:
 workspace = _Workspace()
 
 
+# ------------------------------------------------------------------ fills / copies / casts
+# Library kernels for what would otherwise be the step's last ATen launches: a step plan (hip/replay.py) replays
+# the launches of THIS library, so a training step must not depend on a kernel torch launches.
+def fill_zero(t):
+    """t[...] = 0 for a contiguous device tensor."""
+    assert t.is_contiguous()
+    if t.numel():
+        L.check(_lib().passl_hip_fill_zero(L.ptr(t), t.numel() * t.element_size(), L.stream()), 'fill_zero')
+    return t
+
+
+def zeros(*shape, dtype=None, device=None):
+    return fill_zero(torch.empty(*shape, dtype=dtype, device=device))
+
+
+def zeros_like(x):
+    return fill_zero(torch.empty(x.shape, dtype=x.dtype, device=x.device))
+
+
+def copy_into(dst, src):
+    """dst[...] = src[...]: same dtype and element count, both contiguous, no overlap."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+    if dst.numel():
+        L.check(_lib().passl_hip_copy_bytes(L.ptr(dst), L.ptr(src), dst.numel() * dst.element_size(), L.stream()),
+                'copy_bytes')
+    return dst
+
+
+def clone(x):
+    return copy_into(torch.empty(x.shape, dtype=x.dtype, device=x.device), x.contiguous())
+
+
+def cast_f32(x):
+    """bf16 -> fp32 copy (fp32 input is returned as is)."""
+    if x.dtype == torch.float32:
+        return x
+    assert x.dtype == torch.bfloat16
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.check(_lib().passl_hip_cast_bf16_to_f32(L.ptr(x), L.ptr(y), x.numel(), L.stream()), 'cast_bf16_to_f32')
+    return y
+
+
+def cast_to(x, dtype):
+    """fp32 <-> bf16 copy through the library's cast kernels (identity when the dtype already matches)."""
+    if x.dtype == dtype:
+        return x
+    if dtype == torch.float32:
+        return cast_f32(x)
+    assert dtype == torch.bfloat16 and x.dtype == torch.float32
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    cast_bf16(x.view(-1), y.view(-1))
+    return y
+
+
+def unpad_add(src, dst, rows, R, dst_S, dst_C, src_S, src_C):
+    """dst[row][r][s][c] += src[row][r][s][c] over the dense extents of a padded block (the stem filter's gradient)."""
+    L.check(_lib().passl_hip_unpad_add(L.ptr(src), L.ptr(dst), rows, R, dst_S, dst_C, src_S, src_C, L.stream()),
+            'unpad_add')
+
+
+_ones = {}
+
+
+def ones_like_cached(t):
+    """A resident all-ones tensor shaped like t (the root gradient of ``loss.backward()``: autograd would otherwise
+    launch a fill kernel per step)."""
+    key = (t.device, t.dtype, tuple(t.shape))
+    o = _ones.get(key)
+    if o is None:
+        o = _ones[key] = torch.ones(t.shape, dtype=t.dtype, device=t.device)
+    return o
+
+
 # ------------------------------------------------------------------ convolution
 _desc_cache = {}
 

@@ -41,6 +41,41 @@ import torch
 
 from . import config
 
+# ---- cross-stream edges, visible to a recording step plan (hip/replay.py) ------------------------------------
+# Every event record / stream wait of the product path goes through these three functions.  They do what the torch
+# calls do; while a step plan records they ALSO report the edge to it (a plan replays the library's launches on the
+# recorded streams and must reproduce the ordering between them).
+_recorder = None          # hip/replay.py sets it for the duration of a recording
+
+
+def record_event(stream):
+    ev = stream.record_event()
+    if _recorder is not None:
+        _recorder.on_record(stream, ev)
+    return ev
+
+
+def wait_event(stream, ev):
+    stream.wait_event(ev)
+    if _recorder is not None:
+        _recorder.on_wait(stream, ev)
+
+
+def wait_stream(stream, other):
+    """stream.wait_stream(other) — which IS wait_event(other.record_event())."""
+    wait_event(stream, record_event(other))
+
+
+def autograd_node_entry(device):
+    """Call at the top of a custom backward.  Autograd runs a node on the stream its forward ran on and orders that
+    stream behind the producers of the node's incoming gradients with events of its own — edges a recording plan
+    cannot see.  For a node that runs off the plan's main stream (the backward of a forked downsample branch) the
+    plan gets a conservative equivalent: this stream waits for everything enqueued on the main stream so far (the
+    producer ran there, or handed its result over through a GradSlot's own event)."""
+    if _recorder is not None:
+        _recorder.on_backward_node(device)
+
+
 _streams = {}
 _pending = {}       # device index -> deque of (event recorded on the side stream, tensors kept alive)
 _HOLD_FRAC = float(os.environ.get('PASSL_OVERLAP_HOLD_FRAC', '0.08'))
@@ -113,14 +148,14 @@ def on_side(device, reads=(), in_backward=False):
     so far.  ``reads``: tensors allocated on the main stream that the enclosed kernels read."""
     main = torch.cuda.current_stream(device)
     s = side_stream(device)
-    s.wait_event(main.record_event())
+    wait_event(s, record_event(main))
     with torch.cuda.stream(s):
         yield s
     key = s.device.index
     q = _pending.setdefault(key, collections.deque())
     held = tuple(t for t in reads if t is not None)
     nbytes = sum(t.numel() * t.element_size() for t in held)
-    q.append((s.record_event(), held, nbytes))
+    q.append((record_event(s), held, nbytes))
     owners = _owners.setdefault(key, [])
     if main != s and main not in owners:
         owners.append(main)         # streams that hand work over (the main stream, the fork stream)
@@ -133,7 +168,7 @@ def on_side(device, reads=(), in_backward=False):
         # the held tensors may come from the pool of any handing-off stream (a forked branch reads the
         # main stream's block input): later work of ALL of them is ordered behind the side stream's reads
         for owner in owners:
-            owner.wait_event(done)
+            wait_event(owner, done)
         _held_bytes[key] -= nbytes
         del held
     if in_backward:
@@ -166,14 +201,14 @@ def join(device):
     for table in (_streams, _fork_streams):
         s = table.get(key)
         if s is not None and s != cur:
-            cur.wait_stream(s)
+            wait_stream(cur, s)
             waited = True
     q = _pending.get(key)
     if q:
         last = q[-1][0]
         for owner in _owners.get(key, ()):
             if owner != cur:
-                owner.wait_event(last)
+                wait_event(owner, last)
         q.clear()                   # every handing-off stream is ordered behind the side stream's reads
         _held_bytes[key] = 0
     return waited

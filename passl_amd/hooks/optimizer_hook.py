@@ -27,7 +27,13 @@ class OptimizerHook(Hook):
         reducer = getattr(trainer, 'grad_reducer', None)
         if reducer is not None:
             reducer.begin()
-        loss.backward()
+        # (an explicit root gradient: autograd's own ones_like would be a fill kernel per step that a step plan —
+        # hip/replay.py — cannot replay)
+        if loss.is_cuda:
+            from ..hip import ops
+            loss.backward(ops.ones_like_cached(loss))
+        else:
+            loss.backward()
         if 'lars' in trainer.optimizer.type:
             trainer.optimizer.minimize(loss)
         else:

@@ -44,12 +44,20 @@ def concat_all_gather(tensor):
         return tensor
     out = torch.empty((ws * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
                       device=tensor.device)
-    dist.all_gather_into_tensor(out, tensor.contiguous())
+    src = tensor.contiguous()
+    # (stays a live call when the step is replayed from a native plan: the plan is cut here, hip/replay.py)
+    from ...hip.replay import host_call
+    host_call(lambda: dist.all_gather_into_tensor(out, src))
     return out
 
 
 @MODELS.register()
 class MoCo(nn.Layer):
+    # the step replays faithfully from a captured launch list (hip/graph.py, hip/replay.py): every step-varying
+    # scalar lives on the device (learning rate, queue pointer), no random numbers are drawn inside the step —
+    # tests/test_moco_gpu.py::test_step_graph_replay_is_bit_identical.  Models opt IN (Trainer._build_step_graph).
+    graph_safe = True
+
     def __init__(self, backbone, neck=None, head=None, dim=128, K=65536, m=0.999, T=0.07,
                  shuffle_bn=False):
         super().__init__()
@@ -163,9 +171,9 @@ class MoCo(nn.Layer):
         state = {'y': img_k, 'hold': [img_k]}      # (a staged input lives in the SIDE stream's pool: keep it until the join)
 
         def unit_done(u):
-            ev = main.record_event()                 # the query unit's statistics are final
+            ev = streams.record_event(main)          # the query unit's statistics are final
             with torch.no_grad(), torch.cuda.stream(key):
-                key.wait_event(ev)
+                streams.wait_event(key, ev)
                 self.arena_k.ema_stats_from(self.arena_q, self.m, self._key_groups[u])
                 state['y'] = bb_k.frozen_unit(u, state['y'], allow_fork=False)
         bb_q._unit_done = unit_done
@@ -177,7 +185,7 @@ class MoCo(nn.Layer):
         with torch.no_grad(), torch.cuda.stream(key):
             k = self.encoder_k[1](state['y'])
             k = nn.normalize(k, axis=1)
-        main.wait_stream(key)
+        streams.wait_stream(main, key)
         state.clear()                                # (inputs / activations of the key path: released after the join)
         return q, k
 
@@ -190,7 +198,7 @@ class MoCo(nn.Layer):
                 img_k = self.encoder_k[0].stage_input(img_k)
             q, k = self._train_iter_overlapped(img_q, img_k)
             with torch.no_grad():
-                queue_snapshot = self.queue.clone()     # `self.queue.clone().detach()`, moco.py:180
+                queue_snapshot = ops.clone(self.queue)     # `self.queue.clone().detach()`, moco.py:180
             outputs = self.head.fused(q, k, queue_snapshot)
             self._dequeue_and_enqueue(k)
             return outputs
@@ -212,7 +220,7 @@ class MoCo(nn.Layer):
             if self.shuffle_bn:
                 k = self._batch_unshuffle_ddp(k, idx_unshuffle)
         with torch.no_grad():
-            queue_snapshot = self.queue.clone()     # `self.queue.clone().detach()`, moco.py:180
+            queue_snapshot = ops.clone(self.queue)     # `self.queue.clone().detach()`, moco.py:180
         outputs = self.head.fused(q, k, queue_snapshot)
         self._dequeue_and_enqueue(k)
         return outputs

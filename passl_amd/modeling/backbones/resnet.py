@@ -61,7 +61,7 @@ class BottleneckBlock(nn.Layer):
         # the weight-gradient side stream and the frozen encoder's fork, which are ordered by our own events, capture fine)
         fork = (self.downsample is not None and torch.is_grad_enabled() and x.requires_grad and
                 streams.enabled(x) and config.fork_downsample() and not torch.cuda.is_current_stream_capturing())
-        x_ready = torch.cuda.current_stream(x.device).record_event() if fork else None
+        x_ready = streams.record_event(torch.cuda.current_stream(x.device)) if fork else None
         out, st = self.conv1(x, want_stats=True, add_slot=slot,
                              producer=nn.bn_link(x) if slot is not None else None)
         out = self.bn1(out, relu=True, stats=st)
@@ -72,11 +72,11 @@ class BottleneckBlock(nn.Layer):
             if fork:
                 main = torch.cuda.current_stream(x.device)
                 side = streams.fork_stream(x.device)
-                side.wait_event(x_ready)
+                streams.wait_event(side, x_ready)
                 with torch.cuda.stream(side):
                     idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
                     identity = self.downsample[1](idn, relu=False, stats=st)
-                main.wait_event(side.record_event())
+                streams.wait_event(main, streams.record_event(side))
                 # `identity` comes from the side stream's pool and is read by bn3 on the main stream.  No
                 # record_stream (hip/streams.py, "Memory"): every later piece of side-stream work starts with
                 # a wait on a main-stream event recorded after this point, so the pool's stream-ordered
@@ -93,7 +93,7 @@ class BottleneckBlock(nn.Layer):
         against the MAIN stream only (hip/streams.py), so a branch forked from a third stream could see its output
         recycled under it."""
         fork = allow_fork and self.downsample is not None and streams.enabled(x) and config.fork_downsample()
-        x_ready = torch.cuda.current_stream(x.device).record_event() if fork else None
+        x_ready = streams.record_event(torch.cuda.current_stream(x.device)) if fork else None
         out = self.conv1.infer(x, self.bn1, relu=True)
         out = self.conv2.infer(out, self.bn2, relu=True)
         identity = x
@@ -101,10 +101,10 @@ class BottleneckBlock(nn.Layer):
             # downsample conv next to conv1 / conv2 on the side stream; joined before conv3 (whose
             # epilogue adds it), so x outlives the side stream's reads
             main, side = torch.cuda.current_stream(x.device), streams.fork_stream(x.device)
-            side.wait_event(x_ready)
+            streams.wait_event(side, x_ready)
             with torch.cuda.stream(side):
                 identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
-            main.wait_event(side.record_event())     # (no record_stream: see forward())
+            streams.wait_event(main, streams.record_event(side))     # (no record_stream: see forward())
         elif self.downsample is not None:
             identity = self.downsample[0].infer(x, self.downsample[1], relu=False)
         return self.conv3.infer(out, self.bn3, residual=identity, relu=True)
@@ -228,10 +228,10 @@ class ResNet(nn.Layer):
         if not streams.enabled(x):
             return x
         main, side = torch.cuda.current_stream(x.device), streams.side_stream(x.device)
-        side.wait_event(main.record_event())
+        streams.wait_event(side, streams.record_event(main))
         with torch.cuda.stream(side):
             xp, H, W = self._stem_input(x)
-        return _StagedInput(xp, H, W, side.record_event())
+        return _StagedInput(xp, H, W, streams.record_event(side))
 
     def units(self):
         """The trunk as a list of pipeline units: unit 0 = stem conv + BatchNorm (+ max-pool) + the first bottleneck,
@@ -248,7 +248,7 @@ class ResNet(nn.Layer):
         if u == 0:
             if isinstance(x, _StagedInput):
                 xp, H, W = x.xp, x.H, x.W
-                torch.cuda.current_stream(xp.device).wait_event(x.ready)
+                streams.wait_event(torch.cuda.current_stream(xp.device), x.ready)
             else:
                 xp, H, W = self._stem_input(x)
             y = self.conv1.infer(xp, self.bn1, relu=True, hw=(H, W))
@@ -266,7 +266,7 @@ class ResNet(nn.Layer):
         if isinstance(x, _StagedInput):
             xp, H, W = x.xp, x.H, x.W
             main = torch.cuda.current_stream(xp.device)
-            main.wait_event(x.ready)      # xp: side-stream pool, read by the stem conv here (no record_stream: see BottleneckBlock.forward)
+            streams.wait_event(main, x.ready)      # xp: side-stream pool, read by the stem conv here (no record_stream: see BottleneckBlock.forward)
         else:
             xp, H, W = self._stem_input(x)
         stages = (self.layer1, self.layer2, self.layer3, self.layer4)

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.passl_hip_abi_version() == 11
+    assert lib.passl_hip_abi_version() == 12
     assert b'invalid' in lib.passl_hip_strerror(-1)
     assert lib.passl_hip_strerror(0) == b'ok'
 
@@ -127,3 +127,30 @@ def test_tuning_options_validate_their_values(lib):
     bad = [(b'bn_stream_unroll', 3), (b'igemm_ring_bm', 7), (b'igemm_8p_dense', 3), (b'no_such_option', 1)]
     for name, v in bad:
         assert lib.passl_hip_set_option(name, v) != 0, (name, v)
+
+
+def test_step_plan_api_without_launches(lib):
+    """The native step plan's bookkeeping (include/passl_hip.h "native step plans") without a GPU: a plan records
+    once, one plan at a time, cut() numbers the segments, replaying an empty segment is a no-op, bad handles /
+    segments / event ids are refused."""
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.passl_hip_plan_create(C.byref(h)) == 0 and h.value
+    assert lib.passl_hip_plan_replay(h, 0) == -1                      # nothing recorded yet
+    assert lib.passl_hip_plan_cut(h) == -1                            # not recording
+    assert lib.passl_hip_plan_record_begin(h) == 0
+    h2 = C.c_void_p()
+    assert lib.passl_hip_plan_create(C.byref(h2)) == 0
+    assert lib.passl_hip_plan_record_begin(h2) == -1                  # one recording per process at a time
+    assert lib.passl_hip_plan_stream_wait(h, None, 0) == -1           # no such event
+    assert lib.passl_hip_plan_cut(h) == 1
+    assert lib.passl_hip_plan_cut(h) == 2
+    assert lib.passl_hip_plan_record_end(h) == 0
+    assert lib.passl_hip_plan_record_begin(h) == -1                   # a plan records once
+    assert lib.passl_hip_plan_info(h, 0) == 3 and lib.passl_hip_plan_info(h, 1) == 0
+    for seg in range(3):
+        assert lib.passl_hip_plan_replay(h, seg) == 0
+    assert lib.passl_hip_plan_replay(h, 3) == -1
+    assert lib.passl_hip_plan_info(h, 6) == 1
+    assert lib.passl_hip_plan_record_begin(h2) == 0 and lib.passl_hip_plan_record_end(h2) == 0
+    assert lib.passl_hip_plan_destroy(h) == 0 and lib.passl_hip_plan_destroy(h2) == 0

@@ -5,16 +5,19 @@ C ABI) against (a) the golden vectors produced by running the reference's own so
 Tolerances: fp32 compute (exact-fp32 MFMA) must meet BASELINE.json's 1e-3 on loss / logits /
 queue; bf16 compute (the benchmark dtype) is compared with the same fp32 goldens at a stated
 looser bound because the reference has no bf16 MoCo path."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 
 import golden_util as G                       # noqa: E402
 import moco_util as U                         # noqa: E402
 from oracle.moco import MoCoOracle            # noqa: E402
-from passl_amd.hip import ops                 # noqa: E402
+from passl_amd.hip import config as hip_config, ops      # noqa: E402
 
 DEV = 'cuda'
 
@@ -513,6 +516,99 @@ def test_step_graph_replay_is_bit_identical(dtype):
     for key in ('losses', 'q', 'k', 'queue'):
         assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), key
     assert float(a['losses'][0, 0]) != float(a['losses'][-1, 0])
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_step_plan_replay_is_bit_identical(dtype):
+    """hip/replay.py: the step (forward with the forked downsample branches and the key pipeline on its own stream,
+    EMA, InfoNCE, enqueue, clear_grad, backward incl. the side stream, momentum-SGD) RECORDED ONCE as the library's
+    native launch plan and replayed from C equals the eager step bit for bit — loss, accuracies, every parameter, the
+    key encoder, the queue and its pointer — over steps that each see a NEW batch and a NEW learning rate, and the
+    recording saw no foreign (ATen) launch inside the step."""
+    from passl_amd.hip.replay import StepPlan
+    K, N, steps = 512, 16, 7
+    gen = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(N, 3, 64, 64, generator=gen).to(DEV), torch.randn(N, 3, 64, 64, generator=gen).to(DEV))
+               for _ in range(steps)]
+    results = {}
+    for mode in ('eager', 'plan'):
+        oracle = MoCoOracle(K=K, seed=2, t_max=50)
+        model, opt, _ = U.build_product(K, dtype)
+        from passl_amd.solver.lr_scheduler import CosineAnnealingDecay
+        from passl_amd.solver.optimizer import Momentum
+        sched = CosineAnnealingDecay(0.03, T_max=20)              # a schedule that visibly moves in 7 steps
+        opt = Momentum(sched, parameters=list(model.parameters()), weight_decay=1e-4)
+        U.load_oracle_state(model, oracle)
+        model.train()
+
+        def full_step(xq, xk):
+            out = model(xq, xk, mode='train')
+            opt.clear_grad()
+            out['loss'].backward(ops.ones_like_cached(out['loss']))
+            opt.step()
+            return out
+        sp = StepPlan(full_step, optimizers=[opt], replay_hooks=[model.on_graph_replay], warmup=1,
+                      enabled=(mode == 'plan'), strict=True)
+        losses = []
+        for xq, xk in batches:
+            out = sp.run(xq, xk)
+            losses.append(torch.stack([out['loss'].detach().reshape(()), out['acc1'].detach().reshape(()).float()]))
+            sched.step()
+        torch.cuda.synchronize()
+        if mode == 'plan':
+            assert sp.failed is None, sp.failed
+            assert not sp.foreign, sp.foreign
+            assert sp.captured and sp.replays == steps - 2          # 1 eager warm-up call, 1 recording call
+            assert sp.info['kernels'] > 300 and sp.info['segments'] == 1
+            if hip_config.overlap():
+                assert sp.info['streams'] >= 2 and sp.info['stream_waits'] > 0
+            print('step plan:', sp.info)
+        results[mode] = dict(losses=torch.stack(losses).cpu(), q=model.arena_q.flat.clone().cpu(),
+                             k=model.arena_k.flat.clone().cpu(), queue=model.queue.clone().cpu(),
+                             ptr=int(model.queue_ptr[0].item()), host_ptr=model._ptr)
+        del sp, model, opt
+        torch.cuda.empty_cache()
+    a, b = results['eager'], results['plan']
+    assert a['ptr'] == b['ptr'] == a['host_ptr'] == b['host_ptr'] == (steps * N) % K
+    for key in ('losses', 'q', 'k', 'queue'):
+        assert torch.equal(a[key].view(torch.int32), b[key].view(torch.int32)), key
+    assert float(a['losses'][0, 0]) != float(a['losses'][-1, 0])
+
+
+def test_trainer_replays_the_step_plan_by_default():
+    """Trainer on the MoCo config: after its warm-up the step runs as a replayed native plan (no opt-in needed), the
+    loss trajectory equals the eager Trainer's bit for bit, PASSL_PLAN=0 / cfg step_plan False keep it eager."""
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+    traj = {}
+    for plan in (False, True):
+        cfg = get_config(os.path.join(ROOT, 'configs/moco/moco_v2_r50_synthetic.yaml'),
+                         ['dataloader.train.sampler.batch_size=16', 'compute_dtype=bf16', 'seed=3'])
+        cfg.timestamp = ''
+        cfg.step_plan = plan
+        tr = Trainer(cfg)
+        assert (tr.step_graph is not None) == plan
+        tr.mode = 'train'
+        tr.model.train()
+        data = next(iter(tr.train_dataloader))
+        tr.call_hook('run_begin')
+        tr.call_hook('train_epoch_begin')
+        losses = []
+        for _ in range(8):
+            tr.inner_iter = tr.current_iter % tr.iters_per_epoch
+            tr.current_iter += 1
+            tr.call_hook('train_iter_begin')
+            tr.train_step(data)
+            tr.call_hook('train_iter_end')
+            losses.append(tr.outputs['loss'].detach().reshape(()).clone())
+        torch.cuda.synchronize()
+        if plan:
+            assert tr.step_graph.captured and tr.step_graph.replays == 4, (tr.step_graph.failed, tr.step_graph.replays)
+        traj[plan] = (torch.stack(losses).cpu(), tr.model.arena_q.flat.clone().cpu())
+        del tr
+        torch.cuda.empty_cache()
+    assert torch.equal(traj[False][0].view(torch.int32), traj[True][0].view(torch.int32))
+    assert torch.equal(traj[False][1].view(torch.int32), traj[True][1].view(torch.int32))
 
 
 def test_contrastive_head_forward_with_materialised_logits():

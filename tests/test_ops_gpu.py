@@ -788,3 +788,37 @@ def test_conv_operands_beyond_2gb(k):
         ops.conv_igemm(dh[0], x[:N // 2], pk.view(dh[0].pack, Cout), dxh[:N // 2])
         ops.conv_igemm(dh[0], x[N // 2:], pk.view(dh[0].pack, Cout), dxh[N // 2:])
         assert torch.equal(dx, dxh)
+
+
+def test_fill_copy_cast_unpad_kernels():
+    """The library's own fills / copies / casts (csrc/plan.hip): what replaces the step's last ATen launches so that
+    a recorded step plan holds library launches only — all sizes incl. unaligned heads / tails."""
+    gen = torch.Generator().manual_seed(5)
+    for n in (1, 3, 4, 1023, 4096, 1000003):
+        x = torch.randn(n + 5, generator=gen).to(DEV)
+        for off in (0, 1, 4):                                  # 16-byte aligned, 4- and 16-byte offsets
+            src = x[off:off + n]
+            dst = torch.full((n + 2,), 7.0, device=DEV)
+            ops.copy_into(dst[1:1 + n] if off == 1 else dst[:n], src.contiguous())
+            got = dst[1:1 + n] if off == 1 else dst[:n]
+            assert torch.equal(got, src)
+            assert float(dst[-1]) == 7.0                       # nothing past the end
+            z = torch.full((n + 2,), 3.0, device=DEV)
+            ops.fill_zero(z[1:1 + n])
+            assert float(z[0]) == 3.0 and float(z[-1]) == 3.0 and float(z[1:1 + n].abs().max()) == 0.0
+    q = torch.randn(128, 513, generator=gen).to(DEV)
+    assert torch.equal(ops.clone(q), q)
+    zz = ops.zeros(5, 7, 9, dtype=torch.bfloat16, device=DEV)
+    assert zz.shape == (5, 7, 9) and zz.dtype == torch.bfloat16 and float(zz.float().abs().max()) == 0.0
+    for n in (8, 24, 1000, 4099):
+        b = torch.randn(n, generator=gen).to(DEV).to(torch.bfloat16)
+        assert torch.equal(ops.cast_f32(b), b.float())
+        f = torch.randn(n - n % 8, generator=gen).to(DEV)
+        assert torch.equal(ops.cast_to(f, torch.bfloat16), f.to(torch.bfloat16))
+    src = torch.randn(64, 7, 8, 4, generator=gen).to(DEV)
+    dst0 = torch.randn(64, 7, 7, 3, generator=gen).to(DEV)
+    dst = dst0.clone()
+    ops.unpad_add(src, dst, 64, 7, 7, 3, 8, 4)
+    assert torch.equal(dst, dst0 + src[:, :, :7, :3])
+    one = torch.zeros(1, device=DEV)
+    assert ops.ones_like_cached(one) is ops.ones_like_cached(one) and float(ops.ones_like_cached(one)) == 1.0
