@@ -73,9 +73,9 @@ typedef std::integral_constant<int, 1> I1;
 // DENSE (compile-time): the operand is a plain [M, C] matrix (Linear / 1x1 stride-1 convolution) — the filter-tap
 // walk, the per-tap bounds checks and the image decomposition of a row drop out of the instruction stream and of the
 // scalar register file (the general form keeps ~20 more scalars live and spills 69 of them to lanes:
-// profiles/r03_kernel_resources.txt).  Same arithmetic, same order, same bits.  Opt-in until measured on the GPU
-// (passl_hip_set_option("igemm_8p_dense", 1) / PASSL_IGEMM_8P_DENSE=1): the default launches are the two
-// instantiations with DENSE = false, unchanged.
+// profiles/r03_kernel_resources.txt).  Same arithmetic, same order, same bits (profiles/r04_8p_dense_ab.txt).
+// passl_hip_set_option("igemm_8p_dense", v) / PASSL_IGEMM_8P_DENSE=v: 0 off, 1 the persistent form (default),
+// 2 also the staged (fused-statistics) form.
 template <bool DIRECT, bool DENSE = false>
 __global__ void __launch_bounds__(kThreads) igemm_8p_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -564,12 +564,14 @@ int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st) {
   }
   if (g_8p_dense < 0) {
     const char* e = getenv("PASSL_IGEMM_8P_DENSE");
-    g_8p_dense = e ? atoi(e) : 0;
-    if (g_8p_dense < 0 || g_8p_dense > 2) g_8p_dense = 0;
+    g_8p_dense = e ? atoi(e) : 1;
+    if (g_8p_dense < 0 || g_8p_dense > 2) g_8p_dense = 1;
   }
-  // the matrix-operand specialisation (opt-in).  1: the ViT Linears' launches (persistent form) — measured
-  // bit-identical and 5-11 % faster on two ViT-B shapes (profiles/r03_8p_dense_ab.txt), the full suite has not run with
-  // it yet.  2: also the 1x1 stride-1 convolutions with fused statistics (staged form) — NOT yet shown exact.
+  // the matrix-operand specialisation.  1 (default since round 4): every plain-matrix launch of the persistent form —
+  // the ViT Linears and the 1x1 stride-1 convolutions without fused statistics; bit-identical to the general form on
+  // every shape of scratch/ab_8p_dense.py incl. ragged tiles and 4-13 % faster on 8 of the 9 shapes this kernel takes
+  // (the K = 512 -> 2048 Linear is 6 % slower; profiles/r04_8p_dense_ab.txt), GPU suite green with it.  2 (opt-in): also the launches with fused statistics
+  // (staged form) — exact as well, but faster on only 2 of 4 R50 shapes (256->1024 @14 is 8 % slower).
   if (g_8p_dense >= 1 && p.dense && direct) return g8::launch<true, true>(p, st);
   if (g_8p_dense >= 2 && p.dense && !direct) return g8::launch<false, true>(p, st);
   return direct ? g8::launch<true>(p, st) : g8::launch<false>(p, st);

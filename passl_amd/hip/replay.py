@@ -69,11 +69,12 @@ class _ForeignOpWatch(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.foreign = {}
+        self.paused = 0                 # > 0 inside a host call: those launches are live at every replay
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
         out = func(*args, **(kwargs or {}))
-        if not name.startswith(_NO_KERNEL_PREFIXES):
+        if not self.paused and not name.startswith(_NO_KERNEL_PREFIXES):
             on_device = any(torch.is_tensor(a) and a.is_cuda for a in args) or \
                 (torch.is_tensor(out) and out.is_cuda)
             if name.startswith('aten.clone') and torch.is_tensor(out) and out.numel() == 0:
@@ -94,7 +95,8 @@ class _Recorder(object):
 
     _serial = 0
 
-    def __init__(self, lib, handle, device):
+    def __init__(self, lib, handle, device, watch=None):
+        self.watch = watch
         _Recorder._serial += 1
         self.serial = _Recorder._serial
         self.lib, self.handle, self.device = lib, handle, device
@@ -140,9 +142,17 @@ def host_call(fn):
     point of every replay.  For work inside a step that is not a launch of this library and must stay a live call: a
     torch.distributed collective (its tensors are the recorded ones: same addresses at every replay)."""
     rec = streams._recorder
-    if rec is not None:
-        rec.cut(fn)
-    return fn()
+    if rec is None:
+        return fn()
+    rec.cut(fn)
+    watch = rec.watch
+    if watch is not None:
+        watch.paused += 1
+    try:
+        return fn()
+    finally:
+        if watch is not None:
+            watch.paused -= 1
 
 
 class StepPlan(object):
@@ -211,8 +221,8 @@ class StepPlan(object):
         handle = C.c_void_p()
         L.check(lib.passl_hip_plan_create(C.byref(handle)), 'plan_create')
         pool = torch.cuda.MemPool()
-        rec = _Recorder(lib, handle, dev)
         watch = _ForeignOpWatch()
+        rec = _Recorder(lib, handle, dev, watch)
         began = False
         try:
             torch._C._cuda_beginAllocateToPool(idx, pool.id)        # every thread: the autograd thread allocates too

@@ -18,6 +18,9 @@ class _InfoNCEFn(Function):
 
     @staticmethod
     def forward(ctx, q, k, queue, T):
+        # (undefined gradients of the non-differentiable outputs stay None: materialising them would be two ATen fill
+        # kernels per step inside a step that a native plan replays, hip/replay.py)
+        ctx.set_materialize_grads(False)
         out, lse, _ = ops.infonce_fwd(q.contiguous(), k.contiguous(), queue, T, want_logits=False)
         ctx.save_for_backward(q, k, queue, lse)
         ctx.T = T
@@ -28,6 +31,8 @@ class _InfoNCEFn(Function):
     @staticmethod
     def backward(ctx, gloss, _g1, _g5):
         q, k, queue, lse = ctx.saved_tensors
+        if gloss is None:
+            return None, None, None, None
         dq = ops.infonce_bwd(q, k, queue, lse, gloss.contiguous().float(), ctx.T)
         return dq, None, None, None
 

@@ -22,6 +22,7 @@ def _world():
 class _NTXentFn(Function):
     @staticmethod
     def forward(ctx, h1, h2, T, co2_weight, gather):
+        ctx.set_materialize_grads(False)        # (see loss/moco.py)
         h1, h2 = h1.contiguous(), h2.contiguous()
         B = h1.shape[0]
         coll = bool(gather) and collectives_active()
@@ -44,6 +45,8 @@ class _NTXentFn(Function):
     @staticmethod
     def backward(ctx, gloss, _gacc):
         h1, h2, a_all, b_all, rowstats = ctx.saved_tensors
+        if gloss is None:
+            return None, None, None, None, None
         da, db, dA, dB = ops.ntxent_bwd(h1, h2, a_all, b_all, rowstats, gloss.contiguous().float(),
                                         ctx.roff, ctx.T, ctx.w)
         B = h1.shape[0]

@@ -31,17 +31,32 @@ class CLIPWrapper(nn.Layer):
         self.arena_q.refresh()
         return r
 
+    @property
+    def graph_safe(self):
+        """May the step be replayed from a recorded native plan (hip/replay.py)?  The reference's local-batch loss:
+        yes (nothing varies from step to step on the host); the cross-rank extension builds offset labels and adds
+        gathered-feature gradients with framework ops: not yet."""
+        return not self.multi_rank
+
+    def _arange(self, n, device):
+        """arange(n) on `device`, built once (a fresh one per step would be an ATen kernel inside the step)."""
+        cache = self.__dict__.setdefault('_label_cache', {})
+        lab = cache.get((n, str(device)))
+        if lab is None:
+            lab = cache[(n, str(device))] = torch.arange(n, device=device)
+            lab._passl_is_arange = True
+        return lab
+
     def train_iter(self, *inputs, **kwargs):
         image, text = inputs
         # the reference's labels are arange(len(image)); CLIPHead's kernel has them built in
-        img_labels = torch.arange(len(image), device=image.device)
-        text_labels = torch.arange(len(text), device=text.device)
+        img_labels = self._arange(len(image), image.device)
+        text_labels = self._arange(len(text), text.device)
         self.arena_q.refresh()
         if self.multi_rank:
             off = len(image) * dist.get_rank() if collectives_active() else 0
             img_logits, text_logits = self.model(image, text, is_train=True, multi_rank=True)
             return self.head(img_logits, text_logits, img_labels + off, text_labels + off)
-        img_labels._passl_is_arange = text_labels._passl_is_arange = True
         img_logits, text_logits = self.model(image, text, is_train=True)
         return self.head(img_logits, text_logits, img_labels, text_labels)
 

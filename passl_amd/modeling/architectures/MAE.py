@@ -15,6 +15,10 @@ from .builder import MODELS
 
 @MODELS.register()
 class MAE_PRETRAIN(nn.Layer):
+    # replayable from a recorded native plan (hip/replay.py): the masking noise is drawn by a live host call between
+    # two plan segments (backbones/mae.py:random_masking_ids), everything else that varies sits in device memory
+    graph_safe = True
+
     def __init__(self, architecture=None, mask_ratio=0.75):
         super().__init__()
         self.backbone = build_backbone(architecture)

@@ -235,7 +235,12 @@ class MAE(nn.Layer):
     def random_masking_ids(self, B, L, mask_ratio, noise=None):
         len_keep = int(L * (1 - mask_ratio))
         if noise is None:
-            noise = torch.rand(B, L, device=self.cls_token.device)     # paddle.rand([N, L])
+            # paddle.rand([N, L]).  torch.rand IS empty + uniform_ (same generator stream); written this way the draw is a
+            # host call that stays live when the step is replayed from a native plan (hip/replay.py) — a fresh mask
+            # at every replay, in the recorded buffer
+            from ...hip.replay import host_call
+            noise = torch.empty(B, L, device=self.cls_token.device)
+            host_call(lambda: noise.uniform_())
         ids_keep, ids_restore, mask = ops.mae_mask(noise.contiguous().float(), len_keep)
         return ids_keep, ids_restore, mask, len_keep
 

@@ -14,6 +14,7 @@ from .builder import HEADS
 class _SoftmaxCEFn(Function):
     @staticmethod
     def forward(ctx, scores, labels):
+        ctx.set_materialize_grads(False)        # (see loss/moco.py)
         scores = scores.contiguous()
         out, lse = ops.softmax_ce_fwd(scores, labels)
         ctx.save_for_backward(scores, lse, labels)
@@ -24,6 +25,8 @@ class _SoftmaxCEFn(Function):
     @staticmethod
     def backward(ctx, gloss, _g1, _g5):
         scores, lse, labels = ctx.saved_tensors
+        if gloss is None:
+            return None, None
         return ops.softmax_ce_bwd(scores, lse, labels, gloss.contiguous().float()), None
 
 

@@ -31,6 +31,7 @@ class _RowCEFn(Function):
 class _SymmetricCEFn(Function):
     @staticmethod
     def forward(ctx, logits):
+        ctx.set_materialize_grads(False)        # (see loss/moco.py)
         out, lse = ops.clip_ce_fwd(logits.contiguous())
         ctx.save_for_backward(logits, lse)
         img_loss, text_loss, loss = out[0:1], out[1:2], out[2:3]
@@ -40,6 +41,8 @@ class _SymmetricCEFn(Function):
     @staticmethod
     def backward(ctx, _gi, _gt, gloss):
         logits, lse = ctx.saved_tensors
+        if gloss is None:
+            return None
         return ops.clip_ce_bwd(logits, lse, gloss.contiguous().float())
 
 

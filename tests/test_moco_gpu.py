@@ -575,42 +575,6 @@ def test_step_plan_replay_is_bit_identical(dtype):
     assert float(a['losses'][0, 0]) != float(a['losses'][-1, 0])
 
 
-def test_trainer_replays_the_step_plan_by_default():
-    """Trainer on the MoCo config: after its warm-up the step runs as a replayed native plan (no opt-in needed), the
-    loss trajectory equals the eager Trainer's bit for bit, PASSL_PLAN=0 / cfg step_plan False keep it eager."""
-    from passl_amd.engine.trainer import Trainer
-    from passl_amd.utils.config import get_config
-    traj = {}
-    for plan in (False, True):
-        cfg = get_config(os.path.join(ROOT, 'configs/moco/moco_v2_r50_synthetic.yaml'),
-                         ['dataloader.train.sampler.batch_size=16', 'compute_dtype=bf16', 'seed=3'])
-        cfg.timestamp = ''
-        cfg.step_plan = plan
-        tr = Trainer(cfg)
-        assert (tr.step_graph is not None) == plan
-        tr.mode = 'train'
-        tr.model.train()
-        data = next(iter(tr.train_dataloader))
-        tr.call_hook('run_begin')
-        tr.call_hook('train_epoch_begin')
-        losses = []
-        for _ in range(8):
-            tr.inner_iter = tr.current_iter % tr.iters_per_epoch
-            tr.current_iter += 1
-            tr.call_hook('train_iter_begin')
-            tr.train_step(data)
-            tr.call_hook('train_iter_end')
-            losses.append(tr.outputs['loss'].detach().reshape(()).clone())
-        torch.cuda.synchronize()
-        if plan:
-            assert tr.step_graph.captured and tr.step_graph.replays == 4, (tr.step_graph.failed, tr.step_graph.replays)
-        traj[plan] = (torch.stack(losses).cpu(), tr.model.arena_q.flat.clone().cpu())
-        del tr
-        torch.cuda.empty_cache()
-    assert torch.equal(traj[False][0].view(torch.int32), traj[True][0].view(torch.int32))
-    assert torch.equal(traj[False][1].view(torch.int32), traj[True][1].view(torch.int32))
-
-
 def test_contrastive_head_forward_with_materialised_logits():
     """ContrastiveHead.forward(pos, neg) (reference contrastive_head.py:37-78: cat, / T, CrossEntropy, top-1/5):
     the compatibility entry runs the row cross-entropy / rank kernel and agrees with torch and with the fused

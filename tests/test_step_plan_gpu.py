@@ -1,0 +1,69 @@
+"""The native step plan (passl_amd/hip/replay.py) through the Trainer: for every workload whose model opts in, the
+Trainer replays the recorded launch list by default and the run equals the eager Trainer's bit for bit — loss
+trajectory and every parameter — including a step-varying learning rate, MAE's fresh masking noise per step (a live
+host call between two plan segments) and the three-stream MoCo schedule.  Reference loop: passl_v110/engine/
+trainer.py:287-337 + hooks/optimizer_hook.py:25-50."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+
+CASES = [('configs/moco/moco_v2_r50_synthetic.yaml', 16, 1), ('configs/clip/vit-b-32_synthetic.yaml', 8, 1),
+         ('configs/mae/mae_vit_b_synthetic.yaml', 8, 2)]
+
+
+def _run(cfg_path, batch, plan, steps=8):
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+    cfg = get_config(os.path.join(ROOT, cfg_path),
+                     ['dataloader.train.sampler.batch_size=%d' % batch, 'compute_dtype=bf16', 'seed=3'])
+    cfg.timestamp = ''
+    cfg.step_plan = plan
+    tr = Trainer(cfg)
+    assert (tr.step_graph is not None) == plan
+    tr.mode = 'train'
+    tr.model.train()
+    data = next(iter(tr.train_dataloader))
+    tr.call_hook('run_begin')
+    tr.call_hook('train_epoch_begin')
+    losses = []
+    for _ in range(steps):
+        tr.inner_iter = tr.current_iter % tr.iters_per_epoch
+        tr.current_iter += 1
+        tr.call_hook('train_iter_begin')
+        tr.train_step(data)
+        tr.call_hook('train_iter_end')
+        losses.append(tr.outputs['loss'].detach().reshape(()).float().clone())
+    torch.cuda.synchronize()
+    arena = getattr(tr.model, 'arena_q', None) or getattr(tr.model, 'arena')
+    out = dict(losses=torch.stack(losses).cpu(), flat=arena.flat.clone().cpu(), sg=tr.step_graph)
+    return out
+
+
+@pytest.mark.parametrize('cfg_path,batch,segments', CASES)
+def test_trainer_replays_the_step_plan_by_default(cfg_path, batch, segments):
+    eager = _run(cfg_path, batch, False)
+    torch.cuda.empty_cache()
+    plan = _run(cfg_path, batch, True)
+    sg = plan['sg']
+    assert sg.failed is None and not sg.foreign, (sg.failed, sg.foreign)
+    assert sg.captured and sg.replays == 4, sg.replays                    # 3 eager warm-up steps, 1 recording step
+    assert sg.info['segments'] == segments and sg.info['kernels'] > 200, sg.info
+    print(cfg_path, sg.info)
+    assert torch.isfinite(eager['losses']).all()
+    assert torch.equal(eager['losses'].view(torch.int32), plan['losses'].view(torch.int32)), \
+        (eager['losses'], plan['losses'])
+    assert torch.equal(eager['flat'].view(torch.int32), plan['flat'].view(torch.int32))
+    assert float(eager['losses'][0]) != float(eager['losses'][-1])
+
+
+def test_plan_kill_switch(monkeypatch):
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+    monkeypatch.setenv('PASSL_PLAN', '0')
+    cfg = get_config(os.path.join(ROOT, CASES[0][0]), ['dataloader.train.sampler.batch_size=8', 'compute_dtype=bf16'])
+    cfg.timestamp = ''
+    assert Trainer(cfg).step_graph is None
