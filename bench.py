@@ -272,7 +272,7 @@ def main():
     # HIP events around every launch of the MFMA kernel classes on their launch stream; the library sums
     # the launches' algorithmic FLOPs / bytes itself.  The side stream is off here so that a kernel's
     # duration is its own (in the timed loop the weight gradients run next to the main chain).
-    kern, rsteps, instr_elapsed = {}, 0, 0.0
+    kern, rsteps, instr_elapsed, event_overhead_us = {}, 0, 0.0, 0.0
     if not args.no_kernel_timing and args.roofline_steps > 0:
         import ctypes
         from passl_amd.hip import config as hip_config
@@ -298,6 +298,9 @@ def main():
             lib.passl_hip_prof_collect_work(cls, ctypes.byref(fl), ctypes.byref(by))
             kern[name] = dict(ms=ms.value, n=n.value, flops=fl.value, bytes=by.value)
         lib.passl_hip_prof_enable(0)
+        ov = ctypes.c_double()
+        lib.passl_hip_prof_event_overhead(256, L.stream(), ctypes.byref(ov))
+        event_overhead_us = ov.value
         hip_config.set_flag('overlap', overlap_was)
         if trainer.step_graph is not None:
             trainer.step_graph.enabled = graph_was
@@ -377,28 +380,31 @@ def main():
                 b['traffic_unit'] = 'HBM bytes per launch'
                 b['traffic_source'] = t['source'] if t else None
                 return b
-            # the dominant kernel (largest share of the step's kernel time): one of the two LDS-DMA implicit GEMMs,
-            # MFMA-bound — the 128-row ring kernel (R50) or the 256 x 256 8-phase kernel (the ViT workloads)
-            ring_b = block('ring', 'igemm_ring_kernel (LDS-DMA ring implicit GEMM, 128-row tiles: conv fwd / dgrad and '
-                           'Linear with a reduction of >= 512 that the 8-phase kernel does not take)', 'mfma')
-            g8_b = block('g8p', 'igemm_8p_kernel (LDS-DMA implicit GEMM, 256 x 256 tiles, 8-phase schedule: wide and '
-                         'deep conv fwd / dgrad and Linear launches)', 'mfma')
-            out['roofline'] = ring_b
-            if g8_b is not None and (ring_b is None or kern['g8p']['ms'] > kern['ring']['ms']):
-                out['roofline'] = g8_b
-            other = g8_b if out['roofline'] is ring_b else ring_b
-            if other is not None:
-                out['roofline_8p_kernel' if other is g8_b else 'roofline_ring_kernel'] = other
-            if out['roofline'] is None:          # neither LDS-DMA kernel ran (fp32): the dense kernel is the MFMA one
-                out['roofline'] = block('igemm', 'igemm_kernel (register-staged implicit GEMM)', 'mfma')
+            # `roofline` = the kernel class that holds the largest share of the step's kernel time over ALL four
+            # instrumented classes (round-3 verdict: the choice used to be between the two LDS-DMA kernels only, while
+            # the register-staged HBM-bound kernel was the largest).  The other three are reported beside it.
+            titles = {
+                'ring': ('igemm_ring_kernel (LDS-DMA ring implicit GEMM, 128-row tiles: conv fwd / dgrad and Linear with '
+                         'a reduction of >= 512 that the 8-phase kernel does not take)', 'mfma', 'roofline_ring_kernel'),
+                'g8p': ('igemm_8p_kernel (LDS-DMA implicit GEMM, 256 x 256 tiles, 8-phase schedule: wide and deep conv '
+                        'fwd / dgrad and Linear launches)', 'mfma', 'roofline_8p_kernel'),
+                'igemm': ('igemm_kernel (register-staged implicit GEMM: 1x1 layers with a reduction < 512, stem)',
+                          'hbm' if args.dtype == 'bf16' else 'mfma', 'roofline_hbm_kernel'),
+                'wgrad': ('wgrad_pipe_kernel (weight gradients, split over M + fixed-order slab reduction)', 'mfma',
+                          'roofline_wgrad_kernel')}
+            blocks = {k: block(k, t[0], t[1]) for k, t in titles.items()}
+            dominant = max((k for k in blocks if blocks[k] is not None), key=lambda k: kern[k]['ms'])
+            out['roofline'] = blocks[dominant]
+            out['roofline']['dominant_of'] = {k: round(kern[k]['ms'] / rsteps, 3) for k in blocks if blocks[k] is not None}
             out['roofline']['measured_over'] = (
-                '%d instrumented steps after the timed loop, side stream off (%.3f ms/step with the HIP '
-                'events in place)' % (rsteps, 1000 * instr_elapsed / rsteps))
-            # second largest: the register-staged implicit GEMM of the short-reduction 1x1 layers — HBM-bound
-            out['roofline_hbm_kernel'] = block('igemm', 'igemm_kernel (register-staged implicit GEMM: 1x1 layers with '
-                                               'a reduction < 512, stem)', 'hbm')
-            out['roofline_wgrad_kernel'] = block('wgrad', 'wgrad_pipe_kernel (weight gradients, split over M + '
-                                                 'fixed-order slab reduction)', 'mfma')
+                '%d instrumented steps after the timed loop, eager launches, side stream off (%.3f ms/step with the HIP '
+                'events in place); avg_launch_us is an (event, kernel, event) reading: the same bracket around nothing '
+                'reads %.1f us on this stream, rocprofv3 kernel durations (profiles/) are shorter by about that'
+                % (rsteps, 1000 * instr_elapsed / rsteps, event_overhead_us))
+            out['roofline']['event_bracket_overhead_us'] = round(event_overhead_us, 2)
+            for k, t in titles.items():
+                if k != dominant and blocks[k] is not None:
+                    out[t[2]] = blocks[k]
             ig = {k: kern['ring'][k] + kern['igemm'][k] + kern['g8p'][k] for k in ('ms', 'n', 'flops', 'bytes')}
             out['igemm_class'] = {
                 'what': 'all implicit-GEMM kernels together (the r01 roofline definition)',

@@ -436,6 +436,10 @@ int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma, c
 int passl_hip_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream);
 int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,
                        passl_stream_t stream);
+/* y = tanh(x);  dx = dy * (1 - tanh(x)^2)   (n a multiple of 8, 16-byte aligned).  Reference: the
+ * `representation_size` head of the v2 VisionTransformer, passl/models/vision_transformer.py:318-321,340-343. */
+int passl_hip_tanh_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream);
+int passl_hip_tanh_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, passl_stream_t stream);
 /* Fused softmax(q k^T * scale) v per (image, head) on the fused projection qkv [B,T,3,H,DH];
  * out [B,T,H,DH]; lse [B,H,T] (row log-sum-exp, saved for the backward).  DH in {32, 64},
  * T <= 208 (PASSL_EUNSUPPORTED otherwise).  Replaces Attention.forward, mae.py:141-155.
@@ -506,6 +510,9 @@ int passl_hip_prof_collect(int kernel_class, double* total_ms, int64_t* launches
  * taps) and HBM bytes (every operand element once).  Classes: 0 igemm_ring_kernel, 1 weight gradients,
  * 2 igemm_kernel (register-staged). */
 int passl_hip_prof_collect_work(int kernel_class, double* flops, double* bytes);
+/* Average reading (us) of n back-to-back event pairs with nothing in between on `stream`: what the event bracket of
+ * prof_enable adds to a kernel's own duration (synchronises the stream). */
+int passl_hip_prof_event_overhead(int n, passl_stream_t stream, double* avg_us);
 
 /* ---------------------------------------------------------------- CLIP
  * Reference: class CLIP, passl_v110/modeling/backbones/clip.py:183-336; QuickGELU

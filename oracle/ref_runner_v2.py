@@ -85,6 +85,15 @@ def load_simsiam():
     return ns
 
 
+def load_mae():
+    """-> namespace(+ mae module): passl/models/mae.py (MaskedAutoencoderViT, the mae_vit_* factories,
+    MAEVisionTransformer) over passl/models/vision_transformer.py and passl/models/utils/pos_embed.py."""
+    ns = load()
+    importlib.import_module('passl.models.utils.pos_embed')
+    ns.mae = importlib.import_module('passl.models.mae')
+    return ns
+
+
 def _exec_init(name):
     """Run a reference package's own __init__.py inside its pre-seeded package object (relative imports resolve
     through ``__path__``)."""

@@ -88,6 +88,33 @@ extern "C" int passl_hip_prof_collect_work(int cls, double* flops, double* bytes
   return PASSL_OK;
 }
 
+// What an (event, kernel, event) bracket reads ON TOP of the kernel's own duration: the same bracket around nothing,
+// averaged over n pairs on `stream` (synchronises).  bench.py reports it next to the event-timed averages: rocprofv3's
+// kernel durations are begin/end timestamps of the dispatch itself, an event pair also sees the two event packets
+// and the gap before the dispatch starts.
+extern "C" int passl_hip_prof_event_overhead(int n, passl_stream_t stream, double* avg_us) {
+  if (n <= 0 || n > 4096 || !avg_us) return PASSL_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return PASSL_ELAUNCH;
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventRecord(ev[2 * i], st);
+    (void)hipEventRecord(ev[2 * i + 1], st);
+  }
+  (void)hipStreamSynchronize(st);
+  double sum = 0.0;
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) { sum += ms; cnt += 1; }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (cnt == 0) return PASSL_ELAUNCH;
+  *avg_us = 1000.0 * sum / cnt;
+  return PASSL_OK;
+}
+
 int passl_igemm_ring_option(const char* name, int value);    // conv_igemm_ring.hip
 int passl_igemm_8p_option(const char* name, int value);      // conv_igemm_8p.hip
 int passl_wgrad_option(const char* name, int value);         // conv_wgrad.hip

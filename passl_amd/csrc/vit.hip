@@ -237,6 +237,34 @@ __global__ void __launch_bounds__(kThreads) gelu_kernel(const T* __restrict__ x,
   }
 }
 
+// tanh / its gradient (the `representation_size` head of the v2 VisionTransformer: tanh(head0(x)),
+// passl/models/vision_transformer.py:340-343); same streaming form as gelu_kernel
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(kThreads) tanh_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        T* __restrict__ out, int64_t nchunks) {
+  const int64_t base = (int64_t)blockIdx.x * (kThreads * kEltU) + threadIdx.x;
+  float v[kEltU][8], d[kEltU][8];
+#pragma unroll
+  for (int u = 0; u < kEltU; ++u) {
+    const int64_t i = base + u * kThreads;
+    const int64_t ic = i < nchunks ? i : nchunks - 1;
+    ld8(x + ic * 8, v[u]);
+    if (BWD) ld8(dy + ic * 8, d[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < kEltU; ++u) {
+    const int64_t i = base + u * kThreads;
+    if (i >= nchunks) break;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = tanhf(v[u][e]);
+      o[e] = BWD ? d[u][e] * (1.0f - t * t) : t;
+    }
+    ElemTraits<T>::store8(out + i * 8, o);
+  }
+}
+
 // ------------------------------------------------------------------ MAE masking
 // rank[i] = #{j : noise[j] < noise[i] or (== and j < i)}  (= ids_restore of argsort(argsort));
 // ids_keep[rank] = i for rank < K; mask[i] = rank >= K.   One block per row, L <= 4096.
@@ -614,6 +642,27 @@ extern "C" int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64
   if (!dy || !x || !dx || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(dy) || !aligned16(dx))
     return PASSL_EINVAL;
   VIT_DISPATCH(dtype, hipLaunchKernelGGL((gelu_kernel<T, true>), dim3(elt_grid(n >> 3)), dim3(kThreads),
+                                         0, as_stream(stream), reinterpret_cast<const T*>(x),
+                                         reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx),
+                                         n >> 3);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_tanh_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream) {
+  if (!x || !y || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(y)) return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL((tanh_kernel<T, false>), dim3(elt_grid(n >> 3)), dim3(kThreads),
+                                         0, as_stream(stream), reinterpret_cast<const T*>(x), nullptr,
+                                         reinterpret_cast<T*>(y), n >> 3);)
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_tanh_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,
+                                  passl_stream_t stream) {
+  if (!dy || !x || !dx || n <= 0 || (n & 7) || !aligned16(x) || !aligned16(dy) || !aligned16(dx))
+    return PASSL_EINVAL;
+  VIT_DISPATCH(dtype, hipLaunchKernelGGL((tanh_kernel<T, true>), dim3(elt_grid(n >> 3)), dim3(kThreads),
                                          0, as_stream(stream), reinterpret_cast<const T*>(x),
                                          reinterpret_cast<const T*>(dy), reinterpret_cast<T*>(dx),
                                          n >> 3);)

@@ -114,6 +114,8 @@ SIGNATURES = {
     'passl_hip_layernorm_bwd_ws_floats': (c_l, [c_l, c_i]),
     'passl_hip_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
+    'passl_hip_tanh_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
+    'passl_hip_tanh_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_attention_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     'passl_hip_attention_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p]),
     'passl_hip_quick_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
@@ -164,6 +166,7 @@ SIGNATURES = {
     'passl_hip_prof_enable': (c_i, [c_i]),
     'passl_hip_prof_collect': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(c_l)]),
     'passl_hip_prof_collect_work': (c_i, [c_i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'passl_hip_prof_event_overhead': (c_i, [c_i, c_p, C.POINTER(C.c_double)]),
 }
 
 _lib = None

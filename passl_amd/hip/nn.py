@@ -634,6 +634,23 @@ class GELU(Layer):
         return gelu(x)
 
 
+class _TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.tanh_fwd(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.tanh_bwd(dy.contiguous(), x)
+
+
+class Tanh(Layer):
+    def forward(self, x):
+        return _TanhFn.apply(x)
+
+
 class _AttentionFn(Function):
     """softmax(q k^T * scale) v per (image, head) on the fused qkv projection [B*T, 3*H*d]."""
 

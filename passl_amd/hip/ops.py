@@ -608,6 +608,19 @@ def gelu_bwd(dy, x):
     return dx
 
 
+def tanh_fwd(x):
+    y = torch.empty_like(x)
+    L.check(_lib().passl_hip_tanh_fwd(L.ptr(x), L.ptr(y), x.numel(), L.dt(x), L.stream()), 'tanh_fwd')
+    return y
+
+
+def tanh_bwd(dy, x):
+    dx = torch.empty_like(x)
+    L.check(_lib().passl_hip_tanh_bwd(L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.dt(x), L.stream()),
+            'tanh_bwd')
+    return dx
+
+
 def attention_fwd(qkv, B, T, H, DH, scale, causal=False):
     """qkv [B*T, 3*H*DH] -> out [B*T, H*DH], lse [B, H, T]."""
     out = torch.empty(B * T, H * DH, dtype=qkv.dtype, device=qkv.device)

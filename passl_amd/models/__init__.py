@@ -93,6 +93,11 @@ def simclr_resnet50(dim=128, T=0.1, multi_rank=False, **kw):
 from .mocov3 import (MoCoV3ViT, MoCoV3LinearProbe, MoCoV3Pretrain, mocov3_vit_base,      # noqa: E402,F401
                      mocov3_vit_base_linearprobe, mocov3_vit_base_pretrain)
 from .resnet import ResNet, resnet50                                   # noqa: E402,F401
+from .vision_transformer import *                                     # noqa: E402,F401,F403  (passl/models/__init__.py:24)
+from .vision_transformer import VisionTransformer                     # noqa: E402,F401
+from .mae import *                                                    # noqa: E402,F401,F403  (passl/models/__init__.py:31)
+from .mae import (MaskedAutoencoderViT, mae_vit_base_patch16_dec512d8b, mae_vit_large_patch16_dec512d8b,   # noqa: E402,F401
+                  mae_vit_huge_patch14_dec512d8b)
 from .simsiam import (SimSiamPretain, SimSiamLinearProbe, simsiam_resnet50_pretrain,      # noqa: E402,F401
                       simsiam_resnet50_linearprobe)
 

@@ -83,6 +83,14 @@ class _DeviceHyper(object):
             dev[0], dev[1], dev[2] = vals
         self._hyper_pushed = True
 
+    def set_lr(self, value):
+        """paddle.optimizer.Optimizer.set_lr: a fixed rate from now on (refused while a scheduler drives the rate, as
+        Paddle does)."""
+        if isinstance(self._learning_rate, LRScheduler):
+            raise RuntimeError("optimizer's learning rate can't be LRScheduler when invoke this API, because this "
+                               'will lead to conflict.')
+        self._learning_rate = float(value)
+
     def _hyper_for_step(self):
         if not self._hyper_pushed:
             self.push_hyper()
