@@ -160,6 +160,30 @@ def pmc_traffic(args):
     return out
 
 
+def pin_rank_to_cores():
+    """One rank per GPU on one node: give every rank its own contiguous slice of the host's cores (LOCAL_RANK-th of
+    LOCAL_WORLD_SIZE equal slices of the cores this process may run on).  The step's host side is one Python thread
+    (plus the autograd thread); without pinning 8 ranks migrate across sockets and a slow host stalls every rank at
+    the next gradient bucket.  PASSL_PIN_CORES=0 switches it off.  -> the core list, or None."""
+    if os.environ.get('PASSL_PIN_CORES', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', 1)))
+        local_rank = int(os.environ.get('LOCAL_RANK', 0))
+        if local_world <= 1:
+            return None
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        os.environ.setdefault('OMP_NUM_THREADS', str(max(1, min(per, 8))))
+        return mine
+    except (OSError, ValueError):
+        return None
+
+
 def step_launch(trainer):
     """How the timed steps were issued."""
     sg = trainer.step_graph
@@ -184,6 +208,8 @@ def main():
         os.environ['PASSL_DP_BUCKETS'] = str(args.dp_buckets)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
+
+    pinned = pin_rank_to_cores()
 
     import torch
     import torch.distributed as dist
@@ -412,6 +438,7 @@ def main():
                 'frac_of_mfma_peak': round(ig['flops'] / (ig['ms'] * 1e-3) / 1e12 / peak, 5),
                 'kernel_ms_per_step': round(ig['ms'] / rsteps, 3), 'launches': int(ig['n'])}
         if dist_info is not None:
+            dist_info['rank0_cores'] = ('%d-%d' % (pinned[0], pinned[-1])) if pinned else None
             out['dist'] = dist_info
         if world == 1 and not args.no_cpu_baseline and args.workload == 'moco':
             out['cpu_baseline'] = cpu_baseline()

@@ -454,3 +454,189 @@ def test_vit_block_teacher_forced_bf16(geometry):
         torch.autograd.backward([h, xr], [dev(rec[name + '.dout']), dev(dres)])
         rep.bf16(name + ' fork d-input', x.grad, rec[name + '.fork_din'])
     rep.finish()
+
+
+# ======================================================================================== BatchNorm-1D MLP heads
+def _head_oracle(dims, N, seed, last_affine, bias_last=False):
+    """Linear(no bias) - BatchNorm1D - ReLU ... chains of the v2 heads (MoCo-v3 projector / predictor,
+    passl/models/mocov3.py:135-157; SimSiam projector / predictor, passl/models/simsiam.py:47-66) evaluated OP BY OP in
+    fp64 under the product's storage contract: a Linear reads the bfloat16 rounding of its input rows and of its fp32
+    master weight and WRITES fp32; BatchNorm1D (batch statistics, biased variance, eps 1e-5) works on fp32 rows; the
+    gradient entering a Linear is rounded to bfloat16, its input gradient is stored as bfloat16.  -> params, rec, grads."""
+    gen = torch.Generator().manual_seed(seed)
+    P, rec, grads = {}, {}, {}
+    n_lin = len(dims) - 1
+    for l in range(n_lin):
+        i, o = dims[l], dims[l + 1]
+        P['lin%d.weight' % l] = ((torch.rand(i, o, generator=gen) * 2 - 1) * math.sqrt(6.0 / (i + o)))
+        if bias_last and l == n_lin - 1:
+            P['lin%d.bias' % l] = 0.05 * torch.randn(o, generator=gen)
+        has_bn = l < n_lin - 1 or not bias_last
+        if has_bn and (l < n_lin - 1 or last_affine):
+            P['bn%d.weight' % l] = 1 + 0.2 * torch.randn(o, generator=gen)
+            P['bn%d.bias' % l] = 0.2 * torch.randn(o, generator=gen)
+
+    def leaf(t):
+        return t.detach().clone().requires_grad_(True)
+
+    def bn(y, g=None, b=None):
+        mu = y.mean(0, keepdim=True)
+        var = ((y - mu) ** 2).mean(0, keepdim=True)
+        z = (y - mu) / torch.sqrt(var + 1e-5)
+        return z if g is None else z * g + b
+
+    x = torch.randn(N, dims[0], generator=gen).double() * 1.3 + 0.2          # fp32-valued rows
+    x = x.float().double()
+    fwd_in = x
+    chain = []
+    for l in range(n_lin):
+        wb = _rb(P['lin%d.weight' % l])
+        xin = fwd_in
+        y = _rb(xin) @ wb
+        if 'lin%d.bias' % l in P:
+            y = y + P['lin%d.bias' % l].double()
+        y = y.float().double()                                            # stored fp32
+        rec['lin%d.in' % l], rec['lin%d.out' % l] = xin, y
+        has_bn = ('bn%d.weight' % l in P) or (l == n_lin - 1 and not bias_last)
+        relu = l < n_lin - 1
+        if has_bn or relu:
+            g = P.get('bn%d.weight' % l)
+            b = P.get('bn%d.bias' % l)
+            z = bn(y, g.double() if g is not None else None, b.double() if b is not None else None)
+            if relu:
+                z = torch.relu(z)
+            z = z.float().double()
+            rec['bn%d.in' % l], rec['bn%d.out' % l] = y, z
+            fwd_in = z
+        else:
+            fwd_in = y
+        chain.append((l, has_bn or relu, relu))
+    dout = (torch.randn(N, dims[-1], generator=gen) * 1e-2).float().double()
+    for l, has_bn, relu in reversed(chain):
+        if has_bn:
+            yl = leaf(rec['bn%d.in' % l])
+            ps = [leaf(P[k].double()) for k in ('bn%d.weight' % l, 'bn%d.bias' % l) if k in P]
+            z = bn(yl, *ps) if ps else bn(yl)
+            if relu:
+                z = torch.relu(z)
+            z.backward(dout)
+            rec['bn%d.dout' % l] = dout
+            rec['bn%d.din' % l] = yl.grad.float().double()
+            for k, p in zip(('bn%d.weight' % l, 'bn%d.bias' % l), ps):
+                grads[k] = p.grad.clone()
+            dout = rec['bn%d.din' % l]
+        # Linear backward: the incoming gradient is cast to bf16, dx is stored bf16, dW / db are fp32 sums
+        dyb = _rb(dout)
+        rec['lin%d.dout' % l] = dout
+        wb = _rb(P['lin%d.weight' % l])
+        rec['lin%d.din' % l] = _rb(dyb @ wb.t())
+        grads['lin%d.weight' % l] = _rb(rec['lin%d.in' % l]).t() @ dyb
+        if 'lin%d.bias' % l in P:
+            grads['lin%d.bias' % l] = dyb.sum(0)
+        dout = rec['lin%d.din' % l]
+    return P, rec, grads
+
+
+@pytest.mark.parametrize('head', ['mocov3_projector', 'mocov3_predictor', 'simsiam_projector', 'simsiam_predictor'])
+def test_bn_mlp_heads_teacher_forced_bf16(head):
+    """The BatchNorm-1D MLP heads of MoCo-v3 and SimSiam under bf16 compute, op by op against the fp64 evaluation of
+    the same storage contract (every op fed the oracle's input / output gradient): Linear outputs and BatchNorm
+    outputs / input gradients / d-gamma / d-beta are fp32 results (relative-to-max bound), a Linear's input gradient is
+    a bf16 tensor (<= 2 ulp max, 1/2 ulp mean), weight gradients fp32.  With the teacher-forced trunk layers
+    (test_r50_layers_teacher_forced_bf16, test_vit_block_teacher_forced_bf16) and the fp32 criterion kernels below,
+    every kernel of the MoCo-v3 / SimSiam bf16 step has an element-wise bound of its own; the whole-step checks of
+    tests/test_mocov3_gpu.py / test_simsiam_gpu.py (direction and size of gradients) are smoke checks on top."""
+    dims, N, last_affine, bias_last = {
+        'mocov3_projector': ([768, 4096, 4096, 256], 64, False, False),
+        'mocov3_predictor': ([256, 4096, 256], 64, False, False),
+        'simsiam_projector': ([2048, 2048, 2048, 2048], 64, False, False),
+        'simsiam_predictor': ([2048, 512, 2048], 64, True, True),
+    }[head]
+    P, rec, grads = _head_oracle(dims, N, seed=23, last_affine=last_affine, bias_last=bias_last)
+    hip_config.set_device('gpu')
+    hip_config.set_compute_dtype(torch.bfloat16)
+    n_lin = len(dims) - 1
+    mods, names = [], []
+    for l in range(n_lin):
+        lin = nn.Linear(dims[l], dims[l + 1], bias_attr=None if ('lin%d.bias' % l) in P else False)
+        mods.append(lin)
+        names.append('lin%d' % l)
+        if ('bn%d.in' % l) in rec:
+            affine = ('bn%d.weight' % l) in P
+            mods.append(nn.BatchNorm1D(dims[l + 1]) if affine else
+                        nn.BatchNorm1D(dims[l + 1], weight_attr=False, bias_attr=False))
+            names.append('bn%d' % l)
+    seq = torch.nn.Sequential(*mods)
+    arena = nn.EncoderArena(seq, trainable=True)
+    with torch.no_grad():
+        for m, nm in zip(mods, names):
+            for pn, p in m.named_parameters():
+                p.copy_(P['%s.%s' % (nm, pn)].to(DEV))
+    arena.refresh()
+    rep = Report('bn_mlp_head_%s' % head)
+    for m, nm in zip(mods, names):
+        arena.clear_grad()
+        x = rec[nm + '.in'].float().to(DEV).requires_grad_(True)
+        if nm.startswith('lin'):
+            out = m(nn.to_compute(x, torch.bfloat16), out_f32=True)
+            rep.f32(nm + ' fwd (fp32 rows)', out, rec[nm + '.out'], 2e-6)
+        else:
+            l = int(nm[2:])
+            out = m(x, relu=l < n_lin - 1)
+            rep.f32(nm + ' fwd (fp32 rows)', out, rec[nm + '.out'], 5e-6)
+        out.backward(rec[nm + '.dout'].float().to(DEV))
+        torch.cuda.synchronize()
+        if nm.startswith('lin'):
+            rep.bf16(nm + ' d-input', x.grad, rec[nm + '.din'])
+            for pn, p in m.named_parameters():
+                rep.f32('%s d %s' % (nm, pn), p.grad, grads['%s.%s' % (nm, pn)], 2e-5)
+        else:
+            # a pre-activation that is zero to within rounding may land on either side of the ReLU (both are valid
+            # evaluations); the gradient is discontinuous there and, through d-gamma / d-beta, moves its whole channel:
+            # such channels are left out (at most 0.5 % of them may be)
+            keep = ~(((out.detach().cpu() > 0) != (rec[nm + '.out'] > 0)).any(0))
+            assert float((~keep).float().mean()) <= 5e-3, 'too many ReLU-boundary channels'
+            rep.lines.append('%s: %d of %d channels left out (ReLU boundary)' % (nm, int((~keep).sum()), keep.numel()))
+            rep.f32(nm + ' d-input', x.grad.cpu()[:, keep], rec[nm + '.din'][:, keep], 2e-5)
+            for pn, p in m.named_parameters():
+                rep.f32('%s d %s' % (nm, pn), p.grad.cpu()[keep], grads['%s.%s' % (nm, pn)][keep], 2e-5)
+    rep.finish()
+
+
+def test_contrastive_criteria_fp32_kernels_against_float64():
+    """What follows the heads in the two v2 methods, all fp32 kernels: MoCo-v3's l2-normalise -> q . k_all^T / T
+    (exact-fp32 MFMA GEMM over the keys of every rank, here 4 ranks' worth) -> row cross-entropy with offset labels
+    (passl/models/mocov3.py:170-198), and SimSiam's negative cosine similarity (passl/models/simsiam.py:69,93),
+    forward and backward against float64."""
+    from passl_amd.models.mocov3 import _KeyLogitsFn
+    from passl_amd.modeling.heads.clip_head import _RowCEFn
+    from passl_amd.loss.simsiam import neg_cosine_similarity
+    gen = torch.Generator().manual_seed(31)
+    N, D, W, T = 64, 256, 4, 0.2
+    q = torch.randn(N, D, generator=gen).requires_grad_(True)
+    k_all = torch.nn.functional.normalize(torch.randn(W * N, D, generator=gen), dim=1)
+    rank = 2
+    labels = torch.arange(N) + N * rank
+    qn = torch.nn.functional.normalize(q.double(), dim=1)
+    logits = qn @ k_all.double().t() / T
+    loss = torch.nn.functional.cross_entropy(logits, labels) * (2 * T)
+    loss.backward()
+    qd = q.detach().to(DEV).requires_grad_(True)
+    alpha = torch.full((1,), 1.0 / T, device=DEV)
+    lg = _KeyLogitsFn.apply(qd, k_all.to(DEV), alpha)
+    ld = _RowCEFn.apply(lg, labels.to(DEV)) * (2 * T)
+    ld.backward()
+    rep = Report('contrastive_criteria_fp32')
+    rep.f32('mocov3 logits', lg, logits.detach(), 2e-6)
+    rep.f32('mocov3 loss', ld.reshape(()), loss.detach().reshape(()), 2e-6)
+    rep.f32('mocov3 d q', qd.grad, q.grad, 2e-5)
+    p = (torch.randn(N, 2048, generator=gen) * 0.7).requires_grad_(True)
+    z = torch.randn(N, 2048, generator=gen)
+    ref = -torch.nn.functional.cosine_similarity(p.double(), z.double(), dim=1).mean()
+    ref.backward()
+    pd = p.detach().to(DEV).requires_grad_(True)
+    got = neg_cosine_similarity(pd, z.to(DEV))
+    got.backward()
+    rep.f32('simsiam -cos', got.reshape(()), ref.detach().reshape(()), 2e-6)
+    rep.f32('simsiam d p', pd.grad, p.grad, 2e-5)
+    rep.finish()
