@@ -267,6 +267,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # PASSL_MAIN_PRIORITY: the whole iteration (hooks included: they read the step's outputs) under a stream of that
+    # priority, so that the dependency chain is served before the side / key streams' fill-in work
+    from passl_amd.hip import streams as hip_streams
+    main_stream = hip_streams.main_stream(torch.device('cuda', torch.cuda.current_device()))
+    if main_stream is not None:
+        torch.cuda.synchronize()
+        _plain_step = step
+
+        def step():
+            with torch.cuda.stream(main_stream):
+                _plain_step()
+
     for _ in range(args.warmup):
         step()
     # a native step plan (hip/replay.py) runs a few eager steps and then records one before it replays: with a very
@@ -376,7 +388,8 @@ def main():
                        'timed_region': 'product path only (full hook bus); kernel instrumentation runs '
                                        'in a separate loop afterwards',
                        'host_enqueue_ms_per_step': round(1000 * host_elapsed / args.steps, 3),
-                       'step_launch': step_launch(trainer), 'extra_untimed_steps': extra_warm},
+                       'step_launch': step_launch(trainer), 'extra_untimed_steps': extra_warm,
+                       'main_stream_priority': main_stream.priority if main_stream is not None else None},
             'step_flop_roofline': {
                 'algorithmic_gflop_per_sample': flop_per_sample / 1e9,
                 'achieved_tflops_per_gpu': round(ips / world * flop_per_sample / 1e12, 2),

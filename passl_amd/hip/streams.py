@@ -84,11 +84,34 @@ _owners = {}
 _budget = {}
 
 
+def _aux_priority():
+    """Priority of the side / fork / key streams (PASSL_AUX_PRIORITY, default 0 = the framework's default; HIP: lower
+    number = served first).  The chain that bounds the step runs on the stream the step is called on; see
+    ``main_stream`` for running THAT one at a higher priority."""
+    return int(os.environ.get('PASSL_AUX_PRIORITY', '0'))
+
+
+_main_streams = {}
+
+
+def main_stream(device):
+    """PASSL_MAIN_PRIORITY=p (unset: None): a stream of priority p (-1 = served before the default-priority side /
+    key streams) for the step's dependency chain; the Trainer / bench run the iteration under it."""
+    p = os.environ.get('PASSL_MAIN_PRIORITY')
+    if p is None or p == '':
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _main_streams.get(key)
+    if s is None:
+        s = _main_streams[key] = torch.cuda.Stream(device=device, priority=int(p))
+    return s
+
+
 def side_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     s = _streams.get(key)
     if s is None:
-        s = _streams[key] = torch.cuda.Stream(device=device)
+        s = _streams[key] = torch.cuda.Stream(device=device, priority=_aux_priority())
     return s
 
 
@@ -104,7 +127,7 @@ def fork_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     s = _fork_streams.get(key)
     if s is None:
-        s = _fork_streams[key] = torch.cuda.Stream(device=device)
+        s = _fork_streams[key] = torch.cuda.Stream(device=device, priority=_aux_priority())
     return s
 
 
@@ -117,7 +140,7 @@ def key_stream(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     s = _key_streams.get(key)
     if s is None:
-        s = _key_streams[key] = torch.cuda.Stream(device=device)
+        s = _key_streams[key] = torch.cuda.Stream(device=device, priority=_aux_priority())
     return s
 
 
