@@ -102,6 +102,14 @@ def unpad_add(src, dst, rows, R, dst_S, dst_C, src_S, src_C):
             'unpad_add')
 
 
+def add_into(dst, src):
+    """dst += src for contiguous fp32 tensors of the same size (the fixed-order slab adder with one slab)."""
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.numel() == src.numel()
+    assert dst.is_contiguous() and src.is_contiguous()
+    L.check(_lib().passl_hip_slab_reduce(L.ptr(src), L.ptr(dst), dst.numel(), 1, 1, L.stream()), 'slab_reduce')
+    return dst
+
+
 _ones = {}
 
 
@@ -528,8 +536,8 @@ def ntxent_fwd(a, b, a_all, b_all, row_offset, T, co2_weight=3.0):
 def ntxent_bwd(a, b, a_all, b_all, rowstats, gscale, row_offset, T, co2_weight=3.0):
     """Returns (da, db, da_all, db_all): row-role and column-role gradients."""
     B, Dd = a.shape
-    da, db = torch.zeros_like(a), torch.zeros_like(b)
-    da_all, db_all = torch.zeros_like(a_all), torch.zeros_like(b_all)
+    da, db = zeros_like(a), zeros_like(b)
+    da_all, db_all = zeros_like(a_all), zeros_like(b_all)
     L.check(_lib().passl_hip_ntxent_bwd(L.ptr(a), L.ptr(b), L.ptr(a_all), L.ptr(b_all),
                                         L.ptr(rowstats), L.ptr(gscale), B, a_all.shape[0],
                                         int(row_offset), Dd, T, co2_weight, L.ptr(da), L.ptr(db),

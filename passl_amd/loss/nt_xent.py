@@ -56,6 +56,10 @@ class _NTXentFn(Function):
             dist.reduce_scatter_tensor(rb, dB)
             da += ra
             db += rb
+        elif da.is_cuda:
+            # (library adds: an ATen `+=` would be a foreign launch inside a step that a native plan replays)
+            ops.add_into(da, dA[ctx.roff:ctx.roff + B])
+            ops.add_into(db, dB[ctx.roff:ctx.roff + B])
         else:
             da += dA[ctx.roff:ctx.roff + B]
             db += dB[ctx.roff:ctx.roff + B]

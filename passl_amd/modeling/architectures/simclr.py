@@ -7,7 +7,7 @@ contract are the reference's; the encoder's parameters live in one EncoderArena 
 + flat gradient buffer) so LARS is a two-launch multi-tensor update."""
 import torch
 
-from ...hip import nn
+from ...hip import nn, ops
 from ...hip.nn import EncoderArena
 from ..backbones import build_backbone
 from ..heads import build_head
@@ -15,8 +15,41 @@ from ..necks import build_neck
 from .builder import MODELS
 
 
+class _SplitViews(torch.autograd.Function):
+    """(con[:n], con[n:]) — the two views' rows.  Backward writes the two gradients into ONE buffer with the library's
+    copy kernel; autograd's own slice backward would be two zero fills, two copies and an add per step."""
+
+    @staticmethod
+    def forward(ctx, con, n):
+        ctx.n, ctx.rows = n, con.shape[0]
+        ctx.set_materialize_grads(False)
+        return con[:n], con[n:]
+
+    @staticmethod
+    def backward(ctx, dq, dk):
+        ref = dq if dq is not None else dk
+        if ref is None:
+            return None, None
+        n = ctx.n
+        out = torch.empty((ctx.rows,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device)
+        for part, g in ((out[:n], dq), (out[n:], dk)):
+            if g is None:
+                ops.fill_zero(part) if part.is_cuda else part.zero_()
+            elif part.is_cuda:
+                ops.copy_into(part, g.contiguous())
+            else:
+                part.copy_(g)
+        return out, None
+
+
 @MODELS.register()
 class SimCLR(nn.Layer):
+    @property
+    def graph_safe(self):
+        """Replayable from a recorded native plan (hip/replay.py) unless the head gathers embeddings across ranks
+        (those collectives sit inside the loss function's forward / backward)."""
+        return not getattr(self.head, 'multi_rank', False)
+
     def __init__(self, backbone, neck=None, head=None, dim=128, T=0.5):
         super().__init__()
         self.T = T
@@ -36,11 +69,17 @@ class SimCLR(nn.Layer):
     def train_iter(self, *inputs, **kwargs):
         img_q, img_k = inputs
         self.arena_q.refresh()
-        img_con = torch.cat([img_q, img_k])
+        n = img_q.shape[0]
+        if img_q.is_cuda and img_q.is_contiguous() and img_k.is_contiguous() and img_q.dtype == img_k.dtype:
+            # paddle.concat([img_q, img_k]) with the library's copy kernel (no framework launch inside the step)
+            img_con = torch.empty((2 * n,) + tuple(img_q.shape[1:]), dtype=img_q.dtype, device=img_q.device)
+            ops.copy_into(img_con[:n], img_q)
+            ops.copy_into(img_con[n:], img_k)
+        else:
+            img_con = torch.cat([img_q, img_k])
         con = self.encoder(img_con)
         con = nn.normalize(con, axis=1)                    # layers.l2_normalize(con, -1)
-        n = img_q.shape[0]
-        q, k = con[:n], con[n:]
+        q, k = _SplitViews.apply(con, n)
         return self.head(q, k)
 
     def forward(self, *inputs, mode='train', **kwargs):
