@@ -432,6 +432,10 @@ int passl_hip_layernorm_bwd(const void* dy, const void* x, const float* gamma, c
                             const float* rstd, const void* dres, void* dx, float* dgamma,
                             float* dbeta, int64_t M, int C, int dtype, float* ws, int64_t ws_floats,
                             passl_stream_t stream);
+/* layernorm_bwd with dgamma == dbeta == NULL leaves its per-block partial sums in ws (which must then be the caller's
+ * own buffer, not a shared scratch); this folds them — dgamma / dbeta += the fixed-order sums — on any stream. */
+int passl_hip_layernorm_param_reduce(const float* ws, int64_t M, int C, float* dgamma, float* dbeta,
+                                     passl_stream_t stream);
 /* exact (erf) GELU and its backward dx = dy * gelu'(x); n % 8 == 0. */
 int passl_hip_gelu_fwd(const void* x, void* y, int64_t n, int dtype, passl_stream_t stream);
 int passl_hip_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype,

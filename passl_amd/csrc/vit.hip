@@ -606,7 +606,10 @@ extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const floa
                                        const float* mean, const float* rstd, const void* dres,
                                        void* dx, float* dgamma, float* dbeta, int64_t M, int C,
                                        int dtype, float* ws, int64_t ws_floats, passl_stream_t stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !ws || M <= 0 || C <= 0 ||
+  // dgamma == dbeta == NULL: leave the per-block partial sums in ws; passl_hip_layernorm_param_reduce folds them later
+  // (on another stream: the fold is a latency-bound launch that the input-gradient chain does not depend on)
+  const bool defer = !dgamma && !dbeta;
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || (!defer && (!dgamma || !dbeta)) || !ws || M <= 0 || C <= 0 ||
       (C & 7) || C > 512 * kLnMaxChunks || !aligned16(dy) || !aligned16(x) || !aligned16(dx) ||
       !aligned16(gamma) || (dres && !aligned16(dres)) || ws_floats < passl_hip_layernorm_bwd_ws_floats(M, C))
     return PASSL_EINVAL;
@@ -622,6 +625,18 @@ extern "C" int passl_hip_layernorm_bwd(const void* dy, const void* x, const floa
   else if (C <= 1024) { LN_BWD_LAUNCH(2) }
   else { LN_BWD_LAUNCH(4) }
 #undef LN_BWD_LAUNCH
+  if (!defer)
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 15) / 16), dim3(kThreads), 0, as_stream(stream), ws, nb,
+                       C, dgamma, dbeta);
+  PASSL_RETURN_IF_LAUNCH_FAILED();
+  return PASSL_OK;
+}
+
+extern "C" int passl_hip_layernorm_param_reduce(const float* ws, int64_t M, int C, float* dgamma, float* dbeta,
+                                                passl_stream_t stream) {
+  if (!ws || !dgamma || !dbeta || M <= 0 || C <= 0 || (C & 7) || C > 512 * kLnMaxChunks) return PASSL_EINVAL;
+  int rows, nb;
+  ln_bwd_blocks(M, rows, nb);
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 15) / 16), dim3(kThreads), 0, as_stream(stream), ws, nb,
                      C, dgamma, dbeta);
   PASSL_RETURN_IF_LAUNCH_FAILED();

@@ -15,7 +15,8 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fuse_residual_grad': os.environ.get('PASSL_FUSE_RESIDUAL_GRAD', '1') != '0',
           'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0',
           'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
-          'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0'}
+          'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
+          'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0'}
 
 
 def set_device(name):
@@ -100,6 +101,13 @@ def fork_downsample():
     return _state['fork_downsample']
 
 
+def side_reductions():
+    """With `overlap`: the small parameter-gradient reductions of a backward node (a Linear's bias column sums, the
+    fold of LayerNorm's d-gamma / d-beta partials) run on the second HIP stream, off the data-gradient chain."""
+    return _state['side_reductions']
+
+
 def set_flag(name, value):
-    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample')
+    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample',
+                    'side_reductions')
     _state[name] = bool(value)

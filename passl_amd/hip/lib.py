@@ -112,6 +112,7 @@ SIGNATURES = {
     'passl_hip_layernorm_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p]),
     'passl_hip_layernorm_bwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_l, c_p]),
     'passl_hip_layernorm_bwd_ws_floats': (c_l, [c_l, c_i]),
+    'passl_hip_layernorm_param_reduce': (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
     'passl_hip_gelu_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_gelu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     'passl_hip_tanh_fwd': (c_i, [c_p, c_p, c_l, c_i, c_p]),

@@ -590,16 +590,31 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None):
-    """dres: gradient of the residual branch that forked off x (added to dx inside the kernel)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, defer_params=False):
+    """dres: gradient of the residual branch that forked off x (added to dx inside the kernel).
+    defer_params: only dx now; -> (dx, partials, fold) where ``fold()`` adds the fixed-order parameter sums into
+    dgamma / dbeta on whatever stream is current when it is called (hip/nn.py runs it on the side stream: a
+    latency-bound launch the input-gradient chain does not wait for)."""
     Cc = x.shape[-1]
     M = x.numel() // Cc
     dx = torch.empty_like(x)
-    ws = workspace.get(-(-M // 16) * 2 * Cc, x.device)       # >= passl_hip_layernorm_bwd_ws_floats(M, C)
-    L.check(_lib().passl_hip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
-                                           L.ptr(dres) if dres is not None else None, L.ptr(dx),
-                                           L.ptr(dgamma), L.ptr(dbeta), M, Cc, L.dt(x), L.ptr(ws), ws.numel(),
-                                           L.stream()), 'layernorm_bwd')
+    need = -(-M // 16) * 2 * Cc                              # >= passl_hip_layernorm_bwd_ws_floats(M, C)
+    lib = _lib()
+    if defer_params:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)      # its own buffer: read later, elsewhere
+        L.check(lib.passl_hip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                                            L.ptr(dres) if dres is not None else None, L.ptr(dx), None, None, M, Cc,
+                                            L.dt(x), L.ptr(ws), ws.numel(), L.stream()), 'layernorm_bwd')
+
+        def fold():
+            L.check(lib.passl_hip_layernorm_param_reduce(L.ptr(ws), M, Cc, L.ptr(dgamma), L.ptr(dbeta), L.stream()),
+                    'layernorm_param_reduce')
+        return dx, ws, fold
+    ws = workspace.get(need, x.device)
+    L.check(lib.passl_hip_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(gamma), L.ptr(mean), L.ptr(rstd),
+                                        L.ptr(dres) if dres is not None else None, L.ptr(dx),
+                                        L.ptr(dgamma), L.ptr(dbeta), M, Cc, L.dt(x), L.ptr(ws), ws.numel(),
+                                        L.stream()), 'layernorm_bwd')
     return dx
 
 

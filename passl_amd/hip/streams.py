@@ -194,10 +194,21 @@ def on_side(device, reads=(), in_backward=False):
             wait_event(owner, done)
         _held_bytes[key] -= nbytes
         del held
-    if in_backward:
-        # join at the end of this backward pass: whoever reads .grad afterwards sees finished work
-        # (one callback per hand-off; all but the first find nothing left to wait for)
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: join(device))
+    if in_backward and key not in _join_queued:
+        # join at the end of this backward pass: whoever reads .grad afterwards sees finished work.  ONE callback per
+        # backward pass: a join is an event record + a cross-stream wait, and on this GPU every such wait costs the
+        # waiting stream ~10 us even when the event has long fired — one callback per hand-off (r02-r03) was 55
+        # waits = 0.32 ms of idle GPU in front of MoCo's optimizer launch and 167 waits = 1.6 ms in front of MAE's
+        # (profiles/r04_trace_timeline_*.txt)
+        _join_queued.add(key)
+
+        def _join_at_end():
+            _join_queued.discard(key)
+            join(device)
+        torch.autograd.Variable._execution_engine.queue_callback(_join_at_end)
+
+
+_join_queued = set()     # devices with an end-of-backward join callback already queued for the running backward pass
 
 
 def reset():
@@ -208,6 +219,7 @@ def reset():
     _pending.clear()
     _owners.clear()
     _held_bytes.clear()
+    _join_queued.clear()
 
 
 def join(device):

@@ -78,6 +78,12 @@ def main():
     print('idle before (ms per step):')
     for n in sorted(gaps, key=lambda k: -gaps[k])[:12]:
         print('  %-64s %.3f' % (n, gaps[n] / steps))
+    # what surrounds the marker launch of the last step in the window (us relative to the marker's start)
+    last = max(i for i, e in enumerate(win) if marker in e[3])
+    m0 = win[last][0]
+    print('around the last %s (start us rel. to it, duration us, stream, workgroups, kernel):' % marker)
+    for s, e, st, n, wg in win[max(0, last - 16):last + 8]:
+        print('  %10.1f %8.1f  s%-3s %6d  %s' % ((s - m0) / 1e3, (e - s) / 1e3, st, wg, n))
 
 
 if __name__ == '__main__':
