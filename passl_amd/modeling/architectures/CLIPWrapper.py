@@ -33,18 +33,17 @@ class CLIPWrapper(nn.Layer):
 
     @property
     def graph_safe(self):
-        """May the step be replayed from a recorded native plan (hip/replay.py)?  The reference's local-batch loss:
-        yes (nothing varies from step to step on the host); the cross-rank extension builds offset labels and adds
-        gathered-feature gradients with framework ops: not yet."""
-        return not self.multi_rank
+        """May the step be replayed from a recorded native plan (hip/replay.py)?  Yes: nothing varies from step to step
+        on the host; the cross-rank extension's collectives stay live host calls between plan segments."""
+        return True
 
-    def _arange(self, n, device):
-        """arange(n) on `device`, built once (a fresh one per step would be an ATen kernel inside the step)."""
+    def _arange(self, n, device, off=0):
+        """arange(n) + off on `device`, built once (a fresh one per step would be an ATen kernel inside the step)."""
         cache = self.__dict__.setdefault('_label_cache', {})
-        lab = cache.get((n, str(device)))
+        lab = cache.get((n, str(device), off))
         if lab is None:
-            lab = cache[(n, str(device))] = torch.arange(n, device=device)
-            lab._passl_is_arange = True
+            lab = cache[(n, str(device), off)] = torch.arange(n, device=device) + off
+            lab._passl_is_arange = off == 0
         return lab
 
     def train_iter(self, *inputs, **kwargs):
@@ -56,7 +55,8 @@ class CLIPWrapper(nn.Layer):
         if self.multi_rank:
             off = len(image) * dist.get_rank() if collectives_active() else 0
             img_logits, text_logits = self.model(image, text, is_train=True, multi_rank=True)
-            return self.head(img_logits, text_logits, img_labels + off, text_labels + off)
+            return self.head(img_logits, text_logits, self._arange(len(image), image.device, off),
+                             self._arange(len(text), text.device, off))
         img_logits, text_logits = self.model(image, text, is_train=True)
         return self.head(img_logits, text_logits, img_labels, text_labels)
 

@@ -84,7 +84,10 @@ def _gather_rows_all(t):
     if not collectives_active():
         return t
     out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous())
+    src = t.contiguous()
+    # (a live call also when the step is replayed from a native plan: the plan is cut here, hip/replay.py)
+    from ...hip.replay import host_call
+    host_call(lambda: dist.all_gather_into_tensor(out, src))
     return out
 
 
@@ -93,7 +96,9 @@ def _reduce_scatter_rows(t, rows):
     if not collectives_active():
         return t
     out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.reduce_scatter_tensor(out, t.contiguous())
+    src = t.contiguous()
+    from ...hip.replay import host_call
+    host_call(lambda: dist.reduce_scatter_tensor(out, src))
     return out
 
 
@@ -133,8 +138,11 @@ class _CrossRankLogitsFn(Function):
         ops.dot_acc(dlt, lt, s.grad)
         nn.param_grad_ready(s)
         # row role (local rows) + column role (this rank's features inside every rank's other matrix)
-        dimg = ops.gemm_f32_gx(dli, txt_all, alpha) + _reduce_scatter_rows(ops.gemm_f32_gx(dlt, txt_n, alpha, trans=True), B)
-        dtxt = ops.gemm_f32_gx(dlt, img_all, alpha) + _reduce_scatter_rows(ops.gemm_f32_gx(dli, img_n, alpha, trans=True), B)
+        # (library adds: no framework launch inside a step that a native plan replays)
+        dimg = ops.add_into(ops.gemm_f32_gx(dli, txt_all, alpha),
+                            _reduce_scatter_rows(ops.gemm_f32_gx(dlt, txt_n, alpha, trans=True), B))
+        dtxt = ops.add_into(ops.gemm_f32_gx(dlt, img_all, alpha),
+                            _reduce_scatter_rows(ops.gemm_f32_gx(dli, img_n, alpha, trans=True), B))
         return (ops.l2norm_bwd(dimg, img_n, img_norm, torch.float32),
                 ops.l2norm_bwd(dtxt, txt_n, txt_norm, torch.float32), None)
 

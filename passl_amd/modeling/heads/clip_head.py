@@ -28,6 +28,31 @@ class _RowCEFn(Function):
         return ops.softmax_ce_bwd(logits, lse, labels, gloss.contiguous().float()), None
 
 
+class _Add2Fn(Function):
+    """a + b for two 1-element fp32 device tensors through the library's fixed-order dot product (a framework add would
+    be a foreign launch inside a step that a native plan replays, hip/replay.py)."""
+
+    _ones = {}
+
+    @staticmethod
+    def forward(ctx, a, b):
+        if not a.is_cuda:
+            return a + b
+        v = torch.empty(2, dtype=torch.float32, device=a.device)
+        ops.copy_into(v[0:1], a.detach().reshape(1).contiguous())
+        ops.copy_into(v[1:2], b.detach().reshape(1).contiguous())
+        ones = _Add2Fn._ones.get(a.device)
+        if ones is None:
+            ones = _Add2Fn._ones[a.device] = torch.ones(2, dtype=torch.float32, device=a.device)
+        out = ops.zeros(1, dtype=torch.float32, device=a.device)
+        ops.dot_acc(v, ones, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class _SymmetricCEFn(Function):
     @staticmethod
     def forward(ctx, logits):
@@ -60,7 +85,7 @@ class CLIPHead(nn.Layer):
             outputs = dict()
             outputs['img_loss'] = _RowCEFn.apply(img_logits, img_labels.contiguous().long())
             outputs['text_loss'] = _RowCEFn.apply(text_logits, text_labels.contiguous().long())
-            outputs['loss'] = outputs['img_loss'] + outputs['text_loss']
+            outputs['loss'] = _Add2Fn.apply(outputs['img_loss'], outputs['text_loss'])
             return outputs
         same = (text_logits.data_ptr() == img_logits.data_ptr() and text_logits.shape == img_logits.shape and
                 text_logits.stride() == img_logits.stride()[::-1] and img_logits.is_contiguous())

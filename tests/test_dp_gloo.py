@@ -255,6 +255,7 @@ def _clip_gather_case(rank, world):
     ops.gemm_f32_nt = lambda a, b, alpha: alpha * (a @ b.t())
     ops.gemm_f32_gx = lambda g, x, alpha, trans=False: alpha * ((g.t() if trans else g) @ x)
     ops.dot_acc, ops.softmax_ce_fwd, ops.softmax_ce_bwd = dot_acc, ce_fwd, ce_bwd
+    ops.add_into = lambda dst, src: dst.add_(src)
 
     gen = torch.Generator().manual_seed(9)
     N, D = 5, 32

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 
 CASES = [('configs/moco/moco_v2_r50_synthetic.yaml', 16, 1), ('configs/clip/vit-b-32_synthetic.yaml', 8, 1),
-         ('configs/mae/mae_vit_b_synthetic.yaml', 8, 2), ('configs/simclr/simclr_r50_synthetic.yaml', 8, 1)]
+         ('configs/mae/mae_vit_b_synthetic.yaml', 8, 2), ('configs/simclr/simclr_r50_synthetic.yaml', 8, 1),
+         ('configs/clip/vit-b-16_synthetic.yaml', 8, 1)]          # cross-rank InfoNCE path (one rank: no collectives)
 
 
 def _run(cfg_path, batch, plan, steps=8):
