@@ -219,9 +219,9 @@ def conv_wgrad(d: P.Desc, a, dy, dw, splits=None):
 
 
 # ------------------------------------------------------------------ batch norm
-def _bn_blocks(M, Cch):
+def _bn_blocks(M, Cch, cap=1024):
     lanes = max(1, 256 // max(Cch // 8, 1))
-    return int(max(1, min(1024, -(-M // (16 * lanes)))))
+    return int(max(1, min(cap, -(-M // (16 * lanes)))))
 
 
 def conv_stats_buffer(d: P.Desc, device):
@@ -319,7 +319,9 @@ def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=Fa
         partial, nb = fused
         r, zp = 0, None
     else:
-        nb = _bn_blocks(M, Cch)
+        # 768 = 3 resident workgroups per CU x 256 CUs: the backward-reduce kernel needs 136 VGPRs (3 waves per SIMD), and
+        # a 1024-block launch ran a second, one-third-occupied round (the stem's reduce: 822 MB in 292 us = 2.8 TB/s)
+        nb = _bn_blocks(M, Cch, cap=768)
         partial = torch.empty(bn_partial_floats(nb, Cch, False), dtype=torch.float32, device=dev)
         L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), zp, L.ptr(x), L.ptr(mean), L.ptr(invstd),
                                             L.ptr(scale), L.ptr(shift), L.ptr(partial), M, Cch, nb, r,

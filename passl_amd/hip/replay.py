@@ -208,6 +208,12 @@ class StepPlan(object):
 
     def _record(self, data):
         lib = L.load()
+        if not (hasattr(torch.cuda, 'MemPool') and hasattr(torch._C, '_cuda_beginAllocateToPool') and
+                hasattr(torch._C, '_cuda_endAllocateToPool')):
+            # (no private allocator pool on this torch build: recorded addresses could not be kept stable)
+            self.failed = 'torch build without the caching-allocator pool API (torch.cuda.MemPool)'
+            logger.warning('StepPlan: %s; continuing with eager launches', self.failed)
+            return self.fn(*data)
         dev = next(d.device for d in data if torch.is_tensor(d))
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         torch.cuda.synchronize(dev)
