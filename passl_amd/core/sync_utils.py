@@ -172,6 +172,50 @@ class GradReducer(object):
         return sum(ms) / len(ms)
 
 
+class ReducerGroup(object):
+    """One overlapped GradReducer per trainable arena behind the single-reducer interface the loops / hooks use
+    (``begin`` before the backward pass; every optimizer waits for its own arena's reducer in ``step``).  A model whose
+    parameter groups live in separate arenas (SimSiam: encoder + predictor, passl/models/simsiam.py with the recipe's
+    two learning rates) used to fall back to the loop's blocking per-buffer ``grad_sync`` after backward; with a group
+    its gradient buckets are all-reduced from inside the backward pass like everyone else's.  The collectives are
+    issued in the order the buckets become ready, which is a property of the graph: identical on every rank."""
+
+    def __init__(self, arenas, optimizer=None, group=None):
+        self.reducers = [GradReducer(a, None, group=group) for a in arenas]
+        self.world = self.reducers[0].world
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+
+    @property
+    def buckets(self):
+        return [b for r in self.reducers for b in r.buckets]
+
+    @property
+    def grads(self):
+        return torch.cat([r.grads for r in self.reducers]) if len(self.reducers) > 1 else self.reducers[0].grads
+
+    @property
+    def measure(self):
+        return self.reducers[0].measure
+
+    @measure.setter
+    def measure(self, v):
+        for r in self.reducers:
+            r.measure = v
+
+    def begin(self):
+        for r in self.reducers:
+            r.begin()
+
+    def finish(self):
+        for r in self.reducers:
+            r.finish()
+
+    def exposed_ms(self):
+        vals = [v for v in (r.exposed_ms() for r in self.reducers) if v is not None]
+        return sum(vals) if vals else None
+
+
 @torch.no_grad()
 def grad_sync(param_groups, comm_group=None, grad_avg=True):
     """v2 spelling (passl/core/sync_utils.py:18-43): blocking all_reduce of every parameter's

@@ -20,6 +20,7 @@ them (MoCo-v3's momentum schedule).
 """
 import inspect
 import copy
+import os
 import logging
 import random
 
@@ -27,7 +28,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from ..core.sync_utils import GradReducer, collectives_active, param_sync
+from ..core.sync_utils import GradReducer, ReducerGroup, collectives_active, param_sync
 from ..hip import config as hip_config
 from ..models import build_model
 from ..solver.builder import LRSCHEDULERS, OPTIMIZERS
@@ -253,10 +254,13 @@ class Engine(object):
             arch = getattr(self.model, 'arch', self.model)
             param_sync(arch)
             arenas = arch.trainable_arenas() if hasattr(arch, 'trainable_arenas') else None
-            if arenas is not None and len(arenas) > 1:
+            if arenas is not None and len(arenas) > 1 and os.environ.get('PASSL_DP_BLOCKING_GROUPS') == '1':
                 # several trainable arenas (parameter groups): the loop's blocking grad_sync reduces each flat
-                # gradient buffer after backward (reference behaviour); the overlapped reducer handles one arena
+                # gradient buffer after backward (the reference's behaviour, sync_utils.py:18-43; kept as a switch)
                 self.grad_reducer = None
+            elif arenas is not None and len(arenas) > 1:
+                # one overlapped reducer per arena: the buckets are all-reduced from inside the backward pass
+                self.grad_reducer = ReducerGroup(arenas, self.optimizer)
             else:
                 self.grad_reducer = GradReducer(arch.arena_q if hasattr(arch, 'arena_q') else arch.arena,
                                                 self.optimizer)

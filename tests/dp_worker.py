@@ -262,11 +262,50 @@ def lp_run():
     dist.destroy_process_group()
 
 
+def simsiam_engine_run():
+    """Two data-parallel ranks of the SimSiam pre-training recipe through the v2 Engine: two trainable arenas (encoder /
+    predictor parameter groups).  Default: one OVERLAPPED reducer per arena (core/sync_utils.py:ReducerGroup);
+    PASSL_DP_BLOCKING_GROUPS=1: the loop's blocking grad_sync (the reference's passl/core/sync_utils.py:18-43).  Prints a
+    digest of both arenas after three steps: the two modes must agree bit for bit (the caller compares), and the
+    replicas must be identical."""
+    import hashlib
+    from passl_amd.core.sync_utils import ReducerGroup
+    from passl_amd.engine.engine import Engine
+    from passl_amd.utils.config import get_config
+    cfg = get_config(os.path.join(ROOT, 'configs', 'v2', 'simsiam_resnet50_pt_synthetic.yaml'),
+                     ['Global.epochs=1', 'Global.print_batch_step=1', 'Global.output_dir=%s' % os.environ['PASSL_DP_OUT'],
+                      'DataLoader.Train.dataset.num_samples=%d' % (2 * 3 * 8), 'DataLoader.Train.dataset.image_size=64',
+                      'DataLoader.Train.sampler.batch_size=8'])
+    cfg.DataLoader.Train.dataset.num_batches_cached = 3
+    eng = Engine(cfg, mode='train')
+    world = cfg['Global']['world_size']
+    blocking = os.environ.get('PASSL_DP_BLOCKING_GROUPS') == '1'
+    assert world == 2
+    assert (eng.grad_reducer is None) if blocking else isinstance(eng.grad_reducer, ReducerGroup)
+    eng.train()
+    torch.cuda.synchronize()
+    arch = getattr(eng.model, 'arch', eng.model)
+    h = hashlib.sha1()
+    for a in arch.trainable_arenas():
+        t = a.flat
+        ref_t = t.clone()
+        dist.broadcast(ref_t, src=0)
+        assert torch.equal(ref_t, t), 'arena differs between ranks'
+        h.update(t.detach().cpu().numpy().tobytes())
+    dist.barrier()
+    if cfg['Global']['rank'] == 0:
+        print('DP-OK simsiam_engine digest=%s' % h.hexdigest(), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     workload = sys.argv[1]
     if workload == 'lp':
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         return lp_run()
+    if workload == 'simsiam_engine':
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        return simsiam_engine_run()
     if workload == 'simsiam':
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         return simsiam_run()

@@ -60,6 +60,17 @@ def test_two_ranks_simsiam_sync_batchnorm_equals_one_rank_on_the_joint_batch():
     _run_worker('simsiam', 2, dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0'))
 
 
+def test_two_ranks_simsiam_engine_overlapped_reducers_equal_blocking_grad_sync(tmp_path):
+    """SimSiam's two parameter groups live in two arenas; the Engine gives each an overlapped gradient reducer
+    (core/sync_utils.py:ReducerGroup) instead of the blocking per-buffer grad_sync of the reference
+    (passl/core/sync_utils.py:18-43).  Two ranks, three steps through Engine.train(): replicas identical, and the
+    overlapped run equals the blocking run bit for bit — see dp_worker.simsiam_engine_run."""
+    env = dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0', PASSL_DP_OUT=str(tmp_path))
+    a = _run_worker('simsiam_engine', 2, env)
+    b = _run_worker('simsiam_engine', 2, dict(env, PASSL_DP_BLOCKING_GROUPS='1'))
+    assert a.split('digest=')[1] == b.split('digest=')[1], (a, b)
+
+
 def test_two_ranks_shuffle_bn_is_output_neutral():
     """MoCo's cross-rank batch shuffle (reference passl_v110/modeling/architectures/moco.py:107-152): all-gather
     the key view, a permutation drawn on rank 0 and broadcast, every rank encodes its slice of the permuted batch,
