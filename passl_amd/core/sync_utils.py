@@ -159,6 +159,9 @@ class GradReducer(object):
         if self._handles or self.world > 1 or self._forced:
             host_call(wait_all)                 # (live at every replay of a recorded step: see _launch)
         self._active = False
+        uses = getattr(self.arena, '_uses', None)
+        if uses:
+            uses.clear()                        # (a forward whose backward never ran must not hold the next step back)
 
     def exposed_ms(self):
         """Average time per step that the compute stream spent between "backward finished" and "every gradient

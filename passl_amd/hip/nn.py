@@ -120,6 +120,8 @@ class _ConvFn(Function):
         pl = layer._plan(N, hw[0], hw[1])
         y = torch.empty(N, pl.fd.OP, pl.fd.OQ, layer.geom.cout, dtype=x.dtype, device=x.device)
         ops.conv_igemm(pl.fd, x, rt.w_fwd, y, stats=stats[0] if stats is not None else None)
+        if any(ctx.needs_input_grad):
+            rt.arena.expect_grad(rt.indices)
         ctx.save_for_backward(x)
         ctx.layer, ctx.pl, ctx.hw = layer, pl, hw
         ctx.add_slot, ctx.sink_slot, ctx.producer = add_slot, sink_slot, producer
@@ -176,8 +178,7 @@ class _ConvFn(Function):
                 ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
         if ctx.side:
             # dW feeds only the optimizer: off the dgrad -> BatchNorm-backward chain (hip/streams.py)
-            with streams.on_side(dy.device, reads=(x, dy), in_backward=True):
-                wgrad()
+            streams.side_later(dy.device, wgrad, reads=(x, dy))
         else:
             wgrad()
         rt.arena.grad_ready(rt.indices)
@@ -279,6 +280,8 @@ class _BNActFn(Function):
         # ReLU mask for the backward: recomputed from y (no residual) or the bit mask (residual):
         # the output z is never re-read by this layer's backward.
         ctx.relu_mode = 0 if not relu else (3 if has_res else 2)
+        if layer._rt is not None and any(ctx.needs_input_grad):
+            layer._rt.arena.expect_grad(layer._rt.indices)
         ctx.save_for_backward(y, st, mask)
         ctx.layer, ctx.has_res, ctx.res_slot = layer, has_res, res_slot
         ctx.link = None
@@ -454,6 +457,8 @@ class _LinearFn(Function):
                         device=x.device)
         ops.conv_igemm(pl.fd, x, rt.w_fwd, y, shift=bias.detach() if bias is not None else None,
                        relu=relu, out_f32=out_f32, residual=residual)
+        if any(ctx.needs_input_grad):
+            rt.arena.expect_grad(rt.indices)
         ctx.save_for_backward(x, y if relu else None)
         ctx.layer, ctx.pl, ctx.relu = layer, pl, relu
         ctx.has_res = residual is not None
@@ -477,17 +482,19 @@ class _LinearFn(Function):
             ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
         want_bias = layer.bias is not None and layer.bias.requires_grad
         if ctx.side and not config.side_reductions():
-            with streams.on_side(dy.device, reads=(x, dy), in_backward=True):
-                ops.conv_wgrad(pl.wd, x, dy, rt.dw)
+            streams.side_later(dy.device, lambda: ops.conv_wgrad(pl.wd, x, dy, rt.dw), reads=(x, dy))
             if want_bias:
                 ops.colsum_into(dy, layer.bias.grad, accumulate=True)
         elif ctx.side:
             # the bias gradient (column sums of dy) rides along: like dW it feeds only the optimizer, and its two small
             # launches are latency-bound — off the data-gradient chain (MAE: 83 of them per step, 1.1 ms)
-            with streams.on_side(dy.device, reads=(x, dy), in_backward=True):
+            bias_grad = layer.bias.grad if want_bias else None
+
+            def side_work():
                 ops.conv_wgrad(pl.wd, x, dy, rt.dw)
                 if want_bias:
-                    ops.colsum_into(dy, layer.bias.grad, accumulate=True)     # straight into the arena's gradient
+                    ops.colsum_into(dy, bias_grad, accumulate=True)     # straight into the arena's gradient
+            streams.side_later(dy.device, side_work, reads=(x, dy))
         else:
             ops.conv_wgrad(pl.wd, x, dy, rt.dw)
             if want_bias:
@@ -553,6 +560,8 @@ class _LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, layer):
         y, mean, rstd = ops.layernorm_fwd(x.contiguous(), gamma.detach(), beta.detach(), layer._epsilon)
+        if layer._rt is not None and any(ctx.needs_input_grad):
+            layer._rt.arena.expect_grad(layer._rt.indices)
         ctx.save_for_backward(x, mean, rstd)
         ctx.layer = layer
         return y
@@ -577,8 +586,7 @@ def _ln_backward(dy, x, layer, mean, rstd, dres):
     if config.side_reductions() and streams.enabled(dy):
         dx, partials, fold = ops.layernorm_bwd(dy, x, layer.weight.detach(), mean, rstd, layer.weight.grad,
                                                layer.bias.grad, dres=dres, defer_params=True)
-        with streams.on_side(dy.device, reads=(partials,), in_backward=True):
-            fold()
+        streams.side_later(dy.device, fold, reads=(partials,))
         return dx
     return ops.layernorm_bwd(dy, x, layer.weight.detach(), mean, rstd, layer.weight.grad, layer.bias.grad, dres=dres)
 
@@ -593,6 +601,8 @@ class _LayerNormForkFn(Function):
     def forward(ctx, x, gamma, beta, layer):
         x = x.contiguous()
         y, mean, rstd = ops.layernorm_fwd(x, gamma.detach(), beta.detach(), layer._epsilon)
+        if layer._rt is not None and any(ctx.needs_input_grad):
+            layer._rt.arena.expect_grad(layer._rt.indices)
         ctx.save_for_backward(x, mean, rstd)
         ctx.layer = layer
         return y, x.view_as(x)
@@ -783,6 +793,7 @@ class EncoderArena:
         self.trainable = trainable
         self.dtype = dtype or config.get_compute_dtype()
         self.reducer = None
+        self._uses = {}          # parameter index -> forward uses of this step still waiting for their backward
         self.bn_affine = None
         params = []      # (owner, name, kind)
         seen = set()
@@ -1032,9 +1043,24 @@ class EncoderArena:
             for p in params:
                 self.reducer.mark_ready(p._passl_index)
 
+    def expect_grad(self, indices):
+        """Called from the FORWARD of a layer (when autograd will run its backward) that will report ``grad_ready(indices)`` from its backward: a parameter
+        used by several forward nodes of one step (SimSiam encodes its two views in two passes) receives one gradient
+        contribution per use and is complete — ready for its all-reduce bucket — only after the last of them."""
+        if self.reducer is not None:
+            u = self._uses
+            for i in indices:
+                u[i] = u.get(i, 0) + 1
+
     def grad_ready(self, indices):
         """Called from the backward kernels' host code once the gradients of parameters
         `indices` (positions in param_slices) are enqueued on the compute stream."""
         if self.reducer is not None:
+            u = self._uses
             for i in indices:
+                left = u.get(i, 0) - 1
+                if left > 0:
+                    u[i] = left                # another forward use of this parameter has not run its backward yet
+                    continue
+                u.pop(i, None)
                 self.reducer.mark_ready(i)

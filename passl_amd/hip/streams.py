@@ -194,7 +194,12 @@ def on_side(device, reads=(), in_backward=False):
             wait_event(owner, done)
         _held_bytes[key] -= nbytes
         del held
-    if in_backward and key not in _join_queued:
+    if in_backward:
+        _queue_end_join(device, key)
+
+
+def _queue_end_join(device, key):
+    if key not in _join_queued:
         # join at the end of this backward pass: whoever reads .grad afterwards sees finished work.  ONE callback per
         # backward pass: a join is an event record + a cross-stream wait, and on this GPU every such wait costs the
         # waiting stream ~10 us even when the event has long fired — one callback per hand-off (r02-r03) was 55
@@ -210,6 +215,45 @@ def on_side(device, reads=(), in_backward=False):
 
 _join_queued = set()     # devices with an end-of-backward join callback already queued for the running backward pass
 
+# ---- side work of a backward pass, handed over in batches ---------------------------------------------------------
+# Every hand-off makes the side stream wait for an event of the handing-off stream, and such a wait stalls the waiting
+# stream for ~10 us on this GPU whether or not the event has fired.  A backward pass hands over 55
+# (MoCo) to 167 (MAE) pieces of work — weight gradients, bias column sums, LayerNorm parameter folds — none of which
+# anything but the optimizer / the gradient reducer reads.  They are therefore queued and handed over PASSL_SIDE_BATCH at
+# a time (default 4; 1 = one hand-off per piece as before): one wait per batch.  ``join`` flushes the queue first, so
+# whoever orders itself behind the side stream (end of backward, a gradient bucket, the optimizer) sees all of it.
+_SIDE_BATCH = max(1, int(os.environ.get('PASSL_SIDE_BATCH', '4')))
+_deferred = {}           # device index -> [(fn, tensors it reads, stream that produced them)]
+
+
+def side_later(device, fn, reads=()):
+    """Queue ``fn()`` (launches that only the optimizer / gradient reducer consume) for the side stream; call from a
+    backward node.  ``reads``: tensors the launches read (kept alive until handed over, then by ``on_side``)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    lst = _deferred.setdefault(key, [])
+    lst.append((fn, tuple(t for t in reads if t is not None), torch.cuda.current_stream(device)))
+    _queue_end_join(device, key)
+    if len(lst) >= _SIDE_BATCH:
+        flush_side(device)
+
+
+def flush_side(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    lst = _deferred.get(key)
+    if not lst:
+        return
+    _deferred[key] = []
+    s = side_stream(device)
+    cur = torch.cuda.current_stream(device)
+    # on_side orders the side stream behind the CURRENT stream; pieces queued by a node that ran on another stream
+    # (a forked branch's backward runs on the side stream itself, the rest on the main stream) need that stream's tail
+    for st in {id(item[2]): item[2] for item in lst}.values():
+        if st != s and st != cur:
+            wait_event(s, record_event(st))
+    with on_side(device, reads=tuple(t for _fn, r, _st in lst for t in r), in_backward=True):
+        for fn, _r, _st in lst:
+            fn()
+
 
 def reset():
     """Forget every hand-off in flight and every stream that handed work over (call with the device idle).
@@ -220,6 +264,7 @@ def reset():
     _owners.clear()
     _held_bytes.clear()
     _join_queued.clear()
+    _deferred.clear()
 
 
 def join(device):
@@ -230,6 +275,7 @@ def join(device):
     finding).  A wait on an idle stream costs a few microseconds of host time."""
     if not device.type == 'cuda':
         return
+    flush_side(device)                   # queued side work first: the caller orders itself behind ALL of it
     key = device.index if device.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(device)
     waited = False

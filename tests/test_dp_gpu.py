@@ -38,6 +38,13 @@ def _run_worker(workload, nproc, env_extra, launcher=True):
     else:
         cmd = [sys.executable, worker, workload]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:                    # keep the whole worker output (pytest truncates the assertion message)
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'dp_fail_%s.log' % workload), 'w') as f:
+                f.write(r.stdout + '\n---- stderr ----\n' + r.stderr)
+        except OSError:
+            pass
     assert r.returncode == 0 and ('DP-OK %s' % workload) in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     line = [l for l in r.stdout.splitlines() if l.startswith('DP-OK')][-1]
     return line
@@ -134,6 +141,13 @@ def test_bench_two_ranks_one_gpu_reports_its_ranks():
            '--roofline-steps', '0', '--dp-buckets', '3']
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0')
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:                    # keep the whole worker output (pytest truncates the assertion message)
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'dp_fail_%s.log' % workload), 'w') as f:
+                f.write(r.stdout + '\n---- stderr ----\n' + r.stderr)
+        except OSError:
+            pass
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
