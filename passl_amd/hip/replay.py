@@ -175,6 +175,7 @@ class StepPlan(object):
         self._src = None
         self._pool = None
         self._host_calls = []
+        self._main = None
         self.replays = 0
         self.info = {}
         self.foreign = {}
@@ -272,6 +273,7 @@ class StepPlan(object):
         self.handle = handle
         self._pool = pool                       # keeps the recorded step's addresses reserved
         self._host_calls = list(rec.host_calls)
+        self._main = rec.main                   # the stream the step was called on (replays must be, too)
         return None
 
     def run(self, *data):
@@ -285,6 +287,10 @@ class StepPlan(object):
             if out is not None:
                 return out                      # recording refused: this was a plain eager step
             return self._outputs()
+        if L.stream() != self._main:
+            # the live pieces around a replay (input copies, the learning-rate push, output clones, host calls) are
+            # ordered against the recorded launches through the CURRENT stream: only valid on the recorded one
+            return self.fn(*data)
         self._load_inputs(data)
         for o in self.optimizers:
             o.push_hyper()
