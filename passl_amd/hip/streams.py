@@ -208,6 +208,7 @@ def _queue_end_join(device, key):
         _join_queued.add(key)
 
         def _join_at_end():
+            flush_side(device)               # (while the flag is still set: its hand-off must not queue another callback)
             _join_queued.discard(key)
             join(device)
         torch.autograd.Variable._execution_engine.queue_callback(_join_at_end)
