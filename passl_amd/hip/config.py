@@ -16,7 +16,8 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0',
           'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
-          'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0'}
+          'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
+          'fused_mlp_act': os.environ.get('PASSL_FUSED_MLP_ACT', '1') != '0'}
 
 
 def set_device(name):
@@ -107,7 +108,14 @@ def side_reductions():
     return _state['side_reductions']
 
 
+def fused_mlp_act():
+    """The activation of a transformer MLP block inside the two Linears' epilogues (bf16): fc1 stores the pre-activation
+    and act(it) in one launch, fc2's data-gradient launch applies act' — no stand-alone GELU / QuickGELU pass in either
+    direction (hip/nn.py: linear_act / act_linear)."""
+    return _state['fused_mlp_act']
+
+
 def set_flag(name, value):
     assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample',
-                    'side_reductions')
+                    'side_reductions', 'fused_mlp_act')
     _state[name] = bool(value)
