@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4, GPU call 13: the MLP activation inside the Linears' epilogues — bit identity, ViT suites, same-box A/B
+cd $GRAFT_REPO_ROOT; O=$GRAFT_REPO_ROOT/gpurun_out/r4_call13; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_layers_gpu.py -m gpu -q -x -k "fused_mlp or vit_block" > $O/tests_fused.log 2>&1; echo "exit $?" >> $O/tests_fused.log
+timeout 1200 python -m pytest tests/test_mae_gpu.py tests/test_mae_v2_gpu.py tests/test_clip_gpu.py tests/test_mocov3_gpu.py tests/test_step_plan_gpu.py -m gpu -q -x > $O/tests.log 2>&1; echo "exit $?" >> $O/tests.log
+for rep in 1 2; do
+for v in 1 0; do
+for w in mae clip16; do
+  echo "PASSL_FUSED_MLP_ACT=$v $w" >> $O/ab.txt
+  PASSL_FUSED_MLP_ACT=$v timeout 400 python bench.py --workload $w --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 6 2>> $O/ab.err | cut -c1-200 >> $O/ab.txt
+done; done; done
+tail -4 $O/tests_fused.log; tail -4 $O/tests.log; cat $O/ab.txt | sed 's/"unit".*"ms_per_step"/ ms/' | sed 's/{"metric".*"value"/ value/' | cut -c1-90

@@ -666,7 +666,7 @@ def test_fused_mlp_activation_is_bit_identical(kind, M, D):
     r0 = torch.randn(M, D, generator=gen).to(DEV).to(torch.bfloat16)
     dy = (torch.randn(M, D, generator=gen) * 0.1).to(DEV).to(torch.bfloat16)
     results = {}
-    kernels = {}
+    was = hip_config.fused_mlp_act()
     for fused in (False, True):
         hip_config.set_flag('fused_mlp_act', fused)
         try:
@@ -680,7 +680,7 @@ def test_fused_mlp_activation_is_bit_identical(kind, M, D):
                 results[(fused, with_res)] = [out.detach().clone(), x.grad.clone(), arena.grads.clone()] + \
                     ([res.grad.clone()] if with_res else [])
         finally:
-            hip_config.set_flag('fused_mlp_act', True)
+            hip_config.set_flag('fused_mlp_act', was)
     for with_res in (False, True):
         a, b = results[(False, with_res)], results[(True, with_res)]
         names = ['out', 'dx', 'parameter gradients', 'd residual']
