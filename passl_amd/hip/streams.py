@@ -280,7 +280,8 @@ def join(device):
     key = device.index if device.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(device)
     waited = False
-    for table in (_streams, _fork_streams):
+    for table in (_streams, _fork_streams, _key_streams):
+        # (the key stream too: CLIP runs its text tower there, forward AND — by autograd's stream affinity — backward)
         s = table.get(key)
         if s is not None and s != cur:
             wait_stream(cur, s)

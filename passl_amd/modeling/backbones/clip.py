@@ -11,6 +11,7 @@ by exact-fp32 MFMA, in-place clip of logit_scale (csrc/clip.hip).  ``text_logits
 the transpose VIEW of ``image_logits`` (equal up to the rounding of exp(s)*x in the reference);
 CLIPHead relies on that to run both cross-entropies over one matrix."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -19,7 +20,7 @@ import torch.nn as tnn
 from torch.autograd import Function
 
 from ...core.sync_utils import collectives_active
-from ...hip import config, nn, ops
+from ...hip import config, nn, ops, streams
 from .builder import BACKBONES
 from .vision_transformer import Transformer, VisionTransformer, alias_matrix_param
 
@@ -77,6 +78,22 @@ class _LogitsFn(Function):
         dimg, dtxt = ops.clip_logits_bwd(dlogits.contiguous(), logits, ws, ctx.D, s.grad)
         nn.param_grad_ready(s)
         return dimg, dtxt, None
+
+
+class _OffMainBoundary(Function):
+    """Identity at the exit of a sub-graph that runs on another stream.  Its backward is the first node of that
+    sub-graph's backward pass and runs on that stream (autograd's stream affinity); autograd orders it behind the
+    producer of its incoming gradient with an event of its own, which a recording step plan cannot see — the plan gets the
+    conservative equivalent (hip/streams.py:autograd_node_entry)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        streams.autograd_node_entry(g.device)
+        return g
 
 
 def _gather_rows_all(t):
@@ -216,6 +233,11 @@ class CLIP(nn.Layer):
         x = self.ln_final(nn.gather_rows(x, ops.eot_index(text)))
         return self.text_projection(x, out_f32=True)
 
+    @staticmethod
+    def _tower_overlap(image):
+        return (os.environ.get('PASSL_CLIP_TOWER_OVERLAP', '1') != '0' and torch.is_grad_enabled() and
+                streams.enabled(image) and not torch.cuda.is_current_stream_capturing())
+
     def clip_logit_scale(self):
         """clip.py:309-311 — performed inside the logits kernel sequence, right after exp(s) is taken."""
 
@@ -224,8 +246,20 @@ class CLIP(nn.Layer):
         against the gathered features of every rank -> (image_logits, text_logits) of shape [B, W*B]."""
         if not is_train:
             raise NotImplementedError('is_train=False (unit logit scale) is an evaluation path')
-        image_features = self.encode_image(image)
-        text_features = self.encode_text(text)
+        if self._tower_overlap(image):
+            # The two towers share nothing until the logits: the text tower (77 tokens: GEMMs that fill a fraction of the
+            # CUs) runs on a stream of its own next to the image tower, forward here and — autograd runs a node on the
+            # stream of its forward — backward as well.  Same kernels, same order within each tower: same bits.
+            dev = image.device
+            main, side = torch.cuda.current_stream(dev), streams.key_stream(dev)
+            streams.wait_event(side, streams.record_event(main))      # tokens, refreshed weights: ready on main
+            with torch.cuda.stream(side):
+                text_features = _OffMainBoundary.apply(self.encode_text(text))
+            image_features = self.encode_image(image)
+            streams.wait_stream(main, side)
+        else:
+            image_features = self.encode_image(image)
+            text_features = self.encode_text(text)
         if multi_rank:
             return _CrossRankLogitsFn.apply(image_features, text_features, self.logit_scale)
         image_logits = _LogitsFn.apply(image_features, text_features, self.logit_scale)
