@@ -218,17 +218,6 @@ typedef struct passl_conv_desc {
   int32_t stats_tiles;     /* must equal ceil(N*OP*OQ / 128) when stats != NULL */
   int32_t bnb_relu;
   int32_t bnb_tile_off;    /* first slab row of this launch (residue-class launches share one slab) */
-  /* Activation fused into the epilogue of a Linear of a transformer MLP block (bf16 output only; 0 / NULL = off).
-   * act: 1 = exact-erf GELU (passl/models/vision_transformer.py:84-113 act_layer=nn.GELU), 2 = QuickGELU
-   * (passl_v110/modeling/backbones/base_transformer.py:25-28).
-   *   y2 != NULL (forward of fc1): besides y = the pre-activation (kept for the backward pass), y2 = act(y) is stored
-   *     (addressed like y) — what the stand-alone activation kernel would have produced from the stored y, bit for bit;
-   *   res_op = 1 (data gradient of fc2): `residual` is not added but holds the pre-activation x of the SAME block;
-   *     the stored value is  y * act'(x)  — the activation's backward applied to the bf16-rounded gradient, bit for bit
-   *     what the stand-alone backward kernel computes from it.  (res_op = 0: residual is added, as above.) */
-  void* y2;
-  int32_t act;
-  int32_t res_op;
 } passl_conv_desc;
 int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream);
 

@@ -36,7 +36,7 @@ inline unsigned grid_for(int64_t n, int per_block = kThreads) {
   else return PASSL_EUNSUPPORTED;
 
 // ------------------------------------------------------------------ QuickGELU
-__device__ __forceinline__ float sigm(float x) { return passl_sigm_f(x); }                  // (common.h)
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // tile form (see gelu_kernel, vit.hip): U x 256 consecutive chunks per workgroup, loads back to back
 constexpr int kEltU = 4;
@@ -62,11 +62,12 @@ __global__ void __launch_bounds__(kThreads) quick_gelu_kernel(const T* __restric
     if (BWD) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        o[e] = d[u][e] * passl_quick_gelu_grad_f(v[u][e]);
+        const float sg = sigm(1.702f * v[u][e]);
+        o[e] = d[u][e] * (sg + 1.702f * v[u][e] * sg * (1.0f - sg));
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = passl_quick_gelu_f(v[u][e]);
+      for (int e = 0; e < 8; ++e) o[e] = v[u][e] * sigm(1.702f * v[u][e]);
     }
     ElemTraits<T>::store8(out + i * 8, o);
   }

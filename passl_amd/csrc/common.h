@@ -79,26 +79,4 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// ---- activations of the ViT MLP blocks.  ONE definition for the stand-alone kernels (vit.hip: exact-erf GELU;
-// clip.hip: QuickGELU) and for the implicit-GEMM epilogues that fuse them (igemm_epi.h): same bits either way.
-// act code: 1 = GELU (paddle.nn.GELU, erf form), 2 = QuickGELU x * sigmoid(1.702 x)
-// (passl_v110/modeling/backbones/base_transformer.py:25-28)
-__device__ __forceinline__ float passl_gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float passl_gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
-}
-__device__ __forceinline__ float passl_sigm_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float passl_quick_gelu_f(float x) { return x * passl_sigm_f(1.702f * x); }
-__device__ __forceinline__ float passl_quick_gelu_grad_f(float x) {
-  const float sg = passl_sigm_f(1.702f * x);
-  return sg + 1.702f * x * sg * (1.0f - sg);
-}
-__device__ __forceinline__ float passl_act_f(int code, float x) {
-  return code == 1 ? passl_gelu_f(x) : passl_quick_gelu_f(x);
-}
-__device__ __forceinline__ float passl_act_grad_f(int code, float x) {
-  return code == 1 ? passl_gelu_grad_f(x) : passl_quick_gelu_grad_f(x);
-}
-
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

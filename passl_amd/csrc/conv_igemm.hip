@@ -73,8 +73,6 @@ struct Params {
   const float* bnb_scale;
   const float* bnb_shift;
   float* bnb_partial;
-  char* y2;          // second output: act(y) (igemm_epi.h); act: 1 GELU, 2 QuickGELU; res_op 1: y *= act'(res)
-  int act, res_op;
   int bnb_relu, bnb_tile_off;
   int M, NCOLS, KDIM;
   int OP, OQ, R, S, C, IH, IW, sh, sw, ph, pw;
@@ -417,7 +415,7 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
     // launches are bound by how many operand waits / epilogues a CU has in flight;
     // 64->256 @56: 117.6 -> 101.1 us, with statistics 152.9 -> 127.0 us.  PASSL_IGEMM_LEAN=0 disables.
     static const bool lean_on = !(getenv("PASSL_IGEMM_LEAN") && atoi(getenv("PASSL_IGEMM_LEAN")) == 0);
-    if (dense && lean_on && nk == 1 && !p.res && !p.bnb_partial && !p.y2)
+    if (dense && lean_on && nk == 1 && !p.res && !p.bnb_partial)
       return launch<T, 128, BN, false, 1, false, true, true>(p, st);
     if (dense)
       return one ? launch<T, 128, BN, false, 1, false, true>(p, st)
@@ -451,13 +449,6 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
       d->C <= 0 || d->IH <= 0 || d->IW <= 0)
     return PASSL_EINVAL;
   if (d->dtype != PASSL_F32 && d->dtype != PASSL_BF16) return PASSL_EUNSUPPORTED;
-  // fused activation (second output / multiplicative "residual"): bf16-output epilogue only, never with the statistics
-  if (d->y2 || d->res_op) {
-    if (d->dtype != PASSL_BF16 || d->out_f32 || d->stats || d->bnb_partial || d->relu) return PASSL_EUNSUPPORTED;
-    if ((d->act != 1 && d->act != 2) || (d->res_op != 0 && d->res_op != 1) || (d->res_op && !d->residual) ||
-        (d->y2 && !aligned16(d->y2)))
-      return PASSL_EINVAL;
-  }
   const int es = d->dtype == PASSL_BF16 ? 2 : 4;
   const int vec = 16 / es, bk = 128 / es;
   if ((d->C % vec) || (d->NCOLS & 7)) return PASSL_EINVAL;
@@ -482,7 +473,6 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
   p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
   p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
-  p.y2 = reinterpret_cast<char*>(d->y2); p.act = d->act; p.res_op = d->res_op;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.R = d->R; p.S = d->S; p.C = d->C;
   p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;

@@ -549,8 +549,7 @@ int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st) {
   if (!ring::fill_params(d, g8::BM, g8::BN, p)) return PASSL_EUNSUPPORTED;
   const int nk = p.KDIM / g8::BK;
   // the persistent form stores from the accumulators: launches with fused statistics keep the staged epilogue
-  // ... and so do launches with a fused activation (igemm_epi.h: second output / multiplicative residual)
-  const bool direct = g_8p_direct && nk >= 2 && !d->stats && !d->bnb_partial && !d->y2 && !d->res_op;
+  const bool direct = g_8p_direct && nk >= 2 && !d->stats && !d->bnb_partial;
   if (g_8p_mode == 1) {
     if (nk < g_8p_min_nk) return PASSL_EUNSUPPORTED;       // short reductions: igemm_kernel's territory
     const int64_t t8 = p.ntiles;

@@ -61,8 +61,6 @@ struct Params {
   const float* bnb_shift;
   float* bnb_partial;
   int bnb_relu, bnb_tile_off;
-  char* y2;                  // (fused activation of igemm_epi.h: never used by the stem — always NULL / 0)
-  int act, res_op;
   int M, NCOLS;
   int OP, OQ;
   int64_t a_sn, a_sh;        // elements: image pitch, padded-row pitch
@@ -172,8 +170,7 @@ __global__ void __launch_bounds__(kThreads, 3) stem_kernel(const Params p) {
     }
     __syncthreads();      // every wave is done with the patch: the epilogue tile aliases it
 
-    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, false, FN, 0, false>(p, smem, rowoff, acc, wm, wn, lane, tid,
-                                                                              0, tile);
+    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN>(p, smem, rowoff, acc, wm, wn, lane, tid, 0, tile);
     __syncthreads();      // the epilogue's LDS reads are done before the next patch is written
   }
 }
@@ -218,7 +215,6 @@ int passl_stem_try(const passl_conv_desc* d, hipStream_t st) {
   p.stats_tiles = (int)(M64 / stem::BM);
   p.bnb_y = nullptr; p.bnb_mask = nullptr; p.bnb_mean = nullptr; p.bnb_invstd = nullptr;
   p.bnb_scale = nullptr; p.bnb_shift = nullptr; p.bnb_partial = nullptr; p.bnb_relu = 0; p.bnb_tile_off = 0;
-  p.y2 = nullptr; p.act = 0; p.res_op = 0;
   p.M = (int)M64; p.NCOLS = d->NCOLS;
   p.OP = d->OP; p.OQ = d->OQ;
   p.a_sn = d->a_sn; p.a_sh = d->a_sh;

@@ -48,8 +48,6 @@ struct Params {
   const float* bnb_scale;
   const float* bnb_shift;
   float* bnb_partial;
-  char* y2;          // second output: act(y) (igemm_epi.h); act: 1 GELU, 2 QuickGELU; res_op 1: y *= act'(res)
-  int act, res_op;
   int bnb_relu, bnb_tile_off;
   int64_t a_total;            // bytes of the whole A tensor (may exceed 32 bits: every workgroup rebases its buffer)
   uint32_t b_bytes;
@@ -100,7 +98,6 @@ static inline bool fill_params(const passl_conv_desc* d, int bm, int bn, Params&
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
   p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
   p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
-  p.y2 = reinterpret_cast<char*>(d->y2); p.act = d->act; p.res_op = d->res_op;
   p.a_total = a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.S = d->S; p.C = d->C;

@@ -28,22 +28,15 @@ __device__ __forceinline__ uint4 pack8(const float (&a)[8]) {
   return make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(a[4], a[5]), pack2bf(a[6], a[7]));
 }
 
-// (c) the activation of a transformer MLP block (include/passl_hip.h: passl_conv_desc.y2 / act / res_op):
-//      y2 != NULL: a second output y2 = act(stored y) — fc1's forward keeps the pre-activation AND hands the next
-//      Linear its input without a separate pass; res_op == 1: the "residual" is the pre-activation x of fc2's input and
-//      the stored value is (bf16-rounded accumulator) * act'(x) — the activation's backward inside fc2's data gradient.
-//      Both use the stand-alone kernels' own device functions on the same bf16-rounded values: identical bits.
-//
 // P needs: y, scale, shift, res, relu, NCOLS, stats, bnb_y, bnb_mask, bnb_mean, bnb_invstd, bnb_scale,
-// bnb_shift, bnb_partial, bnb_relu, bnb_tile_off, y2, act, res_op, M (rows) and stats_tiles (= ceil(M / 128)).
+// bnb_shift, bnb_partial, bnb_relu, bnb_tile_off, M (rows) and stats_tiles (= ceil(M / 128)).
 // smem: the kernel's dynamic LDS (main-loop tiles are dead); rowoff[BM]: element offset of each
 // output row (-1 = out of range).  mt = index of this workgroup's 128-row tile.
 // Column of accumulator fragment j: (j / FNH) * CH + wn * WN + (j % FNH) * 16 (+ 4 * (lane >> 4)); the
 // defaults (FNH = FN, CH = 0) are one contiguous WN-wide strip per wave, the 8-phase kernel's waves own one
 // 32-column strip in each 128-column half of the tile (FNH = 2, CH = 128).
-// ACT = false compiles the fused-activation paths (c) out (the stem kernel: keeps its register budget).
 template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, bool LEAN = false, int FNH = FN, int CH = 0,
-          bool ACT = true, typename P>
+          typename P>
 __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int64_t* rowoff,
                                               const f32x4 (&acc)[FM][FN], int wm, int wn, int lane,
                                               int tid, int n0, int mt) {
@@ -143,16 +136,10 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       float a[8], rr[8];
       unpack8(v, a);
       unpack8(rres[t], rr);
-      if (ACT && !LEAN && p.res_op == 1) {
-        // activation backward: the bf16-rounded gradient times act'(pre-activation)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] *= passl_act_grad_f(p.act, rr[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          a[e] += rr[e];
-          if (p.relu) a[e] = fmaxf(a[e], 0.f);
-        }
+      for (int e = 0; e < 8; ++e) {
+        a[e] += rr[e];
+        if (p.relu) a[e] = fmaxf(a[e], 0.f);
       }
       v = pack8(a);
     }
@@ -175,14 +162,6 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       v = pack8(g);           // exact: g holds bf16 values or zeros
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
-    if (ACT && !LEAN && p.y2) {
-      // second output: the activation of the STORED (bf16) value
-      float a[8];
-      unpack8(v, a);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = passl_act_f(p.act, a[e]);
-      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y2) + o) = pack8(a);
-    }
     if (fstats) {
       float x[8];
       unpack8(v, x);

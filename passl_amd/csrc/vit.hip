@@ -197,8 +197,11 @@ __global__ void __launch_bounds__(kThreads) ln_param_reduce_kernel(const float* 
 }
 
 // ------------------------------------------------------------------ GELU (exact erf form)
-__device__ __forceinline__ float gelu_f(float x) { return passl_gelu_f(x); }              // (common.h)
-__device__ __forceinline__ float gelu_grad_f(float x) { return passl_gelu_grad_f(x); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
 
 // Tile form (as the BatchNorm streaming kernels, bn.hip): a workgroup owns U x 256 consecutive 16-byte
 // chunks, a lane the chunks base + u * 256; all loads are issued back to back, branch-free (a lane past

@@ -16,8 +16,7 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0',
           'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
-          'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
-          'fused_mlp_act': os.environ.get('PASSL_FUSED_MLP_ACT', '0') == '1'}
+          'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0'}
 
 
 def set_device(name):
@@ -108,18 +107,7 @@ def side_reductions():
     return _state['side_reductions']
 
 
-def fused_mlp_act():
-    """The activation of a transformer MLP block inside the two Linears' epilogues (bf16): fc1 stores the pre-activation
-    and act(it) in one launch, fc2's data-gradient launch applies act' — no stand-alone GELU / QuickGELU pass in either
-    direction (hip/nn.py: linear_act / act_linear).  OPT-IN (PASSL_FUSED_MLP_ACT=1): bit-identical, but measured SLOWER
-    on this GPU (MAE ViT-B 29.85 -> 32.46 ms/step, CLIP ViT-B/16 54.5 -> 56.9, same box: profiles/r04_negative_results.txt)
-    — the launches that carry it leave the persistent 8-phase form for the staged one, and ~25 VALU operations per
-    element of erf / exp in the epilogue of a one-workgroup-per-CU kernel idle the matrix pipe for longer than the
-    stand-alone HBM-bound pass takes."""
-    return _state['fused_mlp_act']
-
-
 def set_flag(name, value):
     assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample',
-                    'side_reductions', 'fused_mlp_act')
+                    'side_reductions')
     _state[name] = bool(value)

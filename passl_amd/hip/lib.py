@@ -32,8 +32,7 @@ class ConvDesc(C.Structure):
                 ('a_sn', c_l), ('a_sh', c_l), ('a_sw', c_l),
                 ('y_sn', c_l), ('y_sh', c_l), ('y_sw', c_l),
                 ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32),
-                ('stats_tiles', C.c_int32), ('bnb_relu', C.c_int32), ('bnb_tile_off', C.c_int32),
-                ('y2', c_p), ('act', C.c_int32), ('res_op', C.c_int32)]
+                ('stats_tiles', C.c_int32), ('bnb_relu', C.c_int32), ('bnb_tile_off', C.c_int32)]
 
 
 class WgradDesc(C.Structure):

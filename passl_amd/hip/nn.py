@@ -504,123 +504,6 @@ class _LinearFn(Function):
         return dx, None, None, None, None, None, (dy if ctx.has_res else None)
 
 
-def _linear_param_grads(layer, pl, x, dy, side):
-    """dW (+ d-bias) of a Linear from its input x and output gradient dy: side stream when there is one."""
-    rt = layer._rt
-    want_bias = layer.bias is not None and layer.bias.requires_grad
-    bias_grad = layer.bias.grad if want_bias else None
-
-    def work():
-        ops.conv_wgrad(pl.wd, x, dy, rt.dw)
-        if want_bias:
-            ops.colsum_into(dy, bias_grad, accumulate=True)
-    if side:
-        streams.side_later(dy.device, work, reads=(x, dy))
-    else:
-        work()
-    rt.arena.grad_ready(rt.indices)
-
-
-ACT_CODES = {'gelu': 1, 'quick_gelu': 2}
-
-
-def fused_act_code(act_layer, x):
-    """1 / 2 when `act_layer` (a GELU / QuickGELU layer) can run inside the neighbouring Linears' epilogues for input
-    x (bf16 rows, switch on), else 0."""
-    if not (config.fused_mlp_act() and x.is_cuda and x.dtype == torch.bfloat16):
-        return 0
-    if isinstance(act_layer, GELU):
-        return 1
-    if isinstance(act_layer, QuickGELU):
-        return 2
-    return 0
-
-
-class _LinearActFn(Function):
-    """(y, g) = (x W + b, act(x W + b)) in ONE launch: the Linear's epilogue stores the pre-activation y (the backward
-    pass needs it) and, from the stored bf16 value, g = act(y) — bit for bit what the stand-alone activation kernel
-    writes.  g carries no gradient of its own: it is consumed by ``_ActLinearFn``, whose backward returns d y."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, layer, act):
-        rt = _need_rt(layer)
-        N = x.shape[0]
-        pl = layer._plan(N)
-        y = torch.empty(N, layer.out_features, dtype=x.dtype, device=x.device)
-        g = torch.empty(N, layer.out_features, dtype=x.dtype, device=x.device)
-        ops.conv_igemm(pl.fd, x, rt.w_fwd, y, shift=bias.detach() if bias is not None else None, y2=g, act=act)
-        if any(ctx.needs_input_grad):
-            rt.arena.expect_grad(rt.indices)
-        ctx.save_for_backward(x)
-        ctx.layer, ctx.pl = layer, pl
-        ctx.side = streams.enabled(x)
-        ctx.mark_non_differentiable(g)
-        ctx.set_materialize_grads(False)
-        return y, g
-
-    @staticmethod
-    def backward(ctx, dy, _dg):
-        (x,) = ctx.saved_tensors
-        layer, pl = ctx.layer, ctx.pl
-        rt = layer._rt
-        dy = dy.contiguous()
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(x.shape[0], layer.in_features, dtype=x.dtype, device=x.device)
-            d = pl.dds[0]
-            ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx)
-        _linear_param_grads(layer, pl, x, dy, ctx.side)
-        return dx, None, None, None, None
-
-
-class _ActLinearFn(Function):
-    """out = g W + b (+ residual) with g = act(y) handed over by ``_LinearActFn``; the BACKWARD returns the gradient of
-    y itself: the data-gradient launch multiplies its bf16-rounded result by act'(y) in the epilogue (what the
-    stand-alone activation backward would compute from it, bit for bit), so neither direction runs an activation
-    kernel."""
-
-    @staticmethod
-    def forward(ctx, y, g, weight, bias, layer, residual, act):
-        rt = _need_rt(layer)
-        N = g.shape[0]
-        pl = layer._plan(N)
-        out = torch.empty(N, layer.out_features, dtype=g.dtype, device=g.device)
-        ops.conv_igemm(pl.fd, g, rt.w_fwd, out, shift=bias.detach() if bias is not None else None, residual=residual)
-        if any(ctx.needs_input_grad):
-            rt.arena.expect_grad(rt.indices)
-        ctx.save_for_backward(y, g)
-        ctx.layer, ctx.pl, ctx.act = layer, pl, act
-        ctx.has_res = residual is not None
-        ctx.side = streams.enabled(g)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        y, g = ctx.saved_tensors
-        layer, pl = ctx.layer, ctx.pl
-        rt = layer._rt
-        dout = dout.contiguous()
-        if dout.dtype != g.dtype:
-            dout = ops.cast_to(dout, g.dtype)
-        dy = None
-        if ctx.needs_input_grad[0]:
-            dy = torch.empty(y.shape[0], layer.in_features, dtype=y.dtype, device=y.device)
-            d = pl.dds[0]
-            ops.conv_igemm(d, dout, rt.w_dgrad[id(d.pack)], dy, residual=y, act=ctx.act, res_op=1)
-        _linear_param_grads(layer, pl, g, dout, ctx.side)
-        return dy, None, None, None, None, (dout if ctx.has_res else None), None
-
-
-def linear_act(layer, x, act):
-    """-> (pre-activation, activation) of Linear `layer` applied to x (act: 1 GELU, 2 QuickGELU)."""
-    return _LinearActFn.apply(x, layer.weight, layer.bias, layer, int(act))
-
-
-def act_linear(layer, y, g, residual, act):
-    """Linear `layer` applied to g = act(y) (+ residual in the epilogue); differentiable w.r.t. y."""
-    return _ActLinearFn.apply(y, g, layer.weight, layer.bias, layer, residual, int(act))
-
-
 class Linear(Layer):
     """y = x W + b with W logically [in, out] (the reference's paddle.nn.Linear layout)."""
 

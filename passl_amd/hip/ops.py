@@ -148,15 +148,13 @@ def conv_tiles(d: P.Desc):
 
 
 def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=False,
-               out_f32=False, stats=None, bnb=None, y2=None, act=0, res_op=0):
+               out_f32=False, stats=None, bnb=None):
     """Launch one implicit-GEMM conv described by `d` (plan.Desc).  `a` activation tensor,
     `b` packed weights [NCOLS, R*S*C] (same dtype as a), `y` output tensor (written in place at
     d.y_off with d's strides).  `stats`: fp32 slab from conv_stats_buffer (fused forward BatchNorm
     statistics of the stored output, bf16 only).  `bnb`: dict(y, mask, mean, invstd, scale, shift,
     relu, partial, tile_off) — BatchNorm-backward statistics fused into this data-gradient launch
-    (include/passl_hip.h: passl_conv_desc.bnb_*).  `y2` / `act` / `res_op`: the fused activation of a transformer MLP
-    block (passl_conv_desc.y2: second output act(y); res_op = 1: `residual` holds the pre-activation and the stored
-    value is y * act'(residual)); act 1 = GELU, 2 = QuickGELU."""
+    (include/passl_hip.h: passl_conv_desc.bnb_*)."""
     s = _conv_struct(d)
     esz = 4 if out_f32 else y.element_size()
     s.a = L.ptr(a)
@@ -170,8 +168,6 @@ def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=F
     s.out_f32 = 1 if out_f32 else 0
     s.stats = L.ptr(stats)
     s.stats_tiles = conv_tiles(d) if stats is not None else 0
-    s.y2 = (L.ptr(y2) + d.y_off * esz) if y2 is not None else None
-    s.act, s.res_op = int(act), int(res_op)
     if bnb is not None:
         s.bnb_y = L.ptr(bnb['y']) + d.y_off * esz
         # the bit mask is indexed like the dense tensor: shift it with the sub-lattice origin (y_off % 8 == 0)

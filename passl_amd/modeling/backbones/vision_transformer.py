@@ -89,11 +89,6 @@ class Mlp(nn.Layer):
         self.fc2 = nn.Linear(hidden_features, out_features)
 
     def forward(self, x, residual=None):
-        code = nn.fused_act_code(self.act, x)
-        if code:
-            # the activation runs inside the two Linears' epilogues (hip/nn.py: linear_act / act_linear)
-            y, g = nn.linear_act(self.fc1, x, code)
-            return nn.act_linear(self.fc2, y, g, residual, code)
         return self.fc2(self.act(self.fc1(x)), residual=residual)
 
 

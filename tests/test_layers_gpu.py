@@ -640,52 +640,3 @@ def test_contrastive_criteria_fp32_kernels_against_float64():
     rep.f32('simsiam -cos', got.reshape(()), ref.detach().reshape(()), 2e-6)
     rep.f32('simsiam d p', pd.grad, p.grad, 2e-5)
     rep.finish()
-
-
-@pytest.mark.parametrize('kind', ['gelu', 'quick_gelu'])
-@pytest.mark.parametrize('M,D', [(12800, 768), (3000, 512), (200, 128), (1037, 256)])
-def test_fused_mlp_activation_is_bit_identical(kind, M, D):
-    """The activation of a transformer MLP block inside the two Linears' epilogues (fc1: second output act(y); fc2's
-    data gradient: y * act'(pre-activation); csrc/igemm_epi.h, hip/nn.py:linear_act / act_linear) against the same block
-    with the stand-alone activation kernels: output, input gradient and every parameter gradient must be IDENTICAL bits
-    — both apply the same device functions to the same bf16-rounded values.  Shapes cover the 8-phase kernel (staged
-    form), the ring kernel, the register-staged kernel and ragged tiles; both residual forms."""
-    from passl_amd.modeling.backbones import mae as MB
-    from passl_amd.modeling.backbones import vision_transformer as VB
-    hip_config.set_device('gpu')
-    hip_config.set_compute_dtype(torch.bfloat16)
-    torch.manual_seed(M + D)
-    mlp = (MB.Mlp(D, 4 * D) if kind == 'gelu' else VB.Mlp(D, 4 * D, act_layer=VB.QuickGELU))
-    arena = nn.EncoderArena(mlp, trainable=True)
-    with torch.no_grad():
-        for p in mlp.parameters():
-            p.copy_(torch.randn(p.shape).to(DEV) * (0.05 if p.dim() > 1 else 0.1))
-    arena.refresh()
-    gen = torch.Generator().manual_seed(3)
-    x0 = (torch.randn(M, D, generator=gen) * 1.2).to(DEV).to(torch.bfloat16)
-    r0 = torch.randn(M, D, generator=gen).to(DEV).to(torch.bfloat16)
-    dy = (torch.randn(M, D, generator=gen) * 0.1).to(DEV).to(torch.bfloat16)
-    results = {}
-    was = hip_config.fused_mlp_act()
-    for fused in (False, True):
-        hip_config.set_flag('fused_mlp_act', fused)
-        try:
-            for with_res in (False, True):
-                arena.clear_grad()
-                x = x0.clone().requires_grad_(True)
-                res = r0.clone().requires_grad_(True) if with_res else None
-                out = mlp(x, residual=res)
-                out.backward(dy)
-                torch.cuda.synchronize()
-                results[(fused, with_res)] = [out.detach().clone(), x.grad.clone(), arena.grads.clone()] + \
-                    ([res.grad.clone()] if with_res else [])
-        finally:
-            hip_config.set_flag('fused_mlp_act', was)
-    for with_res in (False, True):
-        a, b = results[(False, with_res)], results[(True, with_res)]
-        names = ['out', 'dx', 'parameter gradients', 'd residual']
-        for n, u, v in zip(names, a, b):
-            assert u.dtype == v.dtype and u.shape == v.shape
-            assert torch.equal(u.view(torch.int16 if u.dtype == torch.bfloat16 else torch.int32),
-                               v.view(torch.int16 if v.dtype == torch.bfloat16 else torch.int32)), (kind, M, D, with_res, n)
-        assert float(a[1].float().abs().max()) > 0 and float(a[2].abs().max()) > 0
