@@ -15,6 +15,7 @@
 // happens in bn_finalize / bn_bwd_finalize in a fixed order: bit-reproducible run to run.
 #pragma once
 #include "common.h"
+#include "halo_geom.h"   // sigma(): the lane -> row map of the spatially tiled kernel's fragments (PERM)
 
 namespace epi {
 
@@ -34,9 +35,10 @@ __device__ __forceinline__ uint4 pack8(const float (&a)[8]) {
 // output row (-1 = out of range).  mt = index of this workgroup's 128-row tile.
 // Column of accumulator fragment j: (j / FNH) * CH + wn * WN + (j % FNH) * 16 (+ 4 * (lane >> 4)); the
 // defaults (FNH = FN, CH = 0) are one contiguous WN-wide strip per wave, the 8-phase kernel's waves own one
-// 32-column strip in each 128-column half of the tile (FNH = 2, CH = 128).
+// 32-column strip in each 128-column half of the tile (FNH = 2, CH = 128).  PERM: lane l15 of an accumulator
+// fragment holds row halo::sigma(l15) of the fragment instead of row l15 (conv_igemm_halo.hip).
 template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, bool LEAN = false, int FNH = FN, int CH = 0,
-          typename P>
+          bool PERM = false, typename P>
 __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int64_t* rowoff,
                                               const f32x4 (&acc)[FM][FN], int wm, int wn, int lane,
                                               int tid, int n0, int mt) {
@@ -46,6 +48,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
   constexpr int NT = BM * CPR / NTHREADS;  // chunks per thread
   static_assert(NTHREADS % CPR == 0, "a thread must keep its column chunk across iterations");
   const int l15 = lane & 15, l4 = lane >> 4;
+  const int frow = PERM ? halo::sigma(l15) : l15;      // this lane's row inside a 16-row fragment
 
   // ---- phase 1: affine (+ReLU when nothing else follows) on the fp32 accumulators; each lane packs
   // its 4 consecutive channels and writes 8 bytes (ds_write_b64) into out[BM][LDOB]
@@ -71,7 +74,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
       }
-      const int row = wm * WM + i * 16 + l15;
+      const int row = wm * WM + i * 16 + frow;
       *reinterpret_cast<uint2*>(outc + row * (LDOB * 2) + col * 2) =
           make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
     }

@@ -1,0 +1,355 @@
+// kbench: convolution check / timing through the C ABI (include/passl_hip.h) without Python or torch.
+//
+// Why: a fresh GPU box spends 1-2 minutes on its first `import torch`; this binary starts in a second, so a
+// kernel experiment can be checked and timed in a GPU call of well under a minute.
+//
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/kbench.cpp -Iinclude -Lpassl_amd/lib -lpassl_hip \
+//         -Wl,-rpath,'$ORIGIN/../passl_amd/lib' -o tools/kbench          (tools/build_kbench.sh)
+//
+//   tools/kbench check [name=value ...]     bit-exact check of passl_hip_conv_igemm on small cases
+//   tools/kbench time  [name=value ...]     per-layer table of the ResNet-50 3x3 / 1x1 shapes at N = 256
+//   tools/kbench ab name=v0,v1 [...]        the same table for two values of ONE option, side by side
+//   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
+//   name=value pairs are passl_hip_set_option() calls made before anything runs.
+//
+// Exactness: operands are multiples of 1/16 with magnitude < 1, so every product is a multiple of 1/256 and
+// every partial sum of up to 4608 of them is exactly representable in fp32 — the fp32 accumulation is exact
+// in ANY order, and the expected output is simply bf16(round-to-nearest-even of the integer sum / 256).
+// A kernel that adds the right products gets every output bit right; the comparison is ==.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include "passl_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+// ------------------------------------------------------------------------------------------------ data
+__host__ __device__ static inline uint32_t mix(uint64_t i, uint32_t seed) {
+  uint64_t z = i * 0x9E3779B97F4A7C15ull + ((uint64_t)seed << 32 | 0x7F4A7C15u);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)(z >> 33);
+}
+// integer in [-15, 15]; the element's value is that / 16
+__host__ __device__ static inline int ival(uint64_t i, uint32_t seed) { return (int)(mix(i, seed) % 31u) - 15; }
+__host__ __device__ static inline uint16_t bf16_of_small(int v) {        // v / 16 exactly, as bf16 bits
+  float f = (float)v * 0.0625f;
+  union { float f; uint32_t u; } c; c.f = f;
+  return (uint16_t)(c.u >> 16);                                           // 5 significant bits: exact
+}
+__global__ void fill_kernel(uint16_t* p, int64_t n, uint32_t seed) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = bf16_of_small(ival((uint64_t)i, seed));
+}
+static void fill(void* p, int64_t n, uint32_t seed) {
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, (uint16_t*)p, n, seed);
+  CK(hipGetLastError());
+}
+static inline uint16_t bf16_rne(float f) {
+  union { float f; uint32_t u; } c; c.f = f;
+  const uint32_t lsb = (c.u >> 16) & 1u;
+  return (uint16_t)((c.u + 0x7fffu + lsb) >> 16);
+}
+static inline float bf16_to_f(uint16_t b) { union { float f; uint32_t u; } c; c.u = (uint32_t)b << 16; return c.f; }
+
+// ------------------------------------------------------------------------------------------------ shapes
+struct Shape { int N, C, K, R, stride, H; const char* note; int mult; };
+static passl_conv_desc make_desc(const Shape& s, const void* a, const void* b, void* y) {
+  passl_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  const int pad = s.R / 2;
+  const int O = (s.H + 2 * pad - s.R) / s.stride + 1;
+  d.a = a; d.b = b; d.y = y;
+  d.N = s.N; d.OP = O; d.OQ = O; d.NCOLS = s.K; d.R = s.R; d.S = s.R; d.C = s.C;
+  d.IH = s.H; d.IW = s.H; d.sh = d.sw = s.stride; d.ph = d.pw = pad;
+  d.a_sw = s.C; d.a_sh = (int64_t)s.H * s.C; d.a_sn = (int64_t)s.H * s.H * s.C;
+  d.y_sw = s.K; d.y_sh = (int64_t)O * s.K; d.y_sn = (int64_t)O * O * s.K;
+  d.dtype = PASSL_BF16;
+  return d;
+}
+
+struct Buffers {
+  void *a = nullptr, *b = nullptr, *y = nullptr; float* stats = nullptr;
+  int64_t na = 0, nb = 0, ny = 0, nstats = 0;
+  void ensure(int64_t a_, int64_t b_, int64_t y_, int64_t s_) {
+    if (a_ > na) { if (a) CK(hipFree(a)); CK(hipMalloc(&a, a_ * 2)); na = a_; }
+    if (b_ > nb) { if (b) CK(hipFree(b)); CK(hipMalloc(&b, b_ * 2)); nb = b_; }
+    if (y_ > ny) { if (y) CK(hipFree(y)); CK(hipMalloc(&y, y_ * 2)); ny = y_; }
+    if (s_ > nstats) { if (stats) CK(hipFree(stats)); CK(hipMalloc((void**)&stats, s_ * 4)); nstats = s_; }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ check
+// The exact sums (x 256) of one case, computed once per shape on the host.
+static void reference(const Shape& s, std::vector<int32_t>& out) {
+  const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+  const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
+  const int64_t na = (int64_t)s.N * s.H * s.H * s.C, nb = (int64_t)s.K * KD;
+  std::vector<int8_t> ha(na), hb(nb);
+  for (int64_t i = 0; i < na; ++i) ha[i] = (int8_t)ival((uint64_t)i, 11u);
+  for (int64_t i = 0; i < nb; ++i) hb[i] = (int8_t)ival((uint64_t)i, 23u);
+  out.assign(M * s.K, 0);
+  for (int64_t m = 0; m < M; ++m) {
+    const int n = (int)(m / ((int64_t)O * O)), rem = (int)(m % ((int64_t)O * O)), op = rem / O, oq = rem % O;
+    int32_t* accum = &out[m * s.K];
+    for (int r = 0; r < s.R; ++r) {
+      const int ih = op * s.stride + r - pad;
+      if (ih < 0 || ih >= s.H) continue;
+      for (int q = 0; q < s.R; ++q) {
+        const int iw = oq * s.stride + q - pad;
+        if (iw < 0 || iw >= s.H) continue;
+        const int8_t* ap = &ha[(((int64_t)n * s.H + ih) * s.H + iw) * s.C];
+        for (int k = 0; k < s.K; ++k) {
+          const int8_t* bp = &hb[(int64_t)k * KD + ((int64_t)r * s.R + q) * s.C];
+          int32_t t = 0;
+          for (int c = 0; c < s.C; ++c) t += (int32_t)ap[c] * (int32_t)bp[c];
+          accum[k] += t;
+        }
+      }
+    }
+  }
+}
+
+// Full-output comparison.  relu / stats exercise the shared epilogue; returns the number of wrong outputs.
+static int64_t check_case(const Shape& s, bool relu, bool with_stats, Buffers& B, int* kernel_used,
+                          const std::vector<int32_t>& ref) {
+  const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+  const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
+  const int64_t na = (int64_t)s.N * s.H * s.H * s.C, nb = (int64_t)s.K * KD, ny = M * s.K;
+  const int tiles = (int)((M + 127) / 128);
+  B.ensure(na, nb, ny, (int64_t)tiles * s.K * 3);
+  fill(B.a, na, 11u); fill(B.b, nb, 23u);
+  CK(hipMemset(B.y, 0xff, ny * 2));
+  passl_conv_desc d = make_desc(s, B.a, B.b, B.y);
+  d.relu = relu ? 1 : 0;
+  if (with_stats) { d.stats = B.stats; d.stats_tiles = tiles; CK(hipMemset(B.stats, 0xff, (int64_t)tiles * s.K * 12)); }
+  int rc = passl_hip_conv_igemm(&d, nullptr);
+  if (rc != PASSL_OK) { printf("    conv_igemm -> %d (%s)\n", rc, passl_hip_strerror(rc)); return -1; }
+  CK(hipDeviceSynchronize());
+  *kernel_used = passl_hip_last_igemm_kernel();
+  std::vector<uint16_t> y(ny);
+  CK(hipMemcpy(y.data(), B.y, ny * 2, hipMemcpyDeviceToHost));
+  int64_t bad = 0, shown = 0;
+  for (int64_t m = 0; m < M; ++m) {
+    const int n = (int)(m / ((int64_t)O * O)), rem = (int)(m % ((int64_t)O * O)), op = rem / O, oq = rem % O;
+    for (int k = 0; k < s.K; ++k) {
+      float v = (float)ref[m * s.K + k] * (1.0f / 256.0f);
+      if (relu && v < 0.f) v = 0.f;
+      const uint16_t want = bf16_rne(v), got = y[m * s.K + k];
+      if (want != got && !((want & 0x7fff) == 0 && (got & 0x7fff) == 0)) {
+        ++bad;
+        if (shown < 6) { printf("    m=%lld (n=%d op=%d oq=%d) col=%d  want %g got %g\n", (long long)m, n, op, oq, k, bf16_to_f(want), bf16_to_f(got)); ++shown; }
+      }
+    }
+  }
+  if (with_stats && bad == 0) {
+    // slab: [tiles][K][2] sums of (v - s), (v - s)^2, then [tiles][K] shifts s; v = the stored outputs
+    std::vector<float> st((int64_t)tiles * s.K * 3);
+    CK(hipMemcpy(st.data(), B.stats, st.size() * 4, hipMemcpyDeviceToHost));
+    for (int t = 0; t < tiles && bad == 0; ++t)
+      for (int k = 0; k < s.K; ++k) {
+        const float sh = st[(int64_t)tiles * s.K * 2 + (int64_t)t * s.K + k];
+        double s0 = 0, s1 = 0;
+        for (int64_t m = (int64_t)t * 128; m < M && m < (int64_t)(t + 1) * 128; ++m) {
+          const double dv = (double)bf16_to_f(y[m * s.K + k]) - sh;
+          s0 += dv; s1 += dv * dv;
+        }
+        const float g0 = st[((int64_t)t * s.K + k) * 2], g1 = st[((int64_t)t * s.K + k) * 2 + 1];
+        const float first = bf16_to_f(y[(int64_t)t * 128 * s.K + k]);
+        if (sh != first || fabs(g0 - s0) > 1e-3 * (1 + fabs(s0)) || fabs(g1 - s1) > 1e-3 * (1 + fabs(s1))) {
+          ++bad;
+          printf("    stats tile %d col %d: shift %g (first row %g) sums %g %g want %g %g\n", t, k, sh, first, g0, g1, s0, s1);
+          break;
+        }
+      }
+  }
+  return bad;
+}
+
+static const char* kname(int k) {
+  switch (k) { case 0: return "igemm"; case 1: return "ring"; case 2: return "stem"; case 3: return "8p"; case 4: return "halo"; default: return "?"; }
+}
+
+static int run_check() {
+  // small batches on the real spatial sizes: tiles that cross image rows and images, a ragged last tile
+  // (3 * 56 * 56 = 9408 = 73.5 tiles), every stage's 3x3 geometry, plus 1x1 and strided cases for the
+  // kernels the options may re-route
+  const Shape cases[] = {
+      {3, 64, 64, 3, 1, 56, "stage-1 3x3", 0},   {2, 128, 128, 3, 1, 28, "stage-2 3x3", 0},
+      {5, 256, 256, 3, 1, 14, "stage-3 3x3", 0}, {7, 512, 512, 3, 1, 7, "stage-4 3x3", 0},
+      {3, 64, 128, 3, 1, 20, "3x3, 64 -> 128, odd width 20", 0}, {1, 128, 64, 3, 1, 9, "3x3, one image 9x9 (81 rows)", 0},
+      {2, 128, 128, 3, 2, 56, "3x3 stride 2", 0}, {2, 64, 256, 1, 1, 56, "1x1 64 -> 256", 0},
+      {2, 512, 128, 1, 1, 28, "1x1 512 -> 128", 0},
+  };
+  Buffers B;
+  int failures = 0;
+  std::vector<int32_t> ref;
+  for (const Shape& s : cases) {
+    reference(s, ref);
+    for (int variant = 0; variant < 2; ++variant) {
+      const bool relu = variant == 0, stats = variant == 1;
+      int used = -1;
+      const int64_t bad = check_case(s, relu, stats, B, &used, ref);
+      printf("%-34s N=%d %s: kernel %-5s %s\n", s.note, s.N, stats ? "stats" : "relu ", kname(used),
+             bad == 0 ? "exact" : (bad < 0 ? "NOT RUN" : "WRONG"));
+      if (bad != 0) { ++failures; if (bad > 0) printf("    %lld wrong outputs\n", (long long)bad); }
+    }
+  }
+  printf(failures ? "CHECK FAILED (%d)\n" : "CHECK OK\n", failures);
+  return failures ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ timing
+static const Shape kR50[] = {
+    {256, 64, 64, 3, 1, 56, "64->64 k3 @56", 3},     {256, 128, 128, 3, 1, 28, "128->128 k3 @28", 3},
+    {256, 256, 256, 3, 1, 14, "256->256 k3 @14", 5}, {256, 512, 512, 3, 1, 7, "512->512 k3 @7", 2},
+    {256, 128, 128, 3, 2, 56, "128->128 k3 s2 @56", 1}, {256, 256, 256, 3, 2, 28, "256->256 k3 s2 @28", 1},
+    {256, 64, 256, 1, 1, 56, "64->256 k1 @56", 4},   {256, 256, 64, 1, 1, 56, "256->64 k1 @56", 2},
+    {256, 128, 512, 1, 1, 28, "128->512 k1 @28", 4}, {256, 512, 128, 1, 1, 28, "512->128 k1 @28", 3},
+    {256, 256, 1024, 1, 1, 14, "256->1024 k1 @14", 6}, {256, 1024, 256, 1, 1, 14, "1024->256 k1 @14", 5},
+};
+
+static float time_shape(const Shape& s, bool with_stats, Buffers& B, int iters, int* used) {
+  const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+  const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
+  const int64_t na = (int64_t)s.N * s.H * s.H * s.C, nb = (int64_t)s.K * KD, ny = M * s.K;
+  const int tiles = (int)((M + 127) / 128);
+  B.ensure(na, nb, ny, (int64_t)tiles * s.K * 3);
+  fill(B.a, na, 11u); fill(B.b, nb, 23u);
+  passl_conv_desc d = make_desc(s, B.a, B.b, B.y);
+  if (with_stats) { d.stats = B.stats; d.stats_tiles = tiles; }
+  for (int i = 0; i < 3; ++i) {
+    const int rc = passl_hip_conv_igemm(&d, nullptr);
+    if (rc != PASSL_OK) { *used = -1; return -1.f; }
+  }
+  *used = passl_hip_last_igemm_kernel();
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) passl_hip_conv_igemm(&d, nullptr);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+  return ms * 1000.f / iters;
+}
+
+static int run_time(const char* ab_name, int v0, int v1) {
+  Buffers B;
+  const int iters = 20;
+  printf("%-22s %9s | %-5s %8s %7s", "shape (N=256, +stats)", "GFLOP", "kern", "us", "TF");
+  if (ab_name) printf(" | %-5s %8s %7s | %s=%d vs %d", "kern", "us", "TF", ab_name, v0, v1);
+  printf("\n");
+  double tot0 = 0, tot1 = 0;
+  for (const Shape& s : kR50) {
+    const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+    const double gf = 2.0 * s.N * O * O * (double)s.K * s.R * s.R * s.C * 1e-9;
+    int u0 = -1, u1 = -1;
+    if (ab_name) passl_hip_set_option(ab_name, v0);
+    const float t0 = time_shape(s, true, B, iters, &u0);
+    printf("%-22s %9.2f | %-5s %8.1f %7.1f", s.note, gf, kname(u0), t0, gf / t0 * 1e3);
+    tot0 += t0 * s.mult;
+    if (ab_name) {
+      passl_hip_set_option(ab_name, v1);
+      const float t1 = time_shape(s, true, B, iters, &u1);
+      printf(" | %-5s %8.1f %7.1f | %+.1f %%", kname(u1), t1, gf / t1 * 1e3, (t0 / t1 - 1.0) * 100.0);
+      tot1 += t1 * s.mult;
+    }
+    printf("\n");
+  }
+  printf("sum over one forward pass of these layers (x multiplicity): %.1f us", tot0);
+  if (ab_name) printf(" vs %.1f us", tot1);
+  printf("\n");
+  return 0;
+}
+
+// sweep: every argument is one configuration "name=value,name=value,...": the 3x3 / stride-1 cases are checked
+// (bit-exact) and the four ResNet-50 3x3 shapes timed under each, one row per configuration.
+static int apply_config(const char* cfg) {
+  std::string c(cfg);
+  size_t pos = 0;
+  while (pos < c.size()) {
+    size_t end = c.find(',', pos);
+    if (end == std::string::npos) end = c.size();
+    const std::string kv = c.substr(pos, end - pos);
+    const size_t eq = kv.find('=');
+    if (eq == std::string::npos) return -1;
+    if (passl_hip_set_option(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)) != PASSL_OK) return -1;
+    pos = end + 1;
+  }
+  return 0;
+}
+static int run_sweep(int n, char** cfgs) {
+  const Shape cases[] = {
+      {3, 64, 64, 3, 1, 56, "stage-1", 0},  {2, 128, 128, 3, 1, 28, "stage-2", 0}, {5, 256, 256, 3, 1, 14, "stage-3", 0},
+      {7, 512, 512, 3, 1, 7, "stage-4", 0}, {3, 64, 128, 3, 1, 20, "w20", 0},      {1, 128, 64, 3, 1, 9, "9x9", 0},
+  };
+  const int ncases = sizeof(cases) / sizeof(cases[0]);
+  std::vector<std::vector<int32_t>> refs(ncases);
+  for (int i = 0; i < ncases; ++i) reference(cases[i], refs[i]);
+  Buffers B;
+  printf("%-58s %-6s |", "configuration", "check");
+  for (int i = 0; i < 4; ++i) printf(" %-16s", kR50[i].note);
+  printf("   (us, kernel)\n");
+  for (int c = 0; c < n; ++c) {
+    if (apply_config(cfgs[c]) != 0) { printf("%-58s bad option\n", cfgs[c]); continue; }
+    int wrong = 0;
+    for (int i = 0; i < ncases; ++i)
+      for (int v = 0; v < 2; ++v) {
+        int used = -1;
+        if (check_case(cases[i], v == 0, v == 1, B, &used, refs[i]) != 0) ++wrong;
+      }
+    printf("%-58s %-6s |", cfgs[c], wrong ? "WRONG" : "exact");
+    for (int i = 0; i < 4; ++i) {
+      int used = -1;
+      const float t = time_shape(kR50[i], true, B, 20, &used);
+      printf(" %8.1f %-7s", t, kname(used));
+    }
+    printf("\n");
+    fflush(stdout);
+    if (getenv("KBENCH_STAMPS") && strstr(cfgs[c], "igemm_halo=1"))
+      for (int i = 0; i < 2; ++i) {          // per-phase time stamps of one launch (stderr)
+        int used = -1;
+        passl_hip_set_option("igemm_halo_dbg", 1);
+        time_shape(kR50[i], true, B, 1, &used);
+        fprintf(stderr, "  %s: ", kR50[i].note);
+        passl_hip_set_option("igemm_halo_dbg", 2);
+      }
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: kbench check|time|ab [name=value ...]\n"); return 2; }
+  const std::string mode = argv[1];
+  if (mode == "sweep") { printf("libpassl_hip ABI %d\n", passl_hip_abi_version()); return run_sweep(argc - 2, argv + 2); }
+  const char* ab_name = nullptr; int v0 = 0, v1 = 0;
+  static char namebuf[128];
+  for (int i = 2; i < argc; ++i) {
+    const char* eq = strchr(argv[i], '=');
+    if (!eq) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
+    std::string name(argv[i], eq - argv[i]);
+    const char* comma = strchr(eq + 1, ',');
+    if (mode == "ab" && comma && !ab_name) {
+      snprintf(namebuf, sizeof(namebuf), "%s", name.c_str());
+      ab_name = namebuf; v0 = atoi(eq + 1); v1 = atoi(comma + 1);
+      continue;
+    }
+    const int rc = passl_hip_set_option(name.c_str(), atoi(eq + 1));
+    if (rc != PASSL_OK) { fprintf(stderr, "set_option(%s) -> %d\n", name.c_str(), rc); return 2; }
+  }
+  printf("libpassl_hip ABI %d\n", passl_hip_abi_version());
+  if (mode == "check") return run_check();
+  if (mode == "time") return run_time(nullptr, 0, 0);
+  if (mode == "ab") { if (!ab_name) { fprintf(stderr, "ab needs name=v0,v1\n"); return 2; } return run_time(ab_name, v0, v1); }
+  fprintf(stderr, "unknown mode %s\n", mode.c_str());
+  return 2;
+}
