@@ -51,10 +51,15 @@ int passl_hip_abi_version(void);
  *   "igemm_8p_min_nk" n         ... (mode 1) only for reductions of at least n 64-element K-tiles (8)
  *   "igemm_8p_tk" / "_te" / "_ring_tk" / "_ring_te" / "_margin"   the cost model's constants (0.01 us per K-tile and
  *                               per tile of either kernel, margin in %: conv_igemm_8p.hip)
+ *   "igemm_halo" 0|1            EXPERIMENTAL spatially tiled kernel for 3x3 / stride 1 / pad 1 layers (conv_igemm_halo.hip):
+ *                               off (default; exact but slower than the ring kernel: profiles/r04_kbench_halo_experiment.txt)
+ *   "igemm_halo_max_c" n        ... only up to n input channels (128);  "igemm_halo_stages" 2..4 weight-ring depth (2);
+ *   "igemm_halo_ck" 0|32|64     channels per halo chunk (0: 64 for C = 64, else 32);  "igemm_halo_dbg" 1|2 time stamps
  * Returns PASSL_EINVAL for an unknown name. */
 int passl_hip_set_option(const char* name, int value);
 /* Which kernel the most recent passl_hip_conv_igemm call of this process launched: 0 = igemm_kernel
- * (register-staged), 1 = igemm_ring_kernel, 2 = stem_kernel, 3 = igemm_8p_kernel; -1 before the first call.
+ * (register-staged), 1 = igemm_ring_kernel, 2 = stem_kernel, 3 = igemm_8p_kernel, 4 = igemm_halo_kernel; -1 before the
+ * first call.
  * Diagnostics for tests and benchmarks (not thread-safe). */
 int passl_hip_last_igemm_kernel(void);
 /* Human readable text for a passl_status. */

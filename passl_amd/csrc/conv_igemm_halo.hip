@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   __syncthreads();      // all fragment reads done before the LDS is reused as the output tile
   stamp(3);
 
-  epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, false, FN, 0, true>(p, smem, rowoff, acc, wm, wn, lane, tid,
-                                                                            n0, mt);
+  epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, false, FN, 0, true, true>(
+      p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt, p.stamps ? p.stamps + (size_t)tile * 8 : nullptr);
   stamp(4);
 }
 
@@ -319,17 +319,20 @@ static void halo_report() {
   const int n = g_halo_stamp_tiles;
   unsigned long long* h = (unsigned long long*)malloc((size_t)n * 64);
   (void)hipMemcpy(h, g_halo_stamps, (size_t)n * 64, hipMemcpyDeviceToHost);
-  double ph[4] = {0, 0, 0, 0};
+  double ph[4] = {0, 0, 0, 0}, ep[3] = {0, 0, 0};
   unsigned long long first = ~0ull, last = 0;
   for (int t = 0; t < n; ++t) {
     for (int k = 0; k < 4; ++k) ph[k] += (double)(h[t * 8 + k + 1] - h[t * 8 + k]);
+    ep[0] += (double)(h[t * 8 + 5] - h[t * 8 + 3]);      // accumulators -> LDS, barrier
+    ep[1] += (double)(h[t * 8 + 6] - h[t * 8 + 5]);      // row stores (+ statistics accumulation)
+    ep[2] += (double)(h[t * 8 + 4] - h[t * 8 + 6]);      // statistics: two barriers, fixed-order reduction, slab store
     if (h[t * 8] < first) first = h[t * 8];
     if (h[t * 8 + 4] > last) last = h[t * 8 + 4];
   }
-  fprintf(stderr, "halo stamps over %d tiles (us per tile): setup %.2f, halo landed %.2f, main loop %.2f, epilogue %.2f; "
-                  "whole launch %.1f us => %.2f tiles in flight on average\n",
-          n, ph[0] / n / 100.0, ph[1] / n / 100.0, ph[2] / n / 100.0, ph[3] / n / 100.0, (double)(last - first) / 100.0,
-          (ph[0] + ph[1] + ph[2] + ph[3]) / (double)(last - first));
+  fprintf(stderr, "halo stamps over %d tiles (us per tile): setup %.2f, halo landed %.2f, main loop %.2f, epilogue %.2f "
+                  "(to LDS + barrier %.2f, row stores %.2f, statistics %.2f); whole launch %.1f us => %.2f tiles in flight on average\n",
+          n, ph[0] / n / 100.0, ph[1] / n / 100.0, ph[2] / n / 100.0, ph[3] / n / 100.0, ep[0] / n / 100.0, ep[1] / n / 100.0,
+          ep[2] / n / 100.0, (double)(last - first) / 100.0, (ph[0] + ph[1] + ph[2] + ph[3]) / (double)(last - first));
   free(h);
 }
 

@@ -38,10 +38,10 @@ __device__ __forceinline__ uint4 pack8(const float (&a)[8]) {
 // 32-column strip in each 128-column half of the tile (FNH = 2, CH = 128).  PERM: lane l15 of an accumulator
 // fragment holds row halo::sigma(l15) of the fragment instead of row l15 (conv_igemm_halo.hip).
 template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, bool LEAN = false, int FNH = FN, int CH = 0,
-          bool PERM = false, typename P>
+          bool PERM = false, bool STAMP = false, typename P>
 __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int64_t* rowoff,
                                               const f32x4 (&acc)[FM][FN], int wm, int wn, int lane,
-                                              int tid, int n0, int mt) {
+                                              int tid, int n0, int mt, unsigned long long* stamps = nullptr) {
   static_assert(BM == 128, "slab rows are per 128-row tile");
   constexpr int LDOB = BN + 8;             // bf16 epilogue pitch (elements): 16-byte aligned rows
   constexpr int CPR = BN / 8;              // 8-column chunks per row
@@ -107,6 +107,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
     }
   }
   __syncthreads();
+  if constexpr (STAMP) { if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memrealtime(); }
   const bf16_t* outb = reinterpret_cast<const bf16_t*>(smem);
 
   // per-column constants of the statistics
@@ -176,6 +177,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       }
     }
   }
+  if constexpr (STAMP) { if (stamps && tid == 0) stamps[6] = __builtin_amdgcn_s_memrealtime(); }
   if (!fstats && !bnb) return;
 
   // threads tid, tid+CPR, ... share a column chunk: each writes its 16 partial values to

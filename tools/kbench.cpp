@@ -327,6 +327,31 @@ static int run_sweep(int n, char** cfgs) {
   return 0;
 }
 
+// ablate: the register-staged kernel's debug switches (PASSL_IGEMM_DBG: 2 = return before the epilogue, 4 = no A
+// loads, 8 = no MFMAs) on the 1x1 shapes it serves: what a tile's time is made of.
+static int run_ablate() {
+  setenv("PASSL_IGEMM_DBG_DYNAMIC", "1", 1);
+  const int sets[] = {0, 2, 8, 4, 2 | 8, 2 | 4 | 8};
+  const Shape shapes[] = {kR50[6], kR50[7], kR50[8], kR50[10], {256, 64, 64, 1, 1, 56, "64->64 k1 @56", 1}};
+  Buffers B;
+  printf("%-22s", "PASSL_IGEMM_DBG =");
+  for (int v : sets) printf(" %8d", v);
+  printf("   (us; 2 no epilogue, 4 no A loads, 8 no MFMA)\n");
+  for (const Shape& sh : shapes) {
+    printf("%-22s", sh.note);
+    for (int v : sets) {
+      char buf[16]; snprintf(buf, sizeof(buf), "%d", v);
+      setenv("PASSL_IGEMM_DBG", buf, 1);
+      int used = -1;
+      const float t = time_shape(sh, true, B, 20, &used);
+      printf(" %8.1f", t);
+    }
+    printf("\n");
+  }
+  setenv("PASSL_IGEMM_DBG", "0", 1);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: kbench check|time|ab [name=value ...]\n"); return 2; }
   const std::string mode = argv[1];
@@ -348,6 +373,7 @@ int main(int argc, char** argv) {
   }
   printf("libpassl_hip ABI %d\n", passl_hip_abi_version());
   if (mode == "check") return run_check();
+  if (mode == "ablate") return run_ablate();
   if (mode == "time") return run_time(nullptr, 0, 0);
   if (mode == "ab") { if (!ab_name) { fprintf(stderr, "ab needs name=v0,v1\n"); return 2; } return run_time(ab_name, v0, v1); }
   fprintf(stderr, "unknown mode %s\n", mode.c_str());
