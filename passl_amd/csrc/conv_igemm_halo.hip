@@ -60,13 +60,14 @@ struct Params {
   uint32_t hbytes;             // bytes of one halo buffer = g.nq * 1024
   FDiv d_tn;
   Geom g;
+  Geom2 g2;                    // 2-D tiles (P2D): two 8 x 8 patches per tile
   unsigned long long* stamps;  // NULL, or 8 time stamps (100 MHz) per tile: igemm_halo_dbg
 };
 
 // 64-byte weight rows (CK = 32): the ring kernel's slot rotation (conv_igemm_ring.hip: swz32)
 __device__ __forceinline__ int swz32(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-template <int BN, int CK, int MINB, int STAGES>
+template <int BN, int CK, int MINB, int STAGES, bool P2D>
 __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   constexpr int BM = kBM;
   constexpr int RB = CK * 2;                 // bytes of a weight-tile row = of the channel chunk of a halo row
@@ -82,7 +83,8 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   constexpr int B_BYTES = BN * RB;
   constexpr int NIB = B_BYTES / 1024 / WAVES;        // weight DMA pieces per wave per k-tile (4, 2 or 1)
   static_assert(NIB >= 1, "a k-tile of weights is at least one DMA piece per wave");
-  constexpr int NHI = CK == 64 ? 11 : 7;             // halo DMA pieces per wave, at most (host: nq <= 4 * NHI)
+  // halo DMA pieces per wave, at most (host: nq <= 4 * NHI): up to 310 rows of 9 / 5 slots, or the 200 rows of two patches
+  constexpr int NHI = P2D ? (CK == 64 ? 8 : 4) : (CK == 64 ? 11 : 7);
   static_assert(STAGES >= 2 && STAGES <= 4, "vmcnt bookkeeping covers 2 to 4 weight stages");
   // the NEXT chunk's halo is issued in slices behind the weights of taps 0 .. NSL-1; the last slice must be older
   // than the (STAGES - 2) weight tiles the counted waits leave in flight when the chunk's last tap is reached
@@ -120,12 +122,13 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.b), 0, p.b_bytes, 0x00020000);
 
   // ---- static DMA geometry
-  const int pbase = padded_index(g, m0) - g.PW - 1;
+  const int pbase = P2D ? 0 : padded_index(g, m0) - g.PW - 1;
   uint32_t h_src[NHI];                       // halo piece q = i * 4 + wave: this lane's source (channel chunk 0)
 #pragma unroll
   for (int i = 0; i < NHI; ++i) {
     const int q = i * WAVES + wave;
-    h_src[i] = q < g.nq ? halo_src<CPRW>(g, pbase, q, lane) : kNoSrc;
+    if constexpr (P2D) h_src[i] = q < g.nq ? halo_src2<CPRW>(p.g2, mt, q, lane) : kNoSrc;
+    else h_src[i] = q < g.nq ? halo_src<CPRW>(g, pbase, q, lane) : kNoSrc;
   }
   uint32_t b_off[NIB];                       // weight piece i: rows 8 (i*4 + wave) .., the ring kernel's swizzle
 #pragma unroll
@@ -138,7 +141,10 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   if (tid < BM) {                            // output row offsets (elements) for the epilogue; -1 = out of range
     const int m = m0 + tid;
     int64_t off = -1;
-    if (m < p.M) {
+    if constexpr (P2D) {
+      int n, oy, ox;
+      if (out_pixel2(p.g2, mt, tid, n, oy, ox)) off = (int64_t)n * p.y_sn + (int64_t)oy * p.y_sh + (int64_t)ox * p.y_sw;
+    } else if (m < p.M) {
       const int n = fdiv(m, g.d_opq);
       const int rem = m - n * g.opq;
       const int op = fdiv(rem, g.d_iw);
@@ -183,7 +189,8 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   // ---- fragment read addresses
   uint32_t a_rd[FM];                         // halo: per fragment (its 16 rows need not be 16 halo rows apart)
 #pragma unroll
-  for (int i = 0; i < FM; ++i) a_rd[i] = a_frag_base<CPRW>(g, m0, wm * WM + i * 16, l15, l4);
+  for (int i = 0; i < FM; ++i)
+    a_rd[i] = P2D ? a_frag_base2<CPRW>(wm * WM + i * 16, l15, l4) : a_frag_base<CPRW>(g, m0, wm * WM + i * 16, l15, l4);
   uint32_t b_rd[KS];                         // weights: the ring kernel's addresses
   {
     const int rb = wn * WN + l15;
@@ -197,7 +204,8 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   int f_t = 0, f_r = 0, f_s = 0, f_chunk = 0;
   auto read_frags = [&](auto SET) {
     constexpr int S_ = decltype(SET)::value;
-    const uint32_t hb = lds0 + (uint32_t)HOFF + (uint32_t)(f_chunk & 1) * p.hbytes + tap_bytes<CPRW>(g, f_r, f_s);
+    const uint32_t hb = lds0 + (uint32_t)HOFF + (uint32_t)(f_chunk & 1) * p.hbytes +
+                        (P2D ? tap_bytes2<CPRW>(f_r, f_s) : tap_bytes<CPRW>(g, f_r, f_s));
     const uint32_t sb = lds0 + (uint32_t)((f_t % STAGES) * B_BYTES);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -294,21 +302,21 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   stamp(4);
 }
 
-template <int BN, int CK, int MINB, int STAGES>
+template <int BN, int CK, int MINB, int STAGES, bool P2D>
 int launch(const Params& p, int lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<BN, CK, MINB, STAGES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<BN, CK, MINB, STAGES, P2D>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_halo_kernel<BN, CK, MINB, STAGES>), dim3(p.ntiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_halo_kernel<BN, CK, MINB, STAGES, P2D>), dim3(p.ntiles), dim3(256), lds, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
 }  // namespace halo
 
-static int g_halo_enabled = -1, g_halo_max_c = 128, g_halo_ck = 0, g_halo_stages = 2;
+static int g_halo_enabled = -1, g_halo_max_c = 128, g_halo_ck = 0, g_halo_stages = 2, g_halo_2d = 1;
 // igemm_halo_dbg: 1 = the next launches write 5 time stamps per tile (kernel entry, setup done, halo landed, main
 // loop done, epilogue done; s_memrealtime, 100 MHz); 2 = print what the LAST launch took per phase and switch off
 static unsigned long long* g_halo_stamps = nullptr;
@@ -345,6 +353,7 @@ int passl_igemm_halo_option(const char* name, int value) {
     g_halo_dbg = value == 1;
     return PASSL_OK;
   }
+  if (!strcmp(name, "igemm_halo_2d")) { g_halo_2d = value != 0; return PASSL_OK; }   // two 8 x 8 patches per tile when IH, IW % 8 == 0
   if (!strcmp(name, "igemm_halo_stages")) {      // depth of the weight ring
     if (value < 2 || value > 4) return PASSL_EINVAL;
     g_halo_stages = value;
@@ -412,9 +421,15 @@ int passl_igemm_halo_try(const passl_conv_desc* d, hipStream_t st) {
   g.N = d->N; g.IH = d->IH; g.IW = d->IW; g.PW = d->IW + 2; g.PH1 = d->IH + 1;
   g.opq = d->IH * d->IW; g.M = (int)M64;
   g.a_sn2 = (int)(d->a_sn * 2); g.a_sh2 = (int)(d->a_sh * 2); g.a_sw2 = (int)(d->a_sw * 2);
-  g.hrows = halo::halo_rows(d->IH, d->IW);
+  const bool p2d = g_halo_2d && (d->IH % 8) == 0 && (d->IW % 8) == 0;
+  g.hrows = p2d ? halo::kHaloRows2 : halo::halo_rows(d->IH, d->IW);
   g.nq = (g.hrows * (CK / 8 + 1) + 63) / 64;
-  const int nhi = CK == 64 ? 11 : 7;
+  const int nhi = p2d ? (CK == 64 ? 8 : 4) : (CK == 64 ? 11 : 7);
+  halo::Geom2& g2 = p.g2;
+  g2.N = d->N; g2.IH = d->IH; g2.IW = d->IW;
+  g2.PXN = p2d ? d->IW / 8 : 1; g2.PN = p2d ? (d->IH / 8) * (d->IW / 8) : 1; g2.npatches = d->N * g2.PN;
+  g2.a_sn2 = g.a_sn2; g2.a_sh2 = g.a_sh2; g2.a_sw2 = g.a_sw2;
+  g2.d_pn = halo::make_fdiv((uint32_t)g2.PN); g2.d_pxn = halo::make_fdiv((uint32_t)g2.PXN);
   g.d_opq = halo::make_fdiv((uint32_t)g.opq); g.d_iw = halo::make_fdiv((uint32_t)g.IW);
   g.d_pw = halo::make_fdiv((uint32_t)g.PW); g.d_ph1 = halo::make_fdiv((uint32_t)g.PH1);
   if (g.nq > 4 * nhi) return PASSL_EUNSUPPORTED;       // pieces per wave the kernel unrolls (images wider than ~56 columns)
@@ -435,14 +450,17 @@ int passl_igemm_halo_try(const passl_conv_desc* d, hipStream_t st) {
   if (lds > 160 * 1024) return PASSL_EUNSUPPORTED;
   // the output tile of the epilogue (128 x (BN + 8) bf16) and its 16 KB reduction scratch live below the row offsets
   if (128 * (bn + 8) * 2 > lds - 1024 || 16 * 1024 > lds - 1024) return PASSL_EUNSUPPORTED;
-  // three workgroups per CU when the LDS allows it (the register budget follows: 168 VGPRs)
-  const bool three = lds * 3 <= 160 * 1024;
-#define PASSL_HALO_LAUNCH(BN_, CK_, ST_) \
-  (three && !(BN_ == 128 && CK_ == 64) ? halo::launch<BN_, CK_, 3, ST_>(p, lds, st) : halo::launch<BN_, CK_, 2, ST_>(p, lds, st))
-#define PASSL_HALO_BY_STAGES(BN_, CK_) \
-  (stages == 2 ? PASSL_HALO_LAUNCH(BN_, CK_, 2) : stages == 3 ? PASSL_HALO_LAUNCH(BN_, CK_, 3) : PASSL_HALO_LAUNCH(BN_, CK_, 4))
-  if (CK == 64) return bn == 64 ? PASSL_HALO_BY_STAGES(64, 64) : PASSL_HALO_BY_STAGES(128, 64);
-  return bn == 64 ? PASSL_HALO_BY_STAGES(64, 32) : PASSL_HALO_BY_STAGES(128, 32);
-#undef PASSL_HALO_BY_STAGES
-#undef PASSL_HALO_LAUNCH
+  // three workgroups per CU when the LDS allows it (the register budget follows: 168 VGPRs; the 128 x 128 tile with
+  // 64-channel k-tiles needs more and stays at two)
+  const bool three = lds * 3 <= 160 * 1024 && !(bn == 128 && CK == 64);
+#define PASSL_HALO_GO(BN_, CK_, MB_, ST_) \
+  (p2d ? halo::launch<BN_, CK_, MB_, ST_, true>(p, lds, st) : halo::launch<BN_, CK_, MB_, ST_, false>(p, lds, st))
+#define PASSL_HALO_ST(BN_, CK_, MB_) \
+  (stages == 2 ? PASSL_HALO_GO(BN_, CK_, MB_, 2) : stages == 3 ? PASSL_HALO_GO(BN_, CK_, MB_, 3) : PASSL_HALO_GO(BN_, CK_, MB_, 4))
+  if (bn == 128 && CK == 64) return PASSL_HALO_ST(128, 64, 2);
+  if (bn == 128) return three ? PASSL_HALO_ST(128, 32, 3) : PASSL_HALO_ST(128, 32, 2);
+  if (CK == 64) return three ? PASSL_HALO_ST(64, 64, 3) : PASSL_HALO_ST(64, 64, 2);
+  return three ? PASSL_HALO_ST(64, 32, 3) : PASSL_HALO_ST(64, 32, 2);
+#undef PASSL_HALO_ST
+#undef PASSL_HALO_GO
 }

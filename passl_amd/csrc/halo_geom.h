@@ -127,4 +127,73 @@ HALO_HD uint32_t a_frag_base(const Geom& g, int m0, int frag_row0, int l15, int 
 template <int CPRW>
 HALO_HD uint32_t tap_bytes(const Geom& g, int r, int s) { return (uint32_t)(r * g.PW + s) * (uint32_t)((CPRW + 1) * 16); }
 
+// ------------------------------------------------------------------------------------------------------------
+// 2-D tiles (IH and IW multiples of 8).  The statistics slabs and the epilogue only need every tile to hold 128
+// output rows — not consecutive ones — so a tile may as well be two 8 x 8 PATCHES (consecutive in the global patch
+// order n, py, px): their halos are two 10 x 10 blocks = 200 LDS rows instead of up to 310, no divisions by run-time
+// numbers per lane, and three workgroups per CU at 56 x 56 x 64.
+//
+//   tile row r' (0..127):  patch b = r' >> 6,  y = ((r' >> 4) & 3) + 4 * ((r' >> 3) & 1),  x = r' & 7
+//   LDS halo row of (r', tap r, s):  b * 100 + (y + r) * 10 + (x + s)
+//
+// i.e. a 16-row fragment holds the patch rows yy and yy + 4: their 16 LDS rows have 16 different residues mod 16
+// (40 = 8 mod 16), even x on even rows — the same lane map sigma and the same slot argument as above.
+struct Geom2 {
+  int N, IH, IW;
+  int PXN, PN;              // patches per image row, per image
+  int npatches;             // N * PN
+  int a_sn2, a_sh2, a_sw2;
+  FDiv d_pn, d_pxn;
+};
+constexpr int kHaloRows2 = 200;
+
+// pixel of tile row r' inside its patch
+HALO_HD void patch_row(int r, int& b, int& y, int& x) {
+  b = r >> 6;
+  y = ((r >> 4) & 3) + 4 * ((r >> 3) & 1);
+  x = r & 7;
+}
+// image and patch origin of global patch gp; false past the last patch
+HALO_HD bool patch_origin(const Geom2& g, int gp, int& n, int& y0, int& x0) {
+  n = fdiv(gp, g.d_pn);
+  const int rem = gp - n * g.PN;
+  const int py = fdiv(rem, g.d_pxn);
+  y0 = py * 8;
+  x0 = (rem - py * g.PXN) * 8;
+  return gp < g.npatches;
+}
+template <int CPRW>
+HALO_HD uint32_t halo_src2(const Geom2& g, int tile, int q, int lane) {
+  const int p = q * 64 + lane;
+  const int hrow = p / (CPRW + 1);
+  const int cpos = p - hrow * (CPRW + 1);
+  if (cpos == CPRW || hrow >= kHaloRows2) return kNoSrc;
+  const int b = hrow >= 100 ? 1 : 0;
+  const int hr = hrow - 100 * b;
+  const int hy = hr / 10, hx = hr - 10 * hy;
+  int n, y0, x0;
+  if (!patch_origin(g, 2 * tile + b, n, y0, x0)) return kNoSrc;
+  const int ih = y0 + hy - 1, iw = x0 + hx - 1;
+  if (ih < 0 || ih >= g.IH || iw < 0 || iw >= g.IW) return kNoSrc;
+  return (uint32_t)n * (uint32_t)g.a_sn2 + (uint32_t)ih * (uint32_t)g.a_sh2 + (uint32_t)iw * (uint32_t)g.a_sw2 +
+         (uint32_t)swap01(cpos) * 16u;
+}
+template <int CPRW>
+HALO_HD uint32_t a_frag_base2(int frag_row0, int l15, int l4) {
+  int b, y, x;
+  patch_row(frag_row0 + sigma(l15), b, y, x);
+  return (uint32_t)(b * 100 + y * 10 + x) * (uint32_t)((CPRW + 1) * 16) + (uint32_t)swap01(l4) * 16u;
+}
+template <int CPRW>
+HALO_HD uint32_t tap_bytes2(int r, int s) { return (uint32_t)(r * 10 + s) * (uint32_t)((CPRW + 1) * 16); }
+// flattened output row (n, oy, ox) of tile row r'; false when the patch does not exist (ragged last tile)
+HALO_HD bool out_pixel2(const Geom2& g, int tile, int r, int& n, int& oy, int& ox) {
+  int b, y, x, y0, x0;
+  patch_row(r, b, y, x);
+  const bool ok = patch_origin(g, 2 * tile + b, n, y0, x0);
+  oy = y0 + y;
+  ox = x0 + x;
+  return ok;
+}
+
 }  // namespace halo

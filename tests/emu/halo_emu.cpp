@@ -28,7 +28,7 @@ static int swz32(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 struct Case { int N, H, W, C, K; };
 
 // one launch; returns the number of wrong outputs
-template <int BN, int CK>
+template <int BN, int CK, bool P2D = false>
 static long run(const Case& cs) {
   constexpr int RB = CK * 2, KS = CK / 32, CPRW = RB / 16, RPI = 1024 / RB, WAVES = 4;
   constexpr int WAVES_N = BN == 128 ? 2 : 1, WAVES_M = WAVES / WAVES_N;
@@ -46,12 +46,17 @@ static long run(const Case& cs) {
   Geom g;
   g.N = N; g.IH = IH; g.IW = IW; g.PW = IW + 2; g.PH1 = IH + 1; g.opq = IH * IW; g.M = (int)M;
   g.a_sw2 = C * 2; g.a_sh2 = IW * C * 2; g.a_sn2 = IH * IW * C * 2;
-  g.hrows = halo_rows(IH, IW);
+  g.hrows = P2D ? kHaloRows2 : halo_rows(IH, IW);
   g.nq = (g.hrows * (CPRW + 1) + 63) / 64;
+  Geom2 g2;
+  g2.N = N; g2.IH = IH; g2.IW = IW; g2.PXN = IW / 8; g2.PN = (IH / 8) * (IW / 8); g2.npatches = N * g2.PN;
+  g2.a_sn2 = g.a_sn2; g2.a_sh2 = g.a_sh2; g2.a_sw2 = g.a_sw2;
+  if (P2D) { g2.d_pn = make_fdiv((uint32_t)g2.PN); g2.d_pxn = make_fdiv((uint32_t)g2.PXN); }
   g.d_opq = make_fdiv((uint32_t)g.opq); g.d_iw = make_fdiv((uint32_t)IW);
   g.d_pw = make_fdiv((uint32_t)g.PW); g.d_ph1 = make_fdiv((uint32_t)g.PH1);
   const int nchunks = C / CK;
-  const int tiles_m = (int)((M + 127) / 128), tiles_n = (K + BN - 1) / BN;
+  const int tiles_m = P2D ? (g2.npatches + 1) / 2 : (int)((M + 127) / 128), tiles_n = (K + BN - 1) / BN;
+  if (P2D && tiles_m != (int)((M + 127) / 128)) { printf("tile count mismatch\n"); return 1; }
 
   std::vector<int32_t> out((size_t)M * K, INT32_MIN);
   std::vector<char> hal((size_t)g.nq * 1024), wt(B_BYTES);
@@ -59,14 +64,14 @@ static long run(const Case& cs) {
   for (int mt = 0; mt < tiles_m; ++mt)
     for (int nt = 0; nt < tiles_n; ++nt) {
       const int m0 = mt * 128, n0 = nt * BN;
-      const int pbase = padded_index(g, m0) - g.PW - 1;
+      const int pbase = P2D ? 0 : padded_index(g, m0) - g.PW - 1;
       // accumulators: [wave][lane][i][j][r]
       std::vector<int32_t> acc((size_t)WAVES * 64 * FM * FN * 4, 0);
       for (int chunk = 0; chunk < nchunks; ++chunk) {
         // ---- halo pieces (buffer_load_dwordx4 ... lds: lane-linear 16-byte writes, out-of-range -> zeros)
         for (int q = 0; q < g.nq; ++q)
           for (int lane = 0; lane < 64; ++lane) {
-            uint32_t off = halo_src<CPRW>(g, pbase, q, lane);
+            uint32_t off = P2D ? halo_src2<CPRW>(g2, mt, q, lane) : halo_src<CPRW>(g, pbase, q, lane);
             char* dst = &hal[(size_t)q * 1024 + lane * 16];
             if (off != kNoSrc) off += (uint32_t)(chunk * RB);
             if (off == kNoSrc || off + 16 > a_bytes) memset(dst, 0, 16);
@@ -97,7 +102,8 @@ static long run(const Case& cs) {
                   int16_t pix[64][8], wgt[64][8];
                   for (int lane = 0; lane < 64; ++lane) {
                     const int l15 = lane & 15, l4 = lane >> 4;
-                    const uint32_t ad = a_frag_base<CPRW>(g, m0, wm * WM + i * 16, l15, l4) + tap_bytes<CPRW>(g, r, s) +
+                    const uint32_t ad = (P2D ? a_frag_base2<CPRW>(wm * WM + i * 16, l15, l4) + tap_bytes2<CPRW>(r, s)
+                                             : a_frag_base<CPRW>(g, m0, wm * WM + i * 16, l15, l4) + tap_bytes<CPRW>(g, r, s)) +
                                         (uint32_t)(64 * ks);
                     if (ad + 16 > hal.size()) { printf("halo read out of the buffer: %u\n", ad); return -1; }
                     if ((long)(ad / ((CPRW + 1) * 16)) > halo_rows_used_max) halo_rows_used_max = ad / ((CPRW + 1) * 16);
@@ -131,7 +137,11 @@ static long run(const Case& cs) {
             for (int j = 0; j < FN; ++j)
               for (int e = 0; e < 4; ++e) {
                 const int row = wm * WM + i * 16 + sigma(lane & 15), col = wn * WN + j * 16 + (lane >> 4) * 4 + e;
-                const long m = m0 + row; const int gc = n0 + col;
+                long m = m0 + row; const int gc = n0 + col;
+                if (P2D) {
+                  int n, oy, ox;
+                  m = out_pixel2(g2, mt, row, n, oy, ox) ? (long)n * IH * IW + (long)oy * IW + ox : M;
+                }
                 if (m < M && gc < K) out[(size_t)m * K + gc] = acc[((((size_t)wave * 64 + lane) * FM + i) * FN + j) * 4 + e];
               }
       }
@@ -159,7 +169,7 @@ static long run(const Case& cs) {
       }
     }
   }
-  printf("N=%d %dx%d C=%d K=%d BN=%d CK=%d: hrows %d (highest row read %ld) nq %d -> %s\n", N, IH, IW, C, K, BN, CK, g.hrows,
+  printf("%sN=%d %dx%d C=%d K=%d BN=%d CK=%d: hrows %d (highest row read %ld) nq %d -> %s\n", P2D ? "2-D tiles " : "", N, IH, IW, C, K, BN, CK, g.hrows,
          halo_rows_used_max, g.nq, bad ? "WRONG" : "exact");
   if (halo_rows_used_max >= g.hrows) { printf("  a fragment read went past the staged halo rows\n"); ++bad; }
   return bad;
@@ -188,10 +198,39 @@ static int bank_check() {
   return conflicts;
 }
 
+// the same for the 2-D tiles: a fragment = patch rows yy and yy + 4, every tap offset
+template <int CPRW>
+static int bank_check2() {
+  static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                    {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+  int conflicts = 0;
+  for (int frag = 0; frag < 8; ++frag)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int gi = 0; gi < 4; ++gi) {
+        int seen[16] = {0};
+        for (int x = 0; x < 16; ++x) {
+          const int lane = groups[gi][x];
+          const uint32_t ad = a_frag_base2<CPRW>(frag * 16, lane & 15, lane >> 4) + tap_bytes2<CPRW>(tap / 3, tap % 3);
+          if (seen[(ad / 16) % 16]++) ++conflicts;
+        }
+      }
+  printf("bank check, 2-D tiles, pitch %d B: %d conflicts over 8 fragments x 9 taps x 4 lane groups\n", (CPRW + 1) * 16, conflicts);
+  return conflicts;
+}
+
 int main() {
   long bad = 0;
   bad += bank_check<8>();
   bad += bank_check<4>();
+  bad += bank_check2<8>();
+  bad += bank_check2<4>();
+  bad += run<64, 64, true>({3, 56, 56, 64, 64});
+  bad += run<64, 32, true>({1, 56, 56, 64, 40});
+  bad += run<128, 32, true>({3, 8, 24, 96, 136});
+  bad += run<128, 64, true>({5, 16, 8, 128, 72});
+  bad += run<64, 64, true>({1, 8, 8, 64, 64});
   { int seen = 0; for (int i = 0; i < 16; ++i) seen |= 1 << sigma(i); if (seen != 0xffff) { printf("sigma is not a permutation\n"); ++bad; } }
   for (int c = 0; c < 8; ++c) if (swap01(swap01(c)) != c) { printf("swap01 is not an involution\n"); ++bad; }
   // images that tiles cross (9408 rows = 73.5 tiles), odd widths, one image smaller than a tile, several chunks

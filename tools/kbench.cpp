@@ -149,25 +149,30 @@ static int64_t check_case(const Shape& s, bool relu, bool with_stats, Buffers& B
     }
   }
   if (with_stats && bad == 0) {
-    // slab: [tiles][K][2] sums of (v - s), (v - s)^2, then [tiles][K] shifts s; v = the stored outputs
+    // slab: [tiles][K][2] sums of (v - s), (v - s)^2, then [tiles][K] shifts s; v = the stored outputs.  Checked the
+    // way passl_hip_bn_finalize consumes it — per column, sum_t (S0_t + n_t s_t) and sum_t (S1_t + 2 s_t S0_t + n_t s_t^2)
+    // with n_t = 128 rows per tile (the rest in the last one) — which does not depend on WHICH rows a tile holds
+    // (the 2-D tiles of the spatially tiled kernel are not runs of consecutive rows).
     std::vector<float> st((int64_t)tiles * s.K * 3);
     CK(hipMemcpy(st.data(), B.stats, st.size() * 4, hipMemcpyDeviceToHost));
-    for (int t = 0; t < tiles && bad == 0; ++t)
-      for (int k = 0; k < s.K; ++k) {
-        const float sh = st[(int64_t)tiles * s.K * 2 + (int64_t)t * s.K + k];
-        double s0 = 0, s1 = 0;
-        for (int64_t m = (int64_t)t * 128; m < M && m < (int64_t)(t + 1) * 128; ++m) {
-          const double dv = (double)bf16_to_f(y[m * s.K + k]) - sh;
-          s0 += dv; s1 += dv * dv;
-        }
-        const float g0 = st[((int64_t)t * s.K + k) * 2], g1 = st[((int64_t)t * s.K + k) * 2 + 1];
-        const float first = bf16_to_f(y[(int64_t)t * 128 * s.K + k]);
-        if (sh != first || fabs(g0 - s0) > 1e-3 * (1 + fabs(s0)) || fabs(g1 - s1) > 1e-3 * (1 + fabs(s1))) {
-          ++bad;
-          printf("    stats tile %d col %d: shift %g (first row %g) sums %g %g want %g %g\n", t, k, sh, first, g0, g1, s0, s1);
-          break;
-        }
+    for (int k = 0; k < s.K && bad == 0; ++k) {
+      double want0 = 0, want1 = 0, wabs = 0, got0 = 0, got1 = 0;
+      for (int64_t m = 0; m < M; ++m) {
+        const double v = (double)bf16_to_f(y[m * s.K + k]);
+        want0 += v; want1 += v * v; wabs += fabs(v);
       }
+      for (int t = 0; t < tiles; ++t) {
+        const double n_t = (double)((t + 1 < tiles) ? 128 : M - (int64_t)128 * t);
+        const double sh = st[(int64_t)tiles * s.K * 2 + (int64_t)t * s.K + k];
+        const double g0 = st[((int64_t)t * s.K + k) * 2], g1 = st[((int64_t)t * s.K + k) * 2 + 1];
+        got0 += g0 + n_t * sh;
+        got1 += g1 + 2.0 * sh * g0 + n_t * sh * sh;
+      }
+      if (!(fabs(got0 - want0) <= 2e-4 * (1 + wabs)) || !(fabs(got1 - want1) <= 2e-4 * (1 + want1))) {
+        ++bad;
+        printf("    stats col %d: sum %g want %g, sum of squares %g want %g\n", k, got0, want0, got1, want1);
+      }
+    }
   }
   return bad;
 }
@@ -184,6 +189,7 @@ static int run_check() {
       {3, 64, 64, 3, 1, 56, "stage-1 3x3", 0},   {2, 128, 128, 3, 1, 28, "stage-2 3x3", 0},
       {5, 256, 256, 3, 1, 14, "stage-3 3x3", 0}, {7, 512, 512, 3, 1, 7, "stage-4 3x3", 0},
       {3, 64, 128, 3, 1, 20, "3x3, 64 -> 128, odd width 20", 0}, {1, 128, 64, 3, 1, 9, "3x3, one image 9x9 (81 rows)", 0},
+      {3, 128, 128, 3, 1, 16, "3x3, 16 x 16 (2-D tiles, 12 patches)", 0}, {5, 64, 64, 3, 1, 8, "3x3, 8 x 8 (5 patches: ragged)", 0},
       {2, 128, 128, 3, 2, 56, "3x3 stride 2", 0}, {2, 64, 256, 1, 1, 56, "1x1 64 -> 256", 0},
       {2, 512, 128, 1, 1, 28, "1x1 512 -> 128", 0},
   };
@@ -291,6 +297,7 @@ static int run_sweep(int n, char** cfgs) {
   const Shape cases[] = {
       {3, 64, 64, 3, 1, 56, "stage-1", 0},  {2, 128, 128, 3, 1, 28, "stage-2", 0}, {5, 256, 256, 3, 1, 14, "stage-3", 0},
       {7, 512, 512, 3, 1, 7, "stage-4", 0}, {3, 64, 128, 3, 1, 20, "w20", 0},      {1, 128, 64, 3, 1, 9, "9x9", 0},
+      {3, 128, 128, 3, 1, 16, "16x16", 0},  {5, 64, 64, 3, 1, 8, "8x8", 0},
   };
   const int ncases = sizeof(cases) / sizeof(cases[0]);
   std::vector<std::vector<int32_t>> refs(ncases);
