@@ -9,6 +9,8 @@
 //   tools/kbench check [name=value ...]     bit-exact check of passl_hip_conv_igemm on small cases
 //   tools/kbench time  [name=value ...]     per-layer table of the ResNet-50 3x3 / 1x1 shapes at N = 256
 //   tools/kbench ab name=v0,v1 [...]        the same table for two values of ONE option, side by side
+//   tools/kbench wcheck | wtime [name=value ...]   the same for passl_hip_conv_wgrad (== on fp32 sums; per-layer table)
+//   tools/kbench ablate                     the register-staged kernel's debug switches on the 1x1 shapes
 //   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
 //   name=value pairs are passl_hip_set_option() calls made before anything runs.
 //
@@ -75,15 +77,19 @@ static passl_conv_desc make_desc(const Shape& s, const void* a, const void* b, v
 }
 
 struct Buffers {
-  void *a = nullptr, *b = nullptr, *y = nullptr; float* stats = nullptr;
-  int64_t na = 0, nb = 0, ny = 0, nstats = 0;
+  void *a = nullptr, *b = nullptr, *y = nullptr, *aux = nullptr; float* stats = nullptr; float* cols = nullptr;
+  int64_t na = 0, nb = 0, ny = 0, nstats = 0, naux = 0;
   void ensure(int64_t a_, int64_t b_, int64_t y_, int64_t s_) {
     if (a_ > na) { if (a) CK(hipFree(a)); CK(hipMalloc(&a, a_ * 2)); na = a_; }
     if (b_ > nb) { if (b) CK(hipFree(b)); CK(hipMalloc(&b, b_ * 2)); nb = b_; }
     if (y_ > ny) { if (y) CK(hipFree(y)); CK(hipMalloc(&y, y_ * 2)); ny = y_; }
     if (s_ > nstats) { if (stats) CK(hipFree(stats)); CK(hipMalloc((void**)&stats, s_ * 4)); nstats = s_; }
+    if (!cols) CK(hipMalloc((void**)&cols, 4 * 4096 * 4));          // four per-column fp32 vectors (<= 4096 columns)
   }
+  void ensure_aux(int64_t n) { if (n > naux) { if (aux) CK(hipFree(aux)); CK(hipMalloc(&aux, n * 2)); naux = n; } }
 };
+enum Variant { V_RELU = 0, V_STATS = 1, V_RESIDUAL = 2, V_BNB = 3 };
+static const char* vname(int v) { static const char* n[] = {"relu ", "stats", "resid", "bnb  "}; return n[v]; }
 
 // ------------------------------------------------------------------------------------------------ check
 // The exact sums (x 256) of one case, computed once per shape on the host.
@@ -116,9 +122,14 @@ static void reference(const Shape& s, std::vector<int32_t>& out) {
   }
 }
 
-// Full-output comparison.  relu / stats exercise the shared epilogue; returns the number of wrong outputs.
-static int64_t check_case(const Shape& s, bool relu, bool with_stats, Buffers& B, int* kernel_used,
-                          const std::vector<int32_t>& ref) {
+// Full-output comparison of one epilogue variant; returns the number of wrong outputs.
+//   V_RELU      y = bf16(relu(sum))
+//   V_STATS     y = bf16(sum) + the fused BatchNorm statistics slab
+//   V_RESIDUAL  y = bf16(relu(bf16(sum) + residual))                (the block-end convolutions)
+//   V_BNB       y = g = bf16(sum) masked by relu(bnb_y * scale + shift) > 0, and the BatchNorm-backward partial sums
+//               sum g, sum g (bnb_y - mean) invstd                    (the data-gradient launches)
+static int64_t check_case(const Shape& s, int variant, Buffers& B, int* kernel_used, const std::vector<int32_t>& ref) {
+  const bool relu = variant == V_RELU || variant == V_RESIDUAL, with_stats = variant == V_STATS;
   const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
   const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
   const int64_t na = (int64_t)s.N * s.H * s.H * s.C, nb = (int64_t)s.K * KD, ny = M * s.K;
@@ -129,6 +140,21 @@ static int64_t check_case(const Shape& s, bool relu, bool with_stats, Buffers& B
   passl_conv_desc d = make_desc(s, B.a, B.b, B.y);
   d.relu = relu ? 1 : 0;
   if (with_stats) { d.stats = B.stats; d.stats_tiles = tiles; CK(hipMemset(B.stats, 0xff, (int64_t)tiles * s.K * 12)); }
+  std::vector<float> hcols(4 * 4096, 0.f);          // mean, invstd, scale, shift per column
+  if (variant == V_RESIDUAL || variant == V_BNB) { B.ensure_aux(ny); fill(B.aux, ny, 37u); }
+  if (variant == V_RESIDUAL) d.residual = B.aux;
+  if (variant == V_BNB) {
+    for (int k = 0; k < s.K; ++k) {
+      hcols[k] = (float)ival((uint64_t)k, 41u) * 0.0625f;                    // mean
+      hcols[4096 + k] = 0.5f + (float)(mix((uint64_t)k, 43u) % 16u) * 0.125f;   // invstd
+      hcols[8192 + k] = (mix((uint64_t)k, 47u) & 1u) ? 1.0f : -0.5f;            // scale
+      hcols[12288 + k] = (float)ival((uint64_t)k, 53u) * 0.0625f;              // shift
+    }
+    CK(hipMemcpy(B.cols, hcols.data(), hcols.size() * 4, hipMemcpyHostToDevice));
+    d.bnb_y = B.aux; d.bnb_mean = B.cols; d.bnb_invstd = B.cols + 4096; d.bnb_scale = B.cols + 8192;
+    d.bnb_shift = B.cols + 12288; d.bnb_partial = B.stats; d.bnb_relu = 2; d.bnb_tile_off = 0;
+    CK(hipMemset(B.stats, 0xff, (int64_t)tiles * s.K * 8));
+  }
   int rc = passl_hip_conv_igemm(&d, nullptr);
   if (rc != PASSL_OK) { printf("    conv_igemm -> %d (%s)\n", rc, passl_hip_strerror(rc)); return -1; }
   CK(hipDeviceSynchronize());
@@ -136,15 +162,44 @@ static int64_t check_case(const Shape& s, bool relu, bool with_stats, Buffers& B
   std::vector<uint16_t> y(ny);
   CK(hipMemcpy(y.data(), B.y, ny * 2, hipMemcpyDeviceToHost));
   int64_t bad = 0, shown = 0;
+  std::vector<double> bsum0, bsum1;
+  if (variant == V_BNB) { bsum0.assign(s.K, 0.0); bsum1.assign(s.K, 0.0); }
   for (int64_t m = 0; m < M; ++m) {
     const int n = (int)(m / ((int64_t)O * O)), rem = (int)(m % ((int64_t)O * O)), op = rem / O, oq = rem % O;
     for (int k = 0; k < s.K; ++k) {
       float v = (float)ref[m * s.K + k] * (1.0f / 256.0f);
-      if (relu && v < 0.f) v = 0.f;
-      const uint16_t want = bf16_rne(v), got = y[m * s.K + k];
+      uint16_t want;
+      if (variant == V_RESIDUAL) {
+        const float r = (float)ival((uint64_t)(m * s.K + k), 37u) * 0.0625f;
+        float t = bf16_to_f(bf16_rne(v)) + r;
+        want = bf16_rne(t < 0.f ? 0.f : t);
+      } else if (variant == V_BNB) {
+        const float yv = (float)ival((uint64_t)(m * s.K + k), 37u) * 0.0625f;
+        const float g = (yv * hcols[8192 + k] + hcols[12288 + k]) > 0.f ? bf16_to_f(bf16_rne(v)) : 0.f;
+        want = bf16_rne(g);
+        bsum0[k] += g;
+        bsum1[k] += (double)(g * (yv - hcols[k]) * hcols[4096 + k]);
+      } else {
+        if (relu && v < 0.f) v = 0.f;
+        want = bf16_rne(v);
+      }
+      const uint16_t got = y[m * s.K + k];
       if (want != got && !((want & 0x7fff) == 0 && (got & 0x7fff) == 0)) {
         ++bad;
         if (shown < 6) { printf("    m=%lld (n=%d op=%d oq=%d) col=%d  want %g got %g\n", (long long)m, n, op, oq, k, bf16_to_f(want), bf16_to_f(got)); ++shown; }
+      }
+    }
+  }
+  if (variant == V_BNB && bad == 0) {
+    // bnb_partial[t][col][0..1], summed over the tiles (the way passl_hip_bn_bwd_finalize consumes it)
+    std::vector<float> st((int64_t)tiles * s.K * 2);
+    CK(hipMemcpy(st.data(), B.stats, st.size() * 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < s.K && bad == 0; ++k) {
+      double g0 = 0, g1 = 0;
+      for (int t = 0; t < tiles; ++t) { g0 += st[((int64_t)t * s.K + k) * 2]; g1 += st[((int64_t)t * s.K + k) * 2 + 1]; }
+      if (!(fabs(g0 - bsum0[k]) <= 1e-3 * (1 + fabs(bsum0[k]))) || !(fabs(g1 - bsum1[k]) <= 2e-3 * (1 + fabs(bsum1[k])) + 1e-2)) {
+        ++bad;
+        printf("    bnb col %d: sum g %g want %g, sum g xhat %g want %g\n", k, g0, bsum0[k], g1, bsum1[k]);
       }
     }
   }
@@ -198,11 +253,10 @@ static int run_check() {
   std::vector<int32_t> ref;
   for (const Shape& s : cases) {
     reference(s, ref);
-    for (int variant = 0; variant < 2; ++variant) {
-      const bool relu = variant == 0, stats = variant == 1;
+    for (int variant = 0; variant < 4; ++variant) {
       int used = -1;
-      const int64_t bad = check_case(s, relu, stats, B, &used, ref);
-      printf("%-34s N=%d %s: kernel %-5s %s\n", s.note, s.N, stats ? "stats" : "relu ", kname(used),
+      const int64_t bad = check_case(s, variant, B, &used, ref);
+      printf("%-34s N=%d %s: kernel %-5s %s\n", s.note, s.N, vname(variant), kname(used),
              bad == 0 ? "exact" : (bad < 0 ? "NOT RUN" : "WRONG"));
       if (bad != 0) { ++failures; if (bad > 0) printf("    %lld wrong outputs\n", (long long)bad); }
     }
@@ -211,7 +265,112 @@ static int run_check() {
   return failures ? 1 : 0;
 }
 
-// ------------------------------------------------------------------------------------------------ timing
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dw[col][r][s][c] (fp32) = sum_m dy[m][col] * x[m @ (r, s)][c].  With at most ~16 K output rows the sum of products
+// (multiples of 1/256, magnitude < 1) is exact in fp32 in any order and over any number of slices: ==.
+static passl_wgrad_desc make_wdesc(const Shape& s, const void* a, const void* dy, float* dw, float* ws, int64_t ws_floats,
+                                   int splits) {
+  passl_wgrad_desc d;
+  memset(&d, 0, sizeof(d));
+  const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+  d.a = a; d.dy = dy; d.dw = dw;
+  d.N = s.N; d.OP = O; d.OQ = O; d.NCOLS = s.K; d.R = s.R; d.S = s.R; d.C = s.C;
+  d.IH = s.H; d.IW = s.H; d.sh = d.sw = s.stride; d.ph = d.pw = pad;
+  d.a_sw = s.C; d.a_sh = (int64_t)s.H * s.C; d.a_sn = (int64_t)s.H * s.H * s.C;
+  d.dy_ld = s.K; d.ws = ws; d.ws_floats = ws_floats; d.dtype = PASSL_BF16; d.splits = splits;
+  return d;
+}
+static int wgrad_splits(int64_t M, int ncols, int64_t kdim) {        // passl_amd/hip/plan.py: wgrad_splits
+  const int64_t tiles = ((ncols + 127) / 128) * ((kdim + 127) / 128), nk = (M + 63) / 64;
+  int64_t sp = 512 / (tiles > 0 ? tiles : 1);
+  if (sp > nk) sp = nk;
+  return (int)(sp < 1 ? 1 : sp);
+}
+struct WBuffers {
+  void *a = nullptr, *dy = nullptr; float *dw = nullptr, *ws = nullptr;
+  int64_t na = 0, ndy = 0, ndw = 0, nws = 0;
+  void ensure(int64_t a_, int64_t dy_, int64_t dw_, int64_t ws_) {
+    if (a_ > na) { if (a) CK(hipFree(a)); CK(hipMalloc(&a, a_ * 2)); na = a_; }
+    if (dy_ > ndy) { if (dy) CK(hipFree(dy)); CK(hipMalloc(&dy, dy_ * 2)); ndy = dy_; }
+    if (dw_ > ndw) { if (dw) CK(hipFree(dw)); CK(hipMalloc((void**)&dw, dw_ * 4)); ndw = dw_; }
+    if (ws_ > nws) { if (ws) CK(hipFree(ws)); CK(hipMalloc((void**)&ws, ws_ * 4)); nws = ws_; }
+  }
+};
+static void wgrad_reference(const Shape& s, std::vector<int32_t>& want) {
+  const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+  const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
+  const int64_t na = (int64_t)s.N * s.H * s.H * s.C, ndy = M * s.K, ndw = (int64_t)s.K * KD;
+  std::vector<int8_t> ha(na), hdy(ndy);
+  for (int64_t i = 0; i < na; ++i) ha[i] = (int8_t)ival((uint64_t)i, 11u);
+  for (int64_t i = 0; i < ndy; ++i) hdy[i] = (int8_t)ival((uint64_t)i, 29u);
+  want.assign(ndw, 0);
+  for (int64_t m = 0; m < M; ++m) {
+    const int n = (int)(m / ((int64_t)O * O)), rem = (int)(m % ((int64_t)O * O)), op = rem / O, oq = rem % O;
+    for (int r = 0; r < s.R; ++r) {
+      const int ih = op * s.stride + r - pad;
+      if (ih < 0 || ih >= s.H) continue;
+      for (int q = 0; q < s.R; ++q) {
+        const int iw = oq * s.stride + q - pad;
+        if (iw < 0 || iw >= s.H) continue;
+        const int8_t* ap = &ha[(((int64_t)n * s.H + ih) * s.H + iw) * s.C];
+        const int8_t* gp = &hdy[m * s.K];
+        for (int k = 0; k < s.K; ++k) {
+          const int32_t gk = gp[k];
+          if (!gk) continue;
+          int32_t* wp = &want[(int64_t)k * KD + ((int64_t)r * s.R + q) * s.C];
+          for (int c = 0; c < s.C; ++c) wp[c] += gk * (int32_t)ap[c];
+        }
+      }
+    }
+  }
+}
+static int64_t wgrad_check_case(const Shape& s, int splits, WBuffers& B, const std::vector<int32_t>& want) {
+  const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+  const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
+  const int64_t na = (int64_t)s.N * s.H * s.H * s.C, ndy = M * s.K, ndw = (int64_t)s.K * KD;
+  if (splits <= 0) splits = wgrad_splits(M, s.K, KD);
+  B.ensure(na, ndy, ndw, (int64_t)splits * ndw);
+  fill(B.a, na, 11u); fill(B.dy, ndy, 29u);
+  CK(hipMemset(B.dw, 0, ndw * 4));
+  passl_wgrad_desc d = make_wdesc(s, B.a, B.dy, B.dw, splits > 1 ? B.ws : nullptr, splits > 1 ? (int64_t)splits * ndw : 0, splits);
+  const int rc = passl_hip_conv_wgrad(&d, nullptr);
+  if (rc != PASSL_OK) { printf("    conv_wgrad -> %d (%s)\n", rc, passl_hip_strerror(rc)); return -1; }
+  CK(hipDeviceSynchronize());
+  std::vector<float> dw(ndw);
+  CK(hipMemcpy(dw.data(), B.dw, ndw * 4, hipMemcpyDeviceToHost));
+  int64_t bad = 0;
+  for (int64_t i = 0; i < ndw; ++i) {
+    const float w = (float)want[i] * (1.0f / 256.0f);
+    if (dw[i] != w) {
+      if (bad < 5) printf("    dw[%lld] (col %lld, k %lld) want %g got %g\n", (long long)i, (long long)(i / KD), (long long)(i % KD), w, dw[i]);
+      ++bad;
+    }
+  }
+  return bad;
+}
+static int run_wcheck() {
+  const Shape cases[] = {
+      {3, 64, 64, 3, 1, 56, "3x3 64->64 @56", 0},    {2, 128, 128, 3, 1, 28, "3x3 128->128 @28", 0},
+      {5, 256, 256, 3, 1, 14, "3x3 256->256 @14", 0}, {7, 512, 512, 3, 1, 7, "3x3 512->512 @7", 0},
+      {2, 128, 128, 3, 2, 56, "3x3 stride 2 @56", 0}, {3, 64, 256, 1, 1, 56, "1x1 64->256 @56", 0},
+      {3, 256, 64, 1, 1, 56, "1x1 256->64 @56", 0},   {4, 512, 128, 1, 1, 28, "1x1 512->128 @28", 0},
+      {3, 64, 128, 3, 1, 20, "3x3 64->128, width 20", 0}, {2, 256, 512, 1, 2, 56, "1x1 stride 2 256->512", 0},
+  };
+  WBuffers B;
+  int failures = 0;
+  std::vector<int32_t> want;
+  for (const Shape& s : cases) {
+    wgrad_reference(s, want);
+    for (int splits : {0, 1, 7}) {
+      const int64_t bad = wgrad_check_case(s, splits, B, want);
+      printf("%-28s N=%d splits %-4s: %s\n", s.note, s.N, splits ? std::to_string(splits).c_str() : "auto",
+             bad == 0 ? "exact" : (bad < 0 ? "NOT RUN" : "WRONG"));
+      if (bad != 0) { ++failures; if (bad > 0) printf("    %lld wrong elements\n", (long long)bad); }
+    }
+  }
+  printf(failures ? "WGRAD CHECK FAILED (%d)\n" : "WGRAD CHECK OK\n", failures);
+  return failures ? 1 : 0;
+}
 static const Shape kR50[] = {
     {256, 64, 64, 3, 1, 56, "64->64 k3 @56", 3},     {256, 128, 128, 3, 1, 28, "128->128 k3 @28", 3},
     {256, 256, 256, 3, 1, 14, "256->256 k3 @14", 5}, {256, 512, 512, 3, 1, 7, "512->512 k3 @7", 2},
@@ -220,6 +379,37 @@ static const Shape kR50[] = {
     {256, 128, 512, 1, 1, 28, "128->512 k1 @28", 4}, {256, 512, 128, 1, 1, 28, "512->128 k1 @28", 3},
     {256, 256, 1024, 1, 1, 14, "256->1024 k1 @14", 6}, {256, 1024, 256, 1, 1, 14, "1024->256 k1 @14", 5},
 };
+static int run_wtime() {
+  WBuffers B;
+  printf("%-22s %9s | %8s %7s  (weight gradient + slab reduction, N = 256, splits as the product chooses them)\n", "shape", "GFLOP", "us", "TF");
+  double tot = 0;
+  for (const Shape& s : kR50) {
+    const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+    const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
+    const int64_t na = (int64_t)s.N * s.H * s.H * s.C, ndy = M * s.K, ndw = (int64_t)s.K * KD;
+    const int splits = wgrad_splits(M, s.K, KD);
+    B.ensure(na, ndy, ndw, (int64_t)splits * ndw);
+    fill(B.a, na, 11u); fill(B.dy, ndy, 29u);
+    passl_wgrad_desc d = make_wdesc(s, B.a, B.dy, B.dw, splits > 1 ? B.ws : nullptr, splits > 1 ? (int64_t)splits * ndw : 0, splits);
+    for (int i = 0; i < 3; ++i) passl_hip_conv_wgrad(&d, nullptr);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) passl_hip_conv_wgrad(&d, nullptr);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1000.0 / 20, gf = 2.0 * M * (double)s.K * KD * 1e-9;
+    printf("%-22s %9.2f | %8.1f %7.1f  (%d slices)\n", s.note, gf, us, gf / us * 1e3, splits);
+    tot += us * s.mult;
+  }
+  printf("sum over one backward pass of these layers (x multiplicity): %.1f us\n", tot);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ timing
 
 static float time_shape(const Shape& s, bool with_stats, Buffers& B, int iters, int* used) {
   const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
@@ -310,9 +500,9 @@ static int run_sweep(int n, char** cfgs) {
     if (apply_config(cfgs[c]) != 0) { printf("%-58s bad option\n", cfgs[c]); continue; }
     int wrong = 0;
     for (int i = 0; i < ncases; ++i)
-      for (int v = 0; v < 2; ++v) {
+      for (int v = 0; v < 4; ++v) {
         int used = -1;
-        if (check_case(cases[i], v == 0, v == 1, B, &used, refs[i]) != 0) ++wrong;
+        if (check_case(cases[i], v, B, &used, refs[i]) != 0) ++wrong;
       }
     printf("%-58s %-6s |", cfgs[c], wrong ? "WRONG" : "exact");
     for (int i = 0; i < 4; ++i) {
@@ -381,6 +571,8 @@ int main(int argc, char** argv) {
   printf("libpassl_hip ABI %d\n", passl_hip_abi_version());
   if (mode == "check") return run_check();
   if (mode == "ablate") return run_ablate();
+  if (mode == "wcheck") return run_wcheck();
+  if (mode == "wtime") return run_wtime();
   if (mode == "time") return run_time(nullptr, 0, 0);
   if (mode == "ab") { if (!ab_name) { fprintf(stderr, "ab needs name=v0,v1\n"); return 2; } return run_time(ab_name, v0, v1); }
   fprintf(stderr, "unknown mode %s\n", mode.c_str());
