@@ -18,6 +18,7 @@
 #include <type_traits>
 #include "common.h"
 #include "prof.h"
+#include "wgrad_halo_geom.h"
 
 namespace {
 
@@ -840,6 +841,8 @@ int launch_dma(const WParams& p, int splits, uint32_t a_bytes, uint32_t dy_bytes
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
+#include "conv_wgrad_halo.inc"
+
 int g_wgrad_tile = 0;     // 0 = by shape; 1 = 64x64, 2 = 64x128, 3 = 128x64, 4 = 128x128 (experiments)
 
 // wgrad_pipe_kernel (register double-buffered fragments): 2 = 2 x 64-row stages for every shape (default),
@@ -894,6 +897,12 @@ int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, 
 int passl_wgrad_option(const char* name, int value) {
   if (strcmp(name, "wgrad_tile") == 0) { g_wgrad_tile = value; return PASSL_OK; }
   if (strcmp(name, "wgrad_pipe") == 0) { g_wgrad_pipe = value; return PASSL_OK; }
+  if (strcmp(name, "wgrad_halo") == 0) { g_wgrad_halo = value != 0; return PASSL_OK; }     // spatially tiled 3x3 kernel (opt-in)
+  if (strcmp(name, "wgrad_halo_stages") == 0) {
+    if (value != 2 && value != 3) return PASSL_EINVAL;
+    g_wgrad_halo_nst = value;
+    return PASSL_OK;
+  }
   return PASSL_EINVAL;
 }
 
@@ -953,6 +962,8 @@ extern "C" int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t st
   (void)lim;
   rc = PASSL_EUNSUPPORTED;
   if (d->dtype == PASSL_BF16 && use_dma && a_bytes > 0)
+    rc = wgrad_halo_try(p, splits, a_bytes, dy_bytes, st);     // opt-in; EUNSUPPORTED otherwise
+  if (rc == PASSL_EUNSUPPORTED && d->dtype == PASSL_BF16 && use_dma && a_bytes > 0)
     rc = dispatch_dma(p, splits, a_bytes, dy_bytes, st);       // EUNSUPPORTED: a slice spans >= 2 GB
   if (rc == PASSL_EUNSUPPORTED)
     rc = d->dtype == PASSL_BF16 ? dispatch<bf16_t>(p, splits, st) : dispatch<float>(p, splits, st);

@@ -355,6 +355,8 @@ static int run_wcheck() {
       {2, 128, 128, 3, 2, 56, "3x3 stride 2 @56", 0}, {3, 64, 256, 1, 1, 56, "1x1 64->256 @56", 0},
       {3, 256, 64, 1, 1, 56, "1x1 256->64 @56", 0},   {4, 512, 128, 1, 1, 28, "1x1 512->128 @28", 0},
       {3, 64, 128, 3, 1, 20, "3x3 64->128, width 20", 0}, {2, 256, 512, 1, 2, 56, "1x1 stride 2 256->512", 0},
+      {2, 128, 128, 3, 1, 16, "3x3 128->128 @16", 0}, {3, 96, 72, 3, 1, 16, "3x3 96->72 @16 (ragged blocks)", 0},
+      {5, 64, 64, 3, 1, 8, "3x3 64->64 @8", 0},
   };
   WBuffers B;
   int failures = 0;
@@ -379,15 +381,18 @@ static const Shape kR50[] = {
     {256, 128, 512, 1, 1, 28, "128->512 k1 @28", 4}, {256, 512, 128, 1, 1, 28, "512->128 k1 @28", 3},
     {256, 256, 1024, 1, 1, 14, "256->1024 k1 @14", 6}, {256, 1024, 256, 1, 1, 14, "1024->256 k1 @14", 5},
 };
+static int g_splits_override = 0, g_rows = 1000;      // pseudo-options "splits=N", "rows=N" of wtime
 static int run_wtime() {
   WBuffers B;
   printf("%-22s %9s | %8s %7s  (weight gradient + slab reduction, N = 256, splits as the product chooses them)\n", "shape", "GFLOP", "us", "TF");
   double tot = 0;
+  int row = 0;
   for (const Shape& s : kR50) {
+    if (row++ >= g_rows) break;
     const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
     const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
     const int64_t na = (int64_t)s.N * s.H * s.H * s.C, ndy = M * s.K, ndw = (int64_t)s.K * KD;
-    const int splits = wgrad_splits(M, s.K, KD);
+    const int splits = g_splits_override ? g_splits_override : wgrad_splits(M, s.K, KD);
     B.ensure(na, ndy, ndw, (int64_t)splits * ndw);
     fill(B.a, na, 11u); fill(B.dy, ndy, 29u);
     passl_wgrad_desc d = make_wdesc(s, B.a, B.dy, B.dw, splits > 1 ? B.ws : nullptr, splits > 1 ? (int64_t)splits * ndw : 0, splits);
@@ -565,6 +570,8 @@ int main(int argc, char** argv) {
       ab_name = namebuf; v0 = atoi(eq + 1); v1 = atoi(comma + 1);
       continue;
     }
+    if (name == "splits") { g_splits_override = atoi(eq + 1); continue; }
+    if (name == "rows") { g_rows = atoi(eq + 1); continue; }
     const int rc = passl_hip_set_option(name.c_str(), atoi(eq + 1));
     if (rc != PASSL_OK) { fprintf(stderr, "set_option(%s) -> %d\n", name.c_str(), rc); return 2; }
   }
