@@ -55,6 +55,9 @@ int passl_hip_abi_version(void);
  *                               off (default; exact but slower than the ring kernel: profiles/r04_kbench_halo_experiment.txt)
  *   "igemm_halo_max_c" n        ... only up to n input channels (128);  "igemm_halo_stages" 2..4 weight-ring depth (2);
  *   "igemm_halo_ck" 0|32|64     channels per halo chunk (0: 64 for C = 64, else 32);  "igemm_halo_dbg" 1|2 time stamps
+ *   "wgrad_halo" 0|1|2          EXPERIMENTAL spatially tiled 3x3 / stride 1 weight-gradient kernel (conv_wgrad_halo.inc): off
+ *                               (default) / images whose sides are multiples of 8 / every such layer;  "wgrad_halo_stages" 2|3.
+ *                               Its grid is one workgroup per 64 x 64 block of dw and slice: pass ~512 / blocks slices.
  * Returns PASSL_EINVAL for an unknown name. */
 int passl_hip_set_option(const char* name, int value);
 /* Which kernel the most recent passl_hip_conv_igemm call of this process launched: 0 = igemm_kernel

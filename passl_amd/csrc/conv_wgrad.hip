@@ -897,7 +897,8 @@ int passl_slab_reduce_launch(const float* ws, float* out, int64_t n, int slabs, 
 int passl_wgrad_option(const char* name, int value) {
   if (strcmp(name, "wgrad_tile") == 0) { g_wgrad_tile = value; return PASSL_OK; }
   if (strcmp(name, "wgrad_pipe") == 0) { g_wgrad_pipe = value; return PASSL_OK; }
-  if (strcmp(name, "wgrad_halo") == 0) { g_wgrad_halo = value != 0; return PASSL_OK; }     // spatially tiled 3x3 kernel (opt-in)
+  // spatially tiled 3x3 kernel (opt-in): 1 = images whose sides are multiples of 8, 2 = every 3x3 / stride-1 layer
+  if (strcmp(name, "wgrad_halo") == 0) { g_wgrad_halo = value < 0 ? 0 : (value > 2 ? 2 : value); return PASSL_OK; }
   if (strcmp(name, "wgrad_halo_stages") == 0) {
     if (value != 2 && value != 3) return PASSL_EINVAL;
     g_wgrad_halo_nst = value;

@@ -3,8 +3,10 @@
 //
 //   dW[oc][(r, s), c] = sum over output pixels m of dY[m][oc] * X[m @ (r, s)][c]        (3x3, stride 1, pad 1)
 //
-// The reduction runs over pixels; a k-tile is one 8 x 8 PATCH of an image (IH, IW multiples of 8; patches in the
-// global order n, py, px), i.e. 64 reduction rows = two 16x16x32 MFMA k-steps of four patch rows each.  Per k-tile
+// The reduction runs over pixels; a k-tile is one 8 x 8 PATCH of an image (patches in the global order n, py, px;
+// images whose sides are not multiples of 8 are covered by ceil(IH / 8) x ceil(IW / 8) patches, the pixels of a patch
+// that lie outside the image are fetched as zeros — 31 % more k-tiles at 28 x 28, 14 x 14 and 7 x 7), i.e. 64 reduction
+// rows = two 16x16x32 MFMA k-steps of four patch rows each.  Per k-tile
 // the workgroup stages
 //   * dY of the patch:  [64 pixels][64 oc], 128-byte rows, the transposing-read swizzle of wgrad_pipe_kernel, and
 //   * X of the patch WITH ITS HALO, once, for all nine taps: [10 rows][12 columns][64 c + pad] — pixel (y, x) of the
@@ -63,6 +65,7 @@ HALO_HD uint32_t dy_src(const Geom& g, int gp, int oc0, int q, int lane) {
   if (oc >= g.NCOLS) return kNoSrc;
   int n, y0, x0;
   patch_origin(g, gp, n, y0, x0);
+  if (y0 + (kk >> 3) >= g.IH || x0 + (kk & 7) >= g.IW) return kNoSrc;      // patch pixel outside the image
   const int m = n * g.IH * g.IW + (y0 + (kk >> 3)) * g.IW + x0 + (kk & 7);
   return (uint32_t)m * (uint32_t)g.dy_pitch + (uint32_t)oc * 2u;
 }
@@ -87,36 +90,34 @@ HALO_HD uint32_t halo_src(const Geom& g, int gp, int c0, int q, int lane) {
 }
 
 // ---- the kernel's split of those offsets into a lane-static part and a per-patch scalar part
-// dY: offset = patch_m(gp) * dy_pitch + dy_static(q, lane)
-HALO_HD uint32_t dy_static(const Geom& g, int oc0, int q, int lane) {
+// dY: offset = patch_m(n, y0, x0) * dy_pitch + dy_static(q, lane)  if  dy_inside(y0, x0, yx),  yx = the lane's pixel
+HALO_HD uint32_t dy_static(const Geom& g, int oc0, int q, int lane, int& yx) {
   const int kk = q * 8 + lane / 8;
   const int chunk = (lane % 8) ^ (hswz8(kk) << 1);
   const int oc = oc0 + chunk * 8;
+  yx = (kk >> 3) | ((kk & 7) << 8);
   if (oc >= g.NCOLS) return kNoSrc;
   return (uint32_t)((kk >> 3) * g.IW + (kk & 7)) * (uint32_t)g.dy_pitch + (uint32_t)oc * 2u;
 }
+HALO_HD bool dy_inside(const Geom& g, int y0, int x0, int yx) { return y0 + (yx & 255) < g.IH && x0 + (yx >> 8) < g.IW; }
 HALO_HD int patch_m(const Geom& g, int n, int y0, int x0) { return n * g.IH * g.IW + y0 * g.IW + x0; }
-// X: offset = patch_x(n, y0, x0) + halo_static(q, lane) unless (halo_flags(q, lane) & edge_mask(y0, x0)) != 0
-// flags: 1 top halo row, 2 bottom, 4 left column, 8 right, 16 never valid (pad slot / unused row / channel >= C)
-HALO_HD uint32_t halo_static(const Geom& g, int c0, int q, int lane, int& flags) {
+// X: offset = patch_x(n, y0, x0) + halo_static(q, lane)  if  halo_inside(y0, x0, hyx);  hyx = halo (row, column) of
+// the lane, or -1 for lanes that never fetch (pad slot, unused row / column, channel >= C)
+HALO_HD uint32_t halo_static(const Geom& g, int c0, int q, int lane, int& hyx) {
   const int p = q * 64 + lane;
   const int hrow = p / kSlots;
   const int cpos = p - hrow * kSlots;
   const int hy = hrow / kPW, hx = hrow - hy * kPW;
   const int c = c0 + cpos * 8;
-  flags = 0;
-  if (cpos >= 8 || hrow >= kRows || hx >= 10 || c >= g.C) { flags = 16; return 0; }
-  if (hy == 0) flags |= 1;
-  if (hy == 9) flags |= 2;
-  if (hx == 0) flags |= 4;
-  if (hx == 9) flags |= 8;
+  if (cpos >= 8 || hrow >= kRows || hx >= 10 || c >= g.C) { hyx = -1; return 0; }
+  hyx = hy | (hx << 8);
   return (uint32_t)((hy - 1) * g.a_sh2) + (uint32_t)((hx - 1) * g.a_sw2) + (uint32_t)c * 2u;     // wraps for hy, hx = 0
+}
+HALO_HD bool halo_inside(const Geom& g, int y0, int x0, int hyx) {
+  return hyx >= 0 && (uint32_t)(y0 + (hyx & 255) - 1) < (uint32_t)g.IH && (uint32_t)(x0 + (hyx >> 8) - 1) < (uint32_t)g.IW;
 }
 HALO_HD uint32_t patch_x(const Geom& g, int n, int y0, int x0) {
   return (uint32_t)n * (uint32_t)g.a_sn2 + (uint32_t)y0 * (uint32_t)g.a_sh2 + (uint32_t)x0 * (uint32_t)g.a_sw2;
-}
-HALO_HD int edge_mask(const Geom& g, int y0, int x0) {
-  return 16 | (y0 == 0 ? 1 : 0) | (y0 == g.IH - 8 ? 2 : 0) | (x0 == 0 ? 4 : 0) | (x0 == g.IW - 8 ? 8 : 0);
 }
 
 // ds_read_b64_tr_b16 addresses (bytes inside a stage).  Lane = (g = lane >> 4, r4 = (lane >> 2) & 3, c4 = lane & 3);

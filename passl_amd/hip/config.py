@@ -16,7 +16,9 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0',
           'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
-          'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0'}
+          'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
+          # the library reads the same variable (conv_wgrad_halo.inc): 0 off (default), 1 images with sides % 8 == 0, 2 all
+          'wgrad_halo': int(os.environ.get('PASSL_WGRAD_HALO', '0') or 0)}
 
 
 def set_device(name):
@@ -105,6 +107,12 @@ def side_reductions():
     """With `overlap`: the small parameter-gradient reductions of a backward node (a Linear's bias column sums, the
     fold of LayerNorm's d-gamma / d-beta partials) run on the second HIP stream, off the data-gradient chain."""
     return _state['side_reductions']
+
+
+def wgrad_halo():
+    """EXPERIMENTAL (off): the spatially tiled 3x3 weight-gradient kernel takes eligible launches; the slice count of
+    those launches is then chosen for ITS grid (one workgroup per 64 x 64 block of dW and slice, all nine taps)."""
+    return _state['wgrad_halo']
 
 
 def set_flag(name, value):

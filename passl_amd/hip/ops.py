@@ -7,6 +7,7 @@ import ctypes as C
 
 import torch
 
+from . import config
 from . import lib as L
 from . import plan as P
 
@@ -188,6 +189,20 @@ def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=F
 _wdesc_cache = {}
 
 
+def wgrad_slices(d: P.Desc, dtype):
+    """Number of reduction slices of a weight-gradient launch (host logic, no GPU): the product kernels' heuristic,
+    or — only with the EXPERIMENTAL spatially tiled kernel switched on (config.wgrad_halo) and for the launches it
+    takes — the count that fits ITS grid."""
+    halo = config.wgrad_halo()
+    if (halo and dtype == torch.bfloat16 and d.R == 3 and d.S == 3 and d.sh == 1 and d.sw == 1 and d.ph == 1 and
+            d.pw == 1 and d.IH == d.OP and d.IW == d.OQ and (halo == 2 or (d.IH % 8 == 0 and d.IW % 8 == 0))):
+        return P.wgrad_halo_splits(d.N, d.IH, d.IW, d.NCOLS, d.C)
+    M = d.N * d.OP * d.OQ
+    bkm = 64 if dtype == torch.bfloat16 else 32
+    esz = 2 if dtype == torch.bfloat16 else 4
+    return P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm, row_bytes=max(d.NCOLS, d.C * d.sh * d.sw) * esz)
+
+
 def conv_wgrad(d: P.Desc, a, dy, dw, splits=None):
     """dw[NCOLS, R*S*C] (fp32) += dy^T . gather(a)."""
     key = id(d)
@@ -205,10 +220,7 @@ def conv_wgrad(d: P.Desc, a, dy, dw, splits=None):
     s.dw = L.ptr(dw)
     s.dy_ld = d.NCOLS
     s.dtype = L.dt(a)
-    M = d.N * d.OP * d.OQ
-    bkm = 64 if a.dtype == torch.bfloat16 else 32
-    s.splits = splits or P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm,
-                                        row_bytes=max(d.NCOLS, d.C * d.sh * d.sw) * a.element_size())
+    s.splits = splits or wgrad_slices(d, a.dtype)
     # split-M partial tiles go to slabs of the shared workspace and are added in slice order
     need = s.splits * d.NCOLS * d.R * d.S * d.C
     ws = workspace.get(need, dw.device) if s.splits > 1 else None

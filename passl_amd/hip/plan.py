@@ -182,6 +182,15 @@ def stem_desc(cout, N, H, W) -> Desc:
                           c_pad=STEM_CP, size=cout * STEM_K * 8 * STEM_CP))
 
 
+def wgrad_halo_splits(N, IH, IW, ncols, C, target_blocks=512):
+    """Slices for the spatially tiled 3x3 weight-gradient kernel (csrc/conv_wgrad_halo.inc): its grid is one
+    workgroup per 64 x 64 block of dW and slice (all nine taps), a k-tile is one 8 x 8 patch.  Measured at 64 -> 64 @56
+    (profiles/r04_kbench_halo_experiment.txt): 256 slices 83 us, 512 slices 77 us, 1024 slices 104 us."""
+    blocks = ((ncols + 63) // 64) * ((C + 63) // 64)
+    patches = N * ((IH + 7) // 8) * ((IW + 7) // 8)
+    return max(1, min(patches, target_blocks // max(blocks, 1)))
+
+
 def wgrad_splits(M, ncols, kdim, bkm, target_blocks=512, row_bytes=0):
     """Number of reduction slices so that the grid has ~target_blocks workgroups (2 per CU on
     256 CUs = one resident wave of workgroups).  Every slice adds a full fp32 tile of global

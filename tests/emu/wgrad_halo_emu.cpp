@@ -45,7 +45,7 @@ static long run(const Case& cs) {
   const uint32_t x_bytes = (uint32_t)(X.size() * 2), dy_bytes = (uint32_t)(DY.size() * 2);
   Geom g;
   g.N = N; g.IH = IH; g.IW = IW; g.C = C; g.NCOLS = K;
-  g.PXN = IW / 8; g.PN = (IH / 8) * (IW / 8); g.npatches = N * g.PN;
+  g.PXN = (IW + 7) / 8; g.PN = ((IH + 7) / 8) * g.PXN; g.npatches = N * g.PN;
   g.a_sw2 = C * 2; g.a_sh2 = IW * C * 2; g.a_sn2 = IH * IW * C * 2; g.dy_pitch = K * 2;
   g.d_pn = halo::make_fdiv((uint32_t)g.PN); g.d_pxn = halo::make_fdiv((uint32_t)g.PXN);
   int splits = cs.splits;
@@ -70,20 +70,20 @@ static long run(const Case& cs) {
           // ---- DMA pieces: the kernel's static + per-patch form, checked against the direct formulas
           const uint32_t dy_base = (uint32_t)patch_m(g, pn, py0, px0) * (uint32_t)g.dy_pitch;
           const uint32_t x_base = patch_x(g, pn, py0, px0);
-          const int emask = edge_mask(g, py0, px0);
           for (int q = 0; q < kDyPieces; ++q)
             for (int lane = 0; lane < 64; ++lane) {
-              const uint32_t st = dy_static(g, oc0, q, lane);
-              const uint32_t off = st == kNoSrc ? kNoSrc : st + dy_base;
+              int yx;
+              const uint32_t st = dy_static(g, oc0, q, lane, yx);
+              const uint32_t off = (st == kNoSrc || !dy_inside(g, py0, px0, yx)) ? kNoSrc : st + dy_base;
               if (off != dy_src(g, gp, oc0, q, lane)) ++split_mismatch;
               char* dst = &stage[(size_t)q * 1024 + lane * 16];
               if (off == kNoSrc || off + 16 > dy_bytes) memset(dst, 0, 16); else memcpy(dst, Db + off, 16);
             }
           for (int q = 0; q < kHaloPieces; ++q)
             for (int lane = 0; lane < 64; ++lane) {
-              int fl;
-              const uint32_t st = halo_static(g, c0, q, lane, fl);
-              const uint32_t off = (fl & emask) ? kNoSrc : st + x_base;
+              int hyx;
+              const uint32_t st = halo_static(g, c0, q, lane, hyx);
+              const uint32_t off = halo_inside(g, py0, px0, hyx) ? st + x_base : kNoSrc;
               if (off != halo_src(g, gp, c0, q, lane)) ++split_mismatch;
               char* dst = &stage[(size_t)kDyBytes + (size_t)q * 1024 + lane * 16];
               if (off == kNoSrc || off + 16 > x_bytes) memset(dst, 0, 16); else memcpy(dst, Xb + off, 16);
@@ -127,7 +127,7 @@ static long run(const Case& cs) {
             }
           }
           px0 += 8;
-          if (px0 == IW) { px0 = 0; py0 += 8; if (py0 == IH) { py0 = 0; ++pn; } }
+          if (px0 >= IW) { px0 = 0; py0 += 8; if (py0 >= IH) { py0 = 0; ++pn; } }
         }
         for (int wave = 0; wave < 4; ++wave)
           for (int lane = 0; lane < 64; ++lane)
@@ -191,6 +191,10 @@ int main() {
   bad += run({2, 8, 24, 128, 64, 3});
   bad += run({1, 16, 16, 96, 72, 2});
   bad += run({1, 56, 56, 64, 64, 7});
+  bad += run({2, 28, 28, 64, 64, 5});           // patches overhang the image
+  bad += run({3, 14, 14, 128, 64, 2});
+  bad += run({5, 7, 7, 64, 128, 3});
+  bad += run({2, 9, 20, 72, 64, 4});
   printf(bad ? "EMULATION FAILED\n" : "EMULATION OK\n");
   return bad ? 1 : 0;
 }

@@ -24,3 +24,37 @@ def test_halo_kernel_addresses_reproduce_a_direct_convolution(tmp_path):
     # the layout claims of halo_geom.h
     assert 'pitch 144 B: 0 conflicts' in r.stdout and 'pitch 80 B: 0 conflicts' in r.stdout
     assert 'WRONG' not in r.stdout
+
+
+@pytest.mark.skipif(shutil.which('g++') is None, reason='needs g++')
+def test_wgrad_halo_kernel_addresses_reproduce_a_direct_weight_gradient(tmp_path):
+    """The spatially tiled 3x3 weight-gradient kernel (passl_amd/csrc/conv_wgrad_halo.inc, opt-in): LDS-DMA pieces in the
+    kernel's lane-static + per-patch form, ds_read_b64_tr_b16 with its 16-lane transposition, MFMA operand layout and the
+    accumulator -> dW map (passl_amd/csrc/wgrad_halo_geom.h), incl. images that the 8 x 8 patches overhang and several
+    reduction slices; autograd of paddle.nn.Conv2D w.r.t. its weight (resnetimagenet.py:121-124)."""
+    exe = str(tmp_path / 'wgrad_halo_emu')
+    subprocess.run(['g++', '-O2', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tests', 'emu', 'wgrad_halo_emu.cpp')],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert 'EMULATION OK' in r.stdout and 'WRONG' not in r.stdout and 'differs' not in r.stdout
+    assert 'under the transposing read: 0 conflicts' in r.stdout
+
+
+def test_wgrad_slice_choice_follows_the_kernel_that_takes_the_launch(monkeypatch):
+    """Host logic (passl_amd/hip/ops.py: wgrad_slices): the product heuristic by default; with the experimental kernel
+    switched on, its own grid shape for the launches it takes and nothing else."""
+    import torch
+    from passl_amd.hip import config, ops, plan as P
+    g3 = P.ConvGeom(cin=64, cout=64, k=3, stride=1, pad=1)
+    d56, d28 = P.fwd_desc(g3, 256, 56, 56), P.fwd_desc(g3, 256, 28, 28)
+    d1 = P.fwd_desc(P.ConvGeom(cin=64, cout=256, k=1, stride=1, pad=0), 256, 56, 56)
+    base = {id(d): ops.wgrad_slices(d, torch.bfloat16) for d in (d56, d28, d1)}
+    assert base[id(d56)] == 102                                  # 5 tiles of 128 x 128 -> 512 // 5
+    monkeypatch.setitem(config._state, 'wgrad_halo', 1)
+    assert ops.wgrad_slices(d56, torch.bfloat16) == 512          # one 64 x 64 block: 512 slices (measured best)
+    assert ops.wgrad_slices(d28, torch.bfloat16) == base[id(d28)]   # 28 is not a multiple of 8: not taken in mode 1
+    assert ops.wgrad_slices(d1, torch.bfloat16) == base[id(d1)]
+    assert ops.wgrad_slices(d56, torch.float32) != 512
+    monkeypatch.setitem(config._state, 'wgrad_halo', 2)
+    assert ops.wgrad_slices(d28, torch.bfloat16) == 512
