@@ -302,6 +302,155 @@ __global__ void __launch_bounds__(256, MINB) igemm_halo_kernel(const Params p) {
   stamp(4);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent form for the stage-1 shape (C = 64, NCOLS <= 64, 2-D tiles; option igemm_halo = 2).  What the time
+// stamps of the kernel above say: of the 10 us a tile spends in a workgroup, 0.96 us are MFMAs; 2.6 us
+// are setup, 0.8 us waiting for the halo, and in the main loop every k-tile pays for its weight DMA and a barrier.
+// Here a workgroup stays on its CU and walks a contiguous range of tiles:
+//   * all nine weight taps (9 x 64 rows x 128 B = 72 KB) are staged ONCE per workgroup;
+//   * the halo of tile T+1 (two 10 x 10 blocks, 29 KB) is fetched while tile T is multiplied and stored: two
+//     buffers; its source offsets are a lane-static part plus two patch origins per tile (no divisions per lane);
+//   * the main loop of a tile is 9 taps x 16 MFMAs per wave with NO DMA and NO barrier in it (fragment reads of tap
+//     t+1 overlap the MFMAs of tap t);
+//   * the shared epilogue runs out of the tile's own halo buffer, which is dead by then.
+// LDS: 72 KB weights | 2 x 29 KB halo | 1 KB row offsets = 131 KB: one workgroup (4 waves) per CU.
+__global__ void __launch_bounds__(256, 1) igemm_halo_pw_kernel(const Params p) {
+  constexpr int BM = kBM, BN = 64, RB = 128, CPRW = 8;
+  constexpr int kThreads = 256, WAVES = 4;
+  constexpr int WM = 32, WN = 64, FM = 2, FN = 4, KS = 2;
+  constexpr int TAP_BYTES = BN * RB;             // 8 KB of weights per tap
+  constexpr int W_BYTES = 9 * TAP_BYTES;
+  constexpr int NHI = 8;                         // halo pieces per wave (29 per tile)
+  constexpr int NWI = 9 * BN * RB / 1024 / WAVES;   // weight pieces per wave (18)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+  int64_t* rowoff = reinterpret_cast<int64_t*>(smem + W_BYTES + 2 * p.hbytes);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const Geom2& g2 = p.g2;
+
+  // this workgroup's tiles: a contiguous range (neighbouring tiles share halo rows: same L2, one after the other)
+  const int t_begin = (int)(((int64_t)blockIdx.x * p.ntiles) / gridDim.x);
+  const int t_end = (int)(((int64_t)(blockIdx.x + 1) * p.ntiles) / gridDim.x);
+  if (t_begin >= t_end) return;
+
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.b), 0, p.b_bytes, 0x00020000);
+
+  // ---- the weights, once: piece = tap * 8 + r8 covers rows 8 r8 .. 8 r8 + 7 of tap `tap` (the ring kernel's row swizzle)
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) {
+    const int piece = i * WAVES + wave;
+    const int tap = piece >> 3, row = (piece & 7) * 8 + lane / CPRW;
+    const uint32_t chunk = (uint32_t)(((lane % CPRW) ^ ((row >> 1) & 7)) * 16);
+    const uint32_t off = row < p.NCOLS ? (uint32_t)row * (uint32_t)(p.KDIM * 2) + (uint32_t)(tap * p.C * 2) + chunk : kNoSrc;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(smem + piece * 1024), 16, off, 0, 0, 0);
+  }
+
+  // ---- lane-static geometry
+  uint32_t h_st[NHI];
+  int h_byx[NHI];
+#pragma unroll
+  for (int i = 0; i < NHI; ++i) h_st[i] = halo_static2<CPRW>(g2, i * WAVES + wave, lane, h_byx[i]);
+  uint32_t a_rd[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) a_rd[i] = a_frag_base2<CPRW>(wave * WM + i * 16, l15, l4);
+  uint32_t b_rd[KS][2];                       // [k-step][taps 0..3 | taps 4..8]: the immediate offset field is 16 bits
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    b_rd[ks][0] = lds0 + (uint32_t)(l15 * RB + (((ks * 4 + l4) ^ ((l15 >> 1) & 7)) << 4));
+    b_rd[ks][1] = b_rd[ks][0] + (uint32_t)(4 * TAP_BYTES);
+  }
+  int rb_, ry_, rx_;                          // this thread's output row of a tile (threads 0..127)
+  patch_row(tid & 127, rb_, ry_, rx_);
+
+  auto issue_halo = [&](int t, int buf) {
+    int n0, y0, x0, n1, y1, x1;
+    const bool ok0 = patch_origin(g2, 2 * t, n0, y0, x0), ok1 = patch_origin(g2, 2 * t + 1, n1, y1, x1);
+    const uint32_t base0 = patch_base2(g2, n0, y0, x0), base1 = patch_base2(g2, n1, y1, x1);
+#pragma unroll
+    for (int i = 0; i < NHI; ++i) {
+      const int q = i * WAVES + wave;
+      if (q < p.g.nq) {
+        const bool b = h_byx[i] & 1;
+        const bool in = halo_inside2(g2, b ? y1 : y0, b ? x1 : x0, b ? ok1 : ok0, h_byx[i]);
+        const uint32_t off = in ? h_st[i] + (b ? base1 : base0) : kNoSrc;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rs_a, (__attribute__((address_space(3))) void*)(smem + W_BYTES + buf * p.hbytes + q * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[FM][FN];
+  u32x4 af[2][KS][FM], bfr[2][KS][FN];
+  auto read_frags = [&](auto TAP, auto SET, uint32_t hb) {
+    constexpr int T_ = decltype(TAP)::value, S_ = decltype(SET)::value;
+    constexpr int TB = (int)((T_ / 3) * 10 + (T_ % 3)) * (CPRW + 1) * 16;        // tap_bytes2
+    constexpr int WB = (T_ < 4 ? T_ : T_ - 4) * TAP_BYTES;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      af[S_][0][i] = lds_read_b128<TB>(hb + a_rd[i]);
+      af[S_][1][i] = lds_read_b128<TB + 64>(hb + a_rd[i]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint32_t wb = b_rd[ks][T_ < 4 ? 0 : 1];
+      bfr[S_][ks][0] = lds_read_b128<WB>(wb);
+      bfr[S_][ks][1] = lds_read_b128<WB + 16 * RB>(wb);
+      bfr[S_][ks][2] = lds_read_b128<WB + 32 * RB>(wb);
+      bfr[S_][ks][3] = lds_read_b128<WB + 48 * RB>(wb);
+    }
+  };
+  auto mfma_tap = [&](auto SET) {
+    constexpr int S_ = decltype(SET)::value;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8_t, bfr[S_][ks][j]), __builtin_bit_cast(bf16x8_t, af[S_][ks][i]), acc[i][j], 0, 0, 0);
+  };
+
+  issue_halo(t_begin, 0);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    // everything this wave has in flight (the weights, the halo of tile t) landed -> barrier: everybody's did, and
+    // everybody is through the epilogue of tile t-1 (its scratch = the buffer the NEXT halo goes to)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < t_end) issue_halo(t + 1, buf ^ 1);
+    if (tid < BM) {
+      int n, y0, x0;
+      const bool ok = patch_origin(g2, 2 * t + rb_, n, y0, x0);
+      rowoff[tid] = ok ? (int64_t)n * p.y_sn + (int64_t)(y0 + ry_) * p.y_sh + (int64_t)(x0 + rx_) * p.y_sw : (int64_t)-1;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t hb = lds0 + (uint32_t)W_BYTES + (uint32_t)buf * p.hbytes;
+    read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, hb);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#define PASSL_PW_TAP(T)                                                                                          \
+    if constexpr (T < 8) read_frags(std::integral_constant<int, (T < 8 ? T + 1 : 8)>{}, std::integral_constant<int, (T + 1) & 1>{}, hb); \
+    mfma_tap(std::integral_constant<int, T & 1>{});                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+    PASSL_PW_TAP(0) PASSL_PW_TAP(1) PASSL_PW_TAP(2) PASSL_PW_TAP(3) PASSL_PW_TAP(4)
+    PASSL_PW_TAP(5) PASSL_PW_TAP(6) PASSL_PW_TAP(7) PASSL_PW_TAP(8)
+#undef PASSL_PW_TAP
+    __syncthreads();      // all fragment reads of the tile done: its halo buffer becomes the epilogue's scratch
+    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, false, FN, 0, true>(p, smem + W_BYTES + buf * p.hbytes, rowoff, acc,
+                                                                            wave, 0, lane, tid, 0, t);
+  }
+}
+
 template <int BN, int CK, int MINB, int STAGES, bool P2D>
 int launch(const Params& p, int lds, hipStream_t st) {
   static bool attr_set = false;
@@ -346,7 +495,8 @@ static void halo_report() {
 
 // passl_hip_set_option("igemm_halo", 0/1) / ("igemm_halo_max_c", n) / ("igemm_halo_ck", 0|32|64)   (runtime.hip)
 int passl_igemm_halo_option(const char* name, int value) {
-  if (!strcmp(name, "igemm_halo")) { g_halo_enabled = value != 0; return PASSL_OK; }
+  // 0 off (default), 1 on, 2 = on, and the persistent weights-resident form for C = 64, NCOLS <= 64 with 2-D tiles
+  if (!strcmp(name, "igemm_halo")) { g_halo_enabled = value < 0 ? 0 : (value > 2 ? 2 : value); return PASSL_OK; }
   if (!strcmp(name, "igemm_halo_max_c")) { g_halo_max_c = value; return PASSL_OK; }
   if (!strcmp(name, "igemm_halo_dbg")) {
     if (value == 2) halo_report();
@@ -372,7 +522,7 @@ int passl_igemm_halo_option(const char* name, int value) {
 int passl_igemm_halo_try(const passl_conv_desc* d, hipStream_t st) {
   if (g_halo_enabled < 0) {
     const char* e = getenv("PASSL_IGEMM_HALO");
-    g_halo_enabled = e ? atoi(e) != 0 : 0;
+    g_halo_enabled = e ? atoi(e) : 0;
     const char* c = getenv("PASSL_IGEMM_HALO_MAX_C");
     if (c) g_halo_max_c = atoi(c);
   }
@@ -443,6 +593,25 @@ int passl_igemm_halo_try(const passl_conv_desc* d, hipStream_t st) {
     }
     g_halo_stamp_tiles = g_halo_stamps ? p.ntiles : 0;
     p.stamps = g_halo_stamps;
+  }
+  if (g_halo_enabled == 2 && p2d && CK == 64 && d->C == 64 && d->NCOLS <= 64) {
+    static int cus = 0;
+    if (!cus) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      cus = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int lds_pw = 9 * 64 * 128 + 2 * (int)p.hbytes + 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&halo::igemm_halo_pw_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    const int grid = p.ntiles < cus ? p.ntiles : cus;
+    hipLaunchKernelGGL(halo::igemm_halo_pw_kernel, dim3(grid), dim3(256), lds_pw, st, p);
+    return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
   }
   const int nbuf = p.nchunks > 1 ? 2 : 1;
   const int stages = g_halo_stages;

@@ -186,6 +186,30 @@ HALO_HD uint32_t a_frag_base2(int frag_row0, int l15, int l4) {
 }
 template <int CPRW>
 HALO_HD uint32_t tap_bytes2(int r, int s) { return (uint32_t)(r * 10 + s) * (uint32_t)((CPRW + 1) * 16); }
+// The persistent form (igemm_halo_pw_kernel) splits halo_src2 into a lane-static part and two patch origins per
+// tile: offset = patch_base[b] + halo_static2(q, lane), valid iff halo_inside2(...);  byx = b | hy << 8 | hx << 16, or -1
+// for lanes that never fetch (pad slot, rows past the two 10 x 10 blocks).
+template <int CPRW>
+HALO_HD uint32_t halo_static2(const Geom2& g, int q, int lane, int& byx) {
+  const int p = q * 64 + lane;
+  const int hrow = p / (CPRW + 1);
+  const int cpos = p - hrow * (CPRW + 1);
+  if (cpos == CPRW || hrow >= kHaloRows2) { byx = -1; return 0; }
+  const int b = hrow >= 100 ? 1 : 0;
+  const int hr = hrow - 100 * b;
+  const int hy = hr / 10, hx = hr - 10 * hy;
+  byx = b | (hy << 8) | (hx << 16);
+  return (uint32_t)((hy - 1) * g.a_sh2) + (uint32_t)((hx - 1) * g.a_sw2) + (uint32_t)swap01(cpos) * 16u;   // wraps for hy, hx = 0
+}
+HALO_HD uint32_t patch_base2(const Geom2& g, int n, int y0, int x0) {
+  return (uint32_t)n * (uint32_t)g.a_sn2 + (uint32_t)y0 * (uint32_t)g.a_sh2 + (uint32_t)x0 * (uint32_t)g.a_sw2;
+}
+// y0 / x0 / ok = origin and existence of the patch the lane's halo row belongs to
+HALO_HD bool halo_inside2(const Geom2& g, int y0, int x0, bool ok, int byx) {
+  return byx >= 0 && ok && (uint32_t)(y0 + ((byx >> 8) & 255) - 1) < (uint32_t)g.IH &&
+         (uint32_t)(x0 + (byx >> 16) - 1) < (uint32_t)g.IW;
+}
+
 // flattened output row (n, oy, ox) of tile row r'; false when the patch does not exist (ragged last tile)
 HALO_HD bool out_pixel2(const Geom2& g, int tile, int r, int& n, int& oy, int& ox) {
   int b, y, x, y0, x0;

@@ -175,6 +175,114 @@ static long run(const Case& cs) {
   return bad;
 }
 
+// The persistent form (igemm_halo_pw_kernel: C = 64, K <= 64, 2-D tiles): weights of all nine taps resident, the halo
+// sources in their lane-static + patch-origin form (cross-checked against halo_src2), tile ranges per workgroup.
+static long run_pw(const Case& cs, int nwg) {
+  constexpr int CPRW = 8, RB = 128, BN = 64, FM = 2, FN = 4, WM = 32, TAP_BYTES = BN * RB, W_BYTES = 9 * TAP_BYTES;
+  const int N = cs.N, IH = cs.H, IW = cs.W, C = cs.C, K = cs.K;
+  if (C != 64 || K > 64) return 1;
+  const long M = (long)N * IH * IW, KDIM = 9L * C;
+  std::vector<int16_t> A((size_t)N * IH * IW * C), B((size_t)K * KDIM);
+  for (size_t i = 0; i < A.size(); ++i) A[i] = ival(i, 11u);
+  for (size_t i = 0; i < B.size(); ++i) B[i] = ival(i, 23u);
+  const char* Ab = reinterpret_cast<const char*>(A.data());
+  const char* Bb = reinterpret_cast<const char*>(B.data());
+  const uint32_t a_bytes = (uint32_t)(A.size() * 2), b_bytes = (uint32_t)(B.size() * 2);
+  Geom2 g2;
+  g2.N = N; g2.IH = IH; g2.IW = IW; g2.PXN = IW / 8; g2.PN = (IH / 8) * (IW / 8); g2.npatches = N * g2.PN;
+  g2.a_sw2 = C * 2; g2.a_sh2 = IW * C * 2; g2.a_sn2 = IH * IW * C * 2;
+  g2.d_pn = make_fdiv((uint32_t)g2.PN); g2.d_pxn = make_fdiv((uint32_t)g2.PXN);
+  const int nq = (kHaloRows2 * (CPRW + 1) + 63) / 64, ntiles = (g2.npatches + 1) / 2;
+  std::vector<int32_t> out((size_t)M * K, INT32_MIN);
+  std::vector<char> wts(W_BYTES), hal((size_t)nq * 1024);
+  // weights: piece = tap * 8 + r8, lane -> row 8 r8 + lane / 8, source chunk (lane % 8) ^ ((row >> 1) & 7)
+  for (int piece = 0; piece < 72; ++piece)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int tap = piece >> 3, row = (piece & 7) * 8 + lane / CPRW;
+      const uint32_t chunk = (uint32_t)(((lane % CPRW) ^ ((row >> 1) & 7)) * 16);
+      char* dst = &wts[(size_t)piece * 1024 + lane * 16];
+      const uint32_t off = (uint32_t)row * (uint32_t)(KDIM * 2) + (uint32_t)(tap * C * 2) + chunk;
+      if (row >= K || off + 16 > b_bytes) memset(dst, 0, 16); else memcpy(dst, Bb + off, 16);
+    }
+  long mism = 0, covered = 0;
+  for (int wg = 0; wg < nwg; ++wg) {
+    const int t_begin = (int)(((int64_t)wg * ntiles) / nwg), t_end = (int)(((int64_t)(wg + 1) * ntiles) / nwg);
+    for (int t = t_begin; t < t_end; ++t) {
+      ++covered;
+      int n0, y0, x0, n1, y1, x1;
+      const bool ok0 = patch_origin(g2, 2 * t, n0, y0, x0), ok1 = patch_origin(g2, 2 * t + 1, n1, y1, x1);
+      const uint32_t base0 = patch_base2(g2, n0, y0, x0), base1 = patch_base2(g2, n1, y1, x1);
+      for (int q = 0; q < nq; ++q)
+        for (int lane = 0; lane < 64; ++lane) {
+          int byx;
+          const uint32_t st = halo_static2<CPRW>(g2, q, lane, byx);
+          const bool b = byx & 1;
+          const bool in = halo_inside2(g2, b ? y1 : y0, b ? x1 : x0, b ? ok1 : ok0, byx);
+          const uint32_t off = in ? st + (b ? base1 : base0) : kNoSrc;
+          if (off != halo_src2<CPRW>(g2, t, q, lane)) ++mism;
+          char* dst = &hal[(size_t)q * 1024 + lane * 16];
+          if (off == kNoSrc || off + 16 > a_bytes) memset(dst, 0, 16); else memcpy(dst, Ab + off, 16);
+        }
+      std::vector<int32_t> acc((size_t)4 * 64 * FM * FN * 4, 0);
+      for (int tap = 0; tap < 9; ++tap)
+        for (int wave = 0; wave < 4; ++wave)
+          for (int ks = 0; ks < 2; ++ks)
+            for (int i = 0; i < FM; ++i)
+              for (int j = 0; j < FN; ++j) {
+                int16_t pix[64][8], wgt[64][8];
+                for (int lane = 0; lane < 64; ++lane) {
+                  const int l15 = lane & 15, l4 = lane >> 4;
+                  const uint32_t ad = a_frag_base2<CPRW>(wave * WM + i * 16, l15, l4) + tap_bytes2<CPRW>(tap / 3, tap % 3) + (uint32_t)(64 * ks);
+                  memcpy(pix[lane], &hal[ad], 16);
+                  const uint32_t base = (uint32_t)(l15 * RB + (((ks * 4 + l4) ^ ((l15 >> 1) & 7)) << 4)) + (tap < 4 ? 0u : (uint32_t)(4 * TAP_BYTES));
+                  const uint32_t bd = base + (uint32_t)((tap < 4 ? tap : tap - 4) * TAP_BYTES + j * 16 * RB);
+                  memcpy(wgt[lane], &wts[bd], 16);
+                }
+                for (int lane = 0; lane < 64; ++lane)
+                  for (int e = 0; e < 4; ++e) {
+                    int32_t sum = 0;
+                    for (int kg = 0; kg < 4; ++kg)
+                      for (int x = 0; x < 8; ++x) sum += (int32_t)wgt[kg * 16 + 4 * (lane >> 4) + e][x] * (int32_t)pix[kg * 16 + (lane & 15)][x];
+                    acc[((((size_t)wave * 64 + lane) * FM + i) * FN + j) * 4 + e] += sum;
+                  }
+              }
+      for (int wave = 0; wave < 4; ++wave)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j)
+              for (int e = 0; e < 4; ++e) {
+                const int row = wave * WM + i * 16 + sigma(lane & 15), col = j * 16 + (lane >> 4) * 4 + e;
+                int rb, ry, rx, n, py0, px0;
+                patch_row(row, rb, ry, rx);
+                if (!patch_origin(g2, 2 * t + rb, n, py0, px0) || col >= K) continue;
+                out[((size_t)n * IH * IW + (size_t)(py0 + ry) * IW + px0 + rx) * K + col] = acc[((((size_t)wave * 64 + lane) * FM + i) * FN + j) * 4 + e];
+              }
+    }
+  }
+  long bad = 0;
+  for (long m = 0; m < M; ++m) {
+    const int n = (int)(m / (IH * IW)), rem = (int)(m % (IH * IW)), op = rem / IW, oq = rem % IW;
+    for (int k = 0; k < K; ++k) {
+      int32_t sum = 0;
+      for (int r = 0; r < 3; ++r) {
+        const int ih = op + r - 1;
+        if (ih < 0 || ih >= IH) continue;
+        for (int s = 0; s < 3; ++s) {
+          const int iw = oq + s - 1;
+          if (iw < 0 || iw >= IW) continue;
+          const int16_t* ap = &A[(((size_t)n * IH + ih) * IW + iw) * C];
+          const int16_t* bp = &B[(size_t)k * KDIM + (size_t)(r * 3 + s) * C];
+          for (int c = 0; c < C; ++c) sum += (int32_t)ap[c] * (int32_t)bp[c];
+        }
+      }
+      if (out[(size_t)m * K + k] != sum) ++bad;
+    }
+  }
+  printf("persistent form N=%d %dx%d C=%d K=%d, %d workgroups: %ld tiles of %d -> %s%s\n", N, IH, IW, C, K, nwg, covered, ntiles,
+         bad ? "WRONG" : "exact", mism ? " (split halo sources differ from halo_src2)" : "");
+  return bad + mism + (covered != ntiles);
+}
+
 // bank check: the 16 lanes of every ds_read_b128 service group must hit 16 different 16-byte slots of the 256-byte
 // bank row, for every tile-relative start row and tap offset (rows of one fragment consecutive)
 template <int CPRW>
@@ -231,6 +339,9 @@ int main() {
   bad += run<128, 32, true>({3, 8, 24, 96, 136});
   bad += run<128, 64, true>({5, 16, 8, 128, 72});
   bad += run<64, 64, true>({1, 8, 8, 64, 64});
+  bad += run_pw({3, 56, 56, 64, 64}, 7);
+  bad += run_pw({5, 8, 16, 64, 40}, 3);
+  bad += run_pw({1, 8, 8, 64, 64}, 4);
   { int seen = 0; for (int i = 0; i < 16; ++i) seen |= 1 << sigma(i); if (seen != 0xffff) { printf("sigma is not a permutation\n"); ++bad; } }
   for (int c = 0; c < 8; ++c) if (swap01(swap01(c)) != c) { printf("swap01 is not an involution\n"); ++bad; }
   // images that tiles cross (9408 rows = 73.5 tiles), odd widths, one image smaller than a tile, several chunks
