@@ -120,6 +120,34 @@ HALO_HD uint32_t patch_x(const Geom& g, int n, int y0, int x0) {
   return (uint32_t)n * (uint32_t)g.a_sn2 + (uint32_t)y0 * (uint32_t)g.a_sh2 + (uint32_t)x0 * (uint32_t)g.a_sw2;
 }
 
+// The form for images whose sides are multiples of 8 (no overhang) — the form that was run on hardware in round 4
+// (exact; 64->64 @56: 77 us): validity of a halo fetch is four border flags against the patch's position.
+HALO_HD uint32_t dy_static_tiled(const Geom& g, int oc0, int q, int lane) {
+  const int kk = q * 8 + lane / 8;
+  const int chunk = (lane % 8) ^ (hswz8(kk) << 1);
+  const int oc = oc0 + chunk * 8;
+  if (oc >= g.NCOLS) return kNoSrc;
+  return (uint32_t)((kk >> 3) * g.IW + (kk & 7)) * (uint32_t)g.dy_pitch + (uint32_t)oc * 2u;
+}
+// flags: 1 top halo row, 2 bottom, 4 left column, 8 right, 16 never valid (pad slot / unused row / channel >= C)
+HALO_HD uint32_t halo_static_tiled(const Geom& g, int c0, int q, int lane, int& flags) {
+  const int p = q * 64 + lane;
+  const int hrow = p / kSlots;
+  const int cpos = p - hrow * kSlots;
+  const int hy = hrow / kPW, hx = hrow - hy * kPW;
+  const int c = c0 + cpos * 8;
+  flags = 0;
+  if (cpos >= 8 || hrow >= kRows || hx >= 10 || c >= g.C) { flags = 16; return 0; }
+  if (hy == 0) flags |= 1;
+  if (hy == 9) flags |= 2;
+  if (hx == 0) flags |= 4;
+  if (hx == 9) flags |= 8;
+  return (uint32_t)((hy - 1) * g.a_sh2) + (uint32_t)((hx - 1) * g.a_sw2) + (uint32_t)c * 2u;     // wraps for hy, hx = 0
+}
+HALO_HD int edge_mask(const Geom& g, int y0, int x0) {
+  return 16 | (y0 == 0 ? 1 : 0) | (y0 == g.IH - 8 ? 2 : 0) | (x0 == 0 ? 4 : 0) | (x0 == g.IW - 8 ? 8 : 0);
+}
+
 // ds_read_b64_tr_b16 addresses (bytes inside a stage).  Lane = (g = lane >> 4, r4 = (lane >> 2) & 3, c4 = lane & 3);
 // a read covers reduction rows 8 g + 4 half + r4 of a 32-row k-step and hands lane l15 column l15 of a 16-column block.
 //   dY fragment (16 oc starting at oc_local): k-step ks, half h

@@ -70,11 +70,13 @@ static long run(const Case& cs) {
           // ---- DMA pieces: the kernel's static + per-patch form, checked against the direct formulas
           const uint32_t dy_base = (uint32_t)patch_m(g, pn, py0, px0) * (uint32_t)g.dy_pitch;
           const uint32_t x_base = patch_x(g, pn, py0, px0);
+          const bool tiled = (IH % 8) == 0 && (IW % 8) == 0;       // the kernel's OVERHANG = false instantiation
+          const int emask = edge_mask(g, py0, px0);
           for (int q = 0; q < kDyPieces; ++q)
             for (int lane = 0; lane < 64; ++lane) {
-              int yx;
-              const uint32_t st = dy_static(g, oc0, q, lane, yx);
-              const uint32_t off = (st == kNoSrc || !dy_inside(g, py0, px0, yx)) ? kNoSrc : st + dy_base;
+              int yx = 0;
+              const uint32_t st = tiled ? dy_static_tiled(g, oc0, q, lane) : dy_static(g, oc0, q, lane, yx);
+              const uint32_t off = (st == kNoSrc || (!tiled && !dy_inside(g, py0, px0, yx))) ? kNoSrc : st + dy_base;
               if (off != dy_src(g, gp, oc0, q, lane)) ++split_mismatch;
               char* dst = &stage[(size_t)q * 1024 + lane * 16];
               if (off == kNoSrc || off + 16 > dy_bytes) memset(dst, 0, 16); else memcpy(dst, Db + off, 16);
@@ -82,8 +84,8 @@ static long run(const Case& cs) {
           for (int q = 0; q < kHaloPieces; ++q)
             for (int lane = 0; lane < 64; ++lane) {
               int hyx;
-              const uint32_t st = halo_static(g, c0, q, lane, hyx);
-              const uint32_t off = halo_inside(g, py0, px0, hyx) ? st + x_base : kNoSrc;
+              const uint32_t st = tiled ? halo_static_tiled(g, c0, q, lane, hyx) : halo_static(g, c0, q, lane, hyx);
+              const uint32_t off = tiled ? ((hyx & emask) ? kNoSrc : st + x_base) : (halo_inside(g, py0, px0, hyx) ? st + x_base : kNoSrc);
               if (off != halo_src(g, gp, c0, q, lane)) ++split_mismatch;
               char* dst = &stage[(size_t)kDyBytes + (size_t)q * 1024 + lane * 16];
               if (off == kNoSrc || off + 16 > x_bytes) memset(dst, 0, 16); else memcpy(dst, Xb + off, 16);

@@ -29,3 +29,14 @@ def test_conv_igemm_is_bit_exact_through_the_c_abi(options):
     if options:
         # eight 3x3 / stride-1 cases x (ReLU, statistics, residual + ReLU, BatchNorm-backward statistics)
         assert r.stdout.count('kernel halo') == 32, r.stdout
+
+
+@pytest.mark.gpu
+def test_conv_wgrad_is_exact_through_the_c_abi_also_with_the_spatially_tiled_kernel():
+    """passl_hip_conv_wgrad compared == with host integer sums (1 / 7 / heuristic reduction slices; 3x3, 1x1, strided,
+    ragged blocks) for the product kernels and with the opt-in spatially tiled 3x3 kernel in its form for images whose
+    sides are multiples of 8 (wgrad_halo=1: the instruction stream that was run on hardware in round 4)."""
+    for options in ((), ('wgrad_halo=1',)):
+        r = subprocess.run([_kbench(), 'wcheck', *options], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert 'WGRAD CHECK OK' in r.stdout
