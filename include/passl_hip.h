@@ -326,6 +326,22 @@ int passl_hip_bn_bwd_finalize_sums(const double* sums_all, int world, int rank, 
 int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* coef,
                            const float* scale, const float* shift, void* dx, void* dres, int64_t M,
                            int C, int relu, int dtype, passl_stream_t stream);
+/* EXPERIMENTAL (ABI 13; the Python side calls them only with PASSL_BN_FUSED_FINALIZE=1): passl_hip_bn_finalize followed
+ * by passl_hip_bn_apply, resp. passl_hip_bn_bwd_finalize followed by passl_hip_bn_bwd_apply — same arguments, same
+ * results, same bits.  On a tall slab (>= 512 row blocks) the finalize runs INSIDE the streaming kernel (every
+ * workgroup turns the <= 16 segment totals of bn_combine into its per-channel constants, workgroup 0 writes the
+ * per-channel outputs): one launch less per BatchNorm and direction on the main chain of the step; otherwise the two
+ * calls are made as they are.  tools/kbench bncheck compares both forms bit for bit. */
+int passl_hip_bn_finalize_apply(const float* partial, int nblocks, int64_t M, int C, int rows_per_block,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                const void* x, const void* residual, void* z, uint8_t* relu_mask, int relu, int dtype,
+                                passl_stream_t stream);
+int passl_hip_bn_bwd_finalize_apply(const float* partial, int nblocks, int64_t M, int C, const float* gamma,
+                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                                    const void* dz, const void* z, const void* x, const float* scale,
+                                    const float* shift, void* dx, void* dres, int relu, int dtype,
+                                    passl_stream_t stream);
 
 /* ---------------------------------------------------------------- pooling */
 

@@ -801,3 +801,5 @@ extern "C" int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void*
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
+
+#include "bn_fused.inc"

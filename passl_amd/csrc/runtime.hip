@@ -132,7 +132,7 @@ extern "C" int passl_hip_set_option(const char* name, int value) {
   return passl_igemm_ring_option(name, value);
 }
 
-extern "C" int passl_hip_abi_version(void) { return 12; }
+extern "C" int passl_hip_abi_version(void) { return 13; }
 
 extern "C" const char* passl_hip_strerror(int status) {
   switch (status) {

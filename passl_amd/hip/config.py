@@ -18,7 +18,8 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
           'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
           # the library reads the same variable (conv_wgrad_halo.inc): 0 off (default), 1 images with sides % 8 == 0, 2 all
-          'wgrad_halo': int(os.environ.get('PASSL_WGRAD_HALO', '0') or 0)}
+          'wgrad_halo': int(os.environ.get('PASSL_WGRAD_HALO', '0') or 0),
+          'bn_fused_finalize': os.environ.get('PASSL_BN_FUSED_FINALIZE', '0') == '1'}
 
 
 def set_device(name):
@@ -113,6 +114,12 @@ def wgrad_halo():
     """EXPERIMENTAL (off): the spatially tiled 3x3 weight-gradient kernel takes eligible launches; the slice count of
     those launches is then chosen for ITS grid (one workgroup per 64 x 64 block of dW and slice, all nine taps)."""
     return _state['wgrad_halo']
+
+
+def bn_fused_finalize():
+    """EXPERIMENTAL (off): training-mode BatchNorm calls passl_hip_bn_finalize_apply / passl_hip_bn_bwd_finalize_apply
+    (the finalize inside the streaming kernel on tall slabs: one launch less per BatchNorm and direction)."""
+    return _state['bn_fused_finalize']
 
 
 def set_flag(name, value):

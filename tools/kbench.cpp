@@ -10,6 +10,7 @@
 //   tools/kbench time  [name=value ...]     per-layer table of the ResNet-50 3x3 / 1x1 shapes at N = 256
 //   tools/kbench ab name=v0,v1 [...]        the same table for two values of ONE option, side by side
 //   tools/kbench wcheck | wtime [name=value ...]   the same for passl_hip_conv_wgrad (== on fp32 sums; per-layer table)
+//   tools/kbench bncheck                    fused BatchNorm finalize + apply against the separate launches, bit for bit
 //   tools/kbench ablate                     the register-staged kernel's debug switches on the 1x1 shapes
 //   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
 //   name=value pairs are passl_hip_set_option() calls made before anything runs.
@@ -472,6 +473,96 @@ static int run_time(const char* ab_name, int v0, int v1) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// bncheck: passl_hip_bn_finalize_apply / passl_hip_bn_bwd_finalize_apply (finalize inside the streaming kernel on tall
+// slabs) against the separate launches they replace — every output compared BIT FOR BIT (no host reference needed: the
+// two forms must agree with each other).
+static void fill_f32(float* d, int n, uint32_t seed, float lo, float hi) {
+  std::vector<float> h(n);
+  for (int i = 0; i < n; ++i) h[i] = lo + (hi - lo) * (float)(mix((uint64_t)i, seed) % 1024u) / 1024.0f;
+  CK(hipMemcpy(d, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+}
+static bool same_bits(const void* a, const void* b, size_t bytes, const char* what) {
+  std::vector<char> ha(bytes), hb(bytes);
+  CK(hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost));
+  if (memcmp(ha.data(), hb.data(), bytes) == 0) return true;
+  size_t i = 0;
+  while (i < bytes && ha[i] == hb[i]) ++i;
+  printf("    %s differs (first at byte %zu of %zu)\n", what, i, bytes);
+  return false;
+}
+static int bn_case(int64_t M, int C, int nb_f, int nb_b, bool residual) {
+  const int64_t n = M * C;
+  void *x, *res, *dz, *zA, *zB, *dxA, *dxB, *drA, *drB;
+  uint8_t *mA, *mB;
+  float *par, *parb, *cols;          // cols: 16 per-channel fp32 vectors
+  for (void** p : {&x, &res, &dz, &zA, &zB, &dxA, &dxB, &drA, &drB}) CK(hipMalloc(p, n * 2));
+  CK(hipMalloc((void**)&mA, n / 8)); CK(hipMalloc((void**)&mB, n / 8));
+  const int64_t pf = passl_hip_bn_partial_floats(nb_f, C, 1), pb = passl_hip_bn_partial_floats(nb_b, C, 0);
+  CK(hipMalloc((void**)&par, pf * 4)); CK(hipMalloc((void**)&parb, pb * 4));
+  CK(hipMalloc((void**)&cols, (size_t)32 * C * 4));
+  fill(x, n, 61u); fill(res, n, 67u); fill(dz, n, 71u);
+  float *gamma = cols, *beta = cols + C, *rm0 = cols + 2 * C, *rv0 = cols + 3 * C;
+  float *rmA = cols + 4 * C, *rvA = cols + 5 * C, *rmB = cols + 6 * C, *rvB = cols + 7 * C;
+  float *stA = cols + 8 * C, *stB = cols + 12 * C;                 // mean, invstd, scale, shift
+  float *dgA = cols + 16 * C, *dbA = cols + 17 * C, *dgB = cols + 18 * C, *dbB = cols + 19 * C;
+  float *cfA = cols + 20 * C, *cfB = cols + 23 * C;                // 3 C each
+  fill_f32(gamma, C, 73u, 0.5f, 1.5f); fill_f32(beta, C, 79u, -0.5f, 0.5f);
+  fill_f32(rm0, C, 83u, -0.1f, 0.1f); fill_f32(rv0, C, 89u, 0.5f, 1.5f);
+  CK(hipMemcpy(rmA, rm0, C * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(rvA, rv0, C * 4, hipMemcpyDeviceToDevice));
+  CK(hipMemcpy(rmB, rm0, C * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(rvB, rv0, C * 4, hipMemcpyDeviceToDevice));
+  int rc = passl_hip_bn_stats(x, par, M, C, nb_f, PASSL_BF16, nullptr);
+  const int rpb = (int)((M + nb_f - 1) / nb_f);
+  bool ok = rc == PASSL_OK;
+  // forward: separate launches (A), fused entry point (B)
+  rc = passl_hip_bn_finalize(par, nb_f, M, C, rpb, gamma, beta, rmA, rvA, 0.9f, 1e-5f, stA, stA + C, stA + 2 * C, stA + 3 * C, nullptr);
+  ok = ok && rc == PASSL_OK;
+  rc = passl_hip_bn_apply(x, stA + 2 * C, stA + 3 * C, residual ? res : nullptr, zA, mA, M, C, 1, PASSL_BF16, nullptr);
+  ok = ok && rc == PASSL_OK;
+  rc = passl_hip_bn_finalize_apply(par, nb_f, M, C, rpb, gamma, beta, rmB, rvB, 0.9f, 1e-5f, stB, stB + C, stB + 2 * C, stB + 3 * C, x,
+                                   residual ? res : nullptr, zB, mB, 1, PASSL_BF16, nullptr);
+  ok = ok && rc == PASSL_OK;
+  CK(hipDeviceSynchronize());
+  ok = same_bits(zA, zB, n * 2, "z") && ok;
+  ok = same_bits(mA, mB, n / 8, "relu mask") && ok;
+  ok = same_bits(stA, stB, (size_t)4 * C * 4, "mean / invstd / scale / shift") && ok;
+  ok = same_bits(rmA, rmB, (size_t)2 * C * 4, "running statistics") && ok;
+  // backward: mask recomputed from x * scale + shift (relu = 2) without residual, bit mask (3) with
+  const int relu_b = residual ? 3 : 2;
+  rc = passl_hip_bn_bwd_reduce(dz, residual ? (const void*)mA : nullptr, x, stA, stA + C, stA + 2 * C, stA + 3 * C, parb, M, C, nb_b, relu_b,
+                               PASSL_BF16, nullptr);
+  ok = ok && rc == PASSL_OK;
+  CK(hipMemset(dgA, 0, (size_t)4 * C * 4));
+  rc = passl_hip_bn_bwd_finalize(parb, nb_b, M, C, gamma, stA, stA + C, dgA, dbA, cfA, nullptr);
+  ok = ok && rc == PASSL_OK;
+  rc = passl_hip_bn_bwd_apply(dz, residual ? (const void*)mA : nullptr, x, cfA, stA + 2 * C, stA + 3 * C, dxA, drA, M, C, relu_b, PASSL_BF16, nullptr);
+  ok = ok && rc == PASSL_OK;
+  rc = passl_hip_bn_bwd_finalize_apply(parb, nb_b, M, C, gamma, stA, stA + C, dgB, dbB, cfB, dz, residual ? (const void*)mA : nullptr, x,
+                                       stA + 2 * C, stA + 3 * C, dxB, drB, relu_b, PASSL_BF16, nullptr);
+  ok = ok && rc == PASSL_OK;
+  CK(hipDeviceSynchronize());
+  ok = same_bits(dxA, dxB, n * 2, "dx") && ok;
+  ok = same_bits(drA, drB, n * 2, "residual gradient") && ok;
+  ok = same_bits(dgA, dgB, (size_t)C * 4, "d-gamma") && ok;
+  ok = same_bits(dbA, dbB, (size_t)C * 4, "d-beta") && ok;
+  ok = same_bits(cfA, cfB, (size_t)3 * C * 4, "coefficients") && ok;
+  printf("BatchNorm M=%lld C=%d, %d / %d row blocks%s: %s\n", (long long)M, C, nb_f, nb_b, residual ? ", residual" : "",
+         ok ? "fused = separate, bit for bit" : "DIFFERENT");
+  for (void* p : {x, res, dz, zA, zB, dxA, dxB, drA, drB, (void*)mA, (void*)mB, (void*)par, (void*)parb, (void*)cols}) CK(hipFree(p));
+  return ok ? 0 : 1;
+}
+static int run_bncheck() {
+  int bad = 0;
+  bad += bn_case(64LL * 56 * 56, 64, 1024, 768, false);       // tall slabs: the fused kernels run
+  bad += bn_case(32LL * 56 * 56, 256, 1024, 768, true);
+  bad += bn_case(64LL * 28 * 28, 512, 784, 768, true);
+  bad += bn_case(16LL * 56 * 56, 64, 392, 392, false);        // short slab: both forms are the separate launches
+  bad += bn_case(8LL * 14 * 14, 1024, 98, 98, true);
+  printf(bad ? "BN CHECK FAILED (%d)\n" : "BN CHECK OK\n", bad);
+  return bad ? 1 : 0;
+}
+
 // sweep: every argument is one configuration "name=value,name=value,...": the 3x3 / stride-1 cases are checked
 // (bit-exact) and the four ResNet-50 3x3 shapes timed under each, one row per configuration.
 static int apply_config(const char* cfg) {
@@ -579,6 +670,7 @@ int main(int argc, char** argv) {
   if (mode == "check") return run_check();
   if (mode == "ablate") return run_ablate();
   if (mode == "wcheck") return run_wcheck();
+  if (mode == "bncheck") return run_bncheck();
   if (mode == "wtime") return run_wtime();
   if (mode == "time") return run_time(nullptr, 0, 0);
   if (mode == "ab") { if (!ab_name) { fprintf(stderr, "ab needs name=v0,v1\n"); return 2; } return run_time(ab_name, v0, v1); }
