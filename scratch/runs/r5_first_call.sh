@@ -9,7 +9,7 @@ K=tools/kbench
   echo "== persistent weights-resident 3x3 kernel (igemm_halo=2): check"; timeout 40 $K check igemm_halo=2 igemm_halo_max_c=512
   echo "== forward 3x3: product | halo 2-D | persistent"
   KBENCH_STAMPS=1 timeout 40 $K sweep igemm_halo=0 igemm_halo=1,igemm_halo_max_c=512 igemm_halo=2,igemm_halo_max_c=512
-  echo "== BatchNorm: finalize inside the streaming kernels against the separate launches"; timeout 60 $K bncheck
+  echo "== BatchNorm: finalize inside the streaming kernels against the separate launches"; timeout 60 $K bncheck; timeout 30 $K bntime
   echo "== weight gradient: overhanging patches (wgrad_halo=2): check"; timeout 60 $K wcheck wgrad_halo=2
   echo "== weight gradient timings: product, then wgrad_halo=2 with its own slice counts (512 / blocks)"
   timeout 20 $K wtime rows=6

@@ -10,6 +10,7 @@
 //   tools/kbench time  [name=value ...]     per-layer table of the ResNet-50 3x3 / 1x1 shapes at N = 256
 //   tools/kbench ab name=v0,v1 [...]        the same table for two values of ONE option, side by side
 //   tools/kbench wcheck | wtime [name=value ...]   the same for passl_hip_conv_wgrad (== on fp32 sums; per-layer table)
+//   tools/kbench bntime                     ... and their times on the tall ResNet-50 shapes
 //   tools/kbench bncheck                    fused BatchNorm finalize + apply against the separate launches, bit for bit
 //   tools/kbench ablate                     the register-staged kernel's debug switches on the 1x1 shapes
 //   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
@@ -552,6 +553,49 @@ static int bn_case(int64_t M, int C, int nb_f, int nb_b, bool residual) {
   for (void* p : {x, res, dz, zA, zB, dxA, dxB, drA, drB, (void*)mA, (void*)mB, (void*)par, (void*)parb, (void*)cols}) CK(hipFree(p));
   return ok ? 0 : 1;
 }
+// bntime: the forward pair (finalize + apply) against the fused entry point on the tall ResNet-50 shapes
+static int run_bntime() {
+  struct S { int64_t M; int C; const char* note; };
+  const S shapes[] = {{256LL * 56 * 56, 64, "802816 x 64"}, {256LL * 56 * 56, 256, "802816 x 256"},
+                      {256LL * 28 * 28, 128, "200704 x 128"}, {256LL * 28 * 28, 512, "200704 x 512"}};
+  printf("%-16s %12s %12s   (us per BatchNorm forward: combine + finalize + apply | combine + fused apply)\n", "rows x C", "separate", "fused");
+  for (const S& sh : shapes) {
+    const int64_t n = sh.M * sh.C;
+    const int nb = (int)((sh.M + 127) / 128), rpb = 128;            // the conv epilogue's slab: one row block per 128 rows
+    void *x, *z; float *par, *cols;
+    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&z, n * 2));
+    const int64_t pf = passl_hip_bn_partial_floats(nb, sh.C, 1);
+    CK(hipMalloc((void**)&par, pf * 4)); CK(hipMalloc((void**)&cols, (size_t)16 * sh.C * 4));
+    fill(x, n, 61u);
+    fill_f32(cols, sh.C, 73u, 0.5f, 1.5f); fill_f32(cols + sh.C, sh.C, 79u, -0.5f, 0.5f);
+    fill_f32(cols + 2 * sh.C, sh.C, 83u, -0.1f, 0.1f); fill_f32(cols + 3 * sh.C, sh.C, 89u, 0.5f, 1.5f);
+    if (passl_hip_bn_stats(x, par, sh.M, sh.C, nb, PASSL_BF16, nullptr) != PASSL_OK) { printf("bn_stats failed\n"); return 1; }
+    float* st = cols + 4 * sh.C;
+    float t[2] = {0, 0};
+    for (int form = 0; form < 2; ++form) {
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      for (int it = -3; it < 20; ++it) {
+        if (it == 0) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
+        if (form == 0) {
+          passl_hip_bn_finalize(par, nb, sh.M, sh.C, rpb, cols, cols + sh.C, cols + 2 * sh.C, cols + 3 * sh.C, 0.9f, 1e-5f, st, st + sh.C,
+                                st + 2 * sh.C, st + 3 * sh.C, nullptr);
+          passl_hip_bn_apply(x, st + 2 * sh.C, st + 3 * sh.C, nullptr, z, nullptr, sh.M, sh.C, 1, PASSL_BF16, nullptr);
+        } else {
+          passl_hip_bn_finalize_apply(par, nb, sh.M, sh.C, rpb, cols, cols + sh.C, cols + 2 * sh.C, cols + 3 * sh.C, 0.9f, 1e-5f, st,
+                                      st + sh.C, st + 2 * sh.C, st + 3 * sh.C, x, nullptr, z, nullptr, 1, PASSL_BF16, nullptr);
+        }
+      }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&t[form], e0, e1));
+      CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+    printf("%-16s %12.1f %12.1f\n", sh.note, t[0] * 50.0f, t[1] * 50.0f);
+    CK(hipFree(x)); CK(hipFree(z)); CK(hipFree(par)); CK(hipFree(cols));
+  }
+  return 0;
+}
+
 static int run_bncheck() {
   int bad = 0;
   bad += bn_case(64LL * 56 * 56, 64, 1024, 768, false);       // tall slabs: the fused kernels run
@@ -671,6 +715,7 @@ int main(int argc, char** argv) {
   if (mode == "ablate") return run_ablate();
   if (mode == "wcheck") return run_wcheck();
   if (mode == "bncheck") return run_bncheck();
+  if (mode == "bntime") return run_bntime();
   if (mode == "wtime") return run_wtime();
   if (mode == "time") return run_time(nullptr, 0, 0);
   if (mode == "ab") { if (!ab_name) { fprintf(stderr, "ab needs name=v0,v1\n"); return 2; } return run_time(ab_name, v0, v1); }
