@@ -51,17 +51,14 @@ int passl_hip_abi_version(void);
  *   "igemm_8p_min_nk" n         ... (mode 1) only for reductions of at least n 64-element K-tiles (8)
  *   "igemm_8p_tk" / "_te" / "_ring_tk" / "_ring_te" / "_margin"   the cost model's constants (0.01 us per K-tile and
  *                               per tile of either kernel, margin in %: conv_igemm_8p.hip)
- *   "igemm_halo" 0|1            EXPERIMENTAL spatially tiled kernel for 3x3 / stride 1 / pad 1 layers (conv_igemm_halo.hip):
- *                               off (default; exact but slower than the ring kernel: profiles/r04_kbench_halo_experiment.txt)
- *   "igemm_halo_max_c" n        ... only up to n input channels (128);  "igemm_halo_stages" 2..4 weight-ring depth (2);
- *   "igemm_halo_ck" 0|32|64     channels per halo chunk (0: 64 for C = 64, else 32);  "igemm_halo_dbg" 1|2 time stamps
- *   "wgrad_halo" 0|1|2          EXPERIMENTAL spatially tiled 3x3 / stride 1 weight-gradient kernel (conv_wgrad_halo.inc): off
- *                               (default) / images whose sides are multiples of 8 / every such layer;  "wgrad_halo_stages" 2|3.
+ *   "wgrad_halo" 0|1|2          spatially tiled 3x3 / stride 1 weight-gradient kernel (conv_wgrad_halo.inc): off / images
+ *                               whose sides are multiples of 8 / every such layer (default: the 8 x 8 patches overhang,
+ *                               out-of-image pixels are fetched as zeros);  "wgrad_halo_stages" 2|3.
  *                               Its grid is one workgroup per 64 x 64 block of dw and slice: pass ~512 / blocks slices.
  * Returns PASSL_EINVAL for an unknown name. */
 int passl_hip_set_option(const char* name, int value);
 /* Which kernel the most recent passl_hip_conv_igemm call of this process launched: 0 = igemm_kernel
- * (register-staged), 1 = igemm_ring_kernel, 2 = stem_kernel, 3 = igemm_8p_kernel, 4 = igemm_halo_kernel; -1 before the
+ * (register-staged), 1 = igemm_ring_kernel, 2 = stem_kernel, 3 = igemm_8p_kernel; -1 before the
  * first call.
  * Diagnostics for tests and benchmarks (not thread-safe). */
 int passl_hip_last_igemm_kernel(void);
@@ -268,7 +265,8 @@ int passl_hip_conv_wgrad(const passl_wgrad_desc* d, passl_stream_t stream);
  *             shifts stored behind the sums at partial + nblocks*C*2  (nblocks*C*3 floats in total;
  *             shifted sums: the variance never comes from E[x^2] - mean^2 of large numbers).
  *             The conv epilogue writes the same layout with rpb = 128 (passl_conv_desc.stats).
- *  finalize:  fixed-order fp64 combine of the slabs (re-centred on slab 0's shift) -> mean/invstd
+ *  finalize:  fixed-order fp64 combine of the slabs (re-centred on slab 0's shift; ONE launch for any slab
+ *             height since ABI 14) -> mean/invstd
  *             (biased var, eps), scale=gamma*invstd, shift=beta-mean*scale,
  *             running = momentum*running + (1-momentum)*batch   [Paddle: momentum 0.9, biased var]
  *  apply:     z = relu?( x*scale + shift + residual )
@@ -326,23 +324,6 @@ int passl_hip_bn_bwd_finalize_sums(const double* sums_all, int world, int rank, 
 int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* coef,
                            const float* scale, const float* shift, void* dx, void* dres, int64_t M,
                            int C, int relu, int dtype, passl_stream_t stream);
-/* EXPERIMENTAL (ABI 13; the Python side calls them only with PASSL_BN_FUSED_FINALIZE=1): passl_hip_bn_finalize followed
- * by passl_hip_bn_apply, resp. passl_hip_bn_bwd_finalize followed by passl_hip_bn_bwd_apply — same arguments, same
- * results, same bits.  On a tall slab (>= 512 row blocks) the finalize runs INSIDE the streaming kernel (every
- * workgroup turns the <= 16 segment totals of bn_combine into its per-channel constants, workgroup 0 writes the
- * per-channel outputs): one launch less per BatchNorm and direction on the main chain of the step; otherwise the two
- * calls are made as they are.  tools/kbench bncheck compares both forms bit for bit. */
-int passl_hip_bn_finalize_apply(const float* partial, int nblocks, int64_t M, int C, int rows_per_block,
-                                const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                                const void* x, const void* residual, void* z, uint8_t* relu_mask, int relu, int dtype,
-                                passl_stream_t stream);
-int passl_hip_bn_bwd_finalize_apply(const float* partial, int nblocks, int64_t M, int C, const float* gamma,
-                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
-                                    const void* dz, const void* z, const void* x, const float* scale,
-                                    const float* shift, void* dx, void* dres, int relu, int dtype,
-                                    passl_stream_t stream);
-
 /* ---------------------------------------------------------------- pooling */
 
 /* 3x3 stride-2 pad-1 max pool, NHWC; idx[n,p,q,c] (uint8) = winning tap r*3+s (first max in

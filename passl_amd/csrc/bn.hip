@@ -139,141 +139,162 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
   }
 }
 
-// ---- fixed-order fp64 combine of a partial slab [nblocks][C][2].  A 1024-thread block owns 8
-// channels (64 contiguous bytes per slab row): lane = (row lane, channel), 128 row lanes stride over
-// the slab rows; the row lanes are folded with wave shuffles (xor 8, 16, 32), then the 16 waves
-// through LDS in wave order.  Returns the totals in threads 0..7 (channel = tid).
+// ---- fixed-order fp64 combine of a partial slab [nblocks][C][2] — ONE launch, one round trip of loads.
+// Until round 4 tall slabs (>= 512 rows) took two launches (bn_combine: 16 row segments per channel group, then
+// bn_finalize over the segment totals) and each thread walked its rows with one dependent load pair per trip.  Inside
+// the training step these launches sit on the main chain between a convolution and the streaming pass that needs
+// their result, 53 + 53 times per MoCo step, and under load every dependent memory round trip of such a latency-bound
+// launch costs 3-4 us: 15.6 + 11.2 us plus two launch gaps per tall BatchNorm and direction
+// (profiles/r04_bench_bs256_bf16_kernel_stats.txt).  Now a 1024-thread block owns 8 channels (64 contiguous bytes of
+// every slab row; 4 channels per block re-fetch every cache line from four blocks: 16 us instead of 7 on 6272 x 256):
+// 4 threads x 2 channels (one 16-byte load of sums + one 8-byte load of shifts per slab row) x 256 row lanes, 16 rows
+// of a lane in flight at once (10 with shifts: 16 spill under the 128-register limit of a 1024-thread block, 38 us
+// instead of 7; the per-channel parameters are fetched with the first batch), rows of a lane added in ascending
+// order, lanes folded with xor shuffles (4, 8, 16, 32), the 16 waves through LDS in wave order.  Totals of channel
+// pair q land in thread q (0..3).  tools/kbench fincheck / fintime.
 constexpr int kFinThreads = 1024;
+constexpr int kFinCh = 8;                        // channels per block
+constexpr int kFinRowLanes = kFinThreads / 4;
 
-constexpr int kFinSegMax = 16;   // row segments of a tall slab (one block per segment and channel group)
+constexpr int kFinSegMax = 16;   // historical: passl_hip_bn_partial_floats keeps the scratch of the two-launch form
 
 template <bool SHIFTED>
 __device__ __forceinline__ void combine_slab(const float* __restrict__ partial, int nblocks, int C,
                                              int64_t M, int rows_per_block, int c, bool c_ok,
-                                             int b0, int b1, double& t1, double& t2, float& g0) {
-  __shared__ double red[kFinThreads / 64][8][2];
-  const int rl = threadIdx.x >> 3;
+                                             double (&t1)[2], double (&t2)[2], float (&g0)[2]) {
+  constexpr int kFinBatch = SHIFTED ? 10 : 16;
+  __shared__ double red[kFinThreads / 64][4][4];
+  const int rl = threadIdx.x >> 2;
   const float* shifts = partial + (int64_t)nblocks * C * 2;
-  double a1 = 0.0, a2 = 0.0;
-  g0 = (SHIFTED && c_ok) ? shifts[c] : 0.f;            // slab 0 always holds rows
+  double a1[2] = {0.0, 0.0}, a2[2] = {0.0, 0.0};
+  g0[0] = g0[1] = 0.f;
   if (c_ok) {
-    for (int b = b0 + rl; b < b1; b += kFinThreads / 8) {
-      const float2 p = *reinterpret_cast<const float2*>(partial + ((int64_t)b * C + c) * 2);
-      if (SHIFTED) {
-        int64_t n = M - (int64_t)b * rows_per_block;
-        if (n > rows_per_block) n = rows_per_block;
-        if (n <= 0) continue;
-        const double d = (double)shifts[(int64_t)b * C + c] - (double)g0;
-        a1 += (double)p.x + (double)n * d;
-        a2 += (double)p.y + 2.0 * d * (double)p.x + (double)n * d * d;
-      } else {
-        a1 += (double)p.x;
-        a2 += (double)p.y;
+    if (SHIFTED) {                                       // slab 0 always holds rows
+      const float2 g = *reinterpret_cast<const float2*>(shifts + c);
+      g0[0] = g.x; g0[1] = g.y;
+    }
+    for (int bb = rl; bb < nblocks; bb += kFinRowLanes * kFinBatch) {
+      float4 p[kFinBatch];
+      float2 sh[kFinBatch];
+#pragma unroll
+      for (int i = 0; i < kFinBatch; ++i) {              // every load of the batch before the first use
+        const int b = bb + i * kFinRowLanes;
+        const int bc = b < nblocks ? b : nblocks - 1;
+        p[i] = *reinterpret_cast<const float4*>(partial + ((int64_t)bc * C + c) * 2);
+        sh[i] = SHIFTED ? *reinterpret_cast<const float2*>(shifts + (int64_t)bc * C + c) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < kFinBatch; ++i) {
+        const int b = bb + i * kFinRowLanes;
+        if (b >= nblocks) break;
+        if (SHIFTED) {
+          int64_t n = M - (int64_t)b * rows_per_block;
+          if (n > rows_per_block) n = rows_per_block;
+          if (n <= 0) continue;
+          const double d0 = (double)sh[i].x - (double)g0[0], d1 = (double)sh[i].y - (double)g0[1];
+          a1[0] += (double)p[i].x + (double)n * d0;
+          a2[0] += (double)p[i].y + 2.0 * d0 * (double)p[i].x + (double)n * d0 * d0;
+          a1[1] += (double)p[i].z + (double)n * d1;
+          a2[1] += (double)p[i].w + 2.0 * d1 * (double)p[i].z + (double)n * d1 * d1;
+        } else {
+          a1[0] += (double)p[i].x; a2[0] += (double)p[i].y;
+          a1[1] += (double)p[i].z; a2[1] += (double)p[i].w;
+        }
       }
     }
   }
 #pragma unroll
-  for (int o = 8; o < 64; o <<= 1) {
-    a1 += __shfl_xor(a1, o, 64);
-    a2 += __shfl_xor(a2, o, 64);
+  for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      a1[e] += __shfl_xor(a1[e], o, 64);
+      a2[e] += __shfl_xor(a2[e], o, 64);
+    }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane < 8) { red[wave][lane][0] = a1; red[wave][lane][1] = a2; }
+  if (lane < 4) { red[wave][lane][0] = a1[0]; red[wave][lane][1] = a2[0]; red[wave][lane][2] = a1[1]; red[wave][lane][3] = a2[1]; }
   __syncthreads();
-  t1 = 0.0; t2 = 0.0;
-  if (threadIdx.x < 8) {
-    for (int w = 0; w < kFinThreads / 64; ++w) { t1 += red[w][threadIdx.x][0]; t2 += red[w][threadIdx.x][1]; }
-  }
-}
-
-// tall slabs: grid (C/8, S) — block (., seg) combines its row segment into scratch[seg][c][0..1] (fp64);
-// the finalize kernel then adds the S segment totals in segment order
-template <bool SHIFTED>
-__global__ void __launch_bounds__(kFinThreads) bn_combine_kernel(const float* __restrict__ partial,
-                                                                 int nblocks, int64_t M, int C,
-                                                                 int rows_per_block, int seg_rows,
-                                                                 double* __restrict__ scratch) {
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
-  const int b0 = blockIdx.y * seg_rows;
-  int b1 = b0 + seg_rows;
-  if (b1 > nblocks) b1 = nblocks;
-  double t1, t2;
-  float g0;
-  combine_slab<SHIFTED>(partial, nblocks, C, M, rows_per_block, c, c < C, b0, b1, t1, t2, g0);
-  if (threadIdx.x >= 8 || c >= C) return;
-  scratch[((int64_t)blockIdx.y * C + c) * 2] = t1;
-  scratch[((int64_t)blockIdx.y * C + c) * 2 + 1] = t2;
-}
-
-// totals of channel c: from the slab (nseg == 1, whole block cooperates) or from the segment scratch
-template <bool SHIFTED>
-__device__ __forceinline__ void slab_totals(const float* __restrict__ partial, int nblocks, int C, int64_t M,
-                                            int rows_per_block, const double* __restrict__ scratch, int nseg,
-                                            int c, double& t1, double& t2, float& g0) {
-  if (nseg <= 1) {
-    combine_slab<SHIFTED>(partial, nblocks, C, M, rows_per_block, c, c < C, 0, nblocks, t1, t2, g0);
-    return;
-  }
-  t1 = 0.0; t2 = 0.0;
-  g0 = (SHIFTED && c < C) ? partial[(int64_t)nblocks * C * 2 + c] : 0.f;
-  if (threadIdx.x < 8 && c < C) {
-    for (int s = 0; s < nseg; ++s) {
-      t1 += scratch[((int64_t)s * C + c) * 2];
-      t2 += scratch[((int64_t)s * C + c) * 2 + 1];
+  t1[0] = t1[1] = t2[0] = t2[1] = 0.0;
+  if (threadIdx.x < 4) {
+    for (int w = 0; w < kFinThreads / 64; ++w) {
+      t1[0] += red[w][threadIdx.x][0]; t2[0] += red[w][threadIdx.x][1];
+      t1[1] += red[w][threadIdx.x][2]; t2[1] += red[w][threadIdx.x][3];
     }
   }
 }
 
 __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block,
-    const double* __restrict__ scratch, int nseg,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
-  double t1, t2;
-  float g0;
-  slab_totals<true>(partial, nblocks, C, M, rows_per_block, scratch, nseg, c, t1, t2, g0);
-  if (threadIdx.x >= 8 || c >= C) return;
+  const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
+  const bool fin = threadIdx.x < 4 && c < C;
+  // the per-channel parameters travel with the slab loads (one round trip), not after the reduction
+  float2 ga = make_float2(0.f, 0.f), be = ga, rm = ga, rv = ga;
+  if (fin) {
+    // scalar loads: parameters are slices of a flat buffer, only 4-byte aligned in general
+    ga = make_float2(gamma[c], gamma[c + 1]);
+    be = make_float2(beta[c], beta[c + 1]);
+    if (rmean) { rm = make_float2(rmean[c], rmean[c + 1]); rv = make_float2(rvar[c], rvar[c + 1]); }
+  }
+  double t1[2], t2[2];
+  float g0[2];
+  combine_slab<true>(partial, nblocks, C, M, rows_per_block, c, c < C, t1, t2, g0);
+  if (!fin) return;
   const double inv_m = 1.0 / (double)M;             // one fp64 division instead of three
-  const double dm = t1 * inv_m;                     // mean - g0
-  const double mu = (double)g0 + dm;
-  double var = t2 * inv_m - dm * dm;                // biased; centred on a sample value: no cancellation
-  if (var < 0.0) var = 0.0;
-  const float is = (float)(1.0 / sqrt(var + (double)eps));
-  mean[c] = (float)mu;
-  invstd[c] = is;
-  const float sc = gamma[c] * is;
-  scale[c] = sc;
-  shift[c] = beta[c] - (float)mu * sc;
-  if (rmean) {
-    rmean[c] = momentum * rmean[c] + (1.0f - momentum) * (float)mu;
-    rvar[c] = momentum * rvar[c] + (1.0f - momentum) * (float)var;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const double dm = t1[e] * inv_m;                // mean - g0
+    const double mu = (double)g0[e] + dm;
+    double var = t2[e] * inv_m - dm * dm;           // biased; centred on a sample value: no cancellation
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c + e] = (float)mu;
+    invstd[c + e] = is;
+    const float sc = (e ? ga.y : ga.x) * is;
+    scale[c + e] = sc;
+    shift[c + e] = (e ? be.y : be.x) - (float)mu * sc;
+    if (rmean) {
+      rmean[c + e] = momentum * (e ? rm.y : rm.x) + (1.0f - momentum) * (float)mu;
+      rvar[c + e] = momentum * (e ? rv.y : rv.x) + (1.0f - momentum) * (float)var;
+    }
   }
 }
 
 __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int64_t M, int C,
-    const double* __restrict__ scratch, int nseg,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ coef) {
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
-  double sg, sgx;
-  float unused;
-  slab_totals<false>(partial, nblocks, C, M, 0, scratch, nseg, c, sg, sgx, unused);
-  if (threadIdx.x >= 8 || c >= C) return;
-  dbeta[c] += (float)sg;      // accumulate: the flat gradient buffer is zeroed by clear_grad()
-  dgamma[c] += (float)sgx;
-  // dx = gamma*invstd*( g - sg/M - xhat*sgx/M ),  xhat = (x-mean)*invstd
-  const double gi = (double)gamma[c] * (double)invstd[c];
+  const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
+  const bool fin = threadIdx.x < 4 && c < C;
+  float2 ga = make_float2(0.f, 0.f), mu = ga, is = ga, dg = ga, db = ga;
+  if (fin) {
+    ga = make_float2(gamma[c], gamma[c + 1]);
+    mu = make_float2(mean[c], mean[c + 1]);
+    is = make_float2(invstd[c], invstd[c + 1]);
+    dg = make_float2(dgamma[c], dgamma[c + 1]);
+    db = make_float2(dbeta[c], dbeta[c + 1]);
+  }
+  double sg[2], sgx[2];
+  float unused[2];
+  combine_slab<false>(partial, nblocks, C, M, 0, c, c < C, sg, sgx, unused);
+  if (!fin) return;
   const double inv_m = 1.0 / (double)M;
-  const double A = gi;
-  const double B = -gi * (double)invstd[c] * sgx * inv_m;
-  const double Cc = -gi * sg * inv_m - B * (double)mean[c];
-  coef[c] = (float)A;
-  coef[C + c] = (float)B;
-  coef[2 * C + c] = (float)Cc;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    dbeta[c + e] = (e ? db.y : db.x) + (float)sg[e];      // accumulate: the flat gradient buffer is zeroed by clear_grad()
+    dgamma[c + e] = (e ? dg.y : dg.x) + (float)sgx[e];
+    // dx = gamma*invstd*( g - sg/M - xhat*sgx/M ),  xhat = (x-mean)*invstd
+    const double isd = (double)(e ? is.y : is.x);
+    const double gi = (double)(e ? ga.y : ga.x) * isd;
+    const double B = -gi * isd * sgx[e] * inv_m;
+    const double Cc = -gi * sg[e] * inv_m - B * (double)(e ? mu.y : mu.x);
+    coef[c + e] = (float)gi;
+    coef[C + c + e] = (float)B;
+    coef[2 * C + c + e] = (float)Cc;
+  }
 }
 
 // ------------------------------------------------------------------ cross-rank (Sync) BatchNorm pieces
@@ -283,18 +304,21 @@ __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
 // ORDER with Chan's update (deterministic, no cancellation); backward the same way with {sum g, sum g xhat}.
 __global__ void __launch_bounds__(kFinThreads) bn_moments_kernel(
     const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block,
-    const double* __restrict__ scratch, int nseg, double* __restrict__ mom) {
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
-  double t1, t2;
-  float g0;
-  slab_totals<true>(partial, nblocks, C, M, rows_per_block, scratch, nseg, c, t1, t2, g0);
-  if (threadIdx.x >= 8 || c >= C) return;
-  const double dm = t1 / (double)M;
-  double m2 = t2 - t1 * dm;                          // sum (x - mean)^2, centred on a sample value first
-  if (m2 < 0.0) m2 = 0.0;
-  mom[c] = (double)g0 + dm;
-  mom[C + c] = m2;
-  mom[2 * C + c] = (double)M;
+    double* __restrict__ mom) {
+  const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
+  double t1[2], t2[2];
+  float g0[2];
+  combine_slab<true>(partial, nblocks, C, M, rows_per_block, c, c < C, t1, t2, g0);
+  if (threadIdx.x >= 4 || c >= C) return;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const double dm = t1[e] / (double)M;
+    double m2 = t2[e] - t1[e] * dm;                  // sum (x - mean)^2, centred on a sample value first
+    if (m2 < 0.0) m2 = 0.0;
+    mom[c + e] = (double)g0[e] + dm;
+    mom[C + c + e] = m2;
+    mom[2 * C + c + e] = (double)M;
+  }
 }
 
 __global__ void __launch_bounds__(256) bn_finalize_moments_kernel(
@@ -328,15 +352,14 @@ __global__ void __launch_bounds__(256) bn_finalize_moments_kernel(
 }
 
 __global__ void __launch_bounds__(kFinThreads) bn_bwd_sums_kernel(
-    const float* __restrict__ partial, int nblocks, int64_t M, int C, const double* __restrict__ scratch,
-    int nseg, double* __restrict__ sums) {
-  const int c = blockIdx.x * 8 + (threadIdx.x & 7);
-  double sg, sgx;
-  float unused;
-  slab_totals<false>(partial, nblocks, C, M, 0, scratch, nseg, c, sg, sgx, unused);
-  if (threadIdx.x >= 8 || c >= C) return;
-  sums[c] = sg;
-  sums[C + c] = sgx;
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, double* __restrict__ sums) {
+  const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
+  double sg[2], sgx[2];
+  float unused[2];
+  combine_slab<false>(partial, nblocks, C, M, 0, c, c < C, sg, sgx, unused);
+  if (threadIdx.x >= 4 || c >= C) return;
+  sums[c] = sg[0]; sums[c + 1] = sg[1];
+  sums[C + c] = sgx[0]; sums[C + c + 1] = sgx[1];
 }
 
 // dgamma / dbeta accumulate THIS rank's sums (the data-parallel reducer averages parameter gradients afterwards);
@@ -574,14 +597,6 @@ int passl_bn_option(const char* name, int value) {
   else if ((dtype) == PASSL_F32) { using T = float; __VA_ARGS__ } \
   else return PASSL_EUNSUPPORTED;
 
-// tall slabs are combined by nseg blocks per channel group (fixed segment order); short ones in one go
-static int fin_segments(int nblocks, int* seg_rows) {
-  int nseg = nblocks >= 512 ? nblocks / 128 : 1;
-  if (nseg > kFinSegMax) nseg = kFinSegMax;
-  *seg_rows = (nblocks + nseg - 1) / nseg;
-  return (nblocks + *seg_rows - 1) / *seg_rows;
-}
-
 extern "C" int64_t passl_hip_bn_partial_floats(int nblocks, int C, int shifted) {
   if (nblocks <= 0 || C <= 0) return 0;
   return (int64_t)nblocks * C * (shifted ? 3 : 2) + (int64_t)kFinSegMax * C * 4;
@@ -608,19 +623,10 @@ extern "C" int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t 
                                      passl_stream_t stream) {
   if (!partial || !gamma || !beta || !mean || !invstd || !scale || !shift || M <= 0 || C <= 0 ||
       (C & 7) || nblocks <= 0 || rows_per_block <= 0 || (int64_t)nblocks * rows_per_block < M ||
-      (running_mean && !running_var) || (reinterpret_cast<uintptr_t>(partial) & 7))
+      (running_mean && !running_var) || !aligned16(partial))
     return PASSL_EINVAL;
-  int seg_rows = 0;
-  const int nseg = fin_segments(nblocks, &seg_rows);
-  // the segment scratch lives behind the slab (passl_hip_bn_partial_floats sizes the buffer)
-  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 3);
-  if (nseg > 1) {
-    hipLaunchKernelGGL(bn_combine_kernel<true>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
-                       partial, nblocks, M, C, rows_per_block, seg_rows, scratch);
-    PASSL_RETURN_IF_LAUNCH_FAILED();
-  }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, rows_per_block, scratch, nseg, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, rows_per_block, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
@@ -689,18 +695,10 @@ extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int6
                                          const float* invstd, float* dgamma, float* dbeta,
                                          float* coef, passl_stream_t stream) {
   if (!partial || !gamma || !mean || !invstd || !dgamma || !dbeta || !coef || M <= 0 || C <= 0 ||
-      (C & 7) || nblocks <= 0 || (reinterpret_cast<uintptr_t>(partial) & 7))
+      (C & 7) || nblocks <= 0 || !aligned16(partial))
     return PASSL_EINVAL;
-  int seg_rows = 0;
-  const int nseg = fin_segments(nblocks, &seg_rows);
-  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 2);
-  if (nseg > 1) {
-    hipLaunchKernelGGL(bn_combine_kernel<false>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
-                       partial, nblocks, M, C, 0, seg_rows, scratch);
-    PASSL_RETURN_IF_LAUNCH_FAILED();
-  }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, scratch, nseg, gamma, mean, invstd, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, gamma, mean, invstd, dgamma, dbeta, coef);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -709,18 +707,10 @@ extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int6
 extern "C" int passl_hip_bn_moments(const float* partial, int nblocks, int64_t M, int C, int rows_per_block,
                                     double* mom, passl_stream_t stream) {
   if (!partial || !mom || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || rows_per_block <= 0 ||
-      (int64_t)nblocks * rows_per_block < M || (reinterpret_cast<uintptr_t>(partial) & 7))
+      (int64_t)nblocks * rows_per_block < M || !aligned16(partial))
     return PASSL_EINVAL;
-  int seg_rows = 0;
-  const int nseg = fin_segments(nblocks, &seg_rows);
-  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 3);
-  if (nseg > 1) {
-    hipLaunchKernelGGL(bn_combine_kernel<true>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
-                       partial, nblocks, M, C, rows_per_block, seg_rows, scratch);
-    PASSL_RETURN_IF_LAUNCH_FAILED();
-  }
-  hipLaunchKernelGGL(bn_moments_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, rows_per_block, scratch, nseg, mom);
+  hipLaunchKernelGGL(bn_moments_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, rows_per_block, mom);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -740,19 +730,10 @@ extern "C" int passl_hip_bn_finalize_moments(const double* mom_all, int world, i
 
 extern "C" int passl_hip_bn_bwd_sums(const float* partial, int nblocks, int64_t M, int C, double* sums,
                                      passl_stream_t stream) {
-  if (!partial || !sums || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 ||
-      (reinterpret_cast<uintptr_t>(partial) & 7))
+  if (!partial || !sums || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || !aligned16(partial))
     return PASSL_EINVAL;
-  int seg_rows = 0;
-  const int nseg = fin_segments(nblocks, &seg_rows);
-  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 2);
-  if (nseg > 1) {
-    hipLaunchKernelGGL(bn_combine_kernel<false>, dim3(C / 8, nseg), dim3(kFinThreads), 0, as_stream(stream),
-                       partial, nblocks, M, C, 0, seg_rows, scratch);
-    PASSL_RETURN_IF_LAUNCH_FAILED();
-  }
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / 8), dim3(nseg > 1 ? 64 : kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, scratch, nseg, sums);
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, sums);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -802,4 +783,3 @@ extern "C" int passl_hip_bn_bwd_apply(const void* dz, const void* z, const void*
   return PASSL_OK;
 }
 
-#include "bn_fused.inc"

@@ -429,7 +429,6 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
 
 int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st);   // conv_igemm_ring.hip
 int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st);     // conv_igemm_8p.hip
-int passl_igemm_halo_try(const passl_conv_desc* d, hipStream_t st);   // conv_igemm_halo.hip (opt-in)
 int passl_stem_try(const passl_conv_desc* d, hipStream_t st);         // conv_stem.hip
 
 static int g_last_kernel = -1;
@@ -515,14 +514,7 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
                          (double)M64 * d->NCOLS * es_out * (1 + (d->residual ? 1 : 0)) +
                          (d->bnb_partial ? (double)M64 * d->NCOLS * es : 0.0);
   passl_prof_begin(0, st);
-  int rc = passl_igemm_halo_try(d, st);        // opt-in: spatially tiled 3x3 / stride 1 (counted with the ring class)
-  if (rc != PASSL_EUNSUPPORTED) {
-    passl_prof_work(0, w_flops, w_bytes);
-    passl_prof_end(0, st);
-    g_last_kernel = 4;
-    return rc;
-  }
-  rc = passl_igemm_8p_try(d, st);              // 256 x 256 tiles, 8-phase schedule: wide, deep GEMMs
+  int rc = passl_igemm_8p_try(d, st);              // 256 x 256 tiles, 8-phase schedule: wide, deep GEMMs
   if (rc != PASSL_EUNSUPPORTED) {
     passl_prof_retag(0, 3);
     passl_prof_work(3, w_flops, w_bytes);

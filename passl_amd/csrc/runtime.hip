@@ -117,7 +117,6 @@ extern "C" int passl_hip_prof_event_overhead(int n, passl_stream_t stream, doubl
 
 int passl_igemm_ring_option(const char* name, int value);    // conv_igemm_ring.hip
 int passl_igemm_8p_option(const char* name, int value);      // conv_igemm_8p.hip
-int passl_igemm_halo_option(const char* name, int value);    // conv_igemm_halo.hip
 int passl_wgrad_option(const char* name, int value);         // conv_wgrad.hip
 int passl_bn_option(const char* name, int value);            // bn.hip
 int passl_stem_option(const char* name, int value);          // conv_stem.hip
@@ -128,11 +127,10 @@ extern "C" int passl_hip_set_option(const char* name, int value) {
   if (passl_bn_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_stem_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_igemm_8p_option(name, value) == PASSL_OK) return PASSL_OK;
-  if (passl_igemm_halo_option(name, value) == PASSL_OK) return PASSL_OK;
   return passl_igemm_ring_option(name, value);
 }
 
-extern "C" int passl_hip_abi_version(void) { return 13; }
+extern "C" int passl_hip_abi_version(void) { return 14; }
 
 extern "C" const char* passl_hip_strerror(int status) {
   switch (status) {

@@ -17,9 +17,8 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
           'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
-          # the library reads the same variable (conv_wgrad_halo.inc): 0 off (default), 1 images with sides % 8 == 0, 2 all
-          'wgrad_halo': int(os.environ.get('PASSL_WGRAD_HALO', '0') or 0),
-          'bn_fused_finalize': os.environ.get('PASSL_BN_FUSED_FINALIZE', '0') == '1'}
+          # the library reads the same variable (conv_wgrad_halo.inc): 0 off, 1 images with sides % 8 == 0, 2 all (default)
+          'wgrad_halo': int(os.environ.get('PASSL_WGRAD_HALO', '2') or 0)}
 
 
 def set_device(name):
@@ -111,15 +110,11 @@ def side_reductions():
 
 
 def wgrad_halo():
-    """EXPERIMENTAL (off): the spatially tiled 3x3 weight-gradient kernel takes eligible launches; the slice count of
-    those launches is then chosen for ITS grid (one workgroup per 64 x 64 block of dW and slice, all nine taps)."""
+    """The spatially tiled 3x3 weight-gradient kernel takes eligible launches (2, the default: every 3x3 / stride-1
+    layer; 1: images whose sides are multiples of 8; 0: off); the slice count of those launches is then chosen for ITS
+    grid (one workgroup per 64 x 64 block of dW and slice, all nine taps).  Measured (profiles/r05_kbench_first_call.txt):
+    64->64 @56 78 vs 147 us, 128->128 @28 87 vs 94, 256->256 @14 84 vs 93, 512->512 @7 84 vs 104."""
     return _state['wgrad_halo']
-
-
-def bn_fused_finalize():
-    """EXPERIMENTAL (off): training-mode BatchNorm calls passl_hip_bn_finalize_apply / passl_hip_bn_bwd_finalize_apply
-    (the finalize inside the streaming kernel on tall slabs: one launch less per BatchNorm and direction)."""
-    return _state['bn_fused_finalize']
 
 
 def set_flag(name, value):

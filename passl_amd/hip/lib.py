@@ -85,10 +85,6 @@ SIGNATURES = {
     'passl_hip_bn_bwd_finalize_sums': (c_i, [c_p, c_i, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     'passl_hip_bn_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i,
                                      c_p]),
-    'passl_hip_bn_finalize_apply': (c_i, [c_p, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p,
-                                          c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
-    'passl_hip_bn_bwd_finalize_apply': (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_p,
-                                              c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'passl_hip_maxpool3x3s2_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_maxpool3x3s2_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -287,16 +287,6 @@ def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum
                                                   L.ptr(rmean), L.ptr(rvar), momentum, eps, L.ptr(stats[0]),
                                                   L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.stream()),
                 'bn_finalize_moments')
-    elif config.bn_fused_finalize():
-        # EXPERIMENTAL: finalize + apply as one entry point (the finalize inside the streaming kernel on tall slabs)
-        z = torch.empty_like(x)
-        mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (want_mask and relu) else None
-        L.check(lib.passl_hip_bn_finalize_apply(L.ptr(partial), nb, M, Cch, rpb, L.ptr(gamma), L.ptr(beta),
-                                                L.ptr(rmean), L.ptr(rvar), momentum, eps, L.ptr(stats[0]),
-                                                L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(x),
-                                                L.ptr(residual), L.ptr(z), L.ptr(mask), 1 if relu else 0, dtc, st),
-                'bn_finalize_apply')
-        return z, stats, mask
     else:
         L.check(lib.passl_hip_bn_finalize(L.ptr(partial), nb, M, Cch, rpb, L.ptr(gamma), L.ptr(beta),
                                           L.ptr(rmean), L.ptr(rvar), momentum, eps,
@@ -357,18 +347,6 @@ def bn_bwd(dz, z, x, gamma, mean, invstd, dgamma, dbeta, relu=True, want_dres=Fa
                                                    M * sums_all.shape[0], Cch, L.ptr(gamma), L.ptr(mean),
                                                    L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
                                                    L.stream()), 'bn_bwd_finalize_sums')
-    elif config.bn_fused_finalize():
-        # EXPERIMENTAL: finalize + apply as one entry point
-        dx = torch.empty_like(x)
-        if fused is not None:
-            dres_out, dres = None, (dz if want_dres else None)
-        else:
-            dres_out = dres = torch.empty_like(x) if want_dres else None
-        L.check(lib.passl_hip_bn_bwd_finalize_apply(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(mean),
-                                                    L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),
-                                                    L.ptr(dz), zp, L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dx),
-                                                    L.ptr(dres_out), r, dtc, st), 'bn_bwd_finalize_apply')
-        return dx, dres
     else:
         L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(partial), nb, M, Cch, L.ptr(gamma), L.ptr(mean),
                                               L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef),

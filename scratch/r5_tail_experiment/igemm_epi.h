@@ -15,6 +15,7 @@
 // happens in bn_finalize / bn_bwd_finalize in a fixed order: bit-reproducible run to run.
 #pragma once
 #include "common.h"
+#include "bn_tail.h"     // in-kernel BatchNorm finalize: the last arriver combines the slab (P::tail)
 
 namespace epi {
 
@@ -124,12 +125,20 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
     }
   }
 
+  // in-kernel finalize (bn_tail.h): the tile's stores are DEFERRED until its statistics are published, so that the
+  // publish / arrive round trips run under the store issue instead of behind a drained store queue
+  const bn_tail::TailPtr tp = bn_tail::kernarg<P>();   // never through p.tail: bn_tail.h
+  const bool tail = (fstats || bnb) && tp->counters != nullptr;
+  uint4 vv[NT];
+  int64_t oo[NT];
   float s0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int row = (tid + t * NTHREADS) / CPR;
     const int64_t roff = rowoff[row];
+    oo[t] = -1;
+    vv[t] = make_uint4(0, 0, 0, 0);
     if (roff < 0 || !col_ok) continue;
     const int64_t o = roff + gcol;
     uint4 v = *reinterpret_cast<const uint4*>(outb + row * LDOB + cc * 8);
@@ -162,7 +171,8 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       }
       v = pack8(g);           // exact: g holds bf16 values or zeros
     }
-    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
+    if (tail) { vv[t] = v; oo[t] = o; }
+    else *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
     if (fstats) {
       float x[8];
       unpack8(v, x);
@@ -188,20 +198,40 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
     for (int e = 0; e < 8; e += 2)
       *reinterpret_cast<float4*>(dst + e * 2) = make_float4(s0[e], s1[e], s0[e + 1], s1[e + 1]);
   }
-  if (fstats && tid < CPR && col_ok) {
+  if (fstats && !tail && tid < CPR && col_ok) {
     // shifts[t][c] live behind the sums: stats + stats_tiles * NCOLS * 2
     float* sp = p.stats + (int64_t)p.stats_tiles * p.NCOLS * 2 + (int64_t)mt * p.NCOLS + gcol;
     *reinterpret_cast<float4*>(sp) = make_float4(c0[0], c0[1], c0[2], c0[3]);
     *reinterpret_cast<float4*>(sp + 4) = make_float4(c0[4], c0[5], c0[6], c0[7]);
   }
   __syncthreads();
+  const int trow = fstats ? mt : p.bnb_tile_off + mt;
+  if (tail) {
+    // every wave publishes its columns of the slab row and arrives; the last arriver of the launch leaves mean / invstd
+    // / scale / shift (forward) or d-gamma, d-beta and the coefficients (backward).  The deferred stores of the tile
+    // are issued in two halves between the protocol's steps.
+    // BRANCH-FREE (buffer stores, rows out of range land beyond num_records and are dropped): the compiler must be
+    // able to COUNT them for the waits of the protocol (a store under a branch makes it wait for vmcnt(0)).  The
+    // host admits the in-kernel finalize only for outputs addressable with 32-bit byte offsets (bn_tail::fill).
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, bn_tail::kYLimit, 0x00020000);
+    auto stores = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if ((t >= NT / 2) == (half != 0)) {
+          typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+          const u4 d = {vv[t].x, vv[t].y, vv[t].z, vv[t].w};
+          __builtin_amdgcn_raw_buffer_store_b128(d, rs_y, oo[t] >= 0 ? (uint32_t)(oo[t] * 2) : bn_tail::kYLimit, 0, 0);
+        }
+    };
+    bn_tail::run<BN, NTHREADS>(p, tp, red, c0, fstats, n0, n0 / BN, trow, tid, stores);
+    return;
+  }
   if (tid < 2 * BN && n0 + (tid >> 1) < p.NCOLS) {
     float a = 0.f;
 #pragma unroll
     for (int j = 0; j < J; ++j) a += red[j * (BN * 2) + tid];
     float* slab = fstats ? p.stats : p.bnb_partial;
-    const int64_t trow = fstats ? (int64_t)mt : (int64_t)p.bnb_tile_off + mt;
-    slab[(trow * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1)] = a;
+    slab[((int64_t)trow * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1)] = a;
   }
 }
 

@@ -1,7 +1,8 @@
 """tools/kbench on the GPU: the convolution entry point of the C ABI checked BIT-EXACTLY without Python in the data
 path (operands are multiples of 1/16, so fp32 accumulation is exact in any order and the expected output is the
-bf16 rounding of an integer sum) — for the default kernel selection and for the opt-in spatially tiled 3x3 kernel
-(conv_igemm_halo.hip).  Reference semantics: paddle.nn.Conv2D as used by resnetimagenet.py:114-131."""
+bf16 rounding of an integer sum), the weight gradient compared == with host integer sums, and the BatchNorm finalize
+launches against the host's fp64 arithmetic on the slab the device produced.  Reference semantics: paddle.nn.Conv2D /
+paddle.nn.BatchNorm2D as used by resnetimagenet.py:114-153."""
 import os
 import subprocess
 
@@ -19,20 +20,29 @@ def _kbench():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('options', [(), ('igemm_halo=1', 'igemm_halo_max_c=512')], ids=['default', 'halo'])
-def test_conv_igemm_is_bit_exact_through_the_c_abi(options):
-    r = subprocess.run([_kbench(), 'check', *options], capture_output=True, text=True, timeout=600)
+def test_conv_igemm_is_bit_exact_through_the_c_abi():
+    r = subprocess.run([_kbench(), 'check'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert 'CHECK OK' in r.stdout
-    if options:
-        assert 'kernel halo' in r.stdout, r.stdout          # the 3x3 / stride-1 cases went through the opt-in kernel
 
 
 @pytest.mark.gpu
-def test_conv_wgrad_is_exact_through_the_c_abi_also_with_the_spatially_tiled_kernel():
+@pytest.mark.parametrize('options', [(), ('wgrad_halo=1',), ('wgrad_halo=0',)], ids=['default', 'halo1', 'per-tap'])
+def test_conv_wgrad_is_exact_through_the_c_abi(options):
     """passl_hip_conv_wgrad compared == with host integer sums (1 / 7 / heuristic reduction slices; 3x3, 1x1, strided,
-    ragged blocks): the product kernels on the images whose sides are not multiples of 8, the opt-in spatially tiled 3x3
-    kernel on the others (wgrad_halo=1: the instruction stream and the command line that ran on hardware in round 4)."""
-    r = subprocess.run([_kbench(), 'wcheck', 'wgrad_halo=1'], capture_output=True, text=True, timeout=900)
+    ragged blocks): the default selection (the spatially tiled kernel on every 3x3 / stride-1 layer, incl. images its
+    8 x 8 patches overhang), that kernel restricted to images whose sides are multiples of 8, and the per-tap kernels
+    alone."""
+    r = subprocess.run([_kbench(), 'wcheck', *options], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert 'WGRAD CHECK OK' in r.stdout
+
+
+@pytest.mark.gpu
+def test_bn_finalize_launches_equal_host_fp64_and_are_bit_reproducible():
+    """passl_hip_bn_finalize / passl_hip_bn_bwd_finalize (one launch for any slab height since ABI 14) against the same
+    arithmetic in fp64 on the host from the slab the device wrote: 128-row slabs as the conv epilogue writes them, a
+    ragged last slab, more rows than one batch of loads, 3 rows; second run bit for bit."""
+    r = subprocess.run([_kbench(), 'fincheck'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert 'FINALIZE CHECK OK' in r.stdout

@@ -10,8 +10,8 @@
 //   tools/kbench time  [name=value ...]     per-layer table of the ResNet-50 3x3 / 1x1 shapes at N = 256
 //   tools/kbench ab name=v0,v1 [...]        the same table for two values of ONE option, side by side
 //   tools/kbench wcheck | wtime [name=value ...]   the same for passl_hip_conv_wgrad (== on fp32 sums; per-layer table)
-//   tools/kbench bntime                     ... and their times on the tall ResNet-50 shapes
-//   tools/kbench bncheck                    fused BatchNorm finalize + apply against the separate launches, bit for bit
+//   tools/kbench fincheck                   BatchNorm finalize launches (forward / backward) against the host's fp64 arithmetic on the same slab
+//   tools/kbench fintime                    ... and their times, alone and next to a stream that loads the memory system
 //   tools/kbench ablate                     the register-staged kernel's debug switches on the 1x1 shapes
 //   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
 //   name=value pairs are passl_hip_set_option() calls made before anything runs.
@@ -235,7 +235,7 @@ static int64_t check_case(const Shape& s, int variant, Buffers& B, int* kernel_u
 }
 
 static const char* kname(int k) {
-  switch (k) { case 0: return "igemm"; case 1: return "ring"; case 2: return "stem"; case 3: return "8p"; case 4: return "halo"; default: return "?"; }
+  switch (k) { case 0: return "igemm"; case 1: return "ring"; case 2: return "stem"; case 3: return "8p"; default: return "?"; }
 }
 
 static int run_check() {
@@ -475,136 +475,140 @@ static int run_time(const char* ab_name, int v0, int v1) {
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm
-// bncheck: passl_hip_bn_finalize_apply / passl_hip_bn_bwd_finalize_apply (finalize inside the streaming kernel on tall
-// slabs) against the separate launches they replace — every output compared BIT FOR BIT (no host reference needed: the
-// two forms must agree with each other).
+// fincheck: passl_hip_bn_finalize / passl_hip_bn_bwd_finalize (one launch per slab since round 5) against the same
+// arithmetic done on the host in fp64 from the slab the device produced; fintime: their times, alone and next to a
+// stream that keeps the memory system busy (inside the training step these launches always run under load).
 static void fill_f32(float* d, int n, uint32_t seed, float lo, float hi) {
   std::vector<float> h(n);
   for (int i = 0; i < n; ++i) h[i] = lo + (hi - lo) * (float)(mix((uint64_t)i, seed) % 1024u) / 1024.0f;
   CK(hipMemcpy(d, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
 }
-static bool same_bits(const void* a, const void* b, size_t bytes, const char* what) {
-  std::vector<char> ha(bytes), hb(bytes);
-  CK(hipMemcpy(ha.data(), a, bytes, hipMemcpyDeviceToHost));
-  CK(hipMemcpy(hb.data(), b, bytes, hipMemcpyDeviceToHost));
-  if (memcmp(ha.data(), hb.data(), bytes) == 0) return true;
-  size_t i = 0;
-  while (i < bytes && ha[i] == hb[i]) ++i;
-  printf("    %s differs (first at byte %zu of %zu)\n", what, i, bytes);
-  return false;
+static int64_t close_f32(const float* a, const double* want, int n, const char* what, double tol) {
+  int64_t bad = 0;
+  for (int i = 0; i < n; ++i) {
+    const double d = fabs((double)a[i] - want[i]);
+    if (!(d <= tol * fabs(want[i]) + 1e-7)) { if (bad < 4) printf("    %s[%d]: %.9g, host fp64 %.9g\n", what, i, a[i], want[i]); ++bad; }
+  }
+  return bad;
 }
-static int bn_case(int64_t M, int C, int nb_f, int nb_b, bool residual) {
+static int fin_case(int64_t M, int C, int nb) {
   const int64_t n = M * C;
-  void *x, *res, *dz, *zA, *zB, *dxA, *dxB, *drA, *drB;
-  uint8_t *mA, *mB;
-  float *par, *parb, *cols;          // cols: 16 per-channel fp32 vectors
-  for (void** p : {&x, &res, &dz, &zA, &zB, &dxA, &dxB, &drA, &drB}) CK(hipMalloc(p, n * 2));
-  CK(hipMalloc((void**)&mA, n / 8)); CK(hipMalloc((void**)&mB, n / 8));
-  const int64_t pf = passl_hip_bn_partial_floats(nb_f, C, 1), pb = passl_hip_bn_partial_floats(nb_b, C, 0);
+  void *x, *dz;
+  float *par, *parb, *cols;
+  CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&dz, n * 2));
+  const int64_t pf = passl_hip_bn_partial_floats(nb, C, 1), pb = passl_hip_bn_partial_floats(nb, C, 0);
   CK(hipMalloc((void**)&par, pf * 4)); CK(hipMalloc((void**)&parb, pb * 4));
-  CK(hipMalloc((void**)&cols, (size_t)32 * C * 4));
-  fill(x, n, 61u); fill(res, n, 67u); fill(dz, n, 71u);
-  float *gamma = cols, *beta = cols + C, *rm0 = cols + 2 * C, *rv0 = cols + 3 * C;
-  float *rmA = cols + 4 * C, *rvA = cols + 5 * C, *rmB = cols + 6 * C, *rvB = cols + 7 * C;
-  float *stA = cols + 8 * C, *stB = cols + 12 * C;                 // mean, invstd, scale, shift
-  float *dgA = cols + 16 * C, *dbA = cols + 17 * C, *dgB = cols + 18 * C, *dbB = cols + 19 * C;
-  float *cfA = cols + 20 * C, *cfB = cols + 23 * C;                // 3 C each
+  CK(hipMalloc((void**)&cols, (size_t)16 * C * 4));
+  fill(x, n, 61u); fill(dz, n, 71u);
+  float *gamma = cols, *beta = cols + C, *rm = cols + 2 * C, *rv = cols + 3 * C, *st = cols + 4 * C;   // st: mean, invstd, scale, shift
+  float *dg = cols + 8 * C, *db = cols + 9 * C, *cf = cols + 10 * C;
   fill_f32(gamma, C, 73u, 0.5f, 1.5f); fill_f32(beta, C, 79u, -0.5f, 0.5f);
-  fill_f32(rm0, C, 83u, -0.1f, 0.1f); fill_f32(rv0, C, 89u, 0.5f, 1.5f);
-  CK(hipMemcpy(rmA, rm0, C * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(rvA, rv0, C * 4, hipMemcpyDeviceToDevice));
-  CK(hipMemcpy(rmB, rm0, C * 4, hipMemcpyDeviceToDevice)); CK(hipMemcpy(rvB, rv0, C * 4, hipMemcpyDeviceToDevice));
-  int rc = passl_hip_bn_stats(x, par, M, C, nb_f, PASSL_BF16, nullptr);
-  const int rpb = (int)((M + nb_f - 1) / nb_f);
-  bool ok = rc == PASSL_OK;
-  // forward: separate launches (A), fused entry point (B)
-  rc = passl_hip_bn_finalize(par, nb_f, M, C, rpb, gamma, beta, rmA, rvA, 0.9f, 1e-5f, stA, stA + C, stA + 2 * C, stA + 3 * C, nullptr);
-  ok = ok && rc == PASSL_OK;
-  rc = passl_hip_bn_apply(x, stA + 2 * C, stA + 3 * C, residual ? res : nullptr, zA, mA, M, C, 1, PASSL_BF16, nullptr);
-  ok = ok && rc == PASSL_OK;
-  rc = passl_hip_bn_finalize_apply(par, nb_f, M, C, rpb, gamma, beta, rmB, rvB, 0.9f, 1e-5f, stB, stB + C, stB + 2 * C, stB + 3 * C, x,
-                                   residual ? res : nullptr, zB, mB, 1, PASSL_BF16, nullptr);
-  ok = ok && rc == PASSL_OK;
+  fill_f32(rm, C, 83u, -0.1f, 0.1f); fill_f32(rv, C, 89u, 0.5f, 1.5f);
+  fill_f32(dg, C, 97u, -1.f, 1.f); fill_f32(db, C, 101u, -1.f, 1.f);
+  std::vector<float> h0(16 * C);
+  CK(hipMemcpy(h0.data(), cols, h0.size() * 4, hipMemcpyDeviceToHost));
+  const int rpb = (int)((M + nb - 1) / nb);
+  bool ok = passl_hip_bn_stats(x, par, M, C, nb, PASSL_BF16, nullptr) == PASSL_OK;
+  ok = ok && passl_hip_bn_finalize(par, nb, M, C, rpb, gamma, beta, rm, rv, 0.9f, 1e-5f, st, st + C, st + 2 * C, st + 3 * C, nullptr) == PASSL_OK;
+  ok = ok && passl_hip_bn_bwd_reduce(dz, nullptr, x, st, st + C, st + 2 * C, st + 3 * C, parb, M, C, nb, 2, PASSL_BF16, nullptr) == PASSL_OK;
+  ok = ok && passl_hip_bn_bwd_finalize(parb, nb, M, C, gamma, st, st + C, dg, db, cf, nullptr) == PASSL_OK;
   CK(hipDeviceSynchronize());
-  ok = same_bits(zA, zB, n * 2, "z") && ok;
-  ok = same_bits(mA, mB, n / 8, "relu mask") && ok;
-  ok = same_bits(stA, stB, (size_t)4 * C * 4, "mean / invstd / scale / shift") && ok;
-  ok = same_bits(rmA, rmB, (size_t)2 * C * 4, "running statistics") && ok;
-  // backward: mask recomputed from x * scale + shift (relu = 2) without residual, bit mask (3) with
-  const int relu_b = residual ? 3 : 2;
-  rc = passl_hip_bn_bwd_reduce(dz, residual ? (const void*)mA : nullptr, x, stA, stA + C, stA + 2 * C, stA + 3 * C, parb, M, C, nb_b, relu_b,
-                               PASSL_BF16, nullptr);
-  ok = ok && rc == PASSL_OK;
-  CK(hipMemset(dgA, 0, (size_t)4 * C * 4));
-  rc = passl_hip_bn_bwd_finalize(parb, nb_b, M, C, gamma, stA, stA + C, dgA, dbA, cfA, nullptr);
-  ok = ok && rc == PASSL_OK;
-  rc = passl_hip_bn_bwd_apply(dz, residual ? (const void*)mA : nullptr, x, cfA, stA + 2 * C, stA + 3 * C, dxA, drA, M, C, relu_b, PASSL_BF16, nullptr);
-  ok = ok && rc == PASSL_OK;
-  rc = passl_hip_bn_bwd_finalize_apply(parb, nb_b, M, C, gamma, stA, stA + C, dgB, dbB, cfB, dz, residual ? (const void*)mA : nullptr, x,
-                                       stA + 2 * C, stA + 3 * C, dxB, drB, relu_b, PASSL_BF16, nullptr);
-  ok = ok && rc == PASSL_OK;
+  std::vector<float> h1(16 * C), hp(pf), hb(pb);
+  CK(hipMemcpy(h1.data(), cols, h1.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hp.data(), par, pf * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hb.data(), parb, pb * 4, hipMemcpyDeviceToHost));
+  int64_t bad = ok ? 0 : 1;
+  std::vector<double> w(7 * C), wb(5 * C);
+  for (int c = 0; c < C; ++c) {
+    const double g0 = hp[(size_t)nb * C * 2 + c];
+    double t1 = 0, t2 = 0;
+    for (int b = 0; b < nb; ++b) {
+      int64_t nr = M - (int64_t)b * rpb; if (nr > rpb) nr = rpb; if (nr <= 0) continue;
+      const double p0 = hp[((size_t)b * C + c) * 2], p1 = hp[((size_t)b * C + c) * 2 + 1];
+      const double d = (double)hp[(size_t)nb * C * 2 + (size_t)b * C + c] - g0;
+      t1 += p0 + nr * d; t2 += p1 + 2.0 * d * p0 + nr * d * d;
+    }
+    const double dm = t1 / M, mu = g0 + dm;
+    double var = t2 / M - dm * dm; if (var < 0) var = 0;
+    const float is = (float)(1.0 / sqrt(var + 1e-5));
+    const float sc = h0[c] * is;
+    w[c] = (float)mu; w[C + c] = is; w[2 * C + c] = sc; w[3 * C + c] = h0[C + c] - (float)mu * sc;
+    w[4 * C + c] = 0.9f * h0[2 * C + c] + 0.1f * (float)mu; w[5 * C + c] = 0.9f * h0[3 * C + c] + 0.1f * (float)var;
+    double sg = 0, sgx = 0;
+    for (int b = 0; b < nb; ++b) { sg += hb[((size_t)b * C + c) * 2]; sgx += hb[((size_t)b * C + c) * 2 + 1]; }
+    const double isd = h1[5 * C + c], gi = (double)h0[c] * isd, B = -gi * isd * sgx / M, Cc = -gi * sg / M - B * (double)h1[4 * C + c];
+    wb[c] = h0[8 * C + c] + (float)sgx; wb[C + c] = h0[9 * C + c] + (float)sg; wb[2 * C + c] = (float)gi; wb[3 * C + c] = (float)B; wb[4 * C + c] = (float)Cc;
+  }
+  bad += close_f32(&h1[4 * C], &w[0], 4 * C, "mean / invstd / scale / shift", 4e-7);
+  bad += close_f32(&h1[2 * C], &w[4 * C], 2 * C, "running statistics", 4e-7);
+  bad += close_f32(&h1[8 * C], &wb[0], 2 * C, "d-gamma / d-beta", 4e-7);
+  bad += close_f32(&h1[10 * C], &wb[2 * C], 3 * C, "coefficients", 2e-6);
+  // run to run: bit for bit
+  std::vector<float> h2(16 * C);
+  CK(hipMemcpy(cols, h0.data(), h0.size() * 4, hipMemcpyHostToDevice));
+  passl_hip_bn_finalize(par, nb, M, C, rpb, gamma, beta, rm, rv, 0.9f, 1e-5f, st, st + C, st + 2 * C, st + 3 * C, nullptr);
+  passl_hip_bn_bwd_finalize(parb, nb, M, C, gamma, st, st + C, dg, db, cf, nullptr);
   CK(hipDeviceSynchronize());
-  ok = same_bits(dxA, dxB, n * 2, "dx") && ok;
-  ok = same_bits(drA, drB, n * 2, "residual gradient") && ok;
-  ok = same_bits(dgA, dgB, (size_t)C * 4, "d-gamma") && ok;
-  ok = same_bits(dbA, dbB, (size_t)C * 4, "d-beta") && ok;
-  ok = same_bits(cfA, cfB, (size_t)3 * C * 4, "coefficients") && ok;
-  printf("BatchNorm M=%lld C=%d, %d / %d row blocks%s: %s\n", (long long)M, C, nb_f, nb_b, residual ? ", residual" : "",
-         ok ? "fused = separate, bit for bit" : "DIFFERENT");
-  for (void* p : {x, res, dz, zA, zB, dxA, dxB, drA, drB, (void*)mA, (void*)mB, (void*)par, (void*)parb, (void*)cols}) CK(hipFree(p));
-  return ok ? 0 : 1;
+  CK(hipMemcpy(h2.data(), cols, h2.size() * 4, hipMemcpyDeviceToHost));
+  if (memcmp(h1.data(), h2.data(), h1.size() * 4) != 0) { printf("    second run differs\n"); ++bad; }
+  printf("BatchNorm finalize M=%lld C=%d, %d slab rows: %s\n", (long long)M, C, nb, bad ? "WRONG" : "= host fp64, bit-reproducible");
+  for (void* q : {x, dz, (void*)par, (void*)parb, (void*)cols}) CK(hipFree(q));
+  return bad ? 1 : 0;
 }
-// bntime: the forward pair (finalize + apply) against the fused entry point on the tall ResNet-50 shapes
-static int run_bntime() {
-  struct S { int64_t M; int C; const char* note; };
-  const S shapes[] = {{256LL * 56 * 56, 64, "802816 x 64"}, {256LL * 56 * 56, 256, "802816 x 256"},
-                      {256LL * 28 * 28, 128, "200704 x 128"}, {256LL * 28 * 28, 512, "200704 x 512"}};
-  printf("%-16s %12s %12s   (us per BatchNorm forward: combine + finalize + apply | combine + fused apply)\n", "rows x C", "separate", "fused");
+static int run_fincheck() {
+  int bad = 0;
+  bad += fin_case(64LL * 56 * 56, 64, 1568);          // 128-row slabs, as the conv epilogue writes them
+  bad += fin_case(32LL * 56 * 56, 256, 784);
+  bad += fin_case(50000, 128, 391);                   // ragged last slab
+  bad += fin_case(8LL * 14 * 14 + 7, 1024, 13);
+  bad += fin_case(64LL * 112 * 112, 64, 6272);        // more rows than one batch of loads (4096)
+  bad += fin_case(300, 2048, 3);
+  printf(bad ? "FINALIZE CHECK FAILED (%d)\n" : "FINALIZE CHECK OK\n", bad);
+  return bad ? 1 : 0;
+}
+__global__ void hog_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+static int run_fintime() {
+  struct S { int nb; int C; };
+  const S shapes[] = {{25088, 64}, {6272, 64}, {6272, 256}, {1568, 128}, {1568, 512}, {392, 256}, {392, 1024}, {98, 512}, {98, 2048}};
+  hipStream_t hog;
+  CK(hipStreamCreate(&hog));
+  void *hs, *hd;
+  const int64_t hog_bytes = 1ll << 30;
+  CK(hipMalloc(&hs, hog_bytes)); CK(hipMalloc(&hd, hog_bytes));
+  printf("%-14s %10s %10s %10s %10s   (us per launch: forward finalize alone | under load, backward finalize alone | under load)\n", "slab rows x C", "fwd", "fwd load", "bwd", "bwd load");
   for (const S& sh : shapes) {
-    const int64_t n = sh.M * sh.C;
-    const int nb = (int)((sh.M + 127) / 128), rpb = 128;            // the conv epilogue's slab: one row block per 128 rows
-    void *x, *z; float *par, *cols;
-    CK(hipMalloc(&x, n * 2)); CK(hipMalloc(&z, n * 2));
-    const int64_t pf = passl_hip_bn_partial_floats(nb, sh.C, 1);
+    const int64_t M = (int64_t)sh.nb * 128;
+    float *par, *cols;
+    const int64_t pf = passl_hip_bn_partial_floats(sh.nb, sh.C, 1);
     CK(hipMalloc((void**)&par, pf * 4)); CK(hipMalloc((void**)&cols, (size_t)16 * sh.C * 4));
-    fill(x, n, 61u);
-    fill_f32(cols, sh.C, 73u, 0.5f, 1.5f); fill_f32(cols + sh.C, sh.C, 79u, -0.5f, 0.5f);
-    fill_f32(cols + 2 * sh.C, sh.C, 83u, -0.1f, 0.1f); fill_f32(cols + 3 * sh.C, sh.C, 89u, 0.5f, 1.5f);
-    if (passl_hip_bn_stats(x, par, sh.M, sh.C, nb, PASSL_BF16, nullptr) != PASSL_OK) { printf("bn_stats failed\n"); return 1; }
+    CK(hipMemset(par, 0, pf * 4));
+    fill_f32(cols, 16 * sh.C, 73u, 0.5f, 1.5f);
     float* st = cols + 4 * sh.C;
-    float t[2] = {0, 0};
-    for (int form = 0; form < 2; ++form) {
+    float t[4];
+    for (int form = 0; form < 4; ++form) {
+      const bool load = form & 1, bwd = form >= 2;
+      if (load) for (int q = 0; q < 8; ++q) hipLaunchKernelGGL(hog_kernel, dim3(2048), dim3(256), 0, hog, (const uint4*)hs, (uint4*)hd, hog_bytes / 16);
       hipEvent_t e0, e1;
       CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-      for (int it = -3; it < 20; ++it) {
-        if (it == 0) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
-        if (form == 0) {
-          passl_hip_bn_finalize(par, nb, sh.M, sh.C, rpb, cols, cols + sh.C, cols + 2 * sh.C, cols + 3 * sh.C, 0.9f, 1e-5f, st, st + sh.C,
-                                st + 2 * sh.C, st + 3 * sh.C, nullptr);
-          passl_hip_bn_apply(x, st + 2 * sh.C, st + 3 * sh.C, nullptr, z, nullptr, sh.M, sh.C, 1, PASSL_BF16, nullptr);
-        } else {
-          passl_hip_bn_finalize_apply(par, nb, sh.M, sh.C, rpb, cols, cols + sh.C, cols + 2 * sh.C, cols + 3 * sh.C, 0.9f, 1e-5f, st,
-                                      st + sh.C, st + 2 * sh.C, st + 3 * sh.C, x, nullptr, z, nullptr, 1, PASSL_BF16, nullptr);
-        }
+      for (int it = -3; it < 50; ++it) {
+        if (it == 0) CK(hipEventRecord(e0, 0));
+        if (!bwd) passl_hip_bn_finalize(par, sh.nb, M, sh.C, 128, cols, cols + sh.C, cols + 2 * sh.C, cols + 3 * sh.C, 0.9f, 1e-5f, st, st + sh.C, st + 2 * sh.C, st + 3 * sh.C, nullptr);
+        else passl_hip_bn_bwd_finalize(par, sh.nb, M, sh.C, cols, st, st + sh.C, cols + 8 * sh.C, cols + 9 * sh.C, cols + 10 * sh.C, nullptr);
       }
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&t[form], e0, e1));
       CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+      CK(hipDeviceSynchronize());
     }
-    printf("%-16s %12.1f %12.1f\n", sh.note, t[0] * 50.0f, t[1] * 50.0f);
-    CK(hipFree(x)); CK(hipFree(z)); CK(hipFree(par)); CK(hipFree(cols));
+    char name[32]; snprintf(name, sizeof(name), "%d x %d", sh.nb, sh.C);
+    printf("%-14s %10.1f %10.1f %10.1f %10.1f\n", name, t[0] * 20.f, t[1] * 20.f, t[2] * 20.f, t[3] * 20.f);
+    CK(hipFree(par)); CK(hipFree(cols));
   }
   return 0;
-}
-
-static int run_bncheck() {
-  int bad = 0;
-  bad += bn_case(64LL * 56 * 56, 64, 1024, 768, false);       // tall slabs: the fused kernels run
-  bad += bn_case(32LL * 56 * 56, 256, 1024, 768, true);
-  bad += bn_case(64LL * 28 * 28, 512, 784, 768, true);
-  bad += bn_case(16LL * 56 * 56, 64, 392, 392, false);        // short slab: both forms are the separate launches
-  bad += bn_case(8LL * 14 * 14, 1024, 98, 98, true);
-  printf(bad ? "BN CHECK FAILED (%d)\n" : "BN CHECK OK\n", bad);
-  return bad ? 1 : 0;
 }
 
 // sweep: every argument is one configuration "name=value,name=value,...": the 3x3 / stride-1 cases are checked
@@ -652,14 +656,6 @@ static int run_sweep(int n, char** cfgs) {
     }
     printf("\n");
     fflush(stdout);
-    if (getenv("KBENCH_STAMPS") && strstr(cfgs[c], "igemm_halo=1"))
-      for (int i = 0; i < 2; ++i) {          // per-phase time stamps of one launch (stderr)
-        int used = -1;
-        passl_hip_set_option("igemm_halo_dbg", 1);
-        time_shape(kR50[i], true, B, 1, &used);
-        fprintf(stderr, "  %s: ", kR50[i].note);
-        passl_hip_set_option("igemm_halo_dbg", 2);
-      }
   }
   return 0;
 }
@@ -714,8 +710,8 @@ int main(int argc, char** argv) {
   if (mode == "check") return run_check();
   if (mode == "ablate") return run_ablate();
   if (mode == "wcheck") return run_wcheck();
-  if (mode == "bncheck") return run_bncheck();
-  if (mode == "bntime") return run_bntime();
+  if (mode == "fincheck") return run_fincheck();
+  if (mode == "fintime") return run_fintime();
   if (mode == "wtime") return run_wtime();
   if (mode == "time") return run_time(nullptr, 0, 0);
   if (mode == "ab") { if (!ab_name) { fprintf(stderr, "ab needs name=v0,v1\n"); return 2; } return run_time(ab_name, v0, v1); }
