@@ -332,6 +332,28 @@ int passl_hip_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int 
                                int dtype, passl_stream_t stream);
 int passl_hip_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W,
                                int C, int dtype, passl_stream_t stream);
+/* Training-mode BatchNorm + ReLU + the 3x3 / stride 2 / pad 1 max pool of the ResNet stem as ONE pass per direction
+ * (csrc/stem_pool.hip): the BatchNorm output z and the pool's input gradient dz are never written.  x = the
+ * BatchNorm input [N,H,W,C] (the stem convolution's output), scale / shift / mean / invstd / coef as produced by
+ * passl_hip_bn_finalize / passl_hip_bn_bwd_finalize, idx as passl_hip_maxpool3x3s2_fwd writes it.
+ *   fwd:        y[n,p,q,c] = max over the window of T(relu(x*scale + shift)), idx = the winning tap
+ *   bwd_reduce: partial[b][c][0..1] = sum g, sum g*(x - mean)*invstd with g = T(max-pool gradient of dy) masked by
+ *               x*scale + shift > 0; nblocks = passl_hip_bn_relu_maxpool_blocks(N,H,W,C) slab rows (buffer sized by
+ *               passl_hip_bn_partial_floats(nblocks, C, 0)), consumed by passl_hip_bn_bwd_finalize with M = N*H*W
+ *   bwd_apply:  dx = A g + B x + C
+ * Element for element the arithmetic of passl_hip_bn_apply -> maxpool3x3s2_fwd resp. maxpool3x3s2_bwd -> bn_bwd_reduce
+ * (relu = 2) -> bn_bwd_apply: y, idx and (for equal coefficients) dx are bit-identical to that chain; the slab is
+ * summed in another fixed order.  C/8 must divide 256; PASSL_EUNSUPPORTED otherwise (use the separate passes).
+ * Replaces BatchNorm2D + ReLU + MaxPool2D at resnetimagenet.py:196-198 and their autograd. */
+int passl_hip_bn_relu_maxpool_blocks(int N, int H, int W, int C);
+int passl_hip_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, int N,
+                                  int H, int W, int C, int dtype, passl_stream_t stream);
+int passl_hip_bn_relu_maxpool_bwd_reduce(const void* dy, const uint8_t* idx, const void* x, const float* mean,
+                                         const float* invstd, const float* scale, const float* shift, float* partial,
+                                         int nblocks, int N, int H, int W, int C, int dtype, passl_stream_t stream);
+int passl_hip_bn_relu_maxpool_bwd_apply(const void* dy, const uint8_t* idx, const void* x, const float* coef,
+                                        const float* scale, const float* shift, void* dx, int N, int H, int W, int C,
+                                        int dtype, passl_stream_t stream);
 /* Global average pool [N,HW,C] -> [N,C] and its backward.  Replaces AdaptiveAvgPool2D((1,1)) at
  * necks/base_neck.py:79,94. */
 int passl_hip_avgpool_fwd(const void* x, void* y, int N, int HW, int C, int dtype,

@@ -13,6 +13,7 @@
 // bwd_reduce 6, bwd_apply 8 (+2 with residual).
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include "common.h"
 
 namespace {
@@ -139,28 +140,35 @@ __global__ void __launch_bounds__(kThreads) bn_reduce_kernel(
   }
 }
 
-// ---- fixed-order fp64 combine of a partial slab [nblocks][C][2] — ONE launch, one round trip of loads.
+// ---- fixed-order fp64 combine of a partial slab [nblocks][C][2] — ONE launch for any slab height.
 // Until round 4 tall slabs (>= 512 rows) took two launches (bn_combine: 16 row segments per channel group, then
 // bn_finalize over the segment totals) and each thread walked its rows with one dependent load pair per trip.  Inside
 // the training step these launches sit on the main chain between a convolution and the streaming pass that needs
-// their result, 53 + 53 times per MoCo step, and under load every dependent memory round trip of such a latency-bound
-// launch costs 3-4 us: 15.6 + 11.2 us plus two launch gaps per tall BatchNorm and direction
-// (profiles/r04_bench_bs256_bf16_kernel_stats.txt).  Now a 1024-thread block owns 8 channels (64 contiguous bytes of
-// every slab row; 4 channels per block re-fetch every cache line from four blocks: 16 us instead of 7 on 6272 x 256):
-// 4 threads x 2 channels (one 16-byte load of sums + one 8-byte load of shifts per slab row) x 256 row lanes, 16 rows
-// of a lane in flight at once (10 with shifts: 16 spill under the 128-register limit of a 1024-thread block, 38 us
-// instead of 7; the per-channel parameters are fetched with the first batch), rows of a lane added in ascending
-// order, lanes folded with xor shuffles (4, 8, 16, 32), the 16 waves through LDS in wave order.  Totals of channel
-// pair q land in thread q (0..3).  tools/kbench fincheck / fintime.
-constexpr int kFinThreads = 1024;
+// their result, 53 + 53 times per MoCo step, and under load every launch and every dependent memory round trip of
+// such a latency-bound kernel costs microseconds: 15.6 + 11.2 us plus two launch gaps per tall BatchNorm and
+// direction (profiles/r04_bench_bs256_bf16_kernel_stats.txt).  Now:
+//  * a 256-thread block owns 8 channels (64 contiguous bytes of every slab row) and one SEGMENT of rows: 4 threads x
+//    2 channels (one 16-byte load of sums + one 8-byte load of shifts per row) x 64 row lanes, the 16 (10 with shifts)
+//    rows of a lane in flight at once = ONE round trip per segment of 1024 (640) rows; rows of a lane are added in
+//    ascending order, lanes folded with xor shuffles (4, 8, 16, 32), the 4 waves through LDS in wave order.  Light
+//    blocks on purpose: a 1024-thread block with 128 registers needs a whole idle CU and waited 44 us on average for
+//    one inside the step (profiles/r05_trace_chain_1024thread_finalize.txt);
+//  * several segments (tall slabs) are combined by the LAST block of the channel group to arrive: a block publishes
+//    its four fp64 segment totals with 8-byte agent-scope atomic stores (write-through `sc1`), waits for them, adds 1
+//    to the group's counter with a returning agent-scope atomic; the block that reads nseg - 1 back re-zeroes the
+//    counter, reads all segment totals (agent-scope atomic loads) and adds them IN SEGMENT ORDER — who is last varies,
+//    the arithmetic does not (bit-reproducible).  Every segment is centred on slab 0's shift, so totals simply add.
+//    The protocol (payload, drained vmcnt, flag; consumer loads control-dependent on the flag's value) is the one
+//    MI355X_MICROARCH.md lists as "8-B agent atomics both sides"; tools/kbench finstress runs it under load.
+constexpr int kFinThreads = 256;
 constexpr int kFinCh = 8;                        // channels per block
 constexpr int kFinRowLanes = kFinThreads / 4;
-
-constexpr int kFinSegMax = 16;   // historical: passl_hip_bn_partial_floats keeps the scratch of the two-launch form
+constexpr int kFinSegMax = 16;                   // row segments of a tall slab (scratch: passl_hip_bn_partial_floats)
+constexpr int kFinSegRowsFwd = kFinRowLanes * 10, kFinSegRowsBwd = kFinRowLanes * 16;
 
 template <bool SHIFTED>
 __device__ __forceinline__ void combine_slab(const float* __restrict__ partial, int nblocks, int C,
-                                             int64_t M, int rows_per_block, int c, bool c_ok,
+                                             int64_t M, int rows_per_block, int c, bool c_ok, int b0, int b1,
                                              double (&t1)[2], double (&t2)[2], float (&g0)[2]) {
   constexpr int kFinBatch = SHIFTED ? 10 : 16;
   __shared__ double red[kFinThreads / 64][4][4];
@@ -173,20 +181,20 @@ __device__ __forceinline__ void combine_slab(const float* __restrict__ partial, 
       const float2 g = *reinterpret_cast<const float2*>(shifts + c);
       g0[0] = g.x; g0[1] = g.y;
     }
-    for (int bb = rl; bb < nblocks; bb += kFinRowLanes * kFinBatch) {
+    for (int bb = b0 + rl; bb < b1; bb += kFinRowLanes * kFinBatch) {
       float4 p[kFinBatch];
       float2 sh[kFinBatch];
 #pragma unroll
       for (int i = 0; i < kFinBatch; ++i) {              // every load of the batch before the first use
         const int b = bb + i * kFinRowLanes;
-        const int bc = b < nblocks ? b : nblocks - 1;
+        const int bc = b < b1 ? b : b1 - 1;
         p[i] = *reinterpret_cast<const float4*>(partial + ((int64_t)bc * C + c) * 2);
         sh[i] = SHIFTED ? *reinterpret_cast<const float2*>(shifts + (int64_t)bc * C + c) : make_float2(0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < kFinBatch; ++i) {
         const int b = bb + i * kFinRowLanes;
-        if (b >= nblocks) break;
+        if (b >= b1) break;
         if (SHIFTED) {
           int64_t n = M - (int64_t)b * rows_per_block;
           if (n > rows_per_block) n = rows_per_block;
@@ -223,25 +231,68 @@ __device__ __forceinline__ void combine_slab(const float* __restrict__ partial, 
   }
 }
 
+__device__ __forceinline__ void fin_st8(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fin_ld8(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Grid (C / 8, nseg).  Returns true in the threads that hold the totals of the WHOLE slab for channels c, c + 1:
+// threads 0..3 of the only block (nseg == 1) or of the last block of the channel group to arrive.
+template <bool SHIFTED>
+__device__ __forceinline__ bool slab_totals(const float* __restrict__ partial, int nblocks, int C, int64_t M,
+                                            int rows_per_block, int seg_rows, double* __restrict__ scratch,
+                                            int* __restrict__ counters, int c, double (&t1)[2], double (&t2)[2],
+                                            float (&g0)[2]) {
+  const int nseg = gridDim.y;
+  const int b0 = blockIdx.y * seg_rows;
+  const int b1 = (b0 + seg_rows) < nblocks ? (b0 + seg_rows) : nblocks;
+  combine_slab<SHIFTED>(partial, nblocks, C, M, rows_per_block, c, c < C, b0, b1, t1, t2, g0);
+  const bool own = threadIdx.x < 4 && c < C;
+  if (nseg == 1) return own;
+  if (threadIdx.x >= 64) return false;                   // wave 0 carries the hand-off
+  if (own) {
+    double* s = scratch + ((int64_t)blockIdx.y * C + c) * 2;
+    fin_st8(s, t1[0]); fin_st8(s + 1, t2[0]); fin_st8(s + 2, t1[1]); fin_st8(s + 3, t2[1]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the totals are written through before the flag moves
+  int old = 0;
+  if (threadIdx.x == 0) old = __hip_atomic_fetch_add(counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old != nseg - 1) return false;
+  if (threadIdx.x == 0) __hip_atomic_store(counters + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!own) return false;
+  t1[0] = t1[1] = t2[0] = t2[1] = 0.0;
+  for (int s0 = 0; s0 < nseg; s0 += 8) {                 // loads of 8 segments in flight, added in segment order
+    double v[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int sg = (s0 + i) < nseg ? (s0 + i) : nseg - 1;
+      const double* s = scratch + ((int64_t)sg * C + c) * 2;
+      v[i][0] = fin_ld8(s); v[i][1] = fin_ld8(s + 1); v[i][2] = fin_ld8(s + 2); v[i][3] = fin_ld8(s + 3);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (s0 + i >= nseg) break;
+      t1[0] += v[i][0]; t2[0] += v[i][1]; t1[1] += v[i][2]; t2[1] += v[i][3];
+    }
+  }
+  return true;
+}
+
 __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
-    const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block,
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block, int seg_rows,
+    double* __restrict__ scratch, int* __restrict__ counters,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rmean,
     float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
-  const bool fin = threadIdx.x < 4 && c < C;
-  // the per-channel parameters travel with the slab loads (one round trip), not after the reduction
-  float2 ga = make_float2(0.f, 0.f), be = ga, rm = ga, rv = ga;
-  if (fin) {
-    // scalar loads: parameters are slices of a flat buffer, only 4-byte aligned in general
-    ga = make_float2(gamma[c], gamma[c + 1]);
-    be = make_float2(beta[c], beta[c + 1]);
-    if (rmean) { rm = make_float2(rmean[c], rmean[c + 1]); rv = make_float2(rvar[c], rvar[c + 1]); }
-  }
   double t1[2], t2[2];
   float g0[2];
-  combine_slab<true>(partial, nblocks, C, M, rows_per_block, c, c < C, t1, t2, g0);
-  if (!fin) return;
+  if (!slab_totals<true>(partial, nblocks, C, M, rows_per_block, seg_rows, scratch, counters, c, t1, t2, g0)) return;
   const double inv_m = 1.0 / (double)M;             // one fp64 division instead of three
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
@@ -252,45 +303,36 @@ __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c + e] = (float)mu;
     invstd[c + e] = is;
-    const float sc = (e ? ga.y : ga.x) * is;
+    const float sc = gamma[c + e] * is;
     scale[c + e] = sc;
-    shift[c + e] = (e ? be.y : be.x) - (float)mu * sc;
+    shift[c + e] = beta[c + e] - (float)mu * sc;
     if (rmean) {
-      rmean[c + e] = momentum * (e ? rm.y : rm.x) + (1.0f - momentum) * (float)mu;
-      rvar[c + e] = momentum * (e ? rv.y : rv.x) + (1.0f - momentum) * (float)var;
+      rmean[c + e] = momentum * rmean[c + e] + (1.0f - momentum) * (float)mu;
+      rvar[c + e] = momentum * rvar[c + e] + (1.0f - momentum) * (float)var;
     }
   }
 }
 
 __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
-    const float* __restrict__ partial, int nblocks, int64_t M, int C,
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, int seg_rows,
+    double* __restrict__ scratch, int* __restrict__ counters,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ coef) {
   const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
-  const bool fin = threadIdx.x < 4 && c < C;
-  float2 ga = make_float2(0.f, 0.f), mu = ga, is = ga, dg = ga, db = ga;
-  if (fin) {
-    ga = make_float2(gamma[c], gamma[c + 1]);
-    mu = make_float2(mean[c], mean[c + 1]);
-    is = make_float2(invstd[c], invstd[c + 1]);
-    dg = make_float2(dgamma[c], dgamma[c + 1]);
-    db = make_float2(dbeta[c], dbeta[c + 1]);
-  }
   double sg[2], sgx[2];
   float unused[2];
-  combine_slab<false>(partial, nblocks, C, M, 0, c, c < C, sg, sgx, unused);
-  if (!fin) return;
+  if (!slab_totals<false>(partial, nblocks, C, M, 0, seg_rows, scratch, counters, c, sg, sgx, unused)) return;
   const double inv_m = 1.0 / (double)M;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    dbeta[c + e] = (e ? db.y : db.x) + (float)sg[e];      // accumulate: the flat gradient buffer is zeroed by clear_grad()
-    dgamma[c + e] = (e ? dg.y : dg.x) + (float)sgx[e];
+    dbeta[c + e] += (float)sg[e];      // accumulate: the flat gradient buffer is zeroed by clear_grad()
+    dgamma[c + e] += (float)sgx[e];
     // dx = gamma*invstd*( g - sg/M - xhat*sgx/M ),  xhat = (x-mean)*invstd
-    const double isd = (double)(e ? is.y : is.x);
-    const double gi = (double)(e ? ga.y : ga.x) * isd;
+    const double isd = (double)invstd[c + e];
+    const double gi = (double)gamma[c + e] * isd;
     const double B = -gi * isd * sgx[e] * inv_m;
-    const double Cc = -gi * sg[e] * inv_m - B * (double)(e ? mu.y : mu.x);
+    const double Cc = -gi * sg[e] * inv_m - B * (double)mean[c + e];
     coef[c + e] = (float)gi;
     coef[C + c + e] = (float)B;
     coef[2 * C + c + e] = (float)Cc;
@@ -303,13 +345,12 @@ __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
 // {mean, M2 = sum (x - mean)^2, n}; the moments of all ranks are gathered (3 C doubles per rank) and combined in RANK
 // ORDER with Chan's update (deterministic, no cancellation); backward the same way with {sum g, sum g xhat}.
 __global__ void __launch_bounds__(kFinThreads) bn_moments_kernel(
-    const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block,
-    double* __restrict__ mom) {
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, int rows_per_block, int seg_rows,
+    double* __restrict__ scratch, int* __restrict__ counters, double* __restrict__ mom) {
   const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
   double t1[2], t2[2];
   float g0[2];
-  combine_slab<true>(partial, nblocks, C, M, rows_per_block, c, c < C, t1, t2, g0);
-  if (threadIdx.x >= 4 || c >= C) return;
+  if (!slab_totals<true>(partial, nblocks, C, M, rows_per_block, seg_rows, scratch, counters, c, t1, t2, g0)) return;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const double dm = t1[e] / (double)M;
@@ -352,12 +393,12 @@ __global__ void __launch_bounds__(256) bn_finalize_moments_kernel(
 }
 
 __global__ void __launch_bounds__(kFinThreads) bn_bwd_sums_kernel(
-    const float* __restrict__ partial, int nblocks, int64_t M, int C, double* __restrict__ sums) {
+    const float* __restrict__ partial, int nblocks, int64_t M, int C, int seg_rows, double* __restrict__ scratch,
+    int* __restrict__ counters, double* __restrict__ sums) {
   const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
   double sg[2], sgx[2];
   float unused[2];
-  combine_slab<false>(partial, nblocks, C, M, 0, c, c < C, sg, sgx, unused);
-  if (threadIdx.x >= 4 || c >= C) return;
+  if (!slab_totals<false>(partial, nblocks, C, M, 0, seg_rows, scratch, counters, c, sg, sgx, unused)) return;
   sums[c] = sg[0]; sums[c + 1] = sg[1];
   sums[C + c] = sgx[0]; sums[C + c + 1] = sgx[1];
 }
@@ -597,6 +638,34 @@ int passl_bn_option(const char* name, int value) {
   else if ((dtype) == PASSL_F32) { using T = float; __VA_ARGS__ } \
   else return PASSL_EUNSUPPORTED;
 
+// row segments of a slab: one per kFinSegRows* rows (one round trip of loads per block), at most kFinSegMax
+static int fin_segments(int nblocks, bool shifted, int* seg_rows) {
+  const int per = shifted ? kFinSegRowsFwd : kFinSegRowsBwd;
+  int nseg = (nblocks + per - 1) / per;
+  if (nseg > kFinSegMax) nseg = kFinSegMax;
+  *seg_rows = (nblocks + nseg - 1) / nseg;
+  return (nblocks + *seg_rows - 1) / *seg_rows;
+}
+
+// Arrival counters of the multi-segment finalize launches: a slice (one int per 8-channel group) of a library-owned
+// ring of ints that is ALL ZERO whenever no launch is using a slice — the block that completes a counter re-zeroes it.
+// A slice is handed out again after 64 K ints of later requests (a MoCo step asks for ~2 K).
+static int* fin_counters(int groups) {
+  static std::mutex mu;
+  static int* pool = nullptr;
+  static int64_t next = 0;
+  constexpr int64_t kPoolInts = 1 << 16;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pool) {
+    if (hipMalloc(reinterpret_cast<void**>(&pool), kPoolInts * sizeof(int)) != hipSuccess) { pool = nullptr; return nullptr; }
+    if (hipMemset(pool, 0, kPoolInts * sizeof(int)) != hipSuccess) return nullptr;
+  }
+  if (next + groups > kPoolInts) next = 0;
+  int* r = pool + next;
+  next += (groups + 3) & ~3;
+  return r;
+}
+
 extern "C" int64_t passl_hip_bn_partial_floats(int nblocks, int C, int shifted) {
   if (nblocks <= 0 || C <= 0) return 0;
   return (int64_t)nblocks * C * (shifted ? 3 : 2) + (int64_t)kFinSegMax * C * 4;
@@ -625,8 +694,14 @@ extern "C" int passl_hip_bn_finalize(const float* partial, int nblocks, int64_t 
       (C & 7) || nblocks <= 0 || rows_per_block <= 0 || (int64_t)nblocks * rows_per_block < M ||
       (running_mean && !running_var) || !aligned16(partial))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, rows_per_block, gamma, beta, running_mean,
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, true, &seg_rows);
+  // the segment scratch lives behind the slab (passl_hip_bn_partial_floats sizes the buffer)
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 3);
+  int* counters = nseg > 1 ? fin_counters(C / kFinCh) : nullptr;
+  if (nseg > 1 && !counters) return PASSL_ELAUNCH;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / kFinCh, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, rows_per_block, seg_rows, scratch, counters, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
@@ -697,8 +772,13 @@ extern "C" int passl_hip_bn_bwd_finalize(const float* partial, int nblocks, int6
   if (!partial || !gamma || !mean || !invstd || !dgamma || !dbeta || !coef || M <= 0 || C <= 0 ||
       (C & 7) || nblocks <= 0 || !aligned16(partial))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, gamma, mean, invstd, dgamma, dbeta, coef);
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, false, &seg_rows);
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 2);
+  int* counters = nseg > 1 ? fin_counters(C / kFinCh) : nullptr;
+  if (nseg > 1 && !counters) return PASSL_ELAUNCH;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / kFinCh, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, seg_rows, scratch, counters, gamma, mean, invstd, dgamma, dbeta, coef);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -709,8 +789,13 @@ extern "C" int passl_hip_bn_moments(const float* partial, int nblocks, int64_t M
   if (!partial || !mom || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || rows_per_block <= 0 ||
       (int64_t)nblocks * rows_per_block < M || !aligned16(partial))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_moments_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, rows_per_block, mom);
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, true, &seg_rows);
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 3);
+  int* counters = nseg > 1 ? fin_counters(C / kFinCh) : nullptr;
+  if (nseg > 1 && !counters) return PASSL_ELAUNCH;
+  hipLaunchKernelGGL(bn_moments_kernel, dim3(C / kFinCh, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, rows_per_block, seg_rows, scratch, counters, mom);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }
@@ -732,8 +817,13 @@ extern "C" int passl_hip_bn_bwd_sums(const float* partial, int nblocks, int64_t 
                                      passl_stream_t stream) {
   if (!partial || !sums || M <= 0 || C <= 0 || (C & 7) || nblocks <= 0 || !aligned16(partial))
     return PASSL_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / kFinCh), dim3(kFinThreads), 0, as_stream(stream),
-                     partial, nblocks, M, C, sums);
+  int seg_rows = 0;
+  const int nseg = fin_segments(nblocks, false, &seg_rows);
+  double* scratch = reinterpret_cast<double*>(const_cast<float*>(partial) + (int64_t)nblocks * C * 2);
+  int* counters = nseg > 1 ? fin_counters(C / kFinCh) : nullptr;
+  if (nseg > 1 && !counters) return PASSL_ELAUNCH;
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(C / kFinCh, nseg), dim3(kFinThreads), 0, as_stream(stream),
+                     partial, nblocks, M, C, seg_rows, scratch, counters, sums);
   PASSL_RETURN_IF_LAUNCH_FAILED();
   return PASSL_OK;
 }

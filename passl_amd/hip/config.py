@@ -17,6 +17,7 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
           'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
+          'fused_stem_pool': os.environ.get('PASSL_FUSED_STEM_POOL', '1') != '0',
           # the library reads the same variable (conv_wgrad_halo.inc): 0 off, 1 images with sides % 8 == 0, 2 all (default)
           'wgrad_halo': int(os.environ.get('PASSL_WGRAD_HALO', '2') or 0)}
 
@@ -109,6 +110,12 @@ def side_reductions():
     return _state['side_reductions']
 
 
+def fused_stem_pool():
+    """Training-mode BatchNorm + ReLU + max-pool of the ResNet stem as one pass per direction (csrc/stem_pool.hip):
+    the BatchNorm output and the pool's input gradient are never written."""
+    return _state['fused_stem_pool']
+
+
 def wgrad_halo():
     """The spatially tiled 3x3 weight-gradient kernel takes eligible launches (2, the default: every 3x3 / stride-1
     layer; 1: images whose sides are multiples of 8; 0: off); the slice count of those launches is then chosen for ITS
@@ -119,5 +126,5 @@ def wgrad_halo():
 
 def set_flag(name, value):
     assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample',
-                    'side_reductions')
+                    'side_reductions', 'fused_stem_pool')
     _state[name] = bool(value)

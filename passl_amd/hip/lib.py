@@ -87,6 +87,11 @@ SIGNATURES = {
                                      c_p]),
     'passl_hip_maxpool3x3s2_fwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_maxpool3x3s2_bwd': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_relu_maxpool_blocks': (c_i, [c_i, c_i, c_i, c_i]),
+    'passl_hip_bn_relu_maxpool_fwd': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    'passl_hip_bn_relu_maxpool_bwd_reduce': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i,
+                                                   c_p]),
+    'passl_hip_bn_relu_maxpool_bwd_apply': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_avgpool_fwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_avgpool_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'passl_hip_relu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),

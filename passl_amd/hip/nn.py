@@ -408,6 +408,49 @@ class _MaxPoolFn(Function):
         return ops.maxpool_bwd(dy.contiguous(), idx, ctx.hw[0], ctx.hw[1])
 
 
+class _BNReluMaxPoolFn(Function):
+    """Training-mode BatchNorm + ReLU + MaxPool2D(3, 2, 1) in one pass per direction (csrc/stem_pool.hip): the stem of
+    the trainable trunk (resnetimagenet.py:196-198).  Saves the BatchNorm input, the batch statistics and one index
+    byte per pooled element; neither the BatchNorm output nor the pool's input gradient is ever written."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, layer, partial):
+        _, st, _ = ops.bn_train_fwd(y, gamma.detach(), beta.detach(), layer._mean, layer._variance, None, True,
+                                    layer._momentum, layer._epsilon, partial=partial, apply=False)
+        out, idx = ops.bn_relu_maxpool_fwd(y, st)
+        if layer._rt is not None and any(ctx.needs_input_grad):
+            layer._rt.arena.expect_grad(layer._rt.indices)
+        ctx.save_for_backward(y, st, idx)
+        ctx.layer = layer
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, st, idx = ctx.saved_tensors
+        layer = ctx.layer
+        streams.autograd_node_entry(dout.device)
+        for p in (layer.weight, layer.bias):
+            if p.grad is None:
+                p.grad = ops.zeros_like(p)
+        dx = ops.bn_relu_maxpool_bwd(dout.contiguous(), idx, y, layer.weight.detach(), st, layer.weight.grad,
+                                     layer.bias.grad)
+        if layer._rt is not None:
+            layer._rt.arena.grad_ready(layer._rt.indices)
+        return dx, None, None, None, None
+
+
+def bn_relu_maxpool(bn, y, stats=None):
+    """bn(y, relu=True) followed by MaxPool2D(3, 2, 1).  One fused pass per direction when `bn` computes batch
+    statistics of this rank (training mode, affine, no SyncBatchNorm) and the shape is covered; the two layers
+    otherwise."""
+    fused = (config.fused_stem_pool() and torch.is_grad_enabled() and not bn.uses_global_stats() and bn.affine and
+             not (getattr(bn, '_sync', False) and _collectives_active()) and y.is_cuda and
+             ops.bn_relu_maxpool_supported(y))
+    if not fused:
+        return _MaxPoolFn.apply(bn(y, relu=True, stats=stats))
+    return _BNReluMaxPoolFn.apply(y, bn.weight, bn.bias, bn, stats)
+
+
 class MaxPool2D(Layer):
     def __init__(self, kernel_size=3, stride=2, padding=1):
         super().__init__()

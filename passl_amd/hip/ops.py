@@ -259,10 +259,11 @@ def _gather_doubles(t):
 
 
 def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum=0.9, eps=1e-5,
-                 partial=None, want_mask=False, sync=False):
+                 partial=None, want_mask=False, sync=False, apply=True):
     """x: [..., C] NHWC rows.  Returns z, stats[4,C] (mean, invstd, scale, shift), relu bit mask
     (or None); updates rmean/rvar in place.  `partial` = (slab, tiles) of fused statistics a conv
     epilogue already wrote (conv_stats_buffer); without it a stats pass over x is launched.
+    `apply=False`: statistics only -> (None, stats, None) (the caller applies them: bn_relu_maxpool_fwd).
     `sync`: statistics over the batches of every rank (SyncBatchNorm): this rank's slab is folded to fp64
     moments, the moments are all-gathered and combined in rank order (csrc/bn.hip)."""
     Cch = x.shape[-1]
@@ -292,6 +293,8 @@ def bn_train_fwd(x, gamma, beta, rmean, rvar, residual=None, relu=True, momentum
                                           L.ptr(rmean), L.ptr(rvar), momentum, eps,
                                           L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
                                           L.ptr(stats[3]), st), 'bn_finalize')
+    if not apply:
+        return None, stats, None
     z = torch.empty_like(x)
     mask = torch.empty(x.numel() // 8, dtype=torch.uint8, device=dev) if (want_mask and relu) \
         else None
@@ -386,6 +389,42 @@ def maxpool_bwd(dy, idx, H, W):
     dx = torch.empty(N, H, W, Cc, dtype=dy.dtype, device=dy.device)
     L.check(_lib().passl_hip_maxpool3x3s2_bwd(L.ptr(dy), L.ptr(idx), L.ptr(dx), N, H, W, Cc,
                                               L.dt(dy), L.stream()), 'maxpool_bwd')
+    return dx
+
+
+def bn_relu_maxpool_supported(x):
+    """The fused stem pass (csrc/stem_pool.hip) takes this BatchNorm input: [N,H,W,C] with C/8 dividing 256."""
+    return x.dim() == 4 and _lib().passl_hip_bn_relu_maxpool_blocks(*x.shape) > 0
+
+
+def bn_relu_maxpool_fwd(x, stats):
+    """max-pool(relu(x * scale + shift)) in one pass; stats[4,C] from bn_train_fwd(..., apply=False) -> y, idx."""
+    N, H, W, Cc = x.shape
+    P_, Q_ = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = torch.empty(N, P_, Q_, Cc, dtype=x.dtype, device=x.device)
+    idx = torch.empty(N, P_, Q_, Cc, dtype=torch.uint8, device=x.device)
+    L.check(_lib().passl_hip_bn_relu_maxpool_fwd(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(y), L.ptr(idx),
+                                                 N, H, W, Cc, L.dt(x), L.stream()), 'bn_relu_maxpool_fwd')
+    return y, idx
+
+
+def bn_relu_maxpool_bwd(dy, idx, x, gamma, stats, dgamma, dbeta):
+    """Backward of bn_relu_maxpool_fwd w.r.t. x; dgamma / dbeta (fp32 [C]) are accumulated into."""
+    N, H, W, Cc = x.shape
+    lib, st, dtc, dev = _lib(), L.stream(), L.dt(x), x.device
+    nb = lib.passl_hip_bn_relu_maxpool_blocks(N, H, W, Cc)
+    partial = torch.empty(bn_partial_floats(nb, Cc, False), dtype=torch.float32, device=dev)
+    coef = torch.empty(3 * Cc, dtype=torch.float32, device=dev)
+    L.check(lib.passl_hip_bn_relu_maxpool_bwd_reduce(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(stats[0]), L.ptr(stats[1]),
+                                                     L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(partial), nb, N, H, W, Cc,
+                                                     dtc, st), 'bn_relu_maxpool_bwd_reduce')
+    L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(partial), nb, N * H * W, Cc, L.ptr(gamma), L.ptr(stats[0]),
+                                          L.ptr(stats[1]), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), st),
+            'bn_bwd_finalize')
+    dx = torch.empty_like(x)
+    L.check(lib.passl_hip_bn_relu_maxpool_bwd_apply(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(coef), L.ptr(stats[2]),
+                                                    L.ptr(stats[3]), L.ptr(dx), N, H, W, Cc, dtc, st),
+            'bn_relu_maxpool_bwd_apply')
     return dx
 
 

@@ -286,9 +286,10 @@ class ResNet(nn.Layer):
                         y = blk.forward_frozen(y)
         else:
             y, st = self.conv1(xp, hw=(H, W), want_stats=True)
-            y = self.bn1(y, relu=True, stats=st)
             if self.stem_pool:
-                y = self.maxpool(y)
+                y = nn.bn_relu_maxpool(self.bn1, y, stats=st)     # one pass per direction (csrc/stem_pool.hip)
+            else:
+                y = self.bn1(y, relu=True, stats=st)
         # unit_done(u): called on the host right after unit u (units(): stem + first bottleneck, then one bottleneck
         # each) was enqueued — MoCo's key pipeline issues the key encoder's same unit from there
         unit_done = getattr(self, '_unit_done', None)

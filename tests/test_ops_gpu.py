@@ -670,6 +670,59 @@ def test_maxpool(dtype, shape):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(4, 32, 32, 64), (3, 17, 21, 64), (2, 9, 8, 256), (256, 112, 112, 64)])
+def test_bn_relu_maxpool_fused_equals_the_separate_passes(dtype, shape):
+    """csrc/stem_pool.hip (BatchNorm + ReLU + MaxPool2D(3, 2, 1) of the stem, resnetimagenet.py:196-198, one pass per
+    direction) against the passes it replaces, fed with the same tensors: the pooled output and the index bytes are
+    bit-identical, the input gradient is bit-identical GIVEN THE SAME coefficients (checked by handing the fused apply
+    pass the separate path's coefficients), and the fused reduce pass's per-channel sums agree to fp32 rounding."""
+    if shape[0] == 256 and dtype == torch.float32:
+        pytest.skip('full stem size in the benchmark dtype only')
+    from passl_amd.hip import lib as L
+    gen = torch.Generator().manual_seed(131)
+    N, H, W, C = shape
+    x = rnd(torch.randn(shape, generator=gen) * 1.5 + 0.3, dtype).to(DEV).to(dtype)
+    gamma = (torch.rand(C, generator=gen) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=gen) * 0.2).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    # the separate passes
+    z, st, _ = ops.bn_train_fwd(x, gamma, beta, rm.clone(), rv.clone(), None, True)
+    y_ref, idx_ref = ops.maxpool_fwd(z)
+    dy = rnd(torch.randn(y_ref.shape, generator=gen), dtype).to(DEV).to(dtype)
+    dz = ops.maxpool_bwd(dy, idx_ref, H, W)
+    dg_ref, db_ref = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx_ref, _ = ops.bn_bwd(dz, None, x, gamma, st[0], st[1], dg_ref, db_ref, relu=2, scale=st[2], shift=st[3])
+    # fused
+    assert ops.bn_relu_maxpool_supported(x)
+    _, st2, _ = ops.bn_train_fwd(x, gamma, beta, rm.clone(), rv.clone(), None, True, apply=False)
+    assert torch.equal(st, st2)
+    y, idx = ops.bn_relu_maxpool_fwd(x, st2)
+    assert torch.equal(y, y_ref) and torch.equal(idx, idx_ref)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.bn_relu_maxpool_bwd(dy, idx, x, gamma, st2, dg, db)
+    tol = 2e-6 if dtype == torch.float32 else 1e-5       # sums of ~N*H*W terms added in another order
+    assert relmax(dg, dg_ref) < tol and relmax(db, db_ref) < tol
+    assert relmax(dx.float(), dx_ref.float()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # the apply pass with the separate path's coefficients: every element the same bits
+    coef = torch.empty(3 * C, dtype=torch.float32, device=DEV)
+    lib = L.load()
+    nb = lib.passl_hip_bn_relu_maxpool_blocks(N, H, W, C)
+    part = torch.empty(ops.bn_partial_floats(nb, C, False), dtype=torch.float32, device=DEV)
+    L.check(lib.passl_hip_bn_bwd_reduce(L.ptr(dz), None, L.ptr(x), L.ptr(st[0]), L.ptr(st[1]), L.ptr(st[2]), L.ptr(st[3]),
+                                        L.ptr(part), N * H * W, C, nb, 2, L.dt(x), L.stream()), 'bn_bwd_reduce')
+    scratch = [torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)]
+    L.check(lib.passl_hip_bn_bwd_finalize(L.ptr(part), nb, N * H * W, C, L.ptr(gamma), L.ptr(st[0]), L.ptr(st[1]),
+                                          L.ptr(scratch[0]), L.ptr(scratch[1]), L.ptr(coef), L.stream()), 'bn_bwd_finalize')
+    dx_a = torch.empty_like(x)
+    L.check(lib.passl_hip_bn_bwd_apply(L.ptr(dz), None, L.ptr(x), L.ptr(coef), L.ptr(st[2]), L.ptr(st[3]), L.ptr(dx_a), None,
+                                       N * H * W, C, 2, L.dt(x), L.stream()), 'bn_bwd_apply')
+    dx_b = torch.empty_like(x)
+    L.check(lib.passl_hip_bn_relu_maxpool_bwd_apply(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(coef), L.ptr(st[2]), L.ptr(st[3]),
+                                                    L.ptr(dx_b), N, H, W, C, L.dt(x), L.stream()), 'fused apply')
+    assert torch.equal(dx_a, dx_b)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_avgpool(dtype):
     gen = torch.Generator().manual_seed(14)
     x = rnd(torch.randn(5, 7, 7, 2048, generator=gen), dtype)

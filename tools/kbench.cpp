@@ -12,6 +12,7 @@
 //   tools/kbench wcheck | wtime [name=value ...]   the same for passl_hip_conv_wgrad (== on fp32 sums; per-layer table)
 //   tools/kbench fincheck                   BatchNorm finalize launches (forward / backward) against the host's fp64 arithmetic on the same slab
 //   tools/kbench fintime                    ... and their times, alone and next to a stream that loads the memory system
+//   tools/kbench finstress [iters=N]        ... and the multi-segment hand-off under load: every result bit-identical run to run
 //   tools/kbench ablate                     the register-staged kernel's debug switches on the 1x1 shapes
 //   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
 //   name=value pairs are passl_hip_set_option() calls made before anything runs.
@@ -383,7 +384,7 @@ static const Shape kR50[] = {
     {256, 128, 512, 1, 1, 28, "128->512 k1 @28", 4}, {256, 512, 128, 1, 1, 28, "512->128 k1 @28", 3},
     {256, 256, 1024, 1, 1, 14, "256->1024 k1 @14", 6}, {256, 1024, 256, 1, 1, 14, "1024->256 k1 @14", 5},
 };
-static int g_splits_override = 0, g_rows = 1000;      // pseudo-options "splits=N", "rows=N" of wtime
+static int g_splits_override = 0, g_rows = 1000, g_iters = 60;      // pseudo-options "splits=N", "rows=N" of wtime
 static int run_wtime() {
   WBuffers B;
   printf("%-22s %9s | %8s %7s  (weight gradient + slab reduction, N = 256, splits as the product chooses them)\n", "shape", "GFLOP", "us", "TF");
@@ -563,6 +564,7 @@ static int run_fincheck() {
   bad += fin_case(8LL * 14 * 14 + 7, 1024, 13);
   bad += fin_case(64LL * 112 * 112, 64, 6272);        // more rows than one batch of loads (4096)
   bad += fin_case(300, 2048, 3);
+  bad += fin_case(6272LL * 128, 256, 6272);          // 10 / 7 row segments combined by the last block to arrive
   printf(bad ? "FINALIZE CHECK FAILED (%d)\n" : "FINALIZE CHECK OK\n", bad);
   return bad ? 1 : 0;
 }
@@ -571,6 +573,60 @@ __global__ void hog_kernel(const uint4* __restrict__ src, uint4* __restrict__ ds
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) dst[i] = src[i];
 }
+// finstress: the multi-segment finalize launches (last block of a channel group to arrive combines the segment totals)
+// under load.  A second stream streams 1 GB copies the whole time; every iteration switches the input (three data
+// sets in turn: a stale segment total of the previous launch gives a wrong answer), recomputes the slab and finalizes:
+// every result must equal the first result of its data set BIT FOR BIT (the first one is checked by fincheck's
+// arithmetic at the same sizes), forward and backward.
+static int run_finstress(int iters) {
+  struct S { int64_t M; int C; int nb; };
+  const S shapes[] = {{6272LL * 128, 64, 6272}, {6272LL * 128, 256, 6272}, {25088LL * 128, 64, 25088}, {1568LL * 128, 512, 1568}};
+  hipStream_t hog;
+  CK(hipStreamCreate(&hog));
+  void *hs, *hd;
+  const int64_t hog_bytes = 1ll << 30;
+  CK(hipMalloc(&hs, hog_bytes)); CK(hipMalloc(&hd, hog_bytes));
+  int failures = 0;
+  for (const S& sh : shapes) {
+    const int64_t n = sh.M * sh.C;
+    void *x[3], *dz;
+    float *par, *parb, *cols;
+    for (int k = 0; k < 3; ++k) { CK(hipMalloc(&x[k], n * 2)); fill(x[k], n, 61u + 100u * k); }
+    CK(hipMalloc(&dz, n * 2)); fill(dz, n, 71u);
+    const int64_t pf = passl_hip_bn_partial_floats(sh.nb, sh.C, 1), pb = passl_hip_bn_partial_floats(sh.nb, sh.C, 0);
+    CK(hipMalloc((void**)&par, pf * 4)); CK(hipMalloc((void**)&parb, pb * 4));
+    CK(hipMalloc((void**)&cols, (size_t)16 * sh.C * 4));
+    std::vector<float> h0(16 * sh.C), h(16 * sh.C), first[3];
+    for (int i = 0; i < 16 * sh.C; ++i) h0[i] = 0.5f + (float)(mix((uint64_t)i, 73u) % 1024u) / 1024.0f;
+    float *gamma = cols, *beta = cols + sh.C, *rm = cols + 2 * sh.C, *rv = cols + 3 * sh.C, *st = cols + 4 * sh.C;
+    float *dg = cols + 8 * sh.C, *db = cols + 9 * sh.C, *cf = cols + 10 * sh.C;
+    int64_t flips = 0;
+    for (int it = 0; it < iters; ++it) {
+      const int set = it % 3;
+      for (int q = 0; q < 3; ++q) hipLaunchKernelGGL(hog_kernel, dim3(2048), dim3(256), 0, hog, (const uint4*)hs, (uint4*)hd, hog_bytes / 16);
+      CK(hipMemcpyAsync(cols, h0.data(), h0.size() * 4, hipMemcpyHostToDevice, 0));
+      bool ok = passl_hip_bn_stats(x[set], par, sh.M, sh.C, sh.nb, PASSL_BF16, nullptr) == PASSL_OK;
+      ok = ok && passl_hip_bn_finalize(par, sh.nb, sh.M, sh.C, 128, gamma, beta, rm, rv, 0.9f, 1e-5f, st, st + sh.C, st + 2 * sh.C, st + 3 * sh.C, nullptr) == PASSL_OK;
+      ok = ok && passl_hip_bn_bwd_reduce(dz, nullptr, x[set], st, st + sh.C, st + 2 * sh.C, st + 3 * sh.C, parb, sh.M, sh.C, sh.nb, 2, PASSL_BF16, nullptr) == PASSL_OK;
+      ok = ok && passl_hip_bn_bwd_finalize(parb, sh.nb, sh.M, sh.C, gamma, st, st + sh.C, dg, db, cf, nullptr) == PASSL_OK;
+      if (!ok) { printf("launch failed\n"); return 1; }
+      CK(hipMemcpyAsync(h.data(), cols, h.size() * 4, hipMemcpyDeviceToHost, 0));
+      CK(hipStreamSynchronize(0));
+      if (first[set].empty()) first[set] = h;
+      else if (memcmp(first[set].data(), h.data(), h.size() * 4) != 0) ++flips;
+    }
+    CK(hipStreamSynchronize(hog));
+    const bool distinct = memcmp(first[0].data(), first[1].data(), first[0].size() * 4) != 0;
+    printf("%lld x %d (%d slab rows): %d launches under load, %lld not bit-identical to the first of their data set%s\n", (long long)sh.M, sh.C,
+           sh.nb, iters, (long long)flips, distinct ? "" : "; DATA SETS GIVE THE SAME RESULT");
+    if (flips || !distinct) ++failures;
+    for (int k = 0; k < 3; ++k) CK(hipFree(x[k]));
+    for (void* q : {dz, (void*)par, (void*)parb, (void*)cols}) CK(hipFree(q));
+  }
+  printf(failures ? "FINALIZE STRESS FAILED (%d)\n" : "FINALIZE STRESS OK\n", failures);
+  return failures ? 1 : 0;
+}
+
 static int run_fintime() {
   struct S { int nb; int C; };
   const S shapes[] = {{25088, 64}, {6272, 64}, {6272, 256}, {1568, 128}, {1568, 512}, {392, 256}, {392, 1024}, {98, 512}, {98, 2048}};
@@ -703,6 +759,7 @@ int main(int argc, char** argv) {
     }
     if (name == "splits") { g_splits_override = atoi(eq + 1); continue; }
     if (name == "rows") { g_rows = atoi(eq + 1); continue; }
+    if (name == "iters") { g_iters = atoi(eq + 1); continue; }
     const int rc = passl_hip_set_option(name.c_str(), atoi(eq + 1));
     if (rc != PASSL_OK) { fprintf(stderr, "set_option(%s) -> %d\n", name.c_str(), rc); return 2; }
   }
@@ -712,6 +769,7 @@ int main(int argc, char** argv) {
   if (mode == "wcheck") return run_wcheck();
   if (mode == "fincheck") return run_fincheck();
   if (mode == "fintime") return run_fintime();
+  if (mode == "finstress") return run_finstress(g_iters);
   if (mode == "wtime") return run_wtime();
   if (mode == "time") return run_time(nullptr, 0, 0);
   if (mode == "ab") { if (!ab_name) { fprintf(stderr, "ab needs name=v0,v1\n"); return 2; } return run_time(ab_name, v0, v1); }
