@@ -250,7 +250,7 @@ def param_sync(model, src_rank=0, comm_group=None):
     Arena-backed state is one broadcast per flat buffer."""
     if not collectives_active(comm_group):
         return
-    arenas = [getattr(model, n) for n in ('arena_q', 'arena_k') if getattr(model, n, None) is not None]
+    arenas = [getattr(model, n) for n in ('arena_q', 'arena_k', 'arena') if getattr(model, n, None) is not None]
     flat_ptrs = set()
     for a in arenas:
         dist.broadcast(a.flat, src=src_rank, group=comm_group)

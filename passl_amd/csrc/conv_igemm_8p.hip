@@ -551,7 +551,9 @@ int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st) {
   // the persistent form stores from the accumulators: launches with fused statistics keep the staged epilogue
   const bool direct = g_8p_direct && nk >= 2 && !d->stats && !d->bnb_partial;
   if (g_8p_mode == 1) {
-    if (nk < g_8p_min_nk) return PASSL_EUNSUPPORTED;       // short reductions: igemm_kernel's territory
+    // short reductions: igemm_kernel's territory (also inside the step: taking the K = 256 launches of stages 3 / 4
+    // here — 4 K-tiles, <= 800 tiles — measured 24.4 vs 24.1 ms per MoCo step, profiles/r05_negative_results.txt)
+    if (nk < g_8p_min_nk) return PASSL_EUNSUPPORTED;
     const int64_t t8 = p.ntiles;
     const int64_t tr = ((int64_t)(p.M + 127) / 128) * ((d->NCOLS + 127) / 128);
     const double time8 = (double)((t8 + 255) / 256) * ((double)nk * g_8p_tk + (direct ? g_8p_ted : g_8p_te));

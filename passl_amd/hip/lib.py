@@ -199,6 +199,11 @@ def load(path=None):
         fn.argtypes = args
     if path is None:
         _lib = lib
+        # PASSL_OPTIONS="name=value,name=value": passl_hip_set_option calls made once at load (kernel-selection A/Bs
+        # without touching code; an unknown name is an error, not a silent no-op)
+        for kv in filter(None, os.environ.get('PASSL_OPTIONS', '').split(',')):
+            name, _, value = kv.partition('=')
+            check(lib.passl_hip_set_option(name.strip().encode(), int(value)), 'PASSL_OPTIONS %s' % kv)
     return lib
 
 

@@ -743,6 +743,18 @@ class _AttentionFn(Function):
             None, None, None, None
 
 
+def param_expect_grad(*params):
+    """Called from the FORWARD of a custom Function that will report ``param_grad_ready`` for these raw arena parameters
+    from its backward: a parameter used by several forward nodes of one step (a trunk run once per view) is complete —
+    ready for its all-reduce bucket — only after the last contribution (EncoderArena.expect_grad)."""
+    if not torch.is_grad_enabled():
+        return
+    for p in params:
+        a = getattr(p, '_passl_arena', None)
+        if a is not None and p.requires_grad:
+            a.expect_grad([p._passl_index])
+
+
 def param_grad_ready(*params):
     """Report raw arena parameters as reduced-ready from a custom backward (no-op outside an arena)."""
     for p in params:
@@ -1082,9 +1094,9 @@ class EncoderArena:
         """grad_ready for raw parameters (class / position embeddings, tokens, logit_scale ...) whose
         gradient is produced by one dedicated backward kernel: without the mark their bucket (and, since
         buckets launch in order, every later one) would only be reduced after the whole backward."""
-        if self.reducer is not None:
-            for p in params:
-                self.reducer.mark_ready(p._passl_index)
+        # through the same use counter as the layers' parameters: a Function whose forward ran twice in one step (two
+        # views through one trunk) reports twice, and only the second report releases the bucket
+        self.grad_ready([p._passl_index for p in params])
 
     def expect_grad(self, indices):
         """Called from the FORWARD of a layer (when autograd will run its backward) that will report ``grad_ready(indices)`` from its backward: a parameter

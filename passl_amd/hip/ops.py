@@ -697,6 +697,11 @@ def tanh_bwd(dy, x):
     return dx
 
 
+# the envelope of csrc/attention.hip / attention_bf16.hip (shape_ok): model constructors check it up front
+ATTENTION_HEAD_DIMS = frozenset((32, 64))
+ATTENTION_MAX_TOKENS = 208
+
+
 def attention_fwd(qkv, B, T, H, DH, scale, causal=False):
     """qkv [B*T, 3*H*DH] -> out [B*T, H*DH], lse [B, H, T]."""
     out = torch.empty(B * T, H * DH, dtype=qkv.dtype, device=qkv.device)

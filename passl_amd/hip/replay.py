@@ -177,6 +177,9 @@ class StepPlan(object):
         self._host_calls = []
         self._main = None
         self.replays = 0
+        self.eager_fallbacks = 0        # steps of another shape than the recorded one (run eagerly)
+        self._warned_shape = False
+        self._scratch_pins = None       # the workspace buffers whose addresses the recorded launches carry
         self.info = {}
         self.foreign = {}
 
@@ -184,6 +187,17 @@ class StepPlan(object):
     @property
     def captured(self):
         return self.handle is not None
+
+    def _fits(self, data):
+        """The batch has the recorded step's shapes and dtypes (a recorded step is shape-specialised)."""
+        if len(data) != len(self.static_in):
+            return False
+        for d, s in zip(data, self.static_in):
+            if torch.is_tensor(d) != torch.is_tensor(s):
+                return False
+            if torch.is_tensor(d) and (tuple(d.shape) != tuple(s.shape) or d.dtype != s.dtype):
+                return False
+        return True
 
     def _load_inputs(self, data):
         from . import ops
@@ -193,9 +207,6 @@ class StepPlan(object):
             src = self._src[i]
             if src is not None and src[0] is d and src[1] == d._version:
                 continue                        # the same resident tensor object, unmodified (see hip/graph.py)
-            if tuple(d.shape) != tuple(s.shape) or d.dtype != s.dtype:
-                raise RuntimeError('StepPlan: input %d changed shape / dtype (%s %s -> %s %s); a recorded step is '
-                                   'shape-specialised' % (i, tuple(s.shape), s.dtype, tuple(d.shape), d.dtype))
             if d.is_cuda and d.is_contiguous() and s.is_contiguous():
                 ops.copy_into(s, d)
             else:
@@ -274,6 +285,13 @@ class StepPlan(object):
         self._pool = pool                       # keeps the recorded step's addresses reserved
         self._host_calls = list(rec.host_calls)
         self._main = rec.main                   # the stream the step was called on (replays must be, too)
+        # The recorded launches carry raw pointers into the shared grow-only scratch (ops.workspace: weight-gradient
+        # slabs, InfoNCE dq slabs, column-sum partials), which was allocated from the general pool during the warm-up
+        # steps.  workspace.get() REPLACES a buffer when a later eager call asks for more (validation, another model,
+        # a tail batch through the eager fallback): without these references the old buffer would be freed and every
+        # replay would write its slabs into memory that belongs to somebody else.
+        from . import ops
+        self._scratch_pins = list(ops.workspace._bufs.values())
         return None
 
     def run(self, *data):
@@ -290,6 +308,16 @@ class StepPlan(object):
         if L.stream() != self._main:
             # the live pieces around a replay (input copies, the learning-rate push, output clones, host calls) are
             # ordered against the recorded launches through the CURRENT stream: only valid on the recorded one
+            return self.fn(*data)
+        if not self._fits(data):
+            # another batch shape (the tail batch of a `drop_last: False` loader, reference
+            # configs/simclr/simclr_r50_IM.yaml:88-90): this one step runs eagerly, the plan stays for the next
+            if not self._warned_shape:
+                self._warned_shape = True
+                logger.warning('StepPlan: a batch of another shape / dtype than the recorded step (%s): eager launches '
+                               'for such steps, replays continue for the recorded shape',
+                               [tuple(d.shape) for d in data if torch.is_tensor(d)])
+            self.eager_fallbacks += 1
             return self.fn(*data)
         self._load_inputs(data)
         for o in self.optimizers:
@@ -316,7 +344,7 @@ class StepPlan(object):
         if self.handle is not None:
             torch.cuda.synchronize()
             L.load().passl_hip_plan_destroy(self.handle)
-        self.handle = self.static_in = self.static_out = self._src = self._pool = None
+        self.handle = self.static_in = self.static_out = self._src = self._pool = self._scratch_pins = None
         self._host_calls = []
         self.failed = None
         self.calls = 0

@@ -47,6 +47,7 @@ class _EmbedFn(Function):
     def forward(ctx, text, table, pos, dtype):
         ctx.save_for_backward(text)
         ctx.params = (table, pos)
+        nn.param_expect_grad(table, pos)
         return ops.embed_fwd(text, table.detach(), pos.detach(), dtype)
 
     @staticmethod
@@ -67,6 +68,7 @@ class _LogitsFn(Function):
         logits, ws = ops.clip_logits_fwd(img.contiguous(), txt.contiguous(), logit_scale.detach())
         ctx.save_for_backward(logits, ws)
         ctx.scale, ctx.D = logit_scale, img.shape[1]
+        nn.param_expect_grad(logit_scale)
         return logits
 
     @staticmethod
@@ -141,6 +143,7 @@ class _CrossRankLogitsFn(Function):
         lt = ops.gemm_f32_nt(txt_n, img_all, alpha)
         ctx.save_for_backward(img_n, img_norm, txt_n, txt_norm, img_all, txt_all, alpha, li, lt)
         ctx.scale = logit_scale
+        nn.param_expect_grad(logit_scale)
         return li, lt
 
     @staticmethod

@@ -137,6 +137,7 @@ class _GatherFn(Function):
     def forward(ctx, x, cls_token, pos, ids_keep, ids_restore, B, L):
         ctx.save_for_backward(ids_restore)
         ctx.cls, ctx.dims = cls_token, (B, L, ids_keep.shape[1])
+        nn.param_expect_grad(cls_token)
         return ops.mae_gather(x, cls_token.detach().view(-1), pos.view(-1, pos.shape[-1]), ids_keep, B, L)
 
     @staticmethod
@@ -156,6 +157,7 @@ class _UnshuffleFn(Function):
     def forward(ctx, x, mask_token, pos, ids_keep, ids_restore, B):
         ctx.save_for_backward(ids_keep, ids_restore)
         ctx.tok, ctx.B = mask_token, B
+        nn.param_expect_grad(mask_token)
         return ops.mae_unshuffle(x, mask_token.detach().view(-1), pos.view(-1, pos.shape[-1]), ids_restore,
                                  B, ids_keep.shape[1])
 

@@ -177,6 +177,7 @@ class _ClsPosFn(Function):
     def forward(ctx, x, cls, pos, ids, B, L):
         ctx.save_for_backward(ids)
         ctx.params, ctx.dims = (cls, pos), (B, L)
+        nn.param_expect_grad(cls, pos)
         return ops.mae_gather(x, cls.detach().view(-1), pos.detach().view(-1, pos.shape[-1]), ids, B, L)
 
     @staticmethod

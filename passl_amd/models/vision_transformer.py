@@ -26,7 +26,7 @@ from functools import partial
 import torch
 import torch.nn as tnn
 
-from ..hip import config
+from ..hip import config, ops
 from ..hip import nn as hnn
 from ..hip.nn import EncoderArena
 from ..modeling.backbones.mae import Attention, Block, Mlp, PatchEmbed          # noqa: F401  (reference names)
@@ -74,6 +74,17 @@ class VisionTransformer(Model):
         self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
                                       embed_dim=embed_dim)
         num_patches = self.patch_embed.num_patches
+        # the attention kernels' envelope (csrc/attention.hip: head dimension 32 or 64, at most 208 tokens): a model
+        # outside it would build and then fail at its first forward — say so at construction (the reference is
+        # shape-generic: passl/models/vision_transformer.py:142-156)
+        if embed_dim % num_heads or embed_dim // num_heads not in ops.ATTENTION_HEAD_DIMS or \
+                num_patches + 1 > ops.ATTENTION_MAX_TOKENS:
+            raise NotImplementedError(
+                'VisionTransformer(img_size=%s, patch_size=%s, embed_dim=%d, num_heads=%d): %d tokens x head dimension '
+                '%s is outside the HIP attention kernels (head dimension in %s, at most %d tokens; csrc/attention.hip) '
+                '— 384^2 inputs and the huge / g / G / 6B widths need the key-tiled kernel that is not built'
+                % (img_size, patch_size, embed_dim, num_heads, num_patches + 1,
+                   embed_dim / float(num_heads), sorted(ops.ATTENTION_HEAD_DIMS), ops.ATTENTION_MAX_TOKENS))
         self.pos_embed = tnn.Parameter(torch.zeros(1, num_patches + 1, embed_dim, device=dev))
         self.cls_token = tnn.Parameter(torch.zeros(1, 1, embed_dim, device=dev))
         self.blocks = tnn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias=qkv_bias, norm_layer=norm_layer)

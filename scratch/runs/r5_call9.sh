@@ -1,0 +1,19 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+O=$GRAFT_REPO_ROOT/gpurun_out/r5_call9; rm -rf $O; mkdir -p $O
+B="python bench.py --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5"
+run() { name=$1; shift; env "$@" timeout 300 $B > $O/$name.json 2> $O/$name.err; python - <<PY
+import json
+try:
+    d=json.loads(open('$O/$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'])
+except Exception as e: print('$name', e); print(open('$O/$name.err').read()[-800:])
+PY
+}
+run base A=1
+run short400 PASSL_OPTIONS=igemm_8p_short_tiles=400
+run short800 PASSL_OPTIONS=igemm_8p_short_tiles=800
+run short800_nostats PASSL_OPTIONS=igemm_8p_short_tiles=800,igemm_8p_short_stats=0
+run short800_stats PASSL_OPTIONS=igemm_8p_short_tiles=800,igemm_8p_short_stats=2
+run short1600 PASSL_OPTIONS=igemm_8p_short_tiles=1600
+run base2 A=1

@@ -83,7 +83,7 @@ def test_every_entry_point_rejects_null_arguments(lib):
     skip = {'passl_hip_abi_version', 'passl_hip_strerror', 'passl_hip_set_option', 'passl_hip_prof_enable',
             'passl_hip_last_igemm_kernel',
             'passl_hip_infonce_workspace_bytes', 'passl_hip_infonce_bwd_workspace_bytes',
-            'passl_hip_bn_partial_floats',
+            'passl_hip_bn_partial_floats', 'passl_hip_bn_relu_maxpool_blocks',
             'passl_hip_clip_logits_ws_floats', 'passl_hip_layernorm_bwd_ws_floats',
             'passl_hip_embed_bwd_acc_bytes', 'passl_hip_embed_bwd_ws_floats'}
     checked = 0

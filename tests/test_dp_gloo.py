@@ -374,3 +374,74 @@ def test_evaluation_loop_gathers_scores_and_drops_the_sampler_repeats():
         assert abs(top1 - want) < 1e-6, (rank, top1, want)              # the metric is global and exact
         assert abs(loss - local_loss) < 1e-6                           # the loss average is per rank (as the reference)
     assert out[0][0] == out[1][0]
+
+
+def _mae_loop_case(rank, world):
+    """engine/loops/mae_pretrain_loop.py under data parallelism, on a CPU stand-in for the model (the loop is device
+    agnostic): parameters broadcast once, ONE reducer, armed before the last micro-batch of every accumulation window."""
+    from passl_amd.engine.loops import mae_pretrain_loop as loop
+    torch.manual_seed(100 + rank)                                     # replicas start DIFFERENT: param_sync must fix it
+    n = 24
+    flat = torch.randn(n)
+    grads = torch.zeros(n)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(flat)                         # the parameter IS the flat buffer
+            self.w.grad = grads
+            self.arena = SimpleNamespace(flat=self.w.data, grads=grads, param_slices=[(0, 8), (8, 16)], reducer=None)
+
+        def forward(self, x, mask_ratio=0.75):
+            return ((self.w * x).sum() ** 2) * 1e-2, None, None
+
+    class SGD(object):
+        def __init__(self, model):
+            self.m, self.lr, self.grad_scale = model, 0.0, 1.0
+
+        def set_lr(self, lr):
+            self.lr = lr
+
+        def step(self):
+            if self.m.arena.reducer is not None:
+                self.m.arena.reducer.finish()
+            with torch.no_grad():
+                self.m.w -= self.lr * self.grad_scale * self.m.w.grad
+
+        def clear_grad(self):
+            self.m.w.grad.zero_()
+
+    model = Toy()
+    opt = SGD(model)
+    data = [torch.full((n,), float(1 + rank + 2 * i)) for i in range(4)]          # each rank its own shard
+    args = SimpleNamespace(accum_iter=2, mask_ratio=0.75, lr=0.05, min_lr=0.0, warmup_epochs=0, epochs=2, print_freq=2)
+    begins = []
+    orig_begin = loop.GradReducer.begin
+    loop.GradReducer.begin = lambda self: (begins.append(1), orig_begin(self))[1]
+    try:
+        for epoch in range(2):
+            loop.train_one_epoch(model, data, opt, epoch, args, log=lambda *_: None)
+    finally:
+        loop.GradReducer.begin = orig_begin
+    assert len(begins) == 4                                           # 2 epochs x 2 accumulation windows
+    assert model._passl_grad_reducer is model.arena.reducer and opt.grad_scale == 1.0 / world
+    return model.w.detach().clone()
+
+
+def test_mae_pretrain_loop_averages_gradients_across_ranks():
+    out = _spawn(_mae_loop_case)
+    assert torch.equal(out[0], out[1])                                # replicas stay identical
+    # ... and equal to one process doing both ranks' batches with averaged gradients from rank 0's start
+    torch.manual_seed(100)
+    w = torch.randn(24)
+    lr_at = lambda e: 0.05 * 0.5 * (1.0 + __import__('math').cos(__import__('math').pi * e / 2))
+    for epoch in range(2):
+        for win in range(2):
+            lr = lr_at(epoch + (2 * win) / 4)
+            g = torch.zeros(24)
+            for rank in range(2):
+                for i in (2 * win, 2 * win + 1):
+                    x = torch.full((24,), float(1 + rank + 2 * i))
+                    g += (2e-2 * (w * x).sum() * x) / 2              # loss / accum_iter
+            w = w - lr * g / 2                                        # mean over the two ranks
+    assert torch.allclose(out[0], w, rtol=1e-5, atol=1e-6), (out[0], w)

@@ -1060,3 +1060,70 @@ def test_trace_timeline_tool_on_a_synthetic_trace(tmp_path):
     assert '1 kernels in flight: 0.450 ms per step' in out
     line = [l for l in out.splitlines() if 'bn_finalize_kernel' in l and '[' in l][0]
     assert '0.050 [0.050]' in line                       # runs alone, and with fewer than 256 workgroups
+
+
+def test_step_plan_runs_a_batch_of_another_shape_eagerly(monkeypatch):
+    """hip/replay.py:StepPlan.run: a recorded step is shape-specialised; a batch of another shape (the tail batch of a
+    `drop_last: False` loader, reference configs/simclr/simclr_r50_IM.yaml:88-90) must run as an eager step, not raise,
+    and must not touch the plan (host logic only: the recorded state is faked, nothing is launched)."""
+    import torch
+    from passl_amd.hip import replay
+    calls = []
+
+    def step(x):
+        calls.append(tuple(x.shape))
+        return {'loss': x.sum()}
+
+    plan = replay.StepPlan(step)
+    monkeypatch.setattr(replay, 'plans_enabled', lambda: True)
+    monkeypatch.setattr(replay.L, 'stream', lambda: 0)
+    plan.handle, plan._main = object(), 0                  # "recorded" for batches of 4 x 3
+    plan.static_in, plan._src = [torch.zeros(4, 3)], [None]
+    plan.__class__.__del__ = lambda self: None             # the fake handle must not reach plan_destroy
+    out = plan.run(torch.ones(2, 3))
+    assert calls == [(2, 3)] and float(out['loss']) == 6.0
+    assert plan.eager_fallbacks == 1 and plan.replays == 0 and plan.handle is not None
+    assert plan._fits([torch.zeros(4, 3)]) and not plan._fits([torch.zeros(4, 3, dtype=torch.float64)])
+    plan.handle = None
+
+
+def test_raw_parameter_readiness_counts_forward_uses():
+    """hip/nn.py: class / position embeddings, tokens and logit_scale report their gradient through the same use
+    counter as layer parameters — a Function whose forward ran twice in one step (a trunk run once per view) releases
+    the all-reduce bucket only with the second backward; without a counted forward the first report releases it."""
+    import types
+    from types import SimpleNamespace
+    import torch
+    from passl_amd.hip import nn
+    marks = []
+    fake = SimpleNamespace(reducer=SimpleNamespace(mark_ready=marks.append), _uses={})
+    for name in ('expect_grad', 'grad_ready', 'param_grad_ready'):
+        setattr(fake, name, types.MethodType(getattr(nn.EncoderArena, name), fake))
+    p = torch.nn.Parameter(torch.zeros(3))
+    p._passl_arena, p._passl_index = fake, 5
+    nn.param_expect_grad(p)
+    nn.param_expect_grad(p)                      # two forward uses in this step
+    nn.param_grad_ready(p)
+    assert marks == []
+    nn.param_grad_ready(p)
+    assert marks == [5] and fake._uses == {}
+    nn.param_grad_ready(p)                       # a backward without a counted forward: ready at once, as before
+    assert marks == [5, 5]
+    with torch.no_grad():
+        nn.param_expect_grad(p)                  # no backward will come: nothing to wait for
+    assert fake._uses == {}
+
+
+def test_vit_factories_outside_the_attention_envelope_refuse_at_construction():
+    """passl.models.vision_transformer: the reference's factories are shape-generic (vision_transformer.py:142-156);
+    the HIP attention kernels cover head dimension 32 / 64 and at most 208 tokens.  A factory outside that envelope
+    must raise when the model is BUILT (not at its first forward); the 224^2 base / large ones build."""
+    import pytest
+    from passl_amd.hip import config
+    config.set_device('cpu')
+    from passl_amd.models import vision_transformer as V
+    for name in ('ViT_base_patch16_384', 'ViT_large_patch16_384', 'ViT_huge_patch14_224', 'ViT_g_patch14_224'):
+        with pytest.raises(NotImplementedError, match='attention'):
+            getattr(V, name)(class_num=0)
+    m = V.VisionTransformer(patch_size=32, embed_dim=128, depth=1, num_heads=4, class_num=0)      # ViT-*/32 @ 224: 50 tokens
+    assert m.pos_embed.shape[1] == 50

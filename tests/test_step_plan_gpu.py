@@ -68,3 +68,43 @@ def test_plan_kill_switch(monkeypatch):
     cfg = get_config(os.path.join(ROOT, CASES[0][0]), ['dataloader.train.sampler.batch_size=8', 'compute_dtype=bf16'])
     cfg.timestamp = ''
     assert Trainer(cfg).step_graph is None
+
+
+def test_tail_batch_runs_eagerly_and_replays_continue():
+    """A batch of another shape than the recorded step (the tail batch of a `drop_last: False` loader, reference
+    configs/simclr/simclr_r50_IM.yaml:88-90) is run with eager launches instead of raising; replays continue for the
+    recorded shape; and the run equals an all-eager Trainer fed the same batches bit for bit (the scratch buffers the
+    recorded launches point into stay pinned although the eager step may grow the shared workspace)."""
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+
+    def run(plan):
+        cfg = get_config(os.path.join(ROOT, CASES[0][0]),
+                         ['dataloader.train.sampler.batch_size=16', 'compute_dtype=bf16', 'seed=3'])
+        cfg.timestamp = ''
+        cfg.step_plan = plan
+        tr = Trainer(cfg)
+        tr.mode = 'train'
+        tr.model.train()
+        data = next(iter(tr.train_dataloader))
+        short = [d[:8].contiguous() if torch.is_tensor(d) else d for d in data] if isinstance(data, (list, tuple)) \
+            else {k: (v[:8].contiguous() if torch.is_tensor(v) else v) for k, v in data.items()}
+        tr.call_hook('run_begin')
+        tr.call_hook('train_epoch_begin')
+        losses = []
+        for it in range(9):
+            tr.inner_iter = tr.current_iter % tr.iters_per_epoch
+            tr.current_iter += 1
+            tr.call_hook('train_iter_begin')
+            tr.train_step(short if it == 6 else data)
+            tr.call_hook('train_iter_end')
+            losses.append(tr.outputs['loss'].detach().reshape(()).float().clone())
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), tr.model.arena_q.flat.clone().cpu(), tr.step_graph
+
+    le, fe, _ = run(False)
+    torch.cuda.empty_cache()
+    lp, fp, sg = run(True)
+    assert sg.captured and sg.eager_fallbacks == 1 and sg.replays == 4, (sg.eager_fallbacks, sg.replays)
+    assert torch.equal(le.view(torch.int32), lp.view(torch.int32)), (le, lp)
+    assert torch.equal(fe.view(torch.int32), fp.view(torch.int32))
