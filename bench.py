@@ -35,7 +35,8 @@ FLOP_PER_SAMPLE = 32.77e9      # 2*[(3+1)*(4.0871+0.00446) + 2*0.00
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured streaming ceiling)
-PMC_TRAFFIC_FILE = os.path.join('profiles', 'r04_pmc_traffic.json')
+PMC_TRAFFIC_FILE = os.path.join('profiles', 'r05_pmc_traffic.json')
+STREAM_HBM_GBS = 6290.0        # measured float4-copy ceiling (MI355X_MICROARCH.md, chip-level parameters)
 
 # workload -> (config, default per-GPU batch, algorithmic FLOP per sample, metric text, workload text)
 WORKLOADS = {
@@ -157,6 +158,8 @@ def pmc_traffic(args):
     for k in ('ring', 'g8p', 'igemm', 'wgrad'):
         if k in z.get('classes', {}):
             out[k] = {'hbm_bytes_per_launch': z['classes'][k]['hbm_bytes_per_launch'], 'source': src}
+    if 'fetch_gb_per_step' in z and 'write_gb_per_step' in z:
+        out['_step'] = {'fetch_gb': z['fetch_gb_per_step'], 'write_gb': z['write_gb_per_step'], 'source': src}
     return out
 
 
@@ -395,6 +398,21 @@ def main():
                 'achieved_tflops_per_gpu': round(ips / world * flop_per_sample / 1e12, 2),
                 'frac_of_peak': round(ips / world * flop_per_sample / 1e12 / peak, 5)},
         }
+        step_traffic = (pmc_traffic(args) or {}).get('_step')
+        if step_traffic is not None:
+            # the whole step against what its HBM traffic alone would cost (round-4 verdict: put the "x times its
+            # traffic floor" claim into the record): counter bytes of the committed PMC passes of this command over
+            # the measured streaming ceiling and over the spec
+            gb = step_traffic['fetch_gb'] + step_traffic['write_gb']
+            out['hbm_bytes_per_step'] = round(gb * 1e9)
+            out['hbm_floor_ms'] = round(gb / STREAM_HBM_GBS * 1e3, 3)
+            out['hbm'] = {'gb_per_step': round(gb, 2), 'fetch_gb': step_traffic['fetch_gb'],
+                          'write_gb': step_traffic['write_gb'],
+                          'floor_ms_at_measured_copy_ceiling_6.29TBs': round(gb / STREAM_HBM_GBS * 1e3, 3),
+                          'floor_ms_at_spec_8TBs': round(gb / PEAK_HBM_GBS * 1e3, 3),
+                          'step_over_floor': round(1000 * elapsed / args.steps / (gb / STREAM_HBM_GBS * 1e3), 3),
+                          'average_tb_per_s': round(gb / (1000 * elapsed / args.steps), 3),
+                          'source': step_traffic['source']}
         if kern and kern['ring']['n'] + kern['igemm']['n'] + kern['g8p']['n'] > 0:
             traffic = pmc_traffic(args)
 
@@ -429,7 +447,8 @@ def main():
                         'fwd / dgrad and Linear launches)', 'mfma', 'roofline_8p_kernel'),
                 'igemm': ('igemm_kernel (register-staged implicit GEMM: 1x1 layers with a reduction < 512, stem)',
                           'hbm' if args.dtype == 'bf16' else 'mfma', 'roofline_hbm_kernel'),
-                'wgrad': ('wgrad_pipe_kernel (weight gradients, split over M + fixed-order slab reduction)', 'mfma',
+                'wgrad': ('wgrad_pipe_kernel + wgrad_halo_kernel (weight gradients, split over M + fixed-order slab reduction; the 3x3 / stride-1 '
+                          'layers on the spatially tiled kernel since round 5)', 'mfma',
                           'roofline_wgrad_kernel')}
             blocks = {k: block(k, t[0], t[1]) for k, t in titles.items()}
             dominant = max((k for k in blocks if blocks[k] is not None), key=lambda k: kern[k]['ms'])

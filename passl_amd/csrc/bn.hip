@@ -290,6 +290,16 @@ __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
     float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
+  // the per-channel parameters travel with the slab loads (one round trip), not behind the reduction: under load
+  // every dependent round trip of this latency-bound launch costs microseconds of the step's main chain
+  float ga[2] = {0.f, 0.f}, be[2] = {0.f, 0.f}, rm[2] = {0.f, 0.f}, rv[2] = {0.f, 0.f};
+  if (threadIdx.x < 4 && c < C) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      ga[e] = gamma[c + e]; be[e] = beta[c + e];
+      if (rmean) { rm[e] = rmean[c + e]; rv[e] = rvar[c + e]; }
+    }
+  }
   double t1[2], t2[2];
   float g0[2];
   if (!slab_totals<true>(partial, nblocks, C, M, rows_per_block, seg_rows, scratch, counters, c, t1, t2, g0)) return;
@@ -303,12 +313,12 @@ __global__ void __launch_bounds__(kFinThreads) bn_finalize_kernel(
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c + e] = (float)mu;
     invstd[c + e] = is;
-    const float sc = gamma[c + e] * is;
+    const float sc = ga[e] * is;
     scale[c + e] = sc;
-    shift[c + e] = beta[c + e] - (float)mu * sc;
+    shift[c + e] = be[e] - (float)mu * sc;
     if (rmean) {
-      rmean[c + e] = momentum * rmean[c + e] + (1.0f - momentum) * (float)mu;
-      rvar[c + e] = momentum * rvar[c + e] + (1.0f - momentum) * (float)var;
+      rmean[c + e] = momentum * rm[e] + (1.0f - momentum) * (float)mu;
+      rvar[c + e] = momentum * rv[e] + (1.0f - momentum) * (float)var;
     }
   }
 }
@@ -320,19 +330,26 @@ __global__ void __launch_bounds__(kFinThreads) bn_bwd_finalize_kernel(
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ coef) {
   const int c = blockIdx.x * kFinCh + (threadIdx.x & 3) * 2;
+  float ga[2] = {0.f, 0.f}, mu[2] = {0.f, 0.f}, is[2] = {0.f, 0.f}, dg[2] = {0.f, 0.f}, db[2] = {0.f, 0.f};
+  if (threadIdx.x < 4 && c < C) {          // with the slab loads, not behind the reduction (bn_finalize_kernel)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      ga[e] = gamma[c + e]; mu[e] = mean[c + e]; is[e] = invstd[c + e]; dg[e] = dgamma[c + e]; db[e] = dbeta[c + e];
+    }
+  }
   double sg[2], sgx[2];
   float unused[2];
   if (!slab_totals<false>(partial, nblocks, C, M, 0, seg_rows, scratch, counters, c, sg, sgx, unused)) return;
   const double inv_m = 1.0 / (double)M;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
-    dbeta[c + e] += (float)sg[e];      // accumulate: the flat gradient buffer is zeroed by clear_grad()
-    dgamma[c + e] += (float)sgx[e];
+    dbeta[c + e] = db[e] + (float)sg[e];      // accumulate: the flat gradient buffer is zeroed by clear_grad()
+    dgamma[c + e] = dg[e] + (float)sgx[e];
     // dx = gamma*invstd*( g - sg/M - xhat*sgx/M ),  xhat = (x-mean)*invstd
-    const double isd = (double)invstd[c + e];
-    const double gi = (double)gamma[c + e] * isd;
+    const double isd = (double)is[e];
+    const double gi = (double)ga[e] * isd;
     const double B = -gi * isd * sgx[e] * inv_m;
-    const double Cc = -gi * sg[e] * inv_m - B * (double)mean[c + e];
+    const double Cc = -gi * sg[e] * inv_m - B * (double)mu[e];
     coef[c + e] = (float)gi;
     coef[C + c + e] = (float)B;
     coef[2 * C + c + e] = (float)Cc;

@@ -27,6 +27,28 @@ __global__ void __launch_bounds__(kThreads) nchw_to_nhwc_pad_kernel(
   }
 }
 
+// The stem's case (Cp = 4, bf16: an output pixel is 8 bytes): one thread per pixel, ONE 8-byte store instead of four
+// 2-byte stores, 32-bit index arithmetic, no grid-stride loop (r05: 112 -> ~50 us per 256 x 3 x 224 x 224 batch).
+__global__ void __launch_bounds__(kThreads) nchw_to_nhwc_pad4_bf16_kernel(
+    const float* __restrict__ x, bf16_t* __restrict__ y, uint32_t total, int C, int H, int W, int pad, int Hp, int Wp) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= total) return;
+  const int wp = (int)(i % (uint32_t)Wp);
+  const uint32_t t = i / (uint32_t)Wp;
+  const int hp = (int)(t % (uint32_t)Hp);
+  const int n = (int)(t / (uint32_t)Hp);
+  const int h = hp - pad, w = wp - pad;
+  const bool in = (h >= 0) && (h < H) && (w >= 0) && (w < W);
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (in) {
+    const float* px = x + ((int64_t)n * C * H + h) * W + w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) v[c] = px[(int64_t)c * H * W];
+  }
+  *reinterpret_cast<uint2*>(y + (int64_t)i * 4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+
 // 3x3 s2 p1 max pool; one thread per (n,p,q, 8-channel chunk), one pass per thread (no grid-stride
 // loop).  Branch-free: the 9 taps are loaded from CLAMPED coordinates back to back (9 x 16 B in flight
 // per lane) and an out-of-range tap simply never wins.
@@ -264,6 +286,12 @@ extern "C" int passl_hip_nchw_to_nhwc_pad(const float* x, void* y, int N, int C,
     return PASSL_EINVAL;
   const int Hp = H + 2 * pad;
   const int64_t total = (int64_t)N * Hp * Wp;
+  if (dtype == PASSL_BF16 && Cp == 4 && C <= 4 && total <= 0x7fffffffll && (reinterpret_cast<uintptr_t>(y) & 7) == 0) {
+    hipLaunchKernelGGL(nchw_to_nhwc_pad4_bf16_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads),
+                       0, as_stream(stream), x, reinterpret_cast<bf16_t*>(y), (uint32_t)total, C, H, W, pad, Hp, Wp);
+    PASSL_RETURN_IF_LAUNCH_FAILED();
+    return PASSL_OK;
+  }
   DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel<T>, dim3(grid_for(total)),
                                            dim3(kThreads), 0, as_stream(stream), x,
                                            reinterpret_cast<T*>(y), N, C, H, W, pad, Hp, Wp, Cp);)
