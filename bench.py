@@ -94,6 +94,9 @@ def parse():
                     help='skip the instrumented loop (use under rocprofv3)')
     ap.add_argument('--dp-buckets', type=int, default=0,
                     help='number of gradient all-reduce buckets (default: 28 MB buckets = 4 for MoCo)')
+    ap.add_argument('--dp-wire', default='', choices=['', 'fp32', 'bf16'],
+                    help='dtype of the gradient buckets on the wire (default fp32 = the reference; bf16 halves the bytes per '
+                         'xGMI link, sums agree to bf16 rounding: core/sync_utils.py)')
     ap.add_argument('--roofline-steps', type=int, default=10,
                     help='steps of the instrumented loop that follows the timed loop')
     return ap.parse_args()
@@ -209,6 +212,8 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if args.dp_buckets:
         os.environ['PASSL_DP_BUCKETS'] = str(args.dp_buckets)
+    if args.dp_wire:
+        os.environ['PASSL_DP_WIRE'] = args.dp_wire
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
 
@@ -369,6 +374,8 @@ def main():
                      'distinct_devices': len({(e['host'], e['uuid'] or e['device']) for e in everyone}),
                      'grad_buckets': len(red.buckets) if red is not None else 0,
                      'grad_bytes': int(red.grads.numel() * 4) if red is not None else 0,
+                     'grad_wire_dtype': ('bf16' if red.wire is not None else 'fp32') if red is not None else None,
+                     'grad_wire_bytes': int(red.grads.numel() * (2 if red.wire is not None else 4)) if red is not None else 0,
                      'allreduce_exposed_ms': round(float(ex.item()), 3) if float(ex.item()) >= 0 else None,
                      'allreduce_exposed_what': 'max over ranks of the time the compute stream waits for gradient '
                                                'collectives after backward has finished (3 extra steps, HIP events)'}

@@ -42,15 +42,38 @@ def collectives_active(group=None):
     return dist.get_world_size(group) > 1 or dp_forced()
 
 
+def _cast(src, dst):
+    """dst[...] = src[...] across fp32 <-> bf16 (contiguous slices of equal length): the library's cast kernels on the
+    device (launches a step plan can replay), torch on the host (gloo tests)."""
+    if src.is_cuda:
+        from ..hip import lib as L
+        fn = L.load().passl_hip_cast_f32_to_bf16 if src.dtype == torch.float32 else L.load().passl_hip_cast_bf16_to_f32
+        L.check(fn(L.ptr(src), L.ptr(dst), src.numel(), L.stream()), 'gradient wire cast')
+    else:
+        dst.copy_(src)
+
+
 class GradReducer(object):
     """Bucketed, overlapped all-reduce over a flat gradient buffer."""
 
-    def __init__(self, arena, optimizer=None, bucket_elems=None, group=None):
+    def __init__(self, arena, optimizer=None, bucket_elems=None, group=None, wire_dtype=None):
         """bucket_elems: fp32 gradients per bucket (default 7 Mi = 28 MB, i.e. 4 buckets for R50 + projector);
-        ``PASSL_DP_BUCKETS=n`` asks for n equal buckets instead (bench.py --dp-buckets)."""
+        ``PASSL_DP_BUCKETS=n`` asks for n equal buckets instead (bench.py --dp-buckets).
+        wire_dtype: torch.bfloat16 (or ``PASSL_DP_WIRE=bf16``) sends every bucket as bf16 — half the bytes per xGMI
+        link (56 MB instead of 112 MB for R50; the last bucket, which backward cannot hide, shrinks with it): the
+        bucket is cast into a resident bf16 twin of the gradient buffer right before its all-reduce and cast back
+        after the final wait, so accumulation, the 1 / world scale and the optimizer stay fp32.  The SUM over ranks is
+        then formed in bf16 by the collective: gradients agree with the fp32 wire to bf16 rounding (~3 significant
+        digits), not bit for bit — opt-in; the default (fp32) is the reference's behaviour."""
         if bucket_elems is None:
             n_b = int(os.environ.get('PASSL_DP_BUCKETS', '0') or 0)
             bucket_elems = -(-arena.n_train // n_b) if n_b > 0 else 7 * 1024 * 1024
+        if wire_dtype is None and os.environ.get('PASSL_DP_WIRE', '').lower() in ('bf16', 'bfloat16'):
+            wire_dtype = torch.bfloat16
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError('wire_dtype must be None / torch.float32 / torch.bfloat16')
+        self.wire = None if wire_dtype in (None, torch.float32) else \
+            torch.empty(arena.grads.numel(), dtype=wire_dtype, device=arena.grads.device)
         self.arena = arena
         self.group = group
         self.world = _ws(group)
@@ -110,6 +133,11 @@ class GradReducer(object):
         if self.world > 1 or self._forced:
             from ..hip.replay import host_call
             grads, group = self.grads, self.group
+            if self.wire is not None:
+                # a launch of the library on the current stream, OUTSIDE the host call: a recorded step replays it as
+                # part of the plan, the live collective below then reads the twin
+                _cast(self.grads[s:e], self.wire[s:e])
+                grads = self.wire
 
             def collective():
                 # a live call also when the step is replayed from a native plan (hip/replay.py: the plan is cut here).
@@ -158,6 +186,9 @@ class GradReducer(object):
             self._handles = []
         if self._handles or self.world > 1 or self._forced:
             host_call(wait_all)                 # (live at every replay of a recorded step: see _launch)
+            if self.wire is not None:
+                for s, e, _ in self.buckets:    # the reduced sums back into the fp32 buffer the optimizer reads
+                    _cast(self.wire[s:e], self.grads[s:e])
         self._active = False
         uses = getattr(self.arena, '_uses', None)
         if uses:

@@ -445,3 +445,37 @@ def test_mae_pretrain_loop_averages_gradients_across_ranks():
                     g += (2e-2 * (w * x).sum() * x) / 2              # loss / accum_iter
             w = w - lr * g / 2                                        # mean over the two ranks
     assert torch.allclose(out[0], w, rtol=1e-5, atol=1e-6), (out[0], w)
+
+
+def _wire_case(rank, world):
+    """GradReducer(wire_dtype=bf16): every bucket travels as bf16 (half the bytes per link), the buffer stays fp32."""
+    from passl_amd.core.sync_utils import GradReducer
+    sizes = [40, 8, 8, 100, 16, 16, 200, 8, 64, 24]
+    out = {}
+    for name, wire in (('fp32', None), ('bf16', torch.bfloat16)):
+        arena = _fake_arena(sizes)
+        red = GradReducer(arena, SimpleNamespace(grad_scale=1.0), bucket_elems=128, wire_dtype=wire)
+        assert (red.wire is not None) == (wire is not None)
+        torch.manual_seed(7 + rank)
+        red.begin()
+        for i in range(len(sizes) - 1, -1, -1):
+            off, n = arena.param_slices[i]
+            arena.grads[off:off + n] = torch.randn(n) * (10.0 ** (i % 4 - 2))      # four decades of magnitudes
+        out['own'] = arena.grads.clone()
+        for i in range(len(sizes) - 1, -1, -1):
+            red.mark_ready(i)
+        red.finish()
+        assert arena.grads.dtype == torch.float32
+        out[name] = arena.grads.clone()
+    return out
+
+
+def test_grad_reducer_bf16_wire_matches_fp32_to_bf16_rounding():
+    out = _spawn(_wire_case)
+    for name in ('fp32', 'bf16'):
+        assert torch.equal(out[0][name], out[1][name])                 # both ranks hold the same sums
+    ref, got = out[0]['fp32'], out[0]['bf16']
+    assert not torch.equal(ref, got)                                   # it really went through bf16 ...
+    # ... each rank's contribution is rounded to bf16 (2^-9 relative to ITS magnitude) and so is their sum
+    bound = 2.0 ** -8 * (out[0]['own'].abs() + out[1]['own'].abs() + ref.abs()) + 1e-30
+    assert bool(((got - ref).abs() <= bound).all()), float(((got - ref).abs() / bound).max())
