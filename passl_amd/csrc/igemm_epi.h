@@ -18,6 +18,10 @@
 
 namespace epi {
 
+// tuning switches of the register-staged kernel (PASSL_IGEMM_DBG, conv_igemm.hip: Params::dbg); 0 for the other kernels
+template <typename P> __device__ __forceinline__ auto dbg_of(const P& p, int) -> decltype(p.dbg) { return p.dbg; }
+template <typename P> __device__ __forceinline__ int dbg_of(const P&, long) { return 0; }
+
 __device__ __forceinline__ void unpack8(const uint4 v, float (&a)[8]) {
   a[0] = __uint_as_float(v.x << 16); a[1] = __uint_as_float(v.x & 0xffff0000u);
   a[2] = __uint_as_float(v.y << 16); a[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -163,7 +167,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       v = pack8(g);           // exact: g holds bf16 values or zeros
     }
     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.y) + o) = v;
-    if (fstats) {
+    if (fstats && !(dbg_of(p, 0) & 32)) {
       float x[8];
       unpack8(v, x);
 #pragma unroll
@@ -175,6 +179,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
     }
   }
   if (!fstats && !bnb) return;
+  if (dbg_of(p, 0) & 16) return;          // (ablation: no cross-thread reduction, no slab)
 
   // threads tid, tid+CPR, ... share a column chunk: each writes its 16 partial values to
   // red[tid / CPR][BN][2] (the output tile is dead by now), 2*BN threads add the NTHREADS/CPR

@@ -720,12 +720,12 @@ static int run_sweep(int n, char** cfgs) {
 // loads, 8 = no MFMAs) on the 1x1 shapes it serves: what a tile's time is made of.
 static int run_ablate() {
   setenv("PASSL_IGEMM_DBG_DYNAMIC", "1", 1);
-  const int sets[] = {0, 2, 8, 4, 2 | 8, 2 | 4 | 8};
+  const int sets[] = {0, 16, 16 | 32, 2, 8, 4, 2 | 8, 2 | 4 | 8};
   const Shape shapes[] = {kR50[6], kR50[7], kR50[8], kR50[10], {256, 64, 64, 1, 1, 56, "64->64 k1 @56", 1}};
   Buffers B;
   printf("%-22s", "PASSL_IGEMM_DBG =");
   for (int v : sets) printf(" %8d", v);
-  printf("   (us; 2 no epilogue, 4 no A loads, 8 no MFMA)\n");
+  printf("   (us, with fused statistics; 16 no statistics reduction / slab, 32 no statistics arithmetic, 2 no epilogue, 4 no A loads, 8 no MFMA)\n");
   for (const Shape& sh : shapes) {
     printf("%-22s", sh.note);
     for (int v : sets) {
