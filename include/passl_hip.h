@@ -223,6 +223,18 @@ typedef struct passl_conv_desc {
   int32_t stats_tiles;     /* must equal ceil(N*OP*OQ / 128) when stats != NULL */
   int32_t bnb_relu;
   int32_t bnb_tile_off;    /* first slab row of this launch (residue-class launches share one slab) */
+  /* A SECOND BatchNorm fed by the same gradient (all NULL = none; needs bnb_partial).  The output of a bottleneck block
+   * with a downsample branch is relu(bn3(y3) + bn_ds(y_ds)): the masked gradient g this launch stores is the output
+   * gradient of BOTH BatchNorm layers.  With bnb2_* set the epilogue also writes, per 128-row tile t,
+   *   bnb2_partial[bnb_tile_off + t][col][0..1] = sum g, sum g * (bnb2_y - bnb2_mean[col]) * bnb2_invstd[col]
+   * (bnb2_y addressed like y), so the second layer's backward needs no reduce pass over (g, bnb2_y) either.
+   * Built for dense 1x1 / stride-1 launches with C % 64 == 0 and NCOLS >= 128 (the conv1 data gradients that follow a
+   * downsample block: resnetimagenet.py:139-153); PASSL_EUNSUPPORTED otherwise — launch without and run
+   * passl_hip_bn_bwd_reduce for the second layer. */
+  const void* bnb2_y;
+  const float* bnb2_mean;
+  const float* bnb2_invstd;
+  float* bnb2_partial;
 } passl_conv_desc;
 int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t stream);
 

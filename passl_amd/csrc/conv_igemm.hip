@@ -74,6 +74,10 @@ struct Params {
   const float* bnb_shift;
   float* bnb_partial;
   int bnb_relu, bnb_tile_off;
+  const char* bnb2_y;         // a second BatchNorm fed by the same gradient (igemm_epi.h: BNB2 instantiation only)
+  const float* bnb2_mean;
+  const float* bnb2_invstd;
+  float* bnb2_partial;
   int M, NCOLS, KDIM;
   int OP, OQ, R, S, C, IH, IW, sh, sw, ph, pw;
   int64_t a_sn, a_sh, a_sw;
@@ -88,7 +92,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1
 
 // DENSE: 1x1 / stride 1 / no padding with dense A and Y: row m lives at m*C resp. m*NCOLS, no
 // (n,op,oq) decomposition at all.
-template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false>
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false, bool BNB2 = false>
 __global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) ? 3 : 2))
     igemm_kernel(const Params p) {
   constexpr int ES = sizeof(T);
@@ -369,11 +373,11 @@ __global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) 
     }
   } else {
     // ---- bf16 epilogue (shared with the ring kernel): igemm_epi.h
-    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, LEAN>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
+    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, LEAN, FN, 0, BNB2>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
   }
 }
 
-template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false>
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false, bool BNB2 = false>
 int launch(const Params& p, hipStream_t st) {
   constexpr int STAGE = STAGES * (BM + BN) * kRowBytes;
   constexpr int EPI = EPI32 ? BM * (BN + 4) * 4 : BM * (BN + 8) * 2;
@@ -381,11 +385,11 @@ int launch(const Params& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN>),
+        reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN, BNB2>),
         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN>), dim3(p.ntiles),
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN, BNB2>), dim3(p.ntiles),
                      dim3(kThreads), LDS, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
@@ -428,6 +432,7 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
 }  // namespace
 
 int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st);   // conv_igemm_ring.hip
+int passl_igemm_ring_bnb2(const passl_conv_desc* d, hipStream_t st);  // ... its two-BatchNorm instantiation
 int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st);     // conv_igemm_8p.hip
 int passl_stem_try(const passl_conv_desc* d, hipStream_t st);         // conv_stem.hip
 
@@ -473,6 +478,8 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
   p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
   p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
+  p.bnb2_y = reinterpret_cast<const char*>(d->bnb2_y); p.bnb2_mean = d->bnb2_mean; p.bnb2_invstd = d->bnb2_invstd;
+  p.bnb2_partial = d->bnb2_partial;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.R = d->R; p.S = d->S; p.C = d->C;
   p.IH = d->IH; p.IW = d->IW; p.sh = d->sh; p.sw = d->sw; p.ph = d->ph; p.pw = d->pw;
@@ -513,6 +520,28 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
   const double w_bytes = in_px * d->C * es + (double)d->NCOLS * K64 * es +
                          (double)M64 * d->NCOLS * es_out * (1 + (d->residual ? 1 : 0)) +
                          (d->bnb_partial ? (double)M64 * d->NCOLS * es : 0.0);
+  if (d->bnb2_partial) {
+    // two BatchNorm layers behind one gradient (passl_conv_desc.bnb2_*): its own instantiations of the register-staged
+    // kernel (reductions below 8 K-tiles) and of the ring kernel, dense 1x1 launches only
+    if (!d->bnb_partial || !d->bnb2_y || !d->bnb2_mean || !d->bnb2_invstd || !aligned16(d->bnb2_y)) return PASSL_EINVAL;
+    if (!dense || generic || narrow || d->dtype != PASSL_BF16) return PASSL_EUNSUPPORTED;
+    const int nk = (p.KDIM + bk - 1) / bk;
+    if (nk >= 8) {
+      passl_prof_begin(0, st);
+      const int rc2 = passl_igemm_ring_bnb2(d, st);
+      passl_prof_work(0, w_flops, w_bytes + (double)M64 * d->NCOLS * es);
+      passl_prof_end(0, st);
+      g_last_kernel = 1;
+      return rc2;
+    }
+    if (nk > nk1_threshold()) return PASSL_EUNSUPPORTED;
+    passl_prof_begin(2, st);
+    const int rc2 = launch<bf16_t, 128, 128, false, 1, false, true, false, true>(p, st);
+    passl_prof_work(2, w_flops, w_bytes + (double)M64 * d->NCOLS * es);
+    passl_prof_end(2, st);
+    g_last_kernel = 0;
+    return rc2;
+  }
   passl_prof_begin(0, st);
   int rc = passl_igemm_8p_try(d, st);              // 256 x 256 tiles, 8-phase schedule: wide, deep GEMMs
   if (rc != PASSL_EUNSUPPORTED) {

@@ -35,7 +35,7 @@ namespace ring {
 // stages keeps the 64 KB ring (2 workgroups per CU) but has up to 3 half-tiles in flight.
 __device__ __forceinline__ int swz32(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-template <int BM, int BN, int STAGES, int BK = 64>
+template <int BM, int BN, int STAGES, int BK = 64, bool BNB2 = false>
 __global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 <= 53 * 1024) ? 3 : 2)
     igemm_ring_kernel(const Params p) {
   constexpr int RB = BK * 2;                // LDS row bytes
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 
 
   // ---- epilogue (shared with igemm_kernel's bf16 path): igemm_epi.h
   if constexpr (BM == 128) {
-    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
+    epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, false, FN, 0, BNB2>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
   } else {
     // 256-row tiles (experimental igemm_ring_bm = 256): plain epilogue, no fused statistics
     // (passl_igemm_ring_try refuses stats / bnb launches for this tile shape)
@@ -323,16 +323,16 @@ __global__ void __launch_bounds__(BM * 2, (STAGES * (BM + BN) * BK * 2 + BM * 8 
   }
 }
 
-template <int BM, int BN, int STAGES, int BK = 64>
+template <int BM, int BN, int STAGES, int BK = 64, bool BNB2 = false>
 int launch(const Params& p, hipStream_t st) {
   constexpr int LDS = STAGES * (BM + BN) * BK * 2 + BM * 8;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, STAGES, BK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_ring_kernel<BM, BN, STAGES, BK, BNB2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, STAGES, BK>), dim3(p.ntiles), dim3(BM * 2), LDS, st, p);
+  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, STAGES, BK, BNB2>), dim3(p.ntiles), dim3(BM * 2), LDS, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
@@ -389,4 +389,11 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st) {
     return bn == 64 ? ring::launch<128, 64, 3, 32>(p, st) : ring::launch<128, 128, 3, 32>(p, st);
   if (g_ring_bk == 32) return bn == 64 ? ring::launch<128, 64, 4, 32>(p, st) : ring::launch<128, 128, 4, 32>(p, st);
   return bn == 64 ? ring::launch<128, 64, 2>(p, st) : ring::launch<128, 128, 2>(p, st);
+}
+
+// The two-BatchNorm instantiation (passl_conv_desc.bnb2_*; the caller has checked: dense 1x1, bf16, >= 8 K-tiles, NCOLS > 64)
+int passl_igemm_ring_bnb2(const passl_conv_desc* d, hipStream_t st) {
+  ring::Params p;
+  if (!ring::fill_params(d, 128, 128, p)) return PASSL_EUNSUPPORTED;
+  return ring::launch<128, 128, 2, 64, true>(p, st);
 }

@@ -49,6 +49,10 @@ struct Params {
   const float* bnb_shift;
   float* bnb_partial;
   int bnb_relu, bnb_tile_off;
+  const char* bnb2_y;         // a second BatchNorm fed by the same gradient (igemm_epi.h: BNB2 instantiation only)
+  const float* bnb2_mean;
+  const float* bnb2_invstd;
+  float* bnb2_partial;
   int64_t a_total;            // bytes of the whole A tensor (may exceed 32 bits: every workgroup rebases its buffer)
   uint32_t b_bytes;
   int M, NCOLS, KDIM;
@@ -98,6 +102,8 @@ static inline bool fill_params(const passl_conv_desc* d, int bm, int bn, Params&
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd;
   p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
   p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
+  p.bnb2_y = reinterpret_cast<const char*>(d->bnb2_y); p.bnb2_mean = d->bnb2_mean; p.bnb2_invstd = d->bnb2_invstd;
+  p.bnb2_partial = d->bnb2_partial;
   p.a_total = a_bytes; p.b_bytes = (uint32_t)b_bytes;
   p.M = (int)M64; p.NCOLS = d->NCOLS; p.KDIM = (int)K64;
   p.OP = d->OP; p.OQ = d->OQ; p.S = d->S; p.C = d->C;

@@ -39,8 +39,10 @@ __device__ __forceinline__ uint4 pack8(const float (&a)[8]) {
 // Column of accumulator fragment j: (j / FNH) * CH + wn * WN + (j % FNH) * 16 (+ 4 * (lane >> 4)); the
 // defaults (FNH = FN, CH = 0) are one contiguous WN-wide strip per wave, the 8-phase kernel's waves own one
 // 32-column strip in each 128-column half of the tile (FNH = 2, CH = 128).
+// BNB2 (compile-time: its own kernel instantiations only): a second BatchNorm fed by the same gradient
+// (passl_conv_desc.bnb2_*): one more row load and one more accumulator in the row loop, a second fold through LDS.
 template <int BM, int BN, int NTHREADS, int FM, int FN, int WM, int WN, bool LEAN = false, int FNH = FN, int CH = 0,
-          typename P>
+          bool BNB2 = false, typename P>
 __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int64_t* rowoff,
                                               const f32x4 (&acc)[FM][FN], int wm, int wn, int lane,
                                               int tid, int n0, int mt) {
@@ -87,6 +89,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
   const int gcol = n0 + cc * 8;
   const bool col_ok = gcol < p.NCOLS;
   uint4 rres[NT], ry[NT];
+  uint4 ry2[BNB2 ? NT : 1];
   uint32_t rmask[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -105,6 +108,7 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       if (bnb) {
         ry[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_y) + roff + gcol);
         if (p.bnb_relu == 3) rmask[t] = p.bnb_mask[(roff + gcol) >> 3];
+        if constexpr (BNB2) ry2[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb2_y) + roff + gcol);
       }
     }
   }
@@ -130,6 +134,16 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
 
   float s0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float s1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // BNB2: sum g * xhat of the second BatchNorm
+  float c4[8], c5[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { c4[e] = 0.f; c5[e] = 0.f; }
+  if constexpr (BNB2) {
+    if (bnb && col_ok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { c4[e] = p.bnb2_mean[gcol + e]; c5[e] = p.bnb2_invstd[gcol + e]; }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int row = (tid + t * NTHREADS) / CPR;
@@ -163,6 +177,12 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       for (int e = 0; e < 8; ++e) {
         s0[e] += g[e];
         s1[e] += g[e] * (yv[e] - c0[e]) * c1[e];
+      }
+      if constexpr (BNB2) {
+        float y2[8];
+        unpack8(ry2[t], y2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s2[e] += g[e] * (y2[e] - c4[e]) * c5[e];
       }
       v = pack8(g);           // exact: g holds bf16 values or zeros
     }
@@ -200,13 +220,31 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
     *reinterpret_cast<float4*>(sp + 4) = make_float4(c0[4], c0[5], c0[6], c0[7]);
   }
   __syncthreads();
+  const int64_t trow = fstats ? (int64_t)mt : (int64_t)p.bnb_tile_off + mt;
   if (tid < 2 * BN && n0 + (tid >> 1) < p.NCOLS) {
     float a = 0.f;
 #pragma unroll
     for (int j = 0; j < J; ++j) a += red[j * (BN * 2) + tid];
     float* slab = fstats ? p.stats : p.bnb_partial;
-    const int64_t trow = fstats ? (int64_t)mt : (int64_t)p.bnb_tile_off + mt;
     slab[(trow * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1)] = a;
+  }
+  if constexpr (BNB2) {
+    if (!bnb) return;
+    // the second layer's slab row: (sum g, sum g * xhat2) folded the same way
+    __syncthreads();
+    {
+      float* dst = red + (tid / CPR) * (BN * 2) + cc * 16;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        *reinterpret_cast<float4*>(dst + e * 2) = make_float4(s0[e], s2[e], s0[e + 1], s2[e + 1]);
+    }
+    __syncthreads();
+    if (tid < 2 * BN && n0 + (tid >> 1) < p.NCOLS) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) a += red[j * (BN * 2) + tid];
+      p.bnb2_partial[(trow * p.NCOLS + n0 + (tid >> 1)) * 2 + (tid & 1)] = a;
+    }
   }
 }
 

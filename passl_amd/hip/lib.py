@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ('a_sn', c_l), ('a_sh', c_l), ('a_sw', c_l),
                 ('y_sn', c_l), ('y_sh', c_l), ('y_sw', c_l),
                 ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32),
-                ('stats_tiles', C.c_int32), ('bnb_relu', C.c_int32), ('bnb_tile_off', C.c_int32)]
+                ('stats_tiles', C.c_int32), ('bnb_relu', C.c_int32), ('bnb_tile_off', C.c_int32),
+                ('bnb2_y', c_p), ('bnb2_mean', c_p), ('bnb2_invstd', c_p), ('bnb2_partial', c_p)]
 
 
 class WgradDesc(C.Structure):
