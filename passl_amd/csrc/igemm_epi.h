@@ -89,7 +89,6 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
   const int gcol = n0 + cc * 8;
   const bool col_ok = gcol < p.NCOLS;
   uint4 rres[NT], ry[NT];
-  uint4 ry2[BNB2 ? NT : 1];
   uint32_t rmask[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -108,7 +107,6 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
       if (bnb) {
         ry[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_y) + roff + gcol);
         if (p.bnb_relu == 3) rmask[t] = p.bnb_mask[(roff + gcol) >> 3];
-        if constexpr (BNB2) ry2[t] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb2_y) + roff + gcol);
       }
     }
   }
@@ -179,8 +177,10 @@ __device__ __forceinline__ void epilogue_bf16(const P& p, char* smem, const int6
         s1[e] += g[e] * (yv[e] - c0[e]) * c1[e];
       }
       if constexpr (BNB2) {
+        // (loaded here, not with the other rows in front of the barrier: 32 more live registers there push the
+        // instantiation from 3 to 2 workgroups per CU)
         float y2[8];
-        unpack8(ry2[t], y2);
+        unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb2_y) + o), y2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s2[e] += g[e] * (y2[e] - c4[e]) * c5[e];
       }

@@ -14,6 +14,7 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fused_bn_stats': os.environ.get('PASSL_FUSED_BN_STATS', '1') != '0',
           'fuse_residual_grad': os.environ.get('PASSL_FUSE_RESIDUAL_GRAD', '1') != '0',
           'fused_bn_backward': os.environ.get('PASSL_FUSED_BN_BACKWARD', '1') != '0',
+          'fused_bn_backward2': os.environ.get('PASSL_FUSED_BN_BACKWARD2', '1') != '0',
           'overlap': os.environ.get('PASSL_OVERLAP', '1') != '0',
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
           'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
@@ -92,6 +93,12 @@ def fused_bn_backward():
     return _state['fused_bn_backward']
 
 
+def fused_bn_backward2():
+    """With `fused_bn_backward`: the data-gradient launch behind a downsample block also reduces the backward
+    statistics of the downsample branch's BatchNorm (same gradient, second (y, mean, invstd): conv desc bnb2_*)."""
+    return _state['fused_bn_backward2']
+
+
 def overlap():
     """Independent work on a second HIP stream: weight-gradient launches next to the data-gradient /
     BatchNorm-backward chain (hip/streams.py)."""
@@ -126,5 +133,5 @@ def wgrad_halo():
 
 def set_flag(name, value):
     assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample',
-                    'side_reductions', 'fused_stem_pool')
+                    'side_reductions', 'fused_stem_pool', 'fused_bn_backward2')
     _state[name] = bool(value)

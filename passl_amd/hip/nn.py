@@ -99,11 +99,16 @@ class BNLink:
     (sum g, sum g*xhat) slab in its epilogue (csrc/igemm_epi.h), and reports it here.  The BatchNorm's
     backward then skips its reduce pass, and the gradient it receives is already g."""
 
-    __slots__ = ('y', 'st', 'mask', 'relu_mode', 'fused')
+    __slots__ = ('y', 'st', 'mask', 'relu_mode', 'fused', 'res_link')
 
-    def __init__(self, y, st, mask, relu_mode):
+    def __init__(self, y, st, mask, relu_mode, res_link=None):
         self.y, self.st, self.mask, self.relu_mode = y, st, mask, relu_mode
         self.fused = None            # (slab, tiles) once a data-gradient launch has done the work
+        # the BNLink of the BatchNorm (without ReLU) whose output is this layer's RESIDUAL input and has no other
+        # consumer — a bottleneck block's downsample branch: relu(bn3(y3) + bn_ds(y_ds)).  The masked gradient g of
+        # this layer's output is then the output gradient of that BatchNorm as well, and the data-gradient launch that
+        # reduces (sum g, sum g*xhat) for this layer can do it for that one in the same pass (conv desc bnb2_*).
+        self.res_link = res_link
 
 
 def bn_link(t):
@@ -149,21 +154,34 @@ class _ConvFn(Function):
             link = ctx.producer
             fuse = (link is not None and dy.dtype == torch.bfloat16 and not pl.dgrad_zero and
                     ctx.sink_slot is None and config.fused_bn_backward())
-            slab, off = None, 0
+            slab, slab2, off = None, None, 0
             if fuse:
                 tiles = sum(ops.conv_tiles(d) for d in pl.dds)
                 slab = torch.empty(ops.bn_partial_floats(tiles, g.cin, False), dtype=torch.float32,
                                    device=dy.device)
+                # the downsample branch's BatchNorm behind the same gradient: reduced by this launch too (the
+                # instantiation covers dense 1x1 launches of at least 128 columns: conv1 of the block that follows)
+                rl = link.res_link
+                if (rl is not None and rl.relu_mode == 0 and rl.y is not None and config.fused_bn_backward2() and
+                        len(pl.dds) == 1 and g.k == 1 and g.stride == 1 and g.pad == 0 and g.cout % 64 == 0 and
+                        g.cin >= 128):
+                    slab2 = torch.empty(ops.bn_partial_floats(tiles, g.cin, False), dtype=torch.float32,
+                                        device=dy.device)
             for d in pl.dds:
                 bnb = None
                 if fuse:
                     bnb = dict(y=link.y, mask=link.mask, mean=link.st[0], invstd=link.st[1],
                                scale=link.st[2], shift=link.st[3], relu=link.relu_mode, partial=slab,
                                tile_off=off)
+                    if slab2 is not None:
+                        bnb.update(y2=link.res_link.y, mean2=link.res_link.st[0], invstd2=link.res_link.st[1],
+                                   partial2=slab2)
                     off += ops.conv_tiles(d)
                 ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx, residual=extra, bnb=bnb)
             if fuse:
                 link.fused = (slab, off)
+                if slab2 is not None:
+                    link.res_link.fused = (slab2, off)
             if ctx.sink_slot is not None:
                 ctx.sink_slot.put(dx)
                 dx = None
@@ -269,7 +287,7 @@ def convert_sync_batchnorm(module):
 
 class _BNActFn(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, layer, relu, partial, res_slot, link_box):
+    def forward(ctx, y, gamma, beta, residual, layer, relu, partial, res_slot, link_box, res_link=None):
         has_res = residual is not None
         # SyncBatchNorm (convert_sync_batchnorm): statistics over every rank's batch when a process group is up
         ctx.sync = bool(getattr(layer, '_sync', False)) and _collectives_active()
@@ -286,7 +304,8 @@ class _BNActFn(Function):
         ctx.layer, ctx.has_res, ctx.res_slot = layer, has_res, res_slot
         ctx.link = None
         if link_box is not None:
-            ctx.link = link_box[0] = BNLink(y, st, mask, ctx.relu_mode)
+            ctx.link = link_box[0] = BNLink(y, st, mask, ctx.relu_mode,
+                                            res_link if (has_res and ctx.relu_mode == 3 and res_slot is None) else None)
         return z
 
     @staticmethod
@@ -305,7 +324,11 @@ class _BNActFn(Function):
         # the consumer conv's data-gradient launch may already have masked dz and reduced it
         fused = ctx.link.fused if ctx.link is not None else None
         if ctx.link is not None:
-            ctx.link.y = ctx.link.st = ctx.link.mask = ctx.link.fused = None     # drop the references
+            ctx.link.y = ctx.link.st = ctx.link.mask = ctx.link.fused = ctx.link.res_link = None   # drop the references
+        if fused is not None and fused[0].is_cuda:
+            # the slab may have been written by a launch on ANOTHER stream (a downsample branch's layer runs its
+            # backward on the side stream; its slab comes from the main stream's data-gradient launch and pool)
+            fused[0].record_stream(torch.cuda.current_stream(dz.device))
         dx, dres = ops.bn_bwd(dz.contiguous(), mask, y, gamma, st[0], st[1],
                               dgamma, dbeta, relu=ctx.relu_mode,
                               want_dres=want_dres, scale=st[2], shift=st[3], fused=fused, sync=ctx.sync)
@@ -314,7 +337,7 @@ class _BNActFn(Function):
             dres = None
         if layer._rt is not None:
             layer._rt.arena.grad_ready(layer._rt.indices)
-        return dx, None, None, dres, None, None, None, None, None
+        return dx, None, None, dres, None, None, None, None, None, None
 
 
 class _BatchNormBase(Layer):
@@ -366,9 +389,10 @@ class _BatchNormBase(Layer):
             return self.weight.detach(), self.bias.detach()
         return self._const[0], self._const[1]
 
-    def forward(self, y, residual=None, relu=False, stats=None, res_slot=None):
+    def forward(self, y, residual=None, relu=False, stats=None, res_slot=None, res_link=None):
         """stats: fused statistics from the producing conv's epilogue (Conv2D.forward(...,
-        want_stats=True)); res_slot: GradSlot that receives the residual branch's gradient."""
+        want_stats=True)); res_slot: GradSlot that receives the residual branch's gradient; res_link: bn_link of the
+        residual when it is the output of a BatchNorm that nothing else consumes (BNLink.res_link)."""
         if self.uses_global_stats():
             if torch.is_grad_enabled() and (y.requires_grad or (self.affine and self.weight.requires_grad)):
                 raise NotImplementedError('frozen BatchNorm inside a differentiated graph is not on '
@@ -379,7 +403,7 @@ class _BatchNormBase(Layer):
         box = [None] if (torch.is_grad_enabled() and y.dtype == torch.bfloat16 and
                          config.fused_bn_backward()) else None
         gamma, beta = (self.weight, self.bias) if self.affine else (self._const[0], self._const[1])
-        z = _BNActFn.apply(y, gamma, beta, residual, self, relu, stats, res_slot, box)
+        z = _BNActFn.apply(y, gamma, beta, residual, self, relu, stats, res_slot, box, res_link)
         if box is not None and box[0] is not None:
             z._passl_bn_link = box[0]
         return z

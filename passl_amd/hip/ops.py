@@ -178,10 +178,17 @@ def conv_igemm(d: P.Desc, a, b, y, scale=None, shift=None, residual=None, relu=F
         s.bnb_scale, s.bnb_shift = L.ptr(bnb.get('scale')), L.ptr(bnb.get('shift'))
         s.bnb_partial = L.ptr(bnb['partial'])
         s.bnb_relu, s.bnb_tile_off = int(bnb['relu']), int(bnb['tile_off'])
+        if bnb.get('partial2') is not None:          # a second BatchNorm behind the same gradient (bnb2_*)
+            s.bnb2_y = L.ptr(bnb['y2']) + d.y_off * esz
+            s.bnb2_mean, s.bnb2_invstd = L.ptr(bnb['mean2']), L.ptr(bnb['invstd2'])
+            s.bnb2_partial = L.ptr(bnb['partial2'])
+        else:
+            s.bnb2_y = s.bnb2_mean = s.bnb2_invstd = s.bnb2_partial = None
     else:
         s.bnb_y = s.bnb_mask = s.bnb_mean = s.bnb_invstd = s.bnb_scale = s.bnb_shift = None
         s.bnb_partial = None
         s.bnb_relu = s.bnb_tile_off = 0
+        s.bnb2_y = s.bnb2_mean = s.bnb2_invstd = s.bnb2_partial = None
     L.check(_lib().passl_hip_conv_igemm(C.byref(s), L.stream()), 'conv_igemm')
     return y
 

@@ -84,7 +84,7 @@ class BottleneckBlock(nn.Layer):
             else:
                 idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
                 identity = self.downsample[1](idn, relu=False, stats=st)
-            return self.bn3(out, residual=identity, relu=True, stats=st3)
+            return self.bn3(out, residual=identity, relu=True, stats=st3, res_link=nn.bn_link(identity))
         return self.bn3(out, residual=x, relu=True, stats=st3, res_slot=slot)   # out += identity; relu
 
     def forward_frozen(self, x, allow_fork=True):

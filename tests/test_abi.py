@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.passl_hip_abi_version() == 14
+    assert lib.passl_hip_abi_version() == 15
     assert b'invalid' in lib.passl_hip_strerror(-1)
     assert lib.passl_hip_strerror(0) == b'ok'
 

@@ -639,6 +639,74 @@ def test_dgrad_fused_bn_backward(geom, nhw, mode):
     assert torch.equal(g2, g) and torch.equal(slab2[:tiles * Cin * 2], slab[:tiles * Cin * 2])   # reproducible
 
 
+@pytest.mark.parametrize('geom,nhw', [
+    (P.ConvGeom(256, 64, 1, 1, 0), (4, 28, 28)),      # stage-1 shape: data gradient K = 64 -> 256 columns, one K-tile
+    (P.ConvGeom(512, 128, 1, 1, 0), (3, 14, 14)),     # two K-tiles
+    (P.ConvGeom(2048, 512, 1, 1, 0), (2, 7, 7)),      # eight K-tiles: the ring kernel's instantiation, ragged M tile
+])
+def test_dgrad_fused_two_batchnorms(geom, nhw):
+    """A bottleneck block with a downsample branch ends in relu(bn3(y3) + bn_ds(y_ds)) (resnetimagenet.py:139-153): the
+    masked output gradient g is the output gradient of BOTH BatchNorm layers.  The data-gradient launch that produces g
+    (conv1 of the next block) writes the (sum g, sum g * xhat) slab of bn3 and — passl_conv_desc.bnb2_* — of bn_ds in
+    one pass; against the separate passes: g bit for bit, both layers' (d-gamma, d-beta, dx) to summation-order
+    accuracy, reproducibly."""
+    dtype = torch.bfloat16
+    N, H, W = nhw
+    gen = torch.Generator().manual_seed(31)
+    C = geom.cin
+
+    def t(*shape, scale=1.0, shift=0.0):
+        return rnd(torch.randn(*shape, generator=gen) * scale + shift, dtype).to(DEV).to(dtype)
+    y3, yds = t(N, H, W, C, scale=1.5, shift=0.3), t(N, H, W, C, scale=0.7, shift=-0.2)
+    g3, b3 = (torch.rand(C, generator=gen) + 0.5).to(DEV), torch.randn(C, generator=gen).to(DEV)
+    gd, bd = (torch.rand(C, generator=gen) + 0.5).to(DEV), torch.randn(C, generator=gen).to(DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    idn, st_ds, _ = ops.bn_train_fwd(yds, gd, bd, rm.clone(), rv.clone(), relu=False)
+    z, st3, mask = ops.bn_train_fwd(y3, g3, b3, rm.clone(), rv.clone(), residual=idn, relu=True, want_mask=True)
+    w = rnd(torch.randn(geom.cout, geom.cin, 1, 1, generator=gen) * 0.1, dtype)
+    dds, skipped = P.dgrad_plan(geom, N, H, W)
+    assert not skipped and len(dds) == 1
+    d = dds[0]
+    packer = WeightPacker()
+    packer.add(0, geom.cout, 1, 1, geom.cin, d.pack)
+    packer.build(DEV, dtype).run(w.permute(0, 2, 3, 1).contiguous().to(DEV).view(-1))
+    dy = t(N, H, W, geom.cout)
+    extra = t(N, H, W, C)                          # the gradient of the block's identity path (GradSlot)
+    # separate passes
+    dz = torch.empty(N, H, W, C, dtype=dtype, device=DEV)
+    ops.conv_igemm(d, dy, packer.view(d.pack, C), dz, residual=extra)
+    dg3, db3 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx3, dres = ops.bn_bwd(dz, mask, y3, g3, st3[0], st3[1], dg3, db3, relu=3, want_dres=True, scale=st3[2], shift=st3[3])
+    dgd, dbd = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dxd, _ = ops.bn_bwd(dres, None, yds, gd, st_ds[0], st_ds[1], dgd, dbd, relu=0)
+
+    def fused_run():
+        tiles = ops.conv_tiles(d)
+        nan = float('nan')
+        slab = torch.full((ops.bn_partial_floats(tiles, C, False),), nan, dtype=torch.float32, device=DEV)
+        slab2 = torch.full((ops.bn_partial_floats(tiles, C, False),), nan, dtype=torch.float32, device=DEV)
+        g = torch.full((N, H, W, C), nan, dtype=dtype, device=DEV)
+        ops.conv_igemm(d, dy, packer.view(d.pack, C), g, residual=extra,
+                       bnb=dict(y=y3, mask=mask, mean=st3[0], invstd=st3[1], scale=st3[2], shift=st3[3], relu=3,
+                                partial=slab, tile_off=0, y2=yds, mean2=st_ds[0], invstd2=st_ds[1], partial2=slab2))
+        return g, slab, slab2, tiles
+    g, slab, slab2, tiles = fused_run()
+    n = tiles * C * 2
+    assert not torch.isnan(slab[:n]).any() and not torch.isnan(slab2[:n]).any() and not torch.isnan(g.float()).any()
+    assert torch.equal(g, dres)                                       # the masked gradient, bit for bit
+    assert torch.equal(slab[:n].view(tiles, C, 2)[..., 0], slab2[:n].view(tiles, C, 2)[..., 0])    # sum g is shared
+    f3g, f3b = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    fx3, _ = ops.bn_bwd(g, None, y3, g3, st3[0], st3[1], f3g, f3b, relu=3, want_dres=True, scale=st3[2], shift=st3[3],
+                        fused=(slab, tiles))
+    fdg, fdb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    fxd, _ = ops.bn_bwd(g, None, yds, gd, st_ds[0], st_ds[1], fdg, fdb, relu=0, fused=(slab2, tiles))
+    for a, b in ((f3g, dg3), (f3b, db3), (fdg, dgd), (fdb, dbd)):
+        assert relmax(a, b) < 2e-5
+    assert relmax(fx3.float(), dx3.float()) < 1e-2 and relmax(fxd.float(), dxd.float()) < 1e-2
+    g_b, slab_b, slab2_b, _ = fused_run()
+    assert torch.equal(g_b, g) and torch.equal(slab_b[:n], slab[:n]) and torch.equal(slab2_b[:n], slab2[:n])
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_bn_statistics_large_mean(dtype):
     """|mean| >> std: E[x^2] - mean^2 from fp32 sums would lose the variance; the shifted sums do not."""
