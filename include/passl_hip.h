@@ -39,6 +39,9 @@ enum passl_status {
 
 enum passl_dtype { PASSL_F32 = 0, PASSL_BF16 = 1 };
 
+/* The value passl_hip_abi_version() of a library built from THIS header returns: a caller compiled against another
+ * layout of the descriptors below must not call it (tools/kbench and passl_amd/hip/lib.py check at start-up). */
+#define PASSL_HIP_ABI_VERSION 15
 int passl_hip_abi_version(void);
 /* Kernel-selection knobs (defaults are tuned for MI355X; tests use them to force a path):
  *   "igemm_ring" 0/1            use the LDS-DMA ring conv kernel when it applies (1)

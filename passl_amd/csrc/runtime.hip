@@ -130,7 +130,7 @@ extern "C" int passl_hip_set_option(const char* name, int value) {
   return passl_igemm_ring_option(name, value);
 }
 
-extern "C" int passl_hip_abi_version(void) { return 15; }
+extern "C" int passl_hip_abi_version(void) { return PASSL_HIP_ABI_VERSION; }
 
 extern "C" const char* passl_hip_strerror(int status) {
   switch (status) {

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libpassl_hip.so')
 
 F32, BF16 = 0, 1
+ABI_VERSION = 15          # include/passl_hip.h: PASSL_HIP_ABI_VERSION (the ctypes structs below mirror THAT layout)
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 c_p = C.c_void_p
@@ -194,6 +195,10 @@ def load(path=None):
             'libpassl_hip.so not found at %s — build it with `python -m passl_amd.csrc.build` '
             '(the HIP path has no CPU fallback)' % p)
     lib = C.CDLL(p)
+    lib.passl_hip_abi_version.restype = c_i
+    if lib.passl_hip_abi_version() != ABI_VERSION:
+        raise PasslHipError('%s is ABI %d, this binding is ABI %d: rebuild it (python -m passl_amd.csrc.build)'
+                            % (p, lib.passl_hip_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res

@@ -37,7 +37,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.passl_hip_abi_version() == 15
+    assert lib.passl_hip_abi_version() == L.ABI_VERSION == 15
+    assert ('#define PASSL_HIP_ABI_VERSION %d' % L.ABI_VERSION) in open(HEADER).read()
     assert b'invalid' in lib.passl_hip_strerror(-1)
     assert lib.passl_hip_strerror(0) == b'ok'
 

@@ -159,3 +159,18 @@ def test_bench_two_ranks_one_gpu_reports_its_ranks():
     assert d['distinct_devices'] == 1                      # both ranks on the single GPU of the test box
     assert d['grad_buckets'] == 3 and d['grad_bytes'] > 100e6
     assert d['allreduce_exposed_ms'] is not None and d['allreduce_exposed_ms'] >= 0
+
+
+def test_two_ranks_bf16_gradient_wire():
+    """GradReducer's optional bf16 wire (PASSL_DP_WIRE=bf16: every bucket cast into a resident bf16 twin by the
+    library's cast kernel right before its all-reduce, cast back after the final wait — half the bytes per link) on the
+    real MoCo step, replayed from a step plan: the replicas stay bit-identical (the worker asserts it), the first loss
+    is the fp32-wire run's (no gradient has been applied yet), later losses agree to the bf16 rounding of the averaged
+    gradients, and the parameters are NOT the fp32-wire run's bit for bit (the wire really was bf16)."""
+    env = dict(PASSL_DIST_BACKEND='gloo', PASSL_DEVICE_INDEX='0')
+    f32 = _run_worker('moco', 2, env)
+    b16 = _run_worker('moco', 2, dict(env, PASSL_DP_WIRE='bf16'))
+    la, lb = ([float(v) for v in line.split('losses=')[1].split(',')] for line in (f32, b16))
+    assert la[0] == lb[0], (f32, b16)
+    assert all(abs(x - y) < 2e-2 for x, y in zip(la, lb)), (f32, b16)
+    assert f32.split('digest=')[1].split()[0] != b16.split('digest=')[1].split()[0], (f32, b16)

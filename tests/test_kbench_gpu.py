@@ -13,7 +13,13 @@ KBENCH = os.path.join(ROOT, 'tools', 'kbench')
 
 
 def _kbench():
-    if not os.path.exists(KBENCH):
+    """tools/kbench, rebuilt when it is missing or older than what it is compiled from / links against (a binary built
+    against an earlier layout of the descriptors would hand the library garbage)."""
+    deps = [os.path.join(ROOT, 'tools', 'kbench.cpp'), os.path.join(ROOT, 'include', 'passl_hip.h'),
+            os.path.join(ROOT, 'passl_amd', 'lib', 'libpassl_hip.so')]
+    stale = not os.path.exists(KBENCH) or any(os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(KBENCH)
+                                              for d in deps)
+    if stale:
         subprocess.run(['bash', os.path.join(ROOT, 'tools', 'build_kbench.sh')], check=True, capture_output=True,
                        text=True, timeout=900)
     return KBENCH

@@ -742,6 +742,11 @@ static int run_ablate() {
 }
 
 int main(int argc, char** argv) {
+  if (passl_hip_abi_version() != PASSL_HIP_ABI_VERSION) {
+    fprintf(stderr, "kbench was built against ABI %d of include/passl_hip.h, libpassl_hip.so is ABI %d: run tools/build_kbench.sh\n",
+            PASSL_HIP_ABI_VERSION, passl_hip_abi_version());
+    return 3;
+  }
   if (argc < 2) { fprintf(stderr, "usage: kbench check|time|ab [name=value ...]\n"); return 2; }
   const std::string mode = argv[1];
   if (mode == "sweep") { printf("libpassl_hip ABI %d\n", passl_hip_abi_version()); return run_sweep(argc - 2, argv + 2); }
