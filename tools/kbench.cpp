@@ -13,6 +13,7 @@
 //   tools/kbench fincheck                   BatchNorm finalize launches (forward / backward) against the host's fp64 arithmetic on the same slab
 //   tools/kbench fintime                    ... and their times, alone and next to a stream that loads the memory system
 //   tools/kbench finstress [iters=N]        ... and the multi-segment hand-off under load: every result bit-identical run to run
+//   tools/kbench vtime                      the four epilogue variants of the K = 64 / 128 1x1 layers (PASSL_IGEMM_LEAN=1|2 to compare)
 //   tools/kbench ablate                     the register-staged kernel's debug switches on the 1x1 shapes
 //   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
 //   name=value pairs are passl_hip_set_option() calls made before anything runs.
@@ -716,6 +717,47 @@ static int run_sweep(int n, char** cfgs) {
   return 0;
 }
 
+// vtime: the four epilogue variants (ReLU, fused statistics, residual + ReLU, BatchNorm-backward) of the K = 64 1x1
+// layers at N = 256 — the launches the 4-workgroup form of the register-staged kernel takes (PASSL_IGEMM_LEAN).
+static int run_vtime() {
+  const Shape shapes[] = {kR50[6], {256, 64, 64, 1, 1, 56, "64->64 k1 @56", 1}, kR50[8]};
+  Buffers B;
+  printf("%-22s %9s %9s %9s %9s   (us: relu | statistics | residual + relu | BatchNorm-backward epilogue)\n", "shape (N=256)", "relu", "stats", "resid", "bnb");
+  for (const Shape& s : shapes) {
+    const int pad = s.R / 2, O = (s.H + 2 * pad - s.R) / s.stride + 1;
+    const int64_t M = (int64_t)s.N * O * O, KD = (int64_t)s.R * s.R * s.C;
+    const int64_t na = (int64_t)s.N * s.H * s.H * s.C, nb = (int64_t)s.K * KD, ny = M * s.K;
+    const int tiles = (int)((M + 127) / 128);
+    B.ensure(na, nb, ny, passl_hip_bn_partial_floats(tiles, s.K, 1));
+    B.ensure_aux(ny);
+    fill(B.a, na, 11u); fill(B.b, nb, 23u); fill(B.aux, ny, 37u);
+    std::vector<float> hcols(4 * 4096, 0.5f);
+    CK(hipMemcpy(B.cols, hcols.data(), hcols.size() * 4, hipMemcpyHostToDevice));
+    float t[4];
+    for (int v = 0; v < 4; ++v) {
+      passl_conv_desc d = make_desc(s, B.a, B.b, B.y);
+      d.relu = (v == V_RELU || v == V_RESIDUAL) ? 1 : 0;
+      if (v == V_STATS) { d.stats = B.stats; d.stats_tiles = tiles; }
+      if (v == V_RESIDUAL) d.residual = B.aux;
+      if (v == V_BNB) {
+        d.bnb_y = B.aux; d.bnb_mean = B.cols; d.bnb_invstd = B.cols + 4096; d.bnb_scale = B.cols + 8192; d.bnb_shift = B.cols + 12288;
+        d.bnb_partial = B.stats; d.bnb_relu = 2;
+      }
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      for (int it = -3; it < 20; ++it) {
+        if (it == 0) { CK(hipDeviceSynchronize()); CK(hipEventRecord(e0, 0)); }
+        if (passl_hip_conv_igemm(&d, nullptr) != PASSL_OK) { printf("conv failed\n"); return 1; }
+      }
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&t[v], e0, e1));
+      CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+    printf("%-22s %9.1f %9.1f %9.1f %9.1f\n", s.note, t[0] * 50.f, t[1] * 50.f, t[2] * 50.f, t[3] * 50.f);
+  }
+  return 0;
+}
+
 // ablate: the register-staged kernel's debug switches (PASSL_IGEMM_DBG: 2 = return before the epilogue, 4 = no A
 // loads, 8 = no MFMAs) on the 1x1 shapes it serves: what a tile's time is made of.
 static int run_ablate() {
@@ -771,6 +813,7 @@ int main(int argc, char** argv) {
   printf("libpassl_hip ABI %d\n", passl_hip_abi_version());
   if (mode == "check") return run_check();
   if (mode == "ablate") return run_ablate();
+  if (mode == "vtime") return run_vtime();
   if (mode == "wcheck") return run_wcheck();
   if (mode == "fincheck") return run_fincheck();
   if (mode == "fintime") return run_fintime();
