@@ -1062,6 +1062,39 @@ def test_trace_timeline_tool_on_a_synthetic_trace(tmp_path):
     assert '0.050 [0.050]' in line                       # runs alone, and with fewer than 256 workgroups
 
 
+def test_trace_chain_tool_on_a_synthetic_trace(tmp_path):
+    """tools/trace_chain.py (which stream is the critical chain, and what its launches and the gaps in front of them
+    cost): on a hand-made two-stream trace with known answers."""
+    import subprocess
+    import sys
+    rows = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name",'
+            '"Correlation_Id","Start_Timestamp","End_Timestamp","LDS_Block_Size","Scratch_Size","VGPR_Count",'
+            '"Accum_VGPR_Count","SGPR_Count","Workgroup_Size_X","Workgroup_Size_Y","Workgroup_Size_Z","Grid_Size_X",'
+            '"Grid_Size_Y","Grid_Size_Z"']
+
+    def k(stream, name, t0, t1):
+        rows.append('"KERNEL_DISPATCH","Agent 2",1,%d,1,1,1,"%s",1,%d,%d,0,0,8,0,16,256,1,1,65536,1,1' % (stream, name, t0, t1))
+    for s in range(3):                      # steps of 1 ms: conv 0-600, finalize 610-650 (10 us gap), sgd 900-1000 (250 us pause)
+        o = s * 1_000_000
+        k(0, 'void conv_kernel<1>(int)', o + 0, o + 600_000)
+        k(1, 'void wgrad_kernel(int)', o + 200_000, o + 500_000)
+        k(0, 'void bn_finalize_kernel(int)', o + 610_000, o + 650_000)
+        k(0, 'void sgd_kernel(float*)', o + 900_000, o + 1_000_000)
+    path = tmp_path / 'trace.csv'
+    path.write_text('\n'.join(rows) + '\n')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'trace_chain.py'), str(path), '2', 'sgd_kernel',
+                        '--list', '0'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert 'window: 2 steps, 1.000 ms per step' in out
+    # the busiest stream first; a pause of 200 us or more is a wait for another stream, not a launch gap
+    first = [l for l in out.splitlines() if l.startswith('stream ')][0]
+    assert first.startswith('stream 0: 3 kernels per step, busy 740.0 us, launch gaps (< 200 us each) 10.0 us per step')
+    fin = [l for l in out.splitlines() if 'bn_finalize_kernel' in l and 'us' not in l][0].split()
+    assert fin[1:] == ['1.0', '40.0', '40.0', '10.0']      # calls, us / step, average us, gap before (us / step)
+    assert 'stream 1: 1 kernels per step, busy 300.0 us' in out
+
+
 def test_step_plan_runs_a_batch_of_another_shape_eagerly(monkeypatch):
     """hip/replay.py:StepPlan.run: a recorded step is shape-specialised; a batch of another shape (the tail batch of a
     `drop_last: False` loader, reference configs/simclr/simclr_r50_IM.yaml:88-90) must run as an eager step, not raise,

@@ -55,7 +55,6 @@ def main():
         for name, (n, t, g) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:28]:
             print('  %-60s %6.1f %10.1f %10.1f %10.1f' % (name, n / steps, t / steps, t / n, g / steps))
         if lst == st:
-            base = evs[0][0]
             last = [e for e in evs if e[0] >= marks[-2]]
             prev_end = None
             for s, e, _, name in last:
