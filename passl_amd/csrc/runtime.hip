@@ -120,12 +120,14 @@ int passl_igemm_8p_option(const char* name, int value);      // conv_igemm_8p.hi
 int passl_wgrad_option(const char* name, int value);         // conv_wgrad.hip
 int passl_bn_option(const char* name, int value);            // bn.hip
 int passl_stem_option(const char* name, int value);          // conv_stem.hip
+int passl_pool_option(const char* name, int value);          // stem_pool.hip
 
 extern "C" int passl_hip_set_option(const char* name, int value) {
   if (!name) return PASSL_EINVAL;
   if (passl_wgrad_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_bn_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_stem_option(name, value) == PASSL_OK) return PASSL_OK;
+  if (passl_pool_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_igemm_8p_option(name, value) == PASSL_OK) return PASSL_OK;
   return passl_igemm_ring_option(name, value);
 }

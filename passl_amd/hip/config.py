@@ -19,6 +19,12 @@ _state = {'device': None, 'dtype': torch.bfloat16,
           'fork_downsample': os.environ.get('PASSL_FORK_DOWNSAMPLE', '1') != '0',
           'side_reductions': os.environ.get('PASSL_SIDE_REDUCTIONS', '1') != '0',
           'fused_stem_pool': os.environ.get('PASSL_FUSED_STEM_POOL', '1') != '0',
+          # pieces of the batch in which the fused stem pass hands its input gradient to the stem's weight gradient
+          'stem_wgrad_parts': max(1, int(os.environ.get('PASSL_STEM_WGRAD_PARTS', '2') or 1)),
+          'stem_tail_flush': os.environ.get('PASSL_STEM_TAIL_FLUSH', '1') != '0',
+          'stem_wgrad_main_last': os.environ.get('PASSL_STEM_WGRAD_MAIN_LAST', '1') != '0',
+          # a weight gradient over at least this many rows is handed to the side stream at once (0: always batched)
+          'side_urgent_rows': int(os.environ.get('PASSL_SIDE_URGENT_ROWS', '500000') or 0),
           # the library reads the same variable (conv_wgrad_halo.inc): 0 off, 1 images with sides % 8 == 0, 2 all (default)
           'wgrad_halo': int(os.environ.get('PASSL_WGRAD_HALO', '2') or 0)}
 
@@ -121,6 +127,33 @@ def fused_stem_pool():
     """Training-mode BatchNorm + ReLU + max-pool of the ResNet stem as one pass per direction (csrc/stem_pool.hip):
     the BatchNorm output and the pool's input gradient are never written."""
     return _state['fused_stem_pool']
+
+
+def stem_wgrad_parts():
+    """With `fused_stem_pool` and `overlap`: the stem's BatchNorm-backward apply pass and the stem's weight gradient —
+    the last two launches of a backward pass, the second reading what the first writes — run over this many pieces
+    of the batch, the weight gradient of a piece on the side stream next to the apply pass of the next (1 = whole)."""
+    return _state['stem_wgrad_parts']
+
+
+def stem_wgrad_main_last():
+    """With `stem_wgrad_parts` > 1: the LAST piece's weight gradient runs on the main stream (which has nothing else left
+    in the backward pass) while the side stream still works on the piece before it."""
+    return _state['stem_wgrad_main_last']
+
+
+def side_urgent_rows():
+    """Weight gradients over at least this many rows (N * OH * OW: the first trunk stage at batch 256) skip the batched
+    hand-off to the side stream (hip/streams.py: PASSL_SIDE_BATCH): they are the longest launches of the side stream and
+    the last ones of a backward pass — queued in fours they all ran behind the main chain's end
+    (profiles/r05_trace_timeline_tail.txt)."""
+    return _state['side_urgent_rows']
+
+
+def stem_tail_flush():
+    """The fused stem backward first hands the weight gradients still queued for the side stream over (they then run
+    next to its two passes instead of behind them, in front of the optimizer)."""
+    return _state['stem_tail_flush']
 
 
 def wgrad_halo():

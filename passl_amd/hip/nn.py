@@ -116,10 +116,38 @@ def bn_link(t):
     return getattr(t, '_passl_bn_link', None)
 
 
+class WgradLink:
+    """Hand-off in the other direction, for the stem: the layer that PRODUCES a convolution's output gradient (the fused
+    BatchNorm + ReLU + max-pool backward, two launches from the end of a backward pass) launches that convolution's
+    weight gradient itself, piece of the batch by piece, each on the side stream as soon as the apply pass has written
+    the piece (`launch`), and says so (`done`); the convolution's own backward then has nothing left to launch."""
+
+    __slots__ = ('launch', 'done')
+
+    def __init__(self):
+        self.launch = None           # launch(dy, n0, n1, i, parts): images n0..n1 of dy (piece i) are written; set by the convolution
+        self.done = False            # set by the producer of dy once every piece has been handed over
+
+
+def wgrad_link(t):
+    """The WgradLink riding on a convolution output tensor (None for anything else)."""
+    return getattr(t, '_passl_wgrad_link', None)
+
+
 # =============================================================================== conv
+def _stem_wgrad(layer, pl, x, dy, tmp):
+    """The stem filter is padded to [K][7][8 taps][4 channels] for the kernel; `tmp` (zeroed) collects its gradient."""
+    ops.conv_wgrad(pl.wd, x, dy.reshape(-1, layer.geom.cout), tmp)
+
+
+def _stem_wgrad_finish(layer, tmp):
+    """... which goes back into the dense [K][7][7][3] slot of the flat gradient buffer."""
+    ops.unpad_add(tmp, layer._rt.dw, layer.geom.cout, 7, 7, 3, P.STEM_ROW // 4, 4)
+
+
 class _ConvFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, layer, hw, stats, add_slot, sink_slot, producer):
+    def forward(ctx, x, weight, layer, hw, stats, add_slot, sink_slot, producer, wlink=None):
         rt = _need_rt(layer)
         N = x.shape[0]
         pl = layer._plan(N, hw[0], hw[1])
@@ -133,6 +161,33 @@ class _ConvFn(Function):
         # latched: forward and backward of one step agree about the side stream even if the allocator-pressure
         # back-off of streams.enabled() flips in between
         ctx.side = streams.enabled(x)
+        ctx.wlink = None
+        if wlink is not None and ctx.side and any(ctx.needs_input_grad):
+            # the producer of dy may launch the weight gradient in pieces of the batch (WgradLink)
+            ctx.wlink = wlink
+            state = {}
+
+            def piece(dy_all, n0, n1, tmp):
+                _stem_wgrad(layer, layer._plan(n1 - n0, hw[0], hw[1]), x[n0:n1], dy_all[n0:n1], tmp)
+
+            def launch(dy_all, n0, n1, i, parts):
+                dev = dy_all.device
+                on_main = parts > 1 and config.stem_wgrad_main_last()      # the last piece
+                if on_main and i == parts - 1:
+                    # the last piece on THIS stream, into a buffer of its own; dW += it once the side stream's pieces
+                    # are in (same order every step)
+                    tmp = ops.zeros(layer.geom.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dev)
+                    piece(dy_all, n0, n1, tmp)
+                    streams.wait_stream(torch.cuda.current_stream(dev), streams.side_stream(dev))
+                    _stem_wgrad_finish(layer, tmp)
+                    return
+                with streams.on_side(dev, reads=(x, dy_all), in_backward=True):
+                    if 'tmp' not in state:
+                        state['tmp'] = ops.zeros(layer.geom.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dev)
+                    piece(dy_all, n0, n1, state['tmp'])
+                    if i == parts - (2 if on_main else 1):
+                        _stem_wgrad_finish(layer, state.pop('tmp'))
+            wlink.launch = launch
         return y
 
     @staticmethod
@@ -187,20 +242,24 @@ class _ConvFn(Function):
                 dx = None
         def wgrad():
             if layer.is_stem:
-                # the stem filter is padded to [K][7][8 taps][4 channels] for the kernel; its gradient goes back into
-                # the dense [K][7][7][3] slot of the flat gradient buffer
                 tmp = ops.zeros(g.cout, P.STEM_K * P.STEM_ROW, dtype=torch.float32, device=dy.device)
-                ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), tmp)
-                ops.unpad_add(tmp, rt.dw, g.cout, 7, 7, 3, P.STEM_ROW // 4, 4)
+                _stem_wgrad(layer, pl, x, dy, tmp)
+                _stem_wgrad_finish(layer, tmp)
             else:
                 ops.conv_wgrad(pl.wd, x, dy.view(-1, g.cout), rt.dw)
-        if ctx.side:
+        wl = ctx.wlink
+        if wl is not None:
+            wl.launch = None                      # (the closure holds x)
+        if wl is not None and wl.done:
+            pass                                  # launched by the producer of dy, piece by piece
+        elif ctx.side:
             # dW feeds only the optimizer: off the dgrad -> BatchNorm-backward chain (hip/streams.py)
-            streams.side_later(dy.device, wgrad, reads=(x, dy))
+            rows = config.side_urgent_rows()
+            streams.side_later(dy.device, wgrad, reads=(x, dy), urgent=rows > 0 and dy.numel() // g.cout >= rows)
         else:
             wgrad()
         rt.arena.grad_ready(rt.indices)
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 class Conv2D(Layer):
@@ -251,7 +310,10 @@ class Conv2D(Layer):
         stats = None
         if want_stats and x.dtype == torch.bfloat16 and config.fused_bn_stats():
             stats = ops.conv_stats_buffer(self._plan(x.shape[0], hw[0], hw[1]).fd, x.device)
-        y = _ConvFn.apply(x, self.weight, self, hw, stats, add_slot, sink_slot, producer)
+        wlink = WgradLink() if (self.is_stem and config.stem_wgrad_parts() > 1) else None
+        y = _ConvFn.apply(x, self.weight, self, hw, stats, add_slot, sink_slot, producer, wlink)
+        if wlink is not None and wlink.launch is not None:
+            y._passl_wgrad_link = wlink
         return (y, stats) if want_stats else y
 
     @torch.no_grad()
@@ -438,29 +500,37 @@ class _BNReluMaxPoolFn(Function):
     byte per pooled element; neither the BatchNorm output nor the pool's input gradient is ever written."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, layer, partial):
+    def forward(ctx, y, gamma, beta, layer, partial, wlink=None):
         _, st, _ = ops.bn_train_fwd(y, gamma.detach(), beta.detach(), layer._mean, layer._variance, None, True,
                                     layer._momentum, layer._epsilon, partial=partial, apply=False)
         out, idx = ops.bn_relu_maxpool_fwd(y, st)
         if layer._rt is not None and any(ctx.needs_input_grad):
             layer._rt.arena.expect_grad(layer._rt.indices)
         ctx.save_for_backward(y, st, idx)
-        ctx.layer = layer
+        ctx.layer, ctx.wlink = layer, wlink
         return out
 
     @staticmethod
     def backward(ctx, dout):
         y, st, idx = ctx.saved_tensors
-        layer = ctx.layer
+        layer, wl = ctx.layer, ctx.wlink
         streams.autograd_node_entry(dout.device)
+        # These launches and the stem's weight gradient are the tail of the backward pass: weight gradients still queued
+        # for the side stream go there now, next to them, not behind them.
+        if config.stem_tail_flush():
+            streams.flush_side(dout.device)
         for p in (layer.weight, layer.bias):
             if p.grad is None:
                 p.grad = ops.zeros_like(p)
+        piecewise = wl is not None and wl.launch is not None and not wl.done
         dx = ops.bn_relu_maxpool_bwd(dout.contiguous(), idx, y, layer.weight.detach(), st, layer.weight.grad,
-                                     layer.bias.grad)
+                                     layer.bias.grad, parts=config.stem_wgrad_parts() if piecewise else 1,
+                                     on_part=wl.launch if piecewise else None)
+        if piecewise:
+            wl.done = True
         if layer._rt is not None:
             layer._rt.arena.grad_ready(layer._rt.indices)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 def bn_relu_maxpool(bn, y, stats=None):
@@ -472,7 +542,7 @@ def bn_relu_maxpool(bn, y, stats=None):
              ops.bn_relu_maxpool_supported(y))
     if not fused:
         return _MaxPoolFn.apply(bn(y, relu=True, stats=stats))
-    return _BNReluMaxPoolFn.apply(y, bn.weight, bn.bias, bn, stats)
+    return _BNReluMaxPoolFn.apply(y, bn.weight, bn.bias, bn, stats, wgrad_link(y))
 
 
 class MaxPool2D(Layer):

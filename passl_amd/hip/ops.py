@@ -415,8 +415,10 @@ def bn_relu_maxpool_fwd(x, stats):
     return y, idx
 
 
-def bn_relu_maxpool_bwd(dy, idx, x, gamma, stats, dgamma, dbeta):
-    """Backward of bn_relu_maxpool_fwd w.r.t. x; dgamma / dbeta (fp32 [C]) are accumulated into."""
+def bn_relu_maxpool_bwd(dy, idx, x, gamma, stats, dgamma, dbeta, parts=1, on_part=None):
+    """Backward of bn_relu_maxpool_fwd w.r.t. x; dgamma / dbeta (fp32 [C]) are accumulated into.
+    parts > 1: the apply pass runs over that many pieces of the batch; on_part(dx, n0, n1, i, parts) is called after the launch
+    that wrote dx[n0:n1], piece i of `parts` (the caller hands the piece to whoever consumes it: the stem's weight gradient)."""
     N, H, W, Cc = x.shape
     lib, st, dtc, dev = _lib(), L.stream(), L.dt(x), x.device
     nb = lib.passl_hip_bn_relu_maxpool_blocks(N, H, W, Cc)
@@ -429,9 +431,14 @@ def bn_relu_maxpool_bwd(dy, idx, x, gamma, stats, dgamma, dbeta):
                                           L.ptr(stats[1]), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), st),
             'bn_bwd_finalize')
     dx = torch.empty_like(x)
-    L.check(lib.passl_hip_bn_relu_maxpool_bwd_apply(L.ptr(dy), L.ptr(idx), L.ptr(x), L.ptr(coef), L.ptr(stats[2]),
-                                                    L.ptr(stats[3]), L.ptr(dx), N, H, W, Cc, dtc, st),
-            'bn_relu_maxpool_bwd_apply')
+    parts = max(1, min(int(parts), N))
+    for i in range(parts):
+        n0, n1 = N * i // parts, N * (i + 1) // parts
+        L.check(lib.passl_hip_bn_relu_maxpool_bwd_apply(L.ptr(dy[n0:n1]), L.ptr(idx[n0:n1]), L.ptr(x[n0:n1]), L.ptr(coef),
+                                                        L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dx[n0:n1]), n1 - n0, H, W,
+                                                        Cc, dtc, st), 'bn_relu_maxpool_bwd_apply')
+        if on_part is not None:
+            on_part(dx, n0, n1, i, parts)
     return dx
 
 

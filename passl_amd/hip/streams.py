@@ -227,14 +227,15 @@ _SIDE_BATCH = max(1, int(os.environ.get('PASSL_SIDE_BATCH', '4')))
 _deferred = {}           # device index -> [(fn, tensors it reads, stream that produced them)]
 
 
-def side_later(device, fn, reads=()):
+def side_later(device, fn, reads=(), urgent=False):
     """Queue ``fn()`` (launches that only the optimizer / gradient reducer consume) for the side stream; call from a
-    backward node.  ``reads``: tensors the launches read (kept alive until handed over, then by ``on_side``)."""
+    backward node.  ``reads``: tensors the launches read (kept alive until handed over, then by ``on_side``).
+    ``urgent``: hand the queue over now (a long launch near the end of the backward pass)."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     lst = _deferred.setdefault(key, [])
     lst.append((fn, tuple(t for t in reads if t is not None), torch.cuda.current_stream(device)))
     _queue_end_join(device, key)
-    if len(lst) >= _SIDE_BATCH:
+    if urgent or len(lst) >= _SIDE_BATCH:
         flush_side(device)
 
 

@@ -1,21 +1,16 @@
 #!/bin/bash
+# timeline of the step's tail with the round's stem-tail changes on (defaults) and off
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=$GRAFT_REPO_ROOT/gpurun_out/r5_call11; rm -rf $O; mkdir -p $O
-B="python bench.py --no-cpu-baseline --no-kernel-timing --steps 20 --warmup 5"
-run() { name=$1; shift; env "$@" timeout 300 $B > $O/$name.json 2> $O/$name.err; python - <<PY
-import json
-try:
-    d=json.loads(open('$O/$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'])
-except Exception as e: print('$name', e); print(open('$O/$name.err').read()[-800:])
-PY
+T=$GRAFT_REPO_ROOT/tools
+cd /tmp
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-timing"
+tr() { name=$1; shift; env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_$name -o t -- $B --steps 8 --warmup 4 > $O/prof_$name.log 2>&1
+  CSV=$(ls /tmp/p_$name/*/*kernel_trace.csv /tmp/p_$name/*kernel_trace.csv 2>/dev/null | head -1)
+  python $T/trace_timeline.py $CSV 6 > $O/timeline_$name.txt 2>&1
+  python $T/trace_chain.py $CSV 4 > $O/chain_$name.txt 2>&1
 }
-run base A=1
-run bk32_4 PASSL_OPTIONS=igemm_ring_bk=32
-run bk32_3 PASSL_OPTIONS=igemm_ring_bk=32,igemm_ring_stages32=3
-run bm256 PASSL_OPTIONS=igemm_ring_bm=256
-run bnu8 PASSL_OPTIONS=bn_stream_unroll=8
-run bnu2 PASSL_OPTIONS=bn_stream_unroll=2
-run sidebatch8 PASSL_SIDE_BATCH=8
-run sidebatch2 PASSL_SIDE_BATCH=2
-run base2 A=1
+tr new A=1
+tr old PASSL_STEM_WGRAD_PARTS=1 PASSL_STEM_TAIL_FLUSH=0 PASSL_OPTIONS=stem_pool_form=0
+tail -32 $O/timeline_new.txt

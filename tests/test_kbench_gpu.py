@@ -52,3 +52,13 @@ def test_bn_finalize_launches_equal_host_fp64_and_are_bit_reproducible():
     r = subprocess.run([_kbench(), 'fincheck'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert 'FINALIZE CHECK OK' in r.stdout
+
+
+@pytest.mark.gpu
+def test_stem_pool_reduce_second_form_agrees_with_the_first():
+    """csrc/stem_pool.hip: the software-pipelined form of the fused BatchNorm + ReLU + max-pool backward's reduce pass
+    against the first form on the same inputs (bf16 and fp32, odd image sides, 8 .. 256 channels, 5 .. 4096
+    workgroups): the column sums of both slabs agree to fp32 rounding."""
+    r = subprocess.run([_kbench(), 'poolcheck'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert 'POOL CHECK OK' in r.stdout

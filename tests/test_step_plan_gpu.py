@@ -61,6 +61,35 @@ def test_trainer_replays_the_step_plan_by_default(cfg_path, batch, segments):
     assert float(eager['losses'][0]) != float(eager['losses'][-1])
 
 
+def test_stem_tail_scheduling_changes_nothing_but_the_stem_filter_rounding():
+    """The backward pass's tail (hip/nn.py: WgradLink, hip/config.py: stem_wgrad_parts / stem_wgrad_main_last /
+    side_urgent_rows): handing every weight gradient to the side stream at once is pure scheduling — bit-identical
+    parameters — and the stem's weight gradient in two pieces of the batch (one per stream) sums the same products in
+    another grouping: only the stem filter (64 x 3 x 7 x 7 values) may differ, and by fp32 rounding."""
+    from passl_amd.hip import config
+    saved = dict(config._state)
+    try:
+        base = _run(CASES[0][0], 16, False, steps=1)['flat']
+        config._state['side_urgent_rows'] = 1
+        urgent = _run(CASES[0][0], 16, False, steps=1)['flat']
+        config._state.update(saved)
+        config._state['stem_wgrad_parts'] = 1
+        whole = _run(CASES[0][0], 16, False, steps=1)['flat']
+        config._state.update(saved)
+        config._state['stem_wgrad_main_last'] = False
+        side_only = _run(CASES[0][0], 16, False, steps=1)['flat']
+    finally:
+        config._state.update(saved)
+    assert config.stem_wgrad_parts() == 2 and config.stem_wgrad_main_last()        # the defaults `base` ran with
+    assert torch.equal(base.view(torch.int32), urgent.view(torch.int32))
+    for other in (whole, side_only):
+        diff = (base != other).nonzero().flatten()
+        assert diff.numel() <= 64 * 3 * 7 * 7, diff.numel()
+        assert torch.allclose(base, other, rtol=1e-5, atol=1e-7)
+        if diff.numel():
+            assert int(diff.max() - diff.min()) < 64 * 3 * 7 * 7 + 64          # one contiguous slot of the arena
+
+
 def test_plan_kill_switch(monkeypatch):
     from passl_amd.engine.trainer import Trainer
     from passl_amd.utils.config import get_config

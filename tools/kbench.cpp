@@ -13,6 +13,7 @@
 //   tools/kbench fincheck                   BatchNorm finalize launches (forward / backward) against the host's fp64 arithmetic on the same slab
 //   tools/kbench fintime                    ... and their times, alone and next to a stream that loads the memory system
 //   tools/kbench finstress [iters=N]        ... and the multi-segment hand-off under load: every result bit-identical run to run
+//   tools/kbench poolcheck | pooltime       the stem's fused BatchNorm + ReLU + max-pool backward: second form == first form; times
 //   tools/kbench vtime                      the four epilogue variants of the K = 64 / 128 1x1 layers (PASSL_IGEMM_LEAN=1|2 to compare)
 //   tools/kbench ablate                     the register-staged kernel's debug switches on the 1x1 shapes
 //   tools/kbench sweep cfg [cfg ...]        cfg = "name=value,name=value": check + time the 3x3 shapes under each
@@ -670,6 +671,148 @@ static int run_fintime() {
 
 // sweep: every argument is one configuration "name=value,name=value,...": the 3x3 / stride-1 cases are checked
 // (bit-exact) and the four ResNet-50 3x3 shapes timed under each, one row per configuration.
+// ------------------------------------------------------------------------------------------------ stem pool
+// The fused BatchNorm + ReLU + max-pool backward (csrc/stem_pool.hip): the second form of its reduce pass against the
+// first on the same inputs — the slab's column sums to fp32 rounding (and dx, which both take from the same apply
+// pass: a launch-to-launch identity check) — and the times of both.
+struct PoolBufs {
+  void *x = nullptr, *out = nullptr, *dy = nullptr, *dx0 = nullptr, *dx1 = nullptr;
+  uint8_t* idx = nullptr;
+  float *par = nullptr, *slab0 = nullptr, *slab1 = nullptr;     // par: scale, shift, mean, invstd, coef[3]
+  void release() {
+    for (void* q : {x, out, dy, dx0, dx1, (void*)idx, (void*)par, (void*)slab0, (void*)slab1}) if (q) CK(hipFree(q));
+  }
+};
+static void pool_upload(void* dst, int64_t n, uint32_t seed, int es) {
+  if (es == 2) { fill(dst, n, seed); return; }
+  std::vector<float> h(n);
+  for (int64_t i = 0; i < n; ++i) h[i] = (float)ival((uint64_t)i, seed) * 0.0625f;
+  CK(hipMemcpy(dst, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+}
+static int pool_setup(PoolBufs& B, int N, int H, int W, int C, int dtype, int max_rows) {
+  const int es = dtype == PASSL_BF16 ? 2 : 4;
+  const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
+  const int64_t nx = (int64_t)N * H * W * C, no = (int64_t)N * P * Q * C;
+  CK(hipMalloc(&B.x, nx * es)); CK(hipMalloc(&B.dx0, nx * es)); CK(hipMalloc(&B.dx1, nx * es));
+  CK(hipMalloc(&B.out, no * es)); CK(hipMalloc(&B.dy, no * es)); CK(hipMalloc((void**)&B.idx, no));
+  CK(hipMalloc((void**)&B.par, (size_t)7 * C * 4));
+  const size_t slab = ((size_t)max_rows * C * 2 + 16 * C * 4) * 4;
+  CK(hipMalloc((void**)&B.slab0, slab)); CK(hipMalloc((void**)&B.slab1, slab));
+  pool_upload(B.x, nx, 5u, es); pool_upload(B.dy, no, 17u, es);
+  fill_f32(B.par, C, 3u, -1.5f, 1.5f);            // scale (both signs)
+  fill_f32(B.par + C, C, 7u, -0.5f, 0.5f);        // shift
+  fill_f32(B.par + 2 * C, C, 9u, -0.5f, 0.5f);    // mean
+  fill_f32(B.par + 3 * C, C, 13u, 0.5f, 2.0f);    // invstd
+  fill_f32(B.par + 4 * C, 3 * C, 19u, -1.0f, 1.0f);   // coef A, B, C
+  const int rc = passl_hip_bn_relu_maxpool_fwd(B.x, B.par, B.par + C, B.out, B.idx, N, H, W, C, dtype, nullptr);
+  if (rc != PASSL_OK) { printf("    bn_relu_maxpool_fwd -> %d\n", rc); return rc; }
+  CK(hipDeviceSynchronize());
+  return 0;
+}
+static int pool_backward(PoolBufs& B, int N, int H, int W, int C, int dtype, float* slab, void* dx, int* rows) {
+  const int nb = passl_hip_bn_relu_maxpool_blocks(N, H, W, C);
+  *rows = nb;
+  int rc = passl_hip_bn_relu_maxpool_bwd_reduce(B.dy, B.idx, B.x, B.par + 2 * C, B.par + 3 * C, B.par, B.par + C, slab, nb, N, H,
+                                                W, C, dtype, nullptr);
+  if (rc == PASSL_OK)
+    rc = passl_hip_bn_relu_maxpool_bwd_apply(B.dy, B.idx, B.x, B.par + 4 * C, B.par, B.par + C, dx, N, H, W, C, dtype, nullptr);
+  if (rc != PASSL_OK) printf("    bn_relu_maxpool_bwd -> %d (%s)\n", rc, passl_hip_strerror(rc));
+  CK(hipDeviceSynchronize());
+  return rc;
+}
+static void pool_colsums(const float* slab_dev, int rows, int C, std::vector<double>& s) {
+  std::vector<float> h((size_t)rows * C * 2);
+  CK(hipMemcpy(h.data(), slab_dev, h.size() * 4, hipMemcpyDeviceToHost));
+  s.assign((size_t)C * 2, 0.0);
+  for (int b = 0; b < rows; ++b)
+    for (int c = 0; c < C * 2; ++c) s[c] += (double)h[(size_t)b * C * 2 + c];
+}
+static int run_poolcheck() {
+  struct Case { int N, H, W, C, dtype; };
+  const Case cases[] = {{3, 112, 112, 64, PASSL_BF16}, {2, 15, 15, 64, PASSL_BF16}, {2, 30, 18, 128, PASSL_BF16},
+                        {3, 16, 16, 8, PASSL_BF16},    {1, 7, 9, 256, PASSL_BF16},  {2, 15, 17, 64, PASSL_F32},
+                        {1, 112, 112, 64, PASSL_F32}};
+  int failures = 0;
+  for (const Case& c : cases) {
+    const int es = c.dtype == PASSL_BF16 ? 2 : 4;
+    const int64_t nx = (int64_t)c.N * c.H * c.W * c.C;
+    PoolBufs B;
+    passl_hip_set_option("stem_pool_form", 0);
+    const int rows_max = passl_hip_bn_relu_maxpool_blocks(c.N, c.H, c.W, c.C) + 4096;
+    if (pool_setup(B, c.N, c.H, c.W, c.C, c.dtype, rows_max)) { ++failures; B.release(); continue; }
+    int rows0 = 0;
+    CK(hipMemset(B.dx0, 0xff, nx * es));
+    if (pool_backward(B, c.N, c.H, c.W, c.C, c.dtype, B.slab0, B.dx0, &rows0)) { ++failures; B.release(); continue; }
+    std::vector<double> want, got;
+    pool_colsums(B.slab0, rows0, c.C, want);
+    std::vector<uint8_t> h0((size_t)nx * es), h1((size_t)nx * es);
+    CK(hipMemcpy(h0.data(), B.dx0, h0.size(), hipMemcpyDeviceToHost));
+    passl_hip_set_option("stem_pool_form", 1);
+      for (int wgs : {1024, 5, 4096}) {
+        passl_hip_set_option("stem_pool_wgs", wgs);
+        int rows1 = 0;
+        CK(hipMemset(B.dx1, 0xff, nx * es));
+        if (pool_backward(B, c.N, c.H, c.W, c.C, c.dtype, B.slab1, B.dx1, &rows1)) { ++failures; continue; }
+        CK(hipMemcpy(h1.data(), B.dx1, h1.size(), hipMemcpyDeviceToHost));
+        int64_t bad = 0;
+        for (size_t i = 0; i < h0.size(); ++i) if (h0[i] != h1[i]) { if (bad < 3) printf("    dx byte %zu: %02x vs %02x\n", i, h0[i], h1[i]); ++bad; }
+        pool_colsums(B.slab1, rows1, c.C, got);
+        int64_t sbad = 0;
+        double scale_ref = 0;
+        for (double v : want) scale_ref = fmax(scale_ref, fabs(v));
+        for (size_t i = 0; i < want.size(); ++i)
+          if (!(fabs(got[i] - want[i]) <= 2e-5 * fabs(want[i]) + 1e-6 * scale_ref)) { if (sbad < 3) printf("    column sum %zu: %.9g vs %.9g\n", i, got[i], want[i]); ++sbad; }
+        printf("%dx%dx%dx%d %s, %4d workgroups asked (%4d slab rows; first form %4d): dx %s, sums %s\n", c.N, c.H, c.W, c.C,
+               es == 2 ? "bf16" : "fp32", wgs, rows1, rows0, bad ? "DIFFERS" : "identical", sbad ? "DIFFER" : "agree");
+        if (bad || sbad) ++failures;
+      }
+    passl_hip_set_option("stem_pool_wgs", 1024);
+    B.release();
+  }
+  printf(failures ? "POOL CHECK FAILED (%d)\n" : "POOL CHECK OK\n", failures);
+  return failures ? 1 : 0;
+}
+static int run_pooltime() {
+  const int N = 256, H = 112, W = 112, C = 64, dtype = PASSL_BF16;
+  PoolBufs B;
+  passl_hip_set_option("stem_pool_form", 0);
+  const int rows_max = passl_hip_bn_relu_maxpool_blocks(N, H, W, C) + 8192;
+  if (pool_setup(B, N, H, W, C, dtype, rows_max)) return 1;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto time_it = [&](auto&& fn) {
+    for (int i = 0; i < 3; ++i) fn();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 20; ++i) fn();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1000.0 / 20;
+  };
+  const double fwd = time_it([&] { passl_hip_bn_relu_maxpool_fwd(B.x, B.par, B.par + C, B.out, B.idx, N, H, W, C, dtype, nullptr); });
+  printf("N = 256, 112 x 112 x 64 bf16.  forward %.1f us (514 + 51 MB)\n", fwd);
+  printf("%-34s %10s %10s\n", "backward", "reduce us", "apply us");
+  auto row = [&](const char* name) {
+    const int nb = passl_hip_bn_relu_maxpool_blocks(N, H, W, C);
+    const double r = time_it([&] { passl_hip_bn_relu_maxpool_bwd_reduce(B.dy, B.idx, B.x, B.par + 2 * C, B.par + 3 * C, B.par, B.par + C, B.slab0, nb, N, H, W, C, dtype, nullptr); });
+    const double a = time_it([&] { passl_hip_bn_relu_maxpool_bwd_apply(B.dy, B.idx, B.x, B.par + 4 * C, B.par, B.par + C, B.dx0, N, H, W, C, dtype, nullptr); });
+    printf("%-34s %10.1f %10.1f   (%d slab rows)\n", name, r, a, nb);
+  };
+  row("first form");
+  passl_hip_set_option("stem_pool_form", 1);
+  for (int wgs : {512, 768, 1024, 1536, 2048, 3136}) {
+    passl_hip_set_option("stem_pool_wgs", wgs);
+    char name[64];
+    snprintf(name, sizeof(name), "second form of the reduce, %d wgs", wgs);
+    row(name);
+  }
+  passl_hip_set_option("stem_pool_wgs", 1024);
+  B.release();
+  return 0;
+}
+
 static int apply_config(const char* cfg) {
   std::string c(cfg);
   size_t pos = 0;
@@ -817,6 +960,8 @@ int main(int argc, char** argv) {
   if (mode == "wcheck") return run_wcheck();
   if (mode == "fincheck") return run_fincheck();
   if (mode == "fintime") return run_fintime();
+  if (mode == "poolcheck") return run_poolcheck();
+  if (mode == "pooltime") return run_pooltime();
   if (mode == "finstress") return run_finstress(g_iters);
   if (mode == "wtime") return run_wtime();
   if (mode == "time") return run_time(nullptr, 0, 0);
