@@ -58,6 +58,10 @@ int passl_hip_abi_version(void);
  *                               whose sides are multiples of 8 / every such layer (default: the 8 x 8 patches overhang,
  *                               out-of-image pixels are fetched as zeros);  "wgrad_halo_stages" 2|3.
  *                               Its grid is one workgroup per 64 x 64 block of dw and slice: pass ~512 / blocks slices.
+ *   "stem_pool_form" 0|1        passl_hip_bn_relu_maxpool_bwd_reduce: one 2048-item block per workgroup / workgroups that
+ *                               walk over their share of the items with the next item's loads in flight (default; tensors
+ *                               below 2^30 elements);  "stem_pool_wgs" n: workgroups of the latter (1024).  Both change
+ *                               what passl_hip_bn_relu_maxpool_blocks returns: set them before sizing a slab.
  * Returns PASSL_EINVAL for an unknown name. */
 int passl_hip_set_option(const char* name, int value);
 /* Which kernel the most recent passl_hip_conv_igemm call of this process launched: 0 = igemm_kernel
@@ -354,7 +358,8 @@ int passl_hip_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int
  *   fwd:        y[n,p,q,c] = max over the window of T(relu(x*scale + shift)), idx = the winning tap
  *   bwd_reduce: partial[b][c][0..1] = sum g, sum g*(x - mean)*invstd with g = T(max-pool gradient of dy) masked by
  *               x*scale + shift > 0; nblocks = passl_hip_bn_relu_maxpool_blocks(N,H,W,C) slab rows (buffer sized by
- *               passl_hip_bn_partial_floats(nblocks, C, 0)), consumed by passl_hip_bn_bwd_finalize with M = N*H*W
+ *               passl_hip_bn_partial_floats(nblocks, C, 0)), consumed by passl_hip_bn_bwd_finalize with M = N*H*W.
+ *               idx must come from the forward pass (a tap outside the image is never the arg-max).
  *   bwd_apply:  dx = A g + B x + C
  * Element for element the arithmetic of passl_hip_bn_apply -> maxpool3x3s2_fwd resp. maxpool3x3s2_bwd -> bn_bwd_reduce
  * (relu = 2) -> bn_bwd_apply: y, idx and (for equal coefficients) dx are bit-identical to that chain; the slab is
