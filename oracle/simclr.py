@@ -58,10 +58,31 @@ def neck_keys():
     return ks
 
 
-def init_encoder_state(gen, in_channels=2048, hid_channels=2048, out_channels=128):
-    """Keys '0.<backbone>' / '1.<neck>' of nn.Sequential(ResNetsimclr, NonLinearNeckfc3)."""
+def basic_conv_specs(layers=(2, 2, 2, 2)):
+    """[(name, cout, cin, k, stride, pad, bn)] of the BasicBlock trunk (depth 18: 2-2-2-2; 34: 3-4-6-3) in
+    construction order — resnetcifar.py:41-118 (block) and :283-311 (_make_layer: a downsample conv + BN on the
+    first block of a stage whose stride or width changes)."""
+    specs = [('conv1', 64, 3, 7, 2, 3, 'bn1')]
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), layers), start=1):
+        stride = 1 if li == 1 else 2
+        for b in range(blocks):
+            p = 'layer%d.%d' % (li, b)
+            s_ = stride if b == 0 else 1
+            specs.append((p + '.conv1', planes, inplanes, 3, s_, 1, p + '.bn1'))
+            specs.append((p + '.conv2', planes, planes, 3, 1, 1, p + '.bn2'))
+            if b == 0 and (s_ != 1 or inplanes != planes):
+                specs.append((p + '.downsample.0', planes, inplanes, 1, s_, 0, p + '.downsample.1'))
+            inplanes = planes
+    return specs
+
+
+def init_encoder_state(gen, in_channels=2048, hid_channels=2048, out_channels=128, depth=50):
+    """Keys '0.<backbone>' / '1.<neck>' of nn.Sequential(ResNetsimclr, NonLinearNeckfc3).  depth 18 / 34: the
+    BasicBlock trunk (configs/simclr/simclr_r18_cifar10.yaml: in / hid channels 512)."""
     st = OrderedDict()
-    for name, cout, cin, k, _s, _p, bn in R.conv_specs():
+    specs = R.conv_specs() if depth == 50 else basic_conv_specs({18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}[depth])
+    for name, cout, cin, k, _s, _p, bn in specs:
         std = math.sqrt(2.0 / (cin * k * k))        # XavierNormal(fan_in=None, fan_out=0)
         st['0.' + name + '.weight'] = torch.randn(cout, cin, k, k, generator=gen) * std
         st['0.' + bn + '.weight'] = torch.ones(cout)
@@ -201,14 +222,18 @@ def paddle_param_names(keys):
 class SimCLROracle:
     def __init__(self, T=0.1, lr=64.0, warmup_steps=3127, t_max=28152, momentum=0.9,
                  lars_coeff=0.001, lars_weight_decay=1e-4, epsilon=0.0,
-                 exclude=('scale', 'offset', '.bias'), seed=0, bf16=False):
+                 exclude=('scale', 'offset', '.bias'), seed=0, bf16=False, depth=50, in_channels=2048,
+                 hid_channels=2048):
         gen = torch.Generator().manual_seed(seed)
         self.T = T
         # bf16=True: bf16-emulating encoder (encoder_forward); head, LARS and lr stay fp32 as in the product
         self.bf16 = bf16
         self.lr0, self.warmup_steps, self.t_max = lr, warmup_steps, t_max
         self.mu, self.coeff, self.wd, self.eps = momentum, lars_coeff, lars_weight_decay, epsilon
-        self.st = init_encoder_state(gen)
+        # depth 18 / 34: state, LARS and schedule only (train_step restates the bottleneck trunk; the R18 goldens are
+        # the reference's own forward / backward, tests/golden/make_golden_simclr_r18.py)
+        self.depth = depth
+        self.st = init_encoder_state(gen, in_channels, hid_channels, depth=depth)
         pnames = paddle_param_names(list(self.st.keys()))
         self.excluded = {k for k, n in pnames.items() if any(e in n for e in exclude)}
         self.velocity = OrderedDict()
@@ -218,6 +243,7 @@ class SimCLROracle:
         return simclr_lr(self.step_count, self.lr0, self.warmup_steps, self.t_max)
 
     def train_step(self, img_q, img_k, taps=None):
+        assert self.depth == 50, 'the restated trunk is the bottleneck one'
         tkeys = R.trainable_keys(self.st)
         for n in tkeys:
             self.st[n] = self.st[n].detach().requires_grad_(True)

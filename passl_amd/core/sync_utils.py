@@ -120,34 +120,42 @@ class GradReducer(object):
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        if not (self.world > 1 or self._forced):
+            return          # nothing to order: the end-of-backward join of hip/streams.py covers whoever reads .grad
+        from ..hip.replay import host_call
+        grads, group = self.grads, self.group
+        comm = None
         if self.grads.is_cuda:
-            # the collective is ordered behind the CURRENT stream only.  Weight gradients are produced on
-            # the side stream (hip/streams.py), BatchNorm / bias gradients on the stream backward() was
-            # called on, and this call may come from a backward node that autograd runs on the side stream
-            # (a forked downsample branch): wait for both
+            # The bucket's producers sit on up to three streams: weight gradients on the side stream
+            # (hip/streams.py), BatchNorm / bias gradients on the stream backward() was called on, and this very
+            # call may come from a node autograd runs on the side stream (a forked downsample branch).  The
+            # collective is ordered behind the CURRENT stream only, so it is issued from a stream of its own that
+            # waits for all of them (streams.comm_stream) — the main chain itself waits for nothing here (until
+            # round 5 it joined the side stream in front of every bucket: four waits per backward pass on the
+            # critical chain).  The waits go through hip/streams.py: a recorded step replays them.
             from ..hip import streams
-            cur = torch.cuda.current_stream(self.grads.device)
-            if self._home is not None and cur != self._home:
-                streams.wait_stream(cur, self._home)
-            streams.join(self.grads.device)
-        if self.world > 1 or self._forced:
-            from ..hip.replay import host_call
-            grads, group = self.grads, self.group
-            if self.wire is not None:
-                # a launch of the library on the current stream, OUTSIDE the host call: a recorded step replays it as
-                # part of the plan, the live collective below then reads the twin
+            comm = streams.comm_stream(self.grads.device)
+            streams.gather_into(comm, self.grads.device, extra=(self._home,) if self._home is not None else ())
+        if self.wire is not None:
+            # a launch of the library, OUTSIDE the host call: a recorded step replays it as part of the plan (on the
+            # issuing stream), the live collective below then reads the twin
+            if comm is not None:
+                with torch.cuda.stream(comm):
+                    _cast(self.grads[s:e], self.wire[s:e])
+            else:
                 _cast(self.grads[s:e], self.wire[s:e])
-                grads = self.wire
+            grads = self.wire
 
-            def collective():
-                # a live call also when the step is replayed from a native plan (hip/replay.py: the plan is cut here).
-                # At a replay it runs on the thread and stream that drive the step, not on the autograd node's: order
-                # that stream behind the streams that may hold this bucket's producers first.
-                if grads.is_cuda:
-                    from ..hip import streams
-                    streams.join(grads.device)
-                self._handles.append(dist.all_reduce(grads[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True))
-            host_call(collective)
+        def collective():
+            # a live call also when the step is replayed from a native plan (hip/replay.py: the plan is cut here);
+            # the replayed segment in front of it contains the issuing stream's waits for the producers
+            if comm is not None:
+                with torch.cuda.stream(comm):
+                    h = dist.all_reduce(grads[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            else:
+                h = dist.all_reduce(grads[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)
+            self._handles.append(h)
+        host_call(collective)
 
     def mark_ready(self, index):
         if not self._active or index in self._ready:

@@ -21,4 +21,8 @@ def build_dataloader(cfg, device):
     dataset = build_dataset(ds_cfg)
     loader = SyntheticLoader(dataset, batch_size=sampler.get('batch_size', 32), device=device,
                              drop_last=sampler.get('drop_last', True))
+    ring = int((cfg.get('loader', None) or {}).get('host_ring', 0) or 0)
+    if ring:
+        from .synthetic import HostRingLoader
+        loader = HostRingLoader(loader, ring=ring)       # batches move host -> device one step ahead of the step
     return loader, None

@@ -34,23 +34,34 @@ from ..solver import build_lr_scheduler, build_lr_scheduler_simclr, build_optimi
 
 
 class IterLoader:
+    """Endless view of a dataloader for the iteration-based loop: ``next()`` never raises, ``epoch``
+    counts the passes that have been exhausted so far (the role of the loader wrapper the reference's
+    ``Trainer.train`` draws from, passl_v110/engine/trainer.py:48-69)."""
+
     def __init__(self, dataloader, epoch=0):
         self._dataloader = dataloader
-        self.iter_loader = iter(self._dataloader)
         self._epoch = epoch
+        self._stream = self._batches()
+
+    def _batches(self):
+        while True:
+            n = 0
+            for batch in self._dataloader:
+                n += 1
+                yield batch
+            if n == 0:
+                raise RuntimeError('IterLoader: the dataloader yields no batch')
+            self._epoch += 1
 
     @property
     def epoch(self):
         return self._epoch
 
+    def __iter__(self):
+        return self
+
     def __next__(self):
-        try:
-            data = next(self.iter_loader)
-        except StopIteration:
-            self._epoch += 1
-            self.iter_loader = iter(self._dataloader)
-            data = next(self.iter_loader)
-        return data
+        return next(self._stream)
 
     def __len__(self):
         return len(self._dataloader)
@@ -116,13 +127,19 @@ class Trainer:
                 cfg.lr_scheduler, self.iters_per_epoch, self.batch_size * 8, cfg.epochs,
                 self.current_iter)
         else:
-            self.lr_scheduler = build_lr_scheduler(cfg.lr_scheduler, self.iters_per_epoch)
+            self.lr_scheduler = build_lr_scheduler(
+                cfg.lr_scheduler, self.iters_per_epoch, epochs=cfg.get('epochs', None),
+                batch_size=int(cfg.dataloader.train.sampler.get('batch_size', 0) or 0) * self.world_size or None)
         self.optimizer = build_optimizer(cfg.optimizer, self.lr_scheduler, [self.model])
 
         self.use_amp = cfg.get('use_amp', False)
+        self.scaler = None
         if self.use_amp:
-            raise NotImplementedError('paddle.amp fp16 O2 is replaced by the bf16 compute dtype of '
-                                      'the HIP path (cfg.compute_dtype); loss scaling is not needed')
+            # paddle.amp O1/O2 (fp16 + GradScaler, trainer.py:186-215) has no counterpart here: the HIP path's mixed
+            # precision is bf16 storage with fp32 accumulation and fp32 master weights, which needs no loss scaling
+            hip_config.set_compute_dtype('bfloat16')
+            self.logger.info('use_amp: mapped to compute_dtype=bfloat16 (fp32 master weights, no loss scaling; '
+                             'AMP.level / scale_loss are ignored)')
 
         self.grad_reducer = None
         if self.world_size > 1 or collectives_active():

@@ -144,6 +144,37 @@ def key_stream(device):
     return s
 
 
+_comm_streams = {}
+
+
+def comm_stream(device):
+    """Stream a gradient bucket's collective is ISSUED from (core/sync_utils.py:GradReducer).  torch.distributed
+    orders its communication stream behind the CURRENT stream, and a bucket has producers on two streams (weight
+    gradients on the side stream, BatchNorm / bias gradients on the stream backward() runs on).  Making the main
+    stream wait for the side stream in front of every bucket (rounds 1-5) put a cross-stream wait — and whatever the
+    side stream was behind by — on the step's critical chain four times per backward pass.  Instead THIS stream waits
+    for both and the collective is issued with it current: RCCL waits for the two producers, the main chain waits
+    for nobody until the optimizer."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _comm_streams.get(key)
+    if s is None:
+        s = _comm_streams[key] = torch.cuda.Stream(device=device, priority=_aux_priority())
+    return s
+
+
+def gather_into(target, device, extra=()):
+    """Order ``target`` behind everything issued so far on the current stream, the side / fork / key streams and
+    ``extra`` — without making any of THEM wait.  Queued side work is handed over first."""
+    flush_side(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    seen = []
+    for st in (torch.cuda.current_stream(device),) + tuple(extra) + tuple(
+            t.get(key) for t in (_streams, _fork_streams, _key_streams)):
+        if st is not None and st != target and st not in seen:
+            seen.append(st)
+            wait_stream(target, st)
+
+
 _TIGHT_FRAC = float(os.environ.get('PASSL_OVERLAP_MAX_RESERVED_FRAC', '0.8'))
 _tight = {}          # device index -> [calls, tight?, capacity]
 

@@ -56,7 +56,19 @@ class SimCLR(nn.Layer):
         self.encoder = torch.nn.Sequential(build_backbone(backbone), build_neck(neck))
         self.backbone = self.encoder[0]
         self.head = build_head(head)
-        self.arena_q = EncoderArena(self.encoder, trainable=True)    # name shared with MoCo (DP reducer)
+        # ``frozen_stages >= 0`` (configs/simclr/simclr_r18_cifar10.yaml:8 freezes the whole trunk): the frozen prefix
+        # lives in a non-trainable arena and runs the fused inference path, the rest shares the trainable arena with
+        # the projector — the split of architectures/clas.py
+        bb = self.backbone
+        frozen = bb.frozen_modules() if hasattr(bb, 'frozen_modules') else []
+        self.arena_k = None
+        if frozen:
+            self.arena_k = EncoderArena(torch.nn.ModuleList(frozen), trainable=False)
+            self.arena_k.update_bn_affine()
+            object.__setattr__(self, '_live', torch.nn.ModuleList(list(bb.trainable_modules()) + [self.encoder[1]]))
+            self.arena_q = EncoderArena(self._live, trainable=True)
+        else:
+            self.arena_q = EncoderArena(self.encoder, trainable=True)    # name shared with MoCo (DP reducer)
 
     def load_state_dict(self, state_dict, strict=True):
         r = super().load_state_dict(state_dict, strict=strict)
@@ -64,6 +76,9 @@ class SimCLR(nn.Layer):
         return r
 
     def sync_runtime_state(self):
+        if self.arena_k is not None:
+            self.arena_k.refresh()
+            self.arena_k.update_bn_affine()
         self.arena_q.refresh()
 
     def train_iter(self, *inputs, **kwargs):

@@ -1,4 +1,4 @@
-"""ResNet backbone on the HIP path (depth 50/101/152, bottleneck blocks).
+"""ResNet backbone on the HIP path (depth 50/101/152 bottleneck blocks; depth 18/34 BasicBlock).
 
 API and state_dict keys follow the reference's ``ResNet`` (passl_v110/modeling/backbones/
 resnet.py:25-104, a subclass of paddle.vision's ResNet whose topology is stated in-tree at
@@ -110,6 +110,54 @@ class BottleneckBlock(nn.Layer):
         return self.conv3.infer(out, self.bn3, residual=identity, relu=True)
 
 
+class BasicBlock(nn.Layer):
+    """The two-convolution block of depth 18 / 34 (reference passl_v110/modeling/backbones/resnetcifar.py:41-118):
+    3x3(stride) -> BN -> ReLU -> 3x3 -> BN -> (+ downsample(x)) -> ReLU, bias-free convolutions.
+
+    Same execution scheme as BottleneckBlock: every convolution is one implicit-GEMM launch with the BatchNorm
+    statistics in its epilogue; the data-gradient launch of conv2 also reduces bn1's backward statistics (BNLink).
+    conv1 is a 3x3 here, so the residual-fork hand-off (GradSlot: the identity gradient added in conv1's
+    data-gradient epilogue, which then also reduces the previous BatchNorm's backward) is taken only when that
+    data gradient is ONE dense launch — stride 1; a stride-2 conv1 (first block of stages 2-4, always next to a
+    downsample branch) writes four sub-lattices of dx and leaves the sum of the two branch gradients to autograd."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1, base_width=64,
+                 dilation=1, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2D
+        if dilation > 1:
+            raise NotImplementedError('Dilation > 1 not supported in BasicBlock')
+        self.conv1 = nn.Conv2D(inplanes, planes, 3, stride=stride, padding=1, bias_attr=False)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = nn.Conv2D(planes, planes, 3, padding=1, bias_attr=False)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        slot = None
+        if (config.fuse_residual_grad() and torch.is_grad_enabled() and x.requires_grad and self.stride == 1):
+            slot = nn.GradSlot()
+            slot.arm()
+        out, st = self.conv1(x, want_stats=True, add_slot=slot,
+                             producer=nn.bn_link(x) if slot is not None else None)
+        out = self.bn1(out, relu=True, stats=st)
+        out, st2 = self.conv2(out, want_stats=True, producer=nn.bn_link(out))
+        if self.downsample is not None:
+            idn, st = self.downsample[0](x, want_stats=True, sink_slot=slot)
+            identity = self.downsample[1](idn, relu=False, stats=st)
+            return self.bn2(out, residual=identity, relu=True, stats=st2)
+        return self.bn2(out, residual=x, relu=True, stats=st2, res_slot=slot)
+
+    def forward_frozen(self, x, allow_fork=True):
+        """Running-statistics BatchNorm folded into the convolution epilogues: 2-3 launches per block."""
+        out = self.conv1.infer(x, self.bn1, relu=True)
+        identity = x if self.downsample is None else self.downsample[0].infer(x, self.downsample[1], relu=False)
+        return self.conv2.infer(out, self.bn2, residual=identity, relu=True)
+
+
 class _StagedInput:
     """An image batch already converted by ResNet.stage_input (tensor, size, completion event)."""
     __slots__ = ('xp', 'H', 'W', 'ready')
@@ -125,9 +173,10 @@ class ResNet(nn.Layer):
     def __init__(self, depth, num_classes=0, with_pool=False, zero_init_residual=False,
                  frozen_stages=-1, pretrained=None):
         super().__init__()
-        layer_cfg = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+        layer_cfg = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
         if depth not in layer_cfg:
-            raise NotImplementedError('HIP path builds bottleneck ResNets only (depth 50/101/152)')
+            raise NotImplementedError('ResNet depth %r (built: 18 / 34 BasicBlock, 50 / 101 / 152 bottleneck)' % (depth,))
+        block = BasicBlock if depth in (18, 34) else BottleneckBlock
         if num_classes > 0:
             raise NotImplementedError('classification fc is outside the MoCo hot path')
         layers = layer_cfg[depth]
@@ -141,10 +190,10 @@ class ResNet(nn.Layer):
         self.relu = nn.ReLU()
         if self.stem_pool:
             self.maxpool = nn.MaxPool2D(kernel_size=3, stride=2, padding=1)
-        self.layer1 = self._make_layer(BottleneckBlock, 64, layers[0])
-        self.layer2 = self._make_layer(BottleneckBlock, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(BottleneckBlock, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(BottleneckBlock, 512, layers[3], stride=2)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
         if with_pool:
             self.avgpool = nn.AdaptiveAvgPool2D((1, 1))
         self.zero_init_residual = zero_init_residual
@@ -185,6 +234,8 @@ class ResNet(nn.Layer):
             for m in self.modules():
                 if isinstance(m, BottleneckBlock):
                     init.constant_init(m.bn3, 0)
+                elif isinstance(m, BasicBlock):
+                    init.constant_init(m.bn2, 0)
 
     def _freeze_stages(self):
         """resnet.py:90-106: ``frozen_stages >= 0`` freezes the stem (conv1 / bn1), every further unit

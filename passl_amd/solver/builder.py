@@ -7,7 +7,22 @@ LRSCHEDULERS = Registry('LRSCHEDULER')
 OPTIMIZERS = Registry('OPTIMIZER')
 
 
-def build_lr_scheduler(cfg, iters_per_epoch):
+def build_lr_scheduler(cfg, iters_per_epoch, batch_size=None, epochs=None):
+    """passl_v110/solver/builder.py:26-42.  ``batch_size`` (global) / ``epochs``: only for the SimCLR key set below."""
+    if cfg.name == 'CosineWarmup' and 'total_images' in cfg:
+        # configs/simclr/simclr_r18_cifar10.yaml:106-113 spells ``name: CosineWarmup`` with the key set of
+        # ``simclrCosineWarmup`` (learning_rate_scaling / total_images / warmup_epochs / start_lr / end_lr / T_max in
+        # epochs) and carries no ``use_simclr_iters``.  The reference's own CosineWarmup.__init__ takes none of those
+        # keys (lr_scheduler.py:78-86: build_from_config raises TypeError there; tests/test_oracle_simclr.py pins that
+        # by running the reference's builder on the yaml).  It is resolved the way builder.py:54-66 resolves the
+        # r50 recipe's block of the same keys, with the job's real global batch.
+        if batch_size is None or epochs is None:
+            raise ValueError('lr_scheduler CosineWarmup with total_images needs the global batch size and the epochs')
+        cfg = copy.deepcopy(cfg)
+        cfg.name = 'simclrCosineWarmup'
+        return build_lr_scheduler_simclr(cfg, iters_per_epoch, batch_size, epochs, 0)
+    if cfg.name in ('CosineWarmup', 'Cosine'):
+        return build_from_config(cfg, LRSCHEDULERS)          # builder.py:39-40: passed through as written
     if cfg.name in ('CosineAnnealingDecay',):
         cfg.T_max *= iters_per_epoch          # yaml T_max is in epochs (builder.py:28-30)
         return build_from_config(cfg, LRSCHEDULERS)

@@ -80,6 +80,39 @@ class LinearWarmup(LRScheduler):
 
 
 @LRSCHEDULERS.register()
+class Cosine(LRScheduler):
+    """The cosine half of ``CosineWarmup`` — passl_v110/solver/lr_scheduler.py:29-62: counted in the wrapper's
+    post-warm-up iterations, period ``T_max - warmup_steps``; the reference's branch for
+    ``(last_epoch - 1 - T_max) % (2 T_max) == 0`` (a restart step taken from the previous value) is kept."""
+
+    def __init__(self, learning_rate, T_max, warmup_steps, eta_min=0, last_epoch=1, verbose=False):
+        self.T_max, self.warmup_steps, self.eta_min = T_max, warmup_steps, eta_min
+        super().__init__(learning_rate, last_epoch=last_epoch, verbose=verbose)
+        self.last_epoch = last_epoch
+
+    def get_lr(self):
+        if self.last_epoch == 0:
+            return self.base_lr
+        if (self.last_epoch - 1 - self.T_max) % (2 * self.T_max) == 0:
+            return self.last_lr + (self.base_lr - self.eta_min) * (1 - math.cos(math.pi / self.T_max)) / 2
+        return self.eta_min + 0.5 * (self.base_lr - self.eta_min) * (
+            1 + math.cos(math.pi * self.last_epoch / (self.T_max - self.warmup_steps)))
+
+
+@LRSCHEDULERS.register()
+class CosineWarmup(LinearWarmup):
+    """Linear warm-up ``start_lr -> end_lr`` over ``warmup_steps``, then ``Cosine`` — passl_v110/solver/
+    lr_scheduler.py:68-102 (every argument in iterations; build_lr_scheduler passes the yaml through)."""
+
+    def __init__(self, learning_rate, warmup_steps, start_lr, end_lr, T_max, eta_min=0, last_epoch=-1,
+                 verbose=False):
+        lr_sch = Cosine(learning_rate, T_max, warmup_steps, eta_min=eta_min, last_epoch=last_epoch, verbose=verbose)
+        super().__init__(learning_rate=lr_sch, warmup_steps=warmup_steps, start_lr=start_lr, end_lr=end_lr,
+                         last_epoch=last_epoch)
+        self.update_specified = False
+
+
+@LRSCHEDULERS.register()
 class Cosinesimclr(LRScheduler):
     """passl_v110/solver/lr_scheduler.py:105-114."""
 

@@ -1,14 +1,18 @@
-"""AverageMeter / accuracy helpers (reference: passl_v110/utils/misc.py)."""
+"""Running-average meter used by the hook bus and the v2 loops.
+
+Serves both spellings of the reference: passl_v110/utils/misc.py:17-39 passes format specs WITH the colon
+(``AverageMeter('loss', ':.4e')``, printed through ``str()``), passl/utils/misc.py:33-76 passes them without
+(``AverageMeter('batch_cost', '.5f', postfix=' s')``, printed through ``.mean / .value / .total``).
+"""
 
 __all__ = ['AverageMeter']
 
 
 class AverageMeter(object):
-    """Computes and stores the average and current value."""
-
-    def __init__(self, name='', fmt='f', need_avg=True):
+    def __init__(self, name='', fmt='f', postfix='', need_avg=True):
         self.name = name
         self.fmt = fmt
+        self.postfix = postfix
         self.need_avg = need_avg
         self.reset()
 
@@ -24,10 +28,24 @@ class AverageMeter(object):
         self.count += n
         self.avg = self.sum / self.count
 
+    def _show(self, x):
+        return format(x, self.fmt.lstrip(':'))
+
     def __str__(self):
-        fmtstr = '{name}: {val' + self.fmt + '} ({avg' + self.fmt + '})'
-        return fmtstr.format(**self.__dict__)
+        return '%s: %s (%s)' % (self.name, self._show(self.val), self._show(self.avg))
 
     @property
     def total(self):
-        return '{self.name}_sum: {self.sum:{self.fmt}}{self.postfix}'.format(self=self)
+        return '%s_sum: %s%s' % (self.name, self._show(self.sum), self.postfix)
+
+    @property
+    def total_minute(self):
+        return '%s %s%s min' % (self.name, self._show(self.sum / 60), self.postfix)
+
+    @property
+    def mean(self):
+        return '%s: %s%s' % (self.name, self._show(self.avg), self.postfix) if self.need_avg else ''
+
+    @property
+    def value(self):
+        return '%s: %s%s' % (self.name, self._show(self.val), self.postfix)

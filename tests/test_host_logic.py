@@ -415,7 +415,7 @@ def test_simclr_registry_names_and_kwargs():
     assert h.temperature == 0.5 and h.co2_weight == 3.0
     with pytest.raises(NotImplementedError):
         hip_config.set_device('cpu')
-        BACKBONES.get('ResNetsimclr')(depth=18)
+        BACKBONES.get('ResNetsimclr')(depth=20)
 
 
 # ------------------------------------------------------------------ checkpoint / weight exchange
@@ -1160,3 +1160,111 @@ def test_vit_factories_outside_the_attention_envelope_refuse_at_construction():
             getattr(V, name)(class_num=0)
     m = V.VisionTransformer(patch_size=32, embed_dim=128, depth=1, num_heads=4, class_num=0)      # ViT-*/32 @ 224: 50 tokens
     assert m.pos_embed.shape[1] == 50
+
+
+def test_iter_loader_average_meter_and_use_amp_mapping(tmp_path):
+    """Verdict r05 hygiene: IterLoader restated (endless, epoch = exhausted passes), AverageMeter.total has its
+    postfix, ``use_amp: True`` maps to the bf16 compute dtype instead of raising (trainer.py:186-215)."""
+    from passl_amd.engine.trainer import IterLoader, Trainer
+    from passl_amd.hip import config as hip_config
+    from passl_amd.utils.misc import AverageMeter
+    it = IterLoader([10, 11, 12], epoch=4)
+    seen = [(next(it), it.epoch) for _ in range(7)]
+    assert seen == [(10, 4), (11, 4), (12, 4), (10, 5), (11, 5), (12, 5), (10, 6)]
+    assert len(it) == 3
+    with pytest.raises(RuntimeError):
+        next(IterLoader([]))
+    m = AverageMeter('batch_cost', '.3f', postfix=' s')
+    m.update(0.5, 2)
+    m.update(1.0)
+    assert m.total == 'batch_cost_sum: 2.000 s' and str(m) == 'batch_cost: 1.000 (0.667)'
+    _register_dummies()
+    before = hip_config.get_compute_dtype()
+    try:
+        hip_config.set_compute_dtype('fp32')
+        cfg = get_config(OUR_CFG, ['device=cpu', 'epochs=1', 'dataloader.train.sampler.batch_size=4',
+                                   'dataloader.train.dataset.num_samples=4',
+                                   'dataloader.train.dataset.image_size=8'])
+        cfg.use_amp = True                       # as configs/*/...yaml spell it (top-level key)
+        cfg.model = AttrDict(name='DummySSL', dim=4)
+        cfg.optimizer = AttrDict(name='PlainSGD')
+        cfg.output_dir = str(tmp_path)
+        tr = Trainer(cfg)
+        assert tr.use_amp is True and tr.scaler is None
+        assert hip_config.get_compute_dtype() == torch.bfloat16
+    finally:
+        hip_config.set_compute_dtype(before)
+
+
+REF_SIMCLR_R18_CFG = '/root/reference/configs/simclr/simclr_r18_cifar10.yaml'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SIMCLR_R18_CFG), reason='reference tree not present')
+def test_reference_simclr_r18_cifar10_config_loads_and_builds_unchanged(tmp_path):
+    """configs/simclr/simclr_r18_cifar10.yaml (round-5 verdict, missing #1): backbone ``ResNetCifar`` depth 18
+    (BasicBlock trunk of resnetcifar.py:41-118, 216-333), ``frozen_stages: 4``, the fc3 neck at 512 channels, lr block
+    ``CosineWarmup`` with the SimCLR key set, LARS.  Built from the YAML as written; only the dataset NAME is replaced."""
+    hip_config.set_device('cpu')
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.modeling import build_model
+    from passl_amd.modeling.backbones.resnet import BasicBlock
+    from oracle.simclr import init_encoder_state
+    cfg = get_config(REF_SIMCLR_R18_CFG, ['dataloader.train.dataset.name=SyntheticCIFAR10'])
+    model = build_model(cfg.model)
+    bb = model.backbone
+    assert type(bb).__name__ == 'ResNetCifar' and bb.frozen_stages == 4 and bb.fully_frozen and bb.with_pool
+    assert not hasattr(bb, 'maxpool') and all(isinstance(b, BasicBlock) for st in (bb.layer1, bb.layer4) for b in st)
+    assert [len(getattr(bb, 'layer%d' % i)) for i in (1, 2, 3, 4)] == [2, 2, 2, 2]
+    assert model.head.temperature == 0.5
+    # the reference's own state_dict layout for this trunk (keys and shapes as its ResNetsimclr(depth=18) + fc3 give them)
+    ost = init_encoder_state(torch.Generator().manual_seed(0), 512, 512, depth=18)
+    sd = model.encoder.state_dict()
+    assert list(sd.keys()) == list(ost.keys()) and all(tuple(sd[k].shape) == tuple(ost[k].shape) for k in ost)
+    assert sum(p.numel() for p in model.parameters()) == 11769792
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 593280      # the projector only
+    # the whole Trainer from the YAML: lr block resolved like the r50 recipe's (builder.py:54-66) at the real global batch
+    cfg.device = 'cpu'
+    cfg.output_dir = str(tmp_path)
+    cfg.timestamp = ''
+    tr = Trainer(cfg)
+    assert tr.iters_per_epoch == 50000 // 512 and 'lars' in tr.optimizer.type
+    s = tr.lr_scheduler
+    assert type(s).__name__ == 'simclrCosineWarmup'
+    assert s.warmup_steps == 10 * 50000 // 512 and s.end_lr == 1.0 * 512 / 256.
+    assert s.learning_rate.T_max == 50000 * 1000 // 512 + 1 - s.warmup_steps
+    assert tr.optimizer._wd == 1e-4 and tr.optimizer._momentum == 0.9
+    with pytest.raises(NotImplementedError):
+        from passl_amd.datasets.builder import DATASETS
+        DATASETS.get('CIFAR10')(dataroot='data/cifar10/train')
+
+
+def test_cosine_warmup_scheduler_known_answers():
+    """``CosineWarmup`` / ``Cosine`` with their own argument list (passl_v110/solver/lr_scheduler.py:29-102)."""
+    from passl_amd.solver import build_lr_scheduler
+    cfg = AttrDict(name='CosineWarmup', learning_rate=0.5, warmup_steps=4, start_lr=0.0, end_lr=0.5, T_max=20)
+    s = build_lr_scheduler(cfg, 7)
+    seen = []
+    for _ in range(8):
+        seen.append(s())
+        s.step()
+    assert seen[:4] == [0.0, 0.125, 0.25, 0.375]
+    # after the warm-up: the wrapped Cosine stepped to (t - warmup), period T_max - warmup_steps
+    assert abs(seen[4] - 0.5) < 1e-12
+    for t in (5, 6, 7):
+        assert abs(seen[t] - 0.25 * (1 + math.cos(math.pi * (t - 4) / 16))) < 1e-12
+    with pytest.raises(ValueError):
+        build_lr_scheduler(AttrDict(name='CosineWarmup', total_images=10, warmup_epochs=1, start_lr=0, end_lr=1.0,
+                                    T_max=2, learning_rate_scaling='linear'), 7)
+
+
+def test_host_ring_loader_cycles_its_pinned_batches_on_cpu():
+    from passl_amd.datasets.synthetic import HostRingLoader, SyntheticLoader, SyntheticTwoView
+    ds = SyntheticTwoView(num_samples=64, image_size=8, seed=5)
+    inner = SyntheticLoader(ds, batch_size=4, device=torch.device('cpu'))
+    ring = HostRingLoader(inner, ring=3)
+    got = [ring.take() for _ in range(7)]
+    assert len(ring) == len(inner) == 16 and ring.bytes_per_batch == 2 * 4 * 3 * 8 * 8 * 4
+    assert all(torch.equal(got[i][0], got[i + 3][0]) and torch.equal(got[i][1], got[i + 3][1]) for i in range(4))
+    assert not torch.equal(got[0][0], got[1][0]) and not torch.equal(got[1][0], got[2][0])
+    assert torch.equal(got[0][0], inner._cache[0][0])        # batch 0 = the resident loader's batch (same seed)
+    assert sum(1 for _ in ring) == 16

@@ -153,3 +153,40 @@ def test_lars_and_schedule_known_answers():
     o.apply_lars({n: torch.zeros_like(p1)})
     lr2 = S.simclr_lr(2, 2.0, 1, 10)
     assert (o.st[n] - (p1 - (0.9 * v + lr2 * 1e-4 * p1))).abs().max() < 1e-6
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/passl_v110'),
+                    reason='reference tree not present (GPU box)')
+def test_reference_cannot_build_its_own_r18_cifar10_yaml_but_builds_the_registered_class_over_the_same_file():
+    """configs/simclr/simclr_r18_cifar10.yaml names ``backbone: ResNetCifar`` — in the reference that is an import alias
+    (backbones/__init__.py:15), never registered, and its lr block gives ``CosineWarmup`` keys its __init__ does not
+    take.  Pinned by running the reference's own builders on the YAML (paddle shim, subprocess); the registered class
+    over the same file, ``ResNetsimclr(depth=18)``, builds the BasicBlock trunk whose state layout the product and
+    tests/golden/simclr_r18_*.npz use."""
+    code = r'''
+import copy, yaml, torch
+from oracle import ref_runner
+from oracle.simclr import init_encoder_state
+ns = ref_runner.load()
+cfg = yaml.safe_load(open('/root/reference/configs/simclr/simclr_r18_cifar10.yaml'))
+try:
+    ns.build_model(copy.deepcopy(cfg['model']))
+    raise SystemExit('the reference built ResNetCifar?')
+except KeyError as e:
+    assert 'ResNetCifar' in str(e), e
+src = open('/root/reference/passl_v110/solver/lr_scheduler.py').read()
+i = src.index('def __init__', src.index('class CosineWarmup')); sig = src[i:src.index('):', i)]
+for key in ('learning_rate_scaling', 'total_images', 'warmup_epochs'):
+    assert key in cfg['lr_scheduler'] and key not in sig, key              # kwargs CosineWarmup.__init__ lacks
+for need in ('learning_rate', 'warmup_steps'):
+    assert need in sig and need not in cfg['lr_scheduler'], need           # ... and required ones the yaml lacks
+c2 = copy.deepcopy(cfg['model']); c2['backbone']['name'] = 'ResNetsimclr'
+m = ns.build_model(c2)
+ost = init_encoder_state(torch.Generator().manual_seed(0), 512, 512, depth=18)
+sd = m.encoder.state_dict()
+assert list(sd.keys()) == list(ost.keys()) and all(tuple(sd[k].shape) == tuple(ost[k].shape) for k in ost)
+assert sum(1 for p in m.parameters() if p.requires_grad) == 12          # frozen_stages: 4 -> the projector only
+print('R18-OK')
+'''
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'R18-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
