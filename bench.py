@@ -233,6 +233,12 @@ def main():
                      ('MASTER_PORT', str(_free_port()))):
             os.environ.setdefault(k, v)
 
+    # stdout carries exactly ONE line (the JSON): everything else that writes to file descriptor 1 — RCCL prints its
+    # version banner there when a communicator is created — goes to stderr from here on
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     pinned = pin_rank_to_cores()
 
     import torch
@@ -545,7 +551,8 @@ def main():
             out['dist'] = dist_info
         if world == 1 and not args.no_cpu_baseline and args.workload == 'moco':
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -199,6 +199,26 @@ def mae_forward(st, imgs, noise, cfg, mask_ratio=0.75):
 
 
 # ------------------------------------------------------------------ solver
+def finetune_state(keys_shapes, seed=0):
+    """Seed-defined state for the fine-tuning model (MAE_FINETUNE: reference architectures/MAE.py:58-94): deterministic
+    non-trivial values for every (key, shape) of the model's own state_dict, in key order — LayerNorm weights around 1,
+    small non-zero biases, N(0, 0.02) elsewhere.  tests/golden/make_golden_mae_finetune.py loads it into the reference's
+    model, tests/test_mae_gpu.py into the product's (the fixture records the key list)."""
+    gen = torch.Generator().manual_seed(seed)
+    st = {}
+    for name, shape in keys_shapes:
+        t = torch.randn(*shape, generator=gen)
+        if name.endswith('.bias'):
+            st[name] = 0.02 * t
+        elif name.endswith('.weight') and 'norm' in (name.split('.')[-2] if name.count('.') else ''):
+            st[name] = 1.0 + 0.1 * t
+        elif name.endswith('cls_token') or name.endswith('pos_embed'):
+            st[name] = 0.02 * t
+        else:
+            st[name] = 0.02 * t
+    return st
+
+
 def warmup_cosine_lr(t, base_lr, t_max, eta_min, warmup_steps, start_lr, end_lr):
     """LinearWarmup(learning_rate=CosineAnnealingDecay(base_lr, T_max, eta_min), warmup_steps,
     start_lr, end_lr) at scheduler epoch t (units already converted to iterations)."""

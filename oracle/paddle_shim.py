@@ -414,6 +414,7 @@ def install():
     paddle.randperm = lambda n: torch.randperm(n)
     paddle.argsort = lambda x, axis=-1: torch.argsort(x, dim=axis)
     paddle.index_select = lambda x, index, axis=0: torch.index_select(x, axis, index)
+    paddle.linspace = lambda start, stop, num, dtype=None: torch.linspace(float(start), float(stop), int(num))   # mae.py:234 (drop-path ladder)
 
     def assign(x, output=None):
         if output is None:

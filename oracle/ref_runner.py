@@ -97,6 +97,8 @@ def load():
     # linear-probe row: heads/clas_head.py, architectures/clas.py
     imp(PKG + '.modeling.heads.clas_head')
     imp(PKG + '.modeling.architectures.clas')
+    # MAE fine-tuning row: heads/vision_transformer_head.py (MAE_FINETUNE / MAE_ViT sit in files loaded above)
+    imp(PKG + '.modeling.heads.vision_transformer_head')
     return _namespace()
 
 

@@ -24,6 +24,17 @@
 //   MFMA-bound.
 // Grid: one workgroup per output tile, N-tiles fastest, remapped so that every XCD (private L2)
 //   walks a contiguous range of tiles: the N-tiles that share an A row-panel hit the same L2.
+// PERSIST (round 6; dense 1x1 launches, bf16): a workgroup walks tiles bid, bid + grid, ... of its XCD's range.  A
+//   wave cannot retire before its stores are acknowledged (s_endpgm waits for vmcnt = 0), and in a write-saturated
+//   launch an acknowledgement takes ~5 us: with one tile per workgroup a CU never has more than (workgroups per CU) x
+//   32 KB of stores in flight and its slots sit idle for most of a tile's life (64->256 @56: stores alone 89 us =
+//   4.6 TB/s against a plain fill's 6.8, profiles/r04_kbench_halo_experiment.txt; 3 -> 4 workgroups per CU bought 14 %).
+//   The persistent form never waits for a store: the first K-tile of the NEXT tile is requested (into the staging
+//   registers) before the current tile's epilogue, whose stores then drain under the next tile's loads and MFMAs.
+//   Same tiles, same arithmetic in the same order, same epilogue: bit-identical output (kbench check igemm_persist=1).
+//   MEASURED (profiles/r06_kbench_persist.txt): exact, and 10-26 % SLOWER than one tile per workgroup — the staging registers
+//   that stay live across the epilogue cost the kernel half its workgroups per CU (229 VGPRs: 2 instead of 3-4), and the
+//   store phase is bound by how many waves issue stores, not by their acknowledgements.  OPT-IN (igemm_persist=1).
 #include <stdlib.h>
 #include "common.h"
 #include "igemm_epi.h"
@@ -92,9 +103,11 @@ __device__ __forceinline__ int swz(int row, int slot) { return slot ^ ((row >> 1
 
 // DENSE: 1x1 / stride 1 / no padding with dense A and Y: row m lives at m*C resp. m*NCOLS, no
 // (n,op,oq) decomposition at all.
-template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false, bool BNB2 = false>
-__global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) ? 3 : 2))
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false, bool BNB2 = false,
+          bool PERSIST = false>
+__global__ void __launch_bounds__(kThreads, PERSIST ? 2 : (LEAN ? 4 : ((STAGES == 1 && !EPI32) ? 3 : 2)))
     igemm_kernel(const Params p) {
+  static_assert(!PERSIST || (DENSE && STAGES == 1 && !EPI32 && !GENERIC), "persistent form: dense bf16 launches");
   constexpr int ES = sizeof(T);
   constexpr int VEC = 16 / ES;          // elements per 16-byte slot
   constexpr int BK = kRowBytes / ES;    // elements per K-tile
@@ -115,66 +128,74 @@ __global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) 
   constexpr int MAIN_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
   int64_t* rowoff = reinterpret_cast<int64_t*>(smem + MAIN_BYTES);
 
-  // ---- XCD-aware tile mapping (bijective for any ntiles)
-  int tile;
-  {
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, local = bid >> 3;
-    const int q = p.ntiles >> 3, r = p.ntiles & 7;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    tile = start + local;
-  }
-  const int mt = fdiv(tile, p.d_tn), nt = tile - mt * p.tiles_n;
-  const int m0 = mt * BM, n0 = nt * BN;
-
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int slot = tid & 7;
   const int opq = p.OP * p.OQ;
 
-  // ---- per-thread A rows
+  // ---- XCD-aware tile mapping (bijective for any ntiles): virtual id v -> tile; a persistent workgroup takes
+  // v = bid, bid + grid, ... (the grid is a multiple of 8, so all of them lie in its XCD's range)
+  auto tile_of = [&](int v) __attribute__((always_inline)) {
+    const int xcd = v & 7, local = v >> 3;
+    const int q = p.ntiles >> 3, r = p.ntiles & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + local;
+  };
+  int vt = blockIdx.x;
+  int tile = tile_of(vt);
+  int mt = fdiv(tile, p.d_tn), nt = tile - mt * p.tiles_n;
+  int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- per-thread A rows of the tile being LOADED (PERSIST: re-derived for the next tile before its first loads)
   int64_t a_base[ACH];
   int ih0[ACH], iw0[ACH];
+  int ld_n0 = n0;                          // column origin of the B tile being loaded
+  auto set_rows = [&](int m0_) __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < ACH; ++i) {
-    const int row = (tid >> 3) + 32 * i;
-    const int m = m0 + row;
-    if (DENSE) {
-      a_base[i] = (int64_t)m * p.C;
-      ih0[i] = m < p.M ? 0 : -(1 << 28);
-      iw0[i] = 0;
-    } else if (m < p.M) {
-      const int n = fdiv(m, p.d_opq);
-      const int rem = m - n * opq;
-      const int op = fdiv(rem, p.d_oq);
-      const int oq = rem - op * p.OQ;
-      a_base[i] = (int64_t)n * p.a_sn;
-      ih0[i] = op * p.sh - p.ph;
-      iw0[i] = oq * p.sw - p.pw;
-    } else {
-      a_base[i] = 0;
-      ih0[i] = -(1 << 28);
-      iw0[i] = 0;
-    }
-  }
-  // output row offsets (elements) for the epilogue; -1 = row out of range
-  if (tid < BM) {
-    const int m = m0 + tid;
-    int64_t off = -1;
-    if (m < p.M) {
+    for (int i = 0; i < ACH; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int m = m0_ + row;
       if (DENSE) {
-        off = (int64_t)m * p.NCOLS;
-      } else {
+        a_base[i] = (int64_t)m * p.C;
+        ih0[i] = m < p.M ? 0 : -(1 << 28);
+        iw0[i] = 0;
+      } else if (m < p.M) {
         const int n = fdiv(m, p.d_opq);
         const int rem = m - n * opq;
         const int op = fdiv(rem, p.d_oq);
         const int oq = rem - op * p.OQ;
-        off = (int64_t)n * p.y_sn + (int64_t)op * p.y_sh + (int64_t)oq * p.y_sw;
+        a_base[i] = (int64_t)n * p.a_sn;
+        ih0[i] = op * p.sh - p.ph;
+        iw0[i] = oq * p.sw - p.pw;
+      } else {
+        a_base[i] = 0;
+        ih0[i] = -(1 << 28);
+        iw0[i] = 0;
       }
     }
-    rowoff[tid] = off;
-  }
+  };
+  set_rows(m0);
+  // output row offsets (elements) for the epilogue; -1 = row out of range
+  auto set_rowoff = [&](int m0_) __attribute__((always_inline)) {
+    if (tid < BM) {
+      const int m = m0_ + tid;
+      int64_t off = -1;
+      if (m < p.M) {
+        if (DENSE) {
+          off = (int64_t)m * p.NCOLS;
+        } else {
+          const int n = fdiv(m, p.d_opq);
+          const int rem = m - n * opq;
+          const int op = fdiv(rem, p.d_oq);
+          const int oq = rem - op * p.OQ;
+          off = (int64_t)n * p.y_sn + (int64_t)op * p.y_sh + (int64_t)oq * p.y_sw;
+        }
+      }
+      rowoff[tid] = off;
+    }
+  };
+  set_rowoff(m0);
 
   uint4 ra[ACH], rb[BCH];
   const int nk = LEAN ? 1 : (p.KDIM + BK - 1) / BK;     // LEAN: single K-tile launches only
@@ -211,7 +232,7 @@ __global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) 
     }
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
-      const int col = n0 + (tid >> 3) + 32 * j;
+      const int col = ld_n0 + (tid >> 3) + 32 * j;
       const int kc = k0 + slot * VEC;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (col < p.NCOLS && kc < p.KDIM)
@@ -289,7 +310,42 @@ __global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) 
   };
 
   load_tile(0);
-  if constexpr (STAGES == 2) {
+  if constexpr (PERSIST) {
+    const int G = gridDim.x;
+    for (;;) {
+      const int nv = vt + G;
+      const bool has_next = nv < p.ntiles;                 // workgroup-uniform
+      int nmt = 0, nnt = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        store_tile(0);
+        __syncthreads();
+        if (kt + 1 < nk) {
+          load_tile(kt + 1);                               // in flight while the MFMAs run
+        } else if (has_next) {
+          // the NEXT tile's first K-tile: requested now, consumed after this tile's epilogue — whose stores are
+          // issued behind these loads and never waited for
+          const int ntile = tile_of(nv);
+          nmt = fdiv(ntile, p.d_tn);
+          nnt = ntile - nmt * p.tiles_n;
+          set_rows(nmt * BM);
+          ld_n0 = nnt * BN;
+          load_tile(0);
+        }
+        if (!(p.dbg & 8)) compute_tile(As, Bs);
+        __syncthreads();
+      }
+      if (!(p.dbg & 2))
+        epi::epilogue_bf16<BM, BN, kThreads, FM, FN, WM, WN, LEAN, FN, 0, BNB2>(p, smem, rowoff, acc, wm, wn, lane, tid, n0, mt);
+      if (!has_next) return;
+      __syncthreads();           // the staging area and the row table are rewritten for the next tile
+      vt = nv; mt = nmt; nt = nnt; m0 = mt * BM; n0 = nt * BN;
+      set_rowoff(m0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else if constexpr (STAGES == 2) {
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -377,21 +433,49 @@ __global__ void __launch_bounds__(kThreads, LEAN ? 4 : ((STAGES == 1 && !EPI32) 
   }
 }
 
-template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false, bool BNB2 = false>
+static int g_persist = -1, g_persist_grid = 0;
+
+template <typename T, int BM, int BN, bool GENERIC, int STAGES, bool EPI32, bool DENSE, bool LEAN = false, bool BNB2 = false,
+          bool PERSIST = false>
 int launch(const Params& p, hipStream_t st) {
   constexpr int STAGE = STAGES * (BM + BN) * kRowBytes;
   constexpr int EPI = EPI32 ? BM * (BN + 4) * 4 : BM * (BN + 8) * 2;
   constexpr int LDS = (STAGE > EPI ? STAGE : EPI) + BM * 8;
+  const void* fn = reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN, BNB2, PERSIST>);
   static bool attr_set = false;
+  static int wg_slots = 0;               // PERSIST: resident workgroups of this instantiation on the whole device
   if (!attr_set) {
-    (void)hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN, BNB2>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (PERSIST) {
+      int occ = 0, dev = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, kThreads, LDS) != hipSuccess || occ < 1) occ = 1;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+        cus = 256;
+      wg_slots = (occ * cus) & ~7;        // a multiple of 8: a workgroup's tiles stay on its XCD's range
+    }
     attr_set = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN, BNB2>), dim3(p.ntiles),
+  const int slots = (PERSIST && g_persist_grid >= 8) ? g_persist_grid : wg_slots;
+  const int grid = (PERSIST && p.ntiles > slots) ? slots : p.ntiles;
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, GENERIC, STAGES, EPI32, DENSE, LEAN, BNB2, PERSIST>), dim3(grid),
                      dim3(kThreads), LDS, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+// igemm_persist: 0 = one tile per workgroup (rounds 1-5), 1 = the persistent form for dense bf16 launches whose tiles
+// outnumber the resident workgroups (passl_hip_set_option("igemm_persist", v) / PASSL_IGEMM_PERSIST)
+}  // namespace
+int passl_igemm_persist_option(int value) { g_persist = value != 0; return PASSL_OK; }
+// igemm_persist_grid: 0 = as many workgroups as the device holds (default); n = that many (tests: small launches walk several tiles)
+int passl_igemm_persist_grid_option(int value) { g_persist_grid = value < 0 ? 0 : (value & ~7); return PASSL_OK; }
+namespace {
+static bool persist_on() {
+  if (g_persist < 0) {
+    const char* e = getenv("PASSL_IGEMM_PERSIST");
+    g_persist = e ? (atoi(e) != 0) : 0;      // measured SLOWER (profiles/r06_negative_results.txt #1): opt-in
+  }
+  return g_persist != 0;
 }
 
 // K-tiles up to which the single-LDS-stage variant is used (tunable: PASSL_IGEMM_NK1)
@@ -420,7 +504,9 @@ int dispatch(const Params& p, bool generic, bool out_f32, bool dense, int nk, hi
     // 64->256 @56: 117.6 -> 101.1 us, with statistics 152.9 -> 127.0 us.  PASSL_IGEMM_LEAN=0 disables.
     static const bool lean_on = !(getenv("PASSL_IGEMM_LEAN") && atoi(getenv("PASSL_IGEMM_LEAN")) == 0);
     if (dense && lean_on && nk == 1 && !p.res && !p.bnb_partial)
-      return launch<T, 128, BN, false, 1, false, true, true>(p, st);
+      return persist_on() ? launch<T, 128, BN, false, 1, false, true, true, false, true>(p, st)
+                          : launch<T, 128, BN, false, 1, false, true, true>(p, st);
+    if (dense && one && persist_on()) return launch<T, 128, BN, false, 1, false, true, false, false, true>(p, st);
     if (dense)
       return one ? launch<T, 128, BN, false, 1, false, true>(p, st)
                  : launch<T, 128, BN, false, 2, false, true>(p, st);
@@ -536,7 +622,8 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
     }
     if (nk > nk1_threshold()) return PASSL_EUNSUPPORTED;
     passl_prof_begin(2, st);
-    const int rc2 = launch<bf16_t, 128, 128, false, 1, false, true, false, true>(p, st);
+    const int rc2 = persist_on() ? launch<bf16_t, 128, 128, false, 1, false, true, false, true, true>(p, st)
+                                 : launch<bf16_t, 128, 128, false, 1, false, true, false, true>(p, st);
     passl_prof_work(2, w_flops, w_bytes + (double)M64 * d->NCOLS * es);
     passl_prof_end(2, st);
     g_last_kernel = 0;

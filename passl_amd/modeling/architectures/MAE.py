@@ -10,6 +10,7 @@ import torch
 from ...hip import nn
 from ...hip.nn import EncoderArena
 from ..backbones import build_backbone
+from ..heads import build_head
 from .builder import MODELS
 
 
@@ -39,6 +40,55 @@ class MAE_PRETRAIN(nn.Layer):
     def forward(self, *inputs, mode='train', **kwargs):
         if mode == 'train':
             return self.train_iter(*inputs, **kwargs)
+        elif mode == 'extract':
+            with torch.no_grad():
+                self.arena_q.refresh()
+                return self.backbone(*inputs)
+        else:
+            raise Exception('No such mode: {}'.format(mode))
+
+
+@MODELS.register()
+class MAE_FINETUNE(nn.Layer):
+    """Fine-tuning wrapper — reference passl_v110/modeling/architectures/MAE.py:58-94: ``train_iter(img, label)`` =
+    backbone -> head -> ``head.loss`` (loss / acc1 / acc5); ``extract`` returns the pooled features.  The reference
+    routes ``mode='test'`` to a ``test_iter`` it never defines (MAE.py:88-89); here it returns the class scores like
+    Classification.test_iter.  Backbone and head share one trainable arena (AdamW over flat buffers, DP reducer)."""
+
+    def __init__(self, architecture=None, head=None):
+        super().__init__()
+        self.backbone = build_backbone(architecture)
+        self.head = build_head(head)
+        object.__setattr__(self, '_live', torch.nn.ModuleList([self.backbone, self.head]))
+        self.arena_q = EncoderArena(self._live, trainable=True)
+
+    def load_state_dict(self, state_dict, strict=True):
+        r = super().load_state_dict(state_dict, strict=strict)
+        self.arena_q.refresh()
+        return r
+
+    def sync_runtime_state(self):
+        self.arena_q.refresh()
+
+    def backbone_forward(self, x):
+        return self.backbone(x)
+
+    def train_iter(self, *inputs, **kwargs):
+        img, label = inputs
+        self.arena_q.refresh()
+        outs = self.head(self.backbone_forward(img))
+        return self.head.loss(outs, label)
+
+    def test_iter(self, *inputs, **kwargs):
+        with torch.no_grad():
+            self.arena_q.refresh()
+            return self.head(self.backbone_forward(inputs[0]))
+
+    def forward(self, *inputs, mode='train', **kwargs):
+        if mode == 'train':
+            return self.train_iter(*inputs, **kwargs)
+        elif mode == 'test':
+            return self.test_iter(*inputs, **kwargs)
         elif mode == 'extract':
             with torch.no_grad():
                 self.arena_q.refresh()

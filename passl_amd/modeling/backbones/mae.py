@@ -279,3 +279,112 @@ class MAE(nn.Layer):
         loss = self.forward_loss(imgs, pred_rows, mask)
         pred = pred_rows.view(B, L + 1, -1)[:, 1:, :]                    # remove cls token
         return loss, pred, mask
+
+
+# ============================================================ fine-tuning trunk (configs/mae/mae_vit_b_finetune.yaml)
+class _PatchMeanFn(Function):
+    """``x[:, 1:, :].mean(axis=1)`` over token rows [B*(L+1), D] (mae.py:308: global average pool of the patch tokens,
+    class token excluded): the NHWC average-pool kernel over all L+1 tokens, minus the class row."""
+
+    @staticmethod
+    def forward(ctx, x, cls_rows, B, L):
+        D = x.shape[-1]
+        ctx.dims = (B, L, D)
+        avg = ops.avgpool_fwd(x.view(B, L + 1, 1, D))
+        cls = ops.gather_rows(x, cls_rows)
+        return ((avg.float() * (L + 1) - cls.float()) / L).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, L, D = ctx.dims
+        # every patch token receives dout / L: the pool's backward hands out dy / (L + 1)
+        dx = ops.avgpool_bwd((dout.float() * ((L + 1.0) / L)).to(dout.dtype).contiguous(), L + 1, 1)
+        dx = dx.view(B, L + 1, D)
+        dx[:, 0].zero_()
+        return dx.view(B * (L + 1), D), None, None, None
+
+
+class VisionTransformer(nn.Layer):
+    """The fine-tuning ViT of the v110 tree (passl_v110/modeling/backbones/mae.py:190-277): learnable ``cls_token`` /
+    ``pos_embed`` (trunc-normal 0.02), pre-norm blocks, final LayerNorm, output = the class token's row.  Same kernels as
+    the pre-training encoder above; dropout / stochastic depth are not built (0 in the yaml's defaults)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 embed_layer=PatchEmbed, norm_layer=None, act_layer=None, weight_init=''):
+        super().__init__()
+        if drop_rate or attn_drop_rate or drop_path_rate:
+            raise NotImplementedError('dropout / stochastic depth are not built on the HIP path')
+        dev = config.get_device()
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        norm_layer = norm_layer or partial(nn.LayerNorm, epsilon=1e-6)
+        act_layer = act_layer or nn.GELU
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        if embed_dim % num_heads or embed_dim // num_heads not in ops.ATTENTION_HEAD_DIMS or \
+                num_patches + 1 > ops.ATTENTION_MAX_TOKENS:
+            raise NotImplementedError('%d tokens x head dimension %s is outside the HIP attention kernels'
+                                      % (num_patches + 1, embed_dim / float(num_heads)))
+        self.cls_token = tnn.Parameter(torch.zeros(1, 1, embed_dim, device=dev))
+        self.pos_embed = tnn.Parameter(torch.zeros(1, num_patches + 1, embed_dim, device=dev))
+        self.blocks = tnn.Sequential(*[Block(embed_dim, num_heads, mlp_ratio, qkv_bias=qkv_bias, norm_layer=norm_layer,
+                                             act_layer=act_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self._ids = {}
+        trunc_normal_(self.cls_token, std=0.02)
+        trunc_normal_(self.pos_embed, std=0.02)
+        with torch.no_grad():
+            # self.apply(self._init_weights): Linear trunc_normal(.02) / zero bias, LayerNorm (1, 0); the patch
+            # convolution keeps nn.Conv2D's default [Paddle-semantics]: Normal(0, sqrt(2 / fan_in)), zero bias
+            w = self.patch_embed.proj.weight
+            w.copy_(torch.randn(w.shape) * math.sqrt(2.0 / (w.shape[1] * w.shape[2] * w.shape[3])))
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    trunc_normal_(m.weight, std=0.02)
+                    if m.bias is not None:
+                        m.bias.zero_()
+
+    def _token_ids(self, B, L, device):
+        key = (B, L)
+        if key not in self._ids:
+            self._ids[key] = (torch.arange(L, dtype=torch.int32, device=device).repeat(B, 1).contiguous(),
+                              (torch.arange(B, dtype=torch.int32, device=device) * (L + 1)).contiguous())
+        return self._ids[key]
+
+    def _tokens(self, x):
+        from .vision_transformer import _ClsPosFn
+        B = x.shape[0]
+        L = self.patch_embed.num_patches
+        x = self.patch_embed(x)                                           # [B*L, D]
+        ids, cls_rows = self._token_ids(B, L, x.device)
+        x = _ClsPosFn.apply(x, self.cls_token, self.pos_embed, ids, B, L)     # concat(cls, x) + pos_embed
+        for blk in self.blocks:
+            x = blk(x, B, L + 1)
+        return x, cls_rows, B, L
+
+    def forward_features(self, x):
+        x, cls_rows, _B, _L = self._tokens(x)
+        return self.norm(nn.gather_rows(x, cls_rows))                     # norm(x)[:, 0]: LayerNorm is per token
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+@BACKBONES.register()
+class MAE_ViT(VisionTransformer):
+    """Vision Transformer with support for global average pooling — passl_v110/modeling/backbones/mae.py:279-314:
+    with ``global_pool`` the final ``norm`` is replaced by ``fc_norm`` over the mean of the patch tokens."""
+
+    def __init__(self, global_pool=True, **kwargs):
+        super().__init__(**kwargs)
+        self.global_pool = global_pool
+        if self.global_pool:
+            self.fc_norm = nn.LayerNorm(kwargs['embed_dim'], epsilon=1e-6)
+            del self.norm                                                  # remove the original norm
+
+    def forward_features(self, x):
+        x, cls_rows, B, L = self._tokens(x)
+        if self.global_pool:
+            return self.fc_norm(_PatchMeanFn.apply(x, cls_rows, B, L))
+        return self.norm(nn.gather_rows(x, cls_rows))

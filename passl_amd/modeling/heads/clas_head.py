@@ -70,3 +70,15 @@ class ClasHead(nn.Layer):
         losses['loss'] = loss
         losses['acc1'], losses['acc5'] = acc1, acc5
         return losses
+
+
+@HEADS.register()
+class VisionTransformerClsHead(ClasHead):
+    """Vision Transformer classifier head — reference passl_v110/modeling/heads/vision_transformer_head.py:23-60:
+    ``fc_cls`` = Linear(in_channels, num_classes), Normal(0, 0.01) / zero bias; loss = cross-entropy + top-1 / top-5.
+    (``hidden_dim`` other than None leaves the reference's head without its ``fc_cls``: refused here.)"""
+
+    def __init__(self, with_avg_pool=False, in_channels=2048, num_classes=1000, hidden_dim=None):
+        if hidden_dim is not None:
+            raise NotImplementedError('VisionTransformerClsHead(hidden_dim=...) defines no classifier in the reference')
+        super().__init__(with_avg_pool=with_avg_pool, in_channels=in_channels, num_classes=num_classes)

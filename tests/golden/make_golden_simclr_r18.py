@@ -27,7 +27,8 @@ from oracle import ref_runner                      # noqa: E402
 from oracle.simclr import SimCLROracle             # noqa: E402
 
 SOLVER = dict(T=0.5, lr=2.0, warmup_steps=2, t_max=1000)
-ORACLE_KW = dict(depth=18, in_channels=512, hid_channels=512)
+# exclude_from_weight_decay as the yaml spells it (simclr_r18_cifar10.yaml:119): 'b_0' matches every bias's Paddle name
+ORACLE_KW = dict(depth=18, in_channels=512, hid_channels=512, exclude=('scale', 'offset', 'b_0'))
 MODEL_CFG = dict(
     name='SimCLR',
     backbone=dict(name='ResNetsimclr', depth=18, frozen_stages=-1),

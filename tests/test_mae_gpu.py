@@ -317,3 +317,125 @@ def test_step_is_bit_reproducible():
         ends.append((torch.cat([l.reshape(1) for l in losses]), model.arena_q.flat.clone()))
     for a, b in zip(*ends):
         assert torch.equal(a, b)
+
+
+# ---- fine-tuning model: configs/mae/mae_vit_b_finetune.yaml (round-5 verdict, missing #2)
+FT_SOLVER = dict(lr=1e-3, beta1=0.9, beta2=0.999, weight_decay=0.05)       # tests/golden/make_golden_mae_finetune.py
+FT_ARCH = dict(name='MAE_ViT', patch_size=16, embed_dim=768, depth=12, num_heads=12, qkv_bias=True, mlp_ratio=4)
+FT_WATCH = ['backbone.cls_token', 'backbone.pos_embed', 'backbone.patch_embed.proj.weight',
+            'backbone.blocks.0.attn.qkv.weight', 'backbone.blocks.1.mlp.fc2.bias', 'backbone.blocks.1.norm2.weight',
+            'backbone.fc_norm.weight', 'backbone.fc_norm.bias', 'head.fc_cls.weight', 'head.fc_cls.bias']
+
+
+def _run_finetune_golden(name, arch, dtype, tol):
+    """MAE_FINETUNE over MAE_ViT + VisionTransformerClsHead against the reference's own sources run on torch-CPU
+    (tests/golden/<name>.npz).  Step 0 is compared at the nominal bounds; later steps follow Adam updates whose sign is
+    rounding-defined wherever a gradient is ~0 (see ADAM_NOISE_DEFINED in test_clip_gpu.py): loss only, x 20."""
+    from oracle.mae import finetune_state
+    from passl_amd.hip import config as hip_config
+    from passl_amd.modeling import build_model
+    from passl_amd.solver.optimizer import AdamW
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    N, hw, steps, classes = [int(v) for v in z['meta']]
+    hip_config.set_device('gpu')
+    hip_config.set_compute_dtype(dtype)
+    torch.manual_seed(0)
+    model = build_model(dict(name='MAE_FINETUNE', architecture=dict(arch),
+                             head=dict(name='VisionTransformerClsHead', num_classes=classes,
+                                       in_channels=arch['embed_dim'])))
+    sd = model.state_dict()
+    keys_shapes = [(k, tuple(v.shape)) for k, v in sd.items()]
+    assert ['%s:%s' % (k, 'x'.join(map(str, s))) for k, s in keys_shapes] == [str(k) for k in z['keys']]
+    missing, unexpected = model.load_state_dict({k: v for k, v in finetune_state(keys_shapes).items()}, strict=False)
+    assert not missing and not unexpected
+    model.train()
+    opt = AdamW(FT_SOLVER['lr'], beta1=FT_SOLVER['beta1'], beta2=FT_SOLVER['beta2'],
+                weight_decay=FT_SOLVER['weight_decay'], parameters=list(model.parameters()))
+    seen = {}
+    head_fwd = model.head.forward
+
+    def spy(x):
+        seen['feat'] = x.detach()
+        seen['score'] = head_fwd(x)
+        return seen['score']
+    model.head.forward = spy
+    gen = torch.Generator().manual_seed(909)
+    report, bad = [], []
+
+    def check(what, got, ref, bound, rel=False):
+        got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+        scale = max(float(np.max(np.abs(ref))), 1e-12) if rel else 1.0
+        err = float(np.max(np.abs(got - ref))) / scale
+        line = '%-52s err %.3e  bound %.3e' % (what, err, bound)
+        report.append(line)
+        if not err <= bound:
+            bad.append(line)
+
+    for s in range(steps):
+        x = torch.randn(N, 3, hw, hw, generator=gen)
+        y = torch.randint(0, classes, (N,), generator=gen)
+        out = model(x.to(DEV), y.to(DEV), mode='train')
+        opt.clear_grad()
+        out['loss'].backward()
+        pre = 's%d_' % s
+        k = 1.0 if s == 0 else 20.0
+        check(pre + 'loss', float(out['loss'].detach()), z[pre + 'loss'], tol['loss'] * k, rel=True)
+        if s == 0:
+            check(pre + 'acc1', float(out['acc1']), z[pre + 'acc1'], 1e-6)
+            check(pre + 'acc5', float(out['acc5']), z[pre + 'acc5'], 1e-6)
+            check(pre + 'feat[:, :8]', seen['feat'].float().cpu()[:, :8].numpy(), z[pre + 'feat_head'], tol['feat'], rel=True)
+            check(pre + 'score[:, :8]', seen['score'].detach().float().cpu()[:, :8].numpy(), z[pre + 'score_head'],
+                  tol['feat'], rel=True)
+            ps = dict(model.named_parameters())
+            for n in FT_WATCH:
+                check(pre + 'gradnorm/' + n, ps[n].grad.double().norm().item(), z[pre + 'gradnorm/' + n], tol['grad'], rel=True)
+        opt.step()
+        if s == 0:
+            ps = dict(model.named_parameters())
+            for n in FT_WATCH:
+                check(pre + 'pnorm/' + n, ps[n].detach().double().norm().item(), z[pre + 'pnorm/' + n], tol['param'], rel=True)
+    print('\n'.join(report))
+    try:
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open('gpurun_out/parity_%s_%s.txt' % (name, str(dtype).split('.')[-1]), 'w') as f:
+            f.write('\n'.join(report) + '\n\nVIOLATIONS (%d)\n' % len(bad) + '\n'.join(bad) + '\n')
+    except OSError:
+        pass
+    assert not bad, 'parity violations:\n' + '\n'.join(bad)
+
+
+FT_TOL_F32 = dict(loss=1e-3, feat=1e-3, grad=2e-3, param=1e-4)
+FT_TOL_BF16 = dict(loss=3e-2, feat=6e-2, grad=8e-2, param=1e-2)      # the CLIP / MAE bf16 bounds (stated, not parity)
+
+
+def test_finetune_golden_small_fp32():
+    _run_finetune_golden('mae_ft_small', dict(FT_ARCH, embed_dim=128, depth=2, num_heads=4, img_size=64),
+                         torch.float32, FT_TOL_F32)
+
+
+def test_finetune_golden_vit_b_fp32():
+    _run_finetune_golden('mae_ft_vit_b', dict(FT_ARCH), torch.float32, FT_TOL_F32)
+
+
+def test_finetune_golden_vit_b_bf16():
+    _run_finetune_golden('mae_ft_vit_b', dict(FT_ARCH), torch.bfloat16, FT_TOL_BF16)
+
+
+def test_trainer_runs_mae_finetune_config_end_to_end(tmp_path):
+    """configs/mae/mae_vit_b_finetune_synthetic.yaml (the reference YAML's model / lr / optimizer blocks over synthetic
+    labelled batches) through the v110 Trainer + hook bus for a few iterations."""
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_config(os.path.join(root, 'configs/mae/mae_vit_b_finetune_synthetic.yaml'),
+                     ['dataloader.train.sampler.batch_size=8', 'dataloader.train.dataset.num_samples=32', 'epochs=1',
+                      'output_dir=%s' % tmp_path, 'log_config.interval=2'])
+    cfg.timestamp = ''
+    tr = Trainer(cfg)
+    assert type(tr.model).__name__ == 'MAE_FINETUNE' and tr.iters_per_epoch == 4 and tr.optimizer.type == 'adamw'
+    w0 = tr.model.head.fc_cls.weight.detach().clone()
+    tr.train()
+    assert tr.current_iter == 4
+    loss = float(tr.outputs['loss'].detach())
+    assert np.isfinite(loss) and 0 < loss < 20 and 'acc1' in tr.outputs
+    assert float((tr.model.head.fc_cls.weight.detach() - w0).abs().max()) > 0

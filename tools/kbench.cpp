@@ -252,6 +252,11 @@ static int run_check() {
       {3, 128, 128, 3, 1, 16, "3x3, 16 x 16 (2-D tiles, 12 patches)", 0}, {5, 64, 64, 3, 1, 8, "3x3, 8 x 8 (5 patches: ragged)", 0},
       {2, 128, 128, 3, 2, 56, "3x3 stride 2", 0}, {2, 64, 256, 1, 1, 56, "1x1 64 -> 256", 0},
       {2, 512, 128, 1, 1, 28, "1x1 512 -> 128", 0},
+      // dense 1x1 launches of the register-staged kernel (persistent form under igemm_persist=1; with
+      // igemm_persist_grid=8 every workgroup walks many tiles): 1 / 2 / 4 K-tiles, 64- and 128-column tiles, ragged M
+      {2, 64, 64, 1, 1, 56, "1x1 64 -> 64", 0},   {2, 256, 64, 1, 1, 56, "1x1 256 -> 64", 0},
+      {3, 128, 512, 1, 1, 28, "1x1 128 -> 512", 0}, {3, 64, 256, 1, 1, 20, "1x1 64 -> 256, 1200 rows (ragged)", 0},
+      {5, 256, 128, 1, 1, 14, "1x1 256 -> 128", 0},
   };
   Buffers B;
   int failures = 0;
