@@ -412,12 +412,17 @@ def main():
         dist.all_gather_object(everyone, me)
         exposed = None
         red = getattr(trainer, 'grad_reducer', None)
+        host_ms = None
         if red is not None:
             red.measure = True
+            for r_ in getattr(red, 'reducers', [red]):
+                r_.host_ms, r_.host_calls = 0.0, 0
             for _ in range(3):
                 step()
             exposed = red.exposed_ms()
             red.measure = False
+            rs_ = getattr(red, 'reducers', [red])
+            host_ms = (round(sum(r_.host_ms for r_ in rs_) / 3, 3), sum(r_.host_calls for r_ in rs_) // 3)
         ex = torch.tensor([exposed if exposed is not None else -1.0], dtype=torch.float64, device='cuda')
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
         dist_info = {'backend': dist.get_backend(), 'world': dist.get_world_size(), 'ranks': everyone,
@@ -427,6 +432,8 @@ def main():
                      'grad_wire_dtype': ('bf16' if red.wire is not None else 'fp32') if red is not None else None,
                      'grad_wire_bytes': int(red.grads.numel() * (2 if red.wire is not None else 4)) if red is not None else 0,
                      'allreduce_exposed_ms': round(float(ex.item()), 3) if float(ex.item()) >= 0 else None,
+                     'collective_host_ms_per_step': host_ms[0] if host_ms else None,
+                     'collective_host_calls_per_step': host_ms[1] if host_ms else None,
                      'allreduce_exposed_what': 'max over ranks of the time the compute stream waits for gradient '
                                                'collectives after backward has finished (3 extra steps, HIP events)'}
 

@@ -18,9 +18,70 @@ gradients in 4 x 28 MB buckets keeps every collective large enough to be bandwid
 latency-bound while leaving 3/4 of the traffic overlappable with backward.
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
+
+# PASSL_DP_DRYRUN=1 (1-rank diagnostic): keep every plan cut, stream edge and host call of the data-parallel path but skip
+# the torch.distributed calls themselves — separates what the MACHINERY costs from what the collective library costs
+_DRYRUN = os.environ.get('PASSL_DP_DRYRUN') == '1'
+# PASSL_DP_DIAG=noedges,nogather,noreducer (1-rank diagnostics of the same kind: drop one part of the machinery)
+_DIAG = set(filter(None, os.environ.get('PASSL_DP_DIAG', '').split(',')))
+
+
+class _Issuer(object):
+    """PASSL_DP_THREAD=1: the live collective calls of a step are made by ONE helper thread instead of the thread that
+    drives the step.  Every stream edge of a bucket is already enqueued when its call is posted (hip/streams.py:
+    gather_into), so the call's only job is to hand the bucket to the collective library — if that call holds the host
+    for a while (communicator bookkeeping, a launch queue that is full), the step's own launches no longer wait behind
+    it.  Order: one thread, FIFO — identical on every rank; ``drain`` (before the handles are waited for) returns when
+    every posted call has been made."""
+
+    def __init__(self, device):
+        import queue
+        import threading
+        self.q = queue.Queue()
+        self.err = None
+        self.device = device
+
+        def run():
+            if device is not None and device.type == 'cuda':
+                torch.cuda.set_device(device)
+            while True:
+                fn = self.q.get()
+                try:
+                    if fn is None:
+                        return
+                    if self.err is None:
+                        fn()
+                except BaseException as e:            # surfaced by drain() on the step's thread
+                    self.err = e
+                finally:
+                    self.q.task_done()
+        self.t = threading.Thread(target=run, name='passl-dp-issuer', daemon=True)
+        self.t.start()
+
+    def post(self, fn):
+        self.q.put(fn)
+
+    def drain(self):
+        self.q.join()
+        if self.err is not None:
+            e, self.err = self.err, None
+            raise e
+
+
+_issuers = {}
+
+
+def _issuer(device):
+    if os.environ.get('PASSL_DP_THREAD') != '1':
+        return None
+    key = (device.type, device.index)
+    if key not in _issuers:
+        _issuers[key] = _Issuer(device)
+    return _issuers[key]
 
 
 def _ws(group=None):
@@ -103,6 +164,7 @@ class GradReducer(object):
         self._active = False
         self._home = None
         self.measure = False          # bench.py: time what the compute stream waits for in finish()
+        self.host_ms, self.host_calls = 0.0, 0      # host time spent inside the live collective calls (bench.py reports it)
         self._exposed = []
         arena.reducer = self
         if optimizer is not None:
@@ -135,7 +197,8 @@ class GradReducer(object):
             # critical chain).  The waits go through hip/streams.py: a recorded step replays them.
             from ..hip import streams
             comm = streams.comm_stream(self.grads.device)
-            streams.gather_into(comm, self.grads.device, extra=(self._home,) if self._home is not None else ())
+            if 'noedges' not in _DIAG:
+                streams.gather_into(comm, self.grads.device, extra=(self._home,) if self._home is not None else ())
         if self.wire is not None:
             # a launch of the library, OUTSIDE the host call: a recorded step replays it as part of the plan (on the
             # issuing stream), the live collective below then reads the twin
@@ -149,13 +212,20 @@ class GradReducer(object):
         def collective():
             # a live call also when the step is replayed from a native plan (hip/replay.py: the plan is cut here);
             # the replayed segment in front of it contains the issuing stream's waits for the producers
-            if comm is not None:
+            t0 = time.perf_counter()
+            if _DRYRUN:
+                h = None                 # (diagnostic, world 1 only: the cuts and stream edges without the library call)
+            elif comm is not None:
                 with torch.cuda.stream(comm):
                     h = dist.all_reduce(grads[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)
             else:
                 h = dist.all_reduce(grads[s:e], op=dist.ReduceOp.SUM, group=group, async_op=True)
-            self._handles.append(h)
-        host_call(collective)
+            if h is not None:
+                self._handles.append(h)
+            self.host_ms += 1e3 * (time.perf_counter() - t0)
+            self.host_calls += 1
+        iss = _issuer(self.grads.device)
+        host_call(collective if iss is None else (lambda: iss.post(collective)))
 
     def mark_ready(self, index):
         if not self._active or index in self._ready:
@@ -181,16 +251,22 @@ class GradReducer(object):
         from ..hip.replay import host_call
 
         def wait_all():
+            h0 = time.perf_counter()
+            iss = _issuer(self.grads.device)
+            if iss is not None:
+                iss.drain()                    # every bucket's call has been made: the handle list is complete
             timed = self.measure and self.grads.is_cuda and self._handles
             if timed:
-                t0 = torch.cuda.Event(enable_timing=True)
-                t0.record()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             for h in self._handles:
                 h.wait()
+            self.host_ms += 1e3 * (time.perf_counter() - h0)
+            self.host_calls += 1
             if timed:
-                t1 = torch.cuda.Event(enable_timing=True)
-                t1.record()
-                self._exposed.append((t0, t1))
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self._exposed.append((e0, e1))
             self._handles = []
         if self._handles or self.world > 1 or self._forced:
             host_call(wait_all)                 # (live at every replay of a recorded step: see _launch)

@@ -668,18 +668,30 @@ static int fin_segments(int nblocks, bool shifted, int* seg_rows) {
 // ring of ints that is ALL ZERO whenever no launch is using a slice — the block that completes a counter re-zeroes it.
 // A slice is handed out again after 64 K ints of later requests (a MoCo step asks for ~2 K).
 static int* fin_counters(int groups) {
-  static std::mutex mu;
-  static int* pool = nullptr;
-  static int64_t next = 0;
+  // one pool per device (a pointer of another device's pool would be foreign memory: round-5 advisor finding); zeroed
+  // with a synchronous memset FOLLOWED by a device synchronisation, so that no launch on any (non-blocking) stream can
+  // run before the zeros are in place; a failed allocation / memset leaves no half-initialised pool behind
+  constexpr int kMaxDev = 16;
   constexpr int64_t kPoolInts = 1 << 16;
+  static std::mutex mu;
+  static int* pool[kMaxDev] = {};
+  static int64_t next[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  if (!pool) {
-    if (hipMalloc(reinterpret_cast<void**>(&pool), kPoolInts * sizeof(int)) != hipSuccess) { pool = nullptr; return nullptr; }
-    if (hipMemset(pool, 0, kPoolInts * sizeof(int)) != hipSuccess) return nullptr;
+  if (!pool[dev]) {
+    int* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), kPoolInts * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kPoolInts * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipFree(p);
+      return nullptr;
+    }
+    pool[dev] = p;
+    next[dev] = 0;
   }
-  if (next + groups > kPoolInts) next = 0;
-  int* r = pool + next;
-  next += (groups + 3) & ~3;
+  if (next[dev] + groups > kPoolInts) next[dev] = 0;
+  int* r = pool[dev] + next[dev];
+  next[dev] += (groups + 3) & ~3;
   return r;
 }
 

@@ -74,7 +74,13 @@ def _init_distributed(device):
         # "nccl" IS RCCL on ROCm.  PASSL_DIST_BACKEND=gloo lets several ranks share ONE GPU (together with
         # PASSL_DEVICE_INDEX) to exercise the data-parallel path on a single-GPU box (tests/test_dp_gpu.py)
         backend = os.environ.get('PASSL_DIST_BACKEND') or ('nccl' if device.type == 'cuda' else 'gloo')
-        kw = {'device_id': device} if (device.type == 'cuda' and backend == 'nccl') else {}
+        # No ``device_id``: the RCCL communicator is then created at the first collective (the start-up broadcast of the
+        # parameters, after the model exists) instead of here.  Measured on MI355X with a world-1 communicator and every
+        # collective issued (profiles/r06_dp_overhead.txt): the same MoCo step takes 23.8 ms with the communicator
+        # created late, 25.3 ms with it created here — merely EXISTING from this point on it slows the step by 8 %, with
+        # no collective ever issued — against 23.2 ms without one.  PASSL_DIST_EAGER=1 restores the eager form.
+        kw = {'device_id': device} if (device.type == 'cuda' and backend == 'nccl' and
+                                       os.environ.get('PASSL_DIST_EAGER') == '1') else {}
         dist.init_process_group(backend=backend, **kw)
     return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
 
@@ -142,8 +148,9 @@ class Trainer:
                              'AMP.level / scale_loss are ignored)')
 
         self.grad_reducer = None
-        if self.world_size > 1 or collectives_active():
-            param_sync(self.model, src_rank=0)
+        if (self.world_size > 1 or collectives_active()) and 'noreducer' not in os.environ.get('PASSL_DP_DIAG', ''):
+            if 'noparamsync' not in os.environ.get('PASSL_DP_DIAG', ''):
+                param_sync(self.model, src_rank=0)
             self.grad_reducer = GradReducer(self.model.arena_q, self.optimizer)
 
         self.hooks = []

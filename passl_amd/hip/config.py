@@ -164,7 +164,28 @@ def wgrad_halo():
     return _state['wgrad_halo']
 
 
+_BOOL_FLAGS = ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample',
+               'side_reductions', 'fused_stem_pool', 'fused_bn_backward2', 'stem_tail_flush', 'stem_wgrad_main_last')
+_INT_FLAGS = ('stem_wgrad_parts', 'side_urgent_rows', 'wgrad_halo')
+
+
 def set_flag(name, value):
-    assert name in ('fused_bn_stats', 'fuse_residual_grad', 'fused_bn_backward', 'overlap', 'fork_downsample',
-                    'side_reductions', 'fused_stem_pool', 'fused_bn_backward2')
-    _state[name] = bool(value)
+    """Switch a scheduling / fusion option at run time (tests, A/B runs).  ``wgrad_halo`` is ONE switch shared with the
+    library (its kernel choice and the slice count chosen here must agree: round-5 advisor finding): setting it here
+    also sets it there."""
+    if name in _BOOL_FLAGS:
+        _state[name] = bool(value)
+    elif name in _INT_FLAGS:
+        _state[name] = max(1, int(value)) if name == 'stem_wgrad_parts' else int(value)
+        if name == 'wgrad_halo':
+            from . import lib as L
+            if L.loaded():
+                L.check(L.load().passl_hip_set_option(b'wgrad_halo', int(value)), 'set_option wgrad_halo')
+    else:
+        raise KeyError('unknown flag %r (known: %s)' % (name, ', '.join(_BOOL_FLAGS + _INT_FLAGS)))
+
+
+def mirror_library_option(name, value):
+    """hip/lib.py tells us about a library option it has just set (PASSL_OPTIONS, set_option) that has a Python-side twin."""
+    if name == 'wgrad_halo':
+        _state['wgrad_halo'] = int(value)

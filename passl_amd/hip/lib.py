@@ -178,6 +178,8 @@ SIGNATURES = {
 }
 
 _lib = None
+# status codes of include/passl_hip.h
+OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
 
 
 class PasslHipError(RuntimeError):
@@ -210,7 +212,24 @@ def load(path=None):
         for kv in filter(None, os.environ.get('PASSL_OPTIONS', '').split(',')):
             name, _, value = kv.partition('=')
             check(lib.passl_hip_set_option(name.strip().encode(), int(value)), 'PASSL_OPTIONS %s' % kv)
+            from . import config
+            config.mirror_library_option(name.strip(), int(value))      # (wgrad_halo: one switch, two readers)
+        # the library reads PASSL_WGRAD_HALO itself; an explicit Python-side value (config.set_flag before load) wins
+        from . import config
+        if 'wgrad_halo' not in os.environ.get('PASSL_OPTIONS', ''):
+            check(lib.passl_hip_set_option(b'wgrad_halo', int(config.wgrad_halo())), 'set_option wgrad_halo')
     return lib
+
+
+def loaded():
+    return _lib is not None
+
+
+def set_option(name, value):
+    """passl_hip_set_option + the Python-side twin of the option, when it has one."""
+    check(load().passl_hip_set_option(name.encode(), int(value)), 'set_option %s' % name)
+    from . import config
+    config.mirror_library_option(name, int(value))
 
 
 def check(rc, what=''):

@@ -233,6 +233,8 @@ class _ConvFn(Function):
                                    partial2=slab2)
                     off += ops.conv_tiles(d)
                 ops.conv_igemm(d, dy, rt.w_dgrad[id(d.pack)], dx, residual=extra, bnb=bnb)
+                if slab2 is not None and not bnb.get('partial2_done', False):
+                    slab2 = None          # the library took the launch without the second layer (ops.conv_igemm)
             if fuse:
                 link.fused = (slab, off)
                 if slab2 is not None:

@@ -40,7 +40,7 @@ def _world_size():
 def concat_all_gather(tensor):
     """all_gather + concat along dim 0 (identity for a single process) — moco.py:198-210."""
     ws = _world_size()
-    if not collectives_active():
+    if not collectives_active() or 'nogather' in os.environ.get('PASSL_DP_DIAG', ''):
         return tensor
     out = torch.empty((ws * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
                       device=tensor.device)
