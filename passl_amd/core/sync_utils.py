@@ -118,17 +118,31 @@ class GradReducer(object):
     """Bucketed, overlapped all-reduce over a flat gradient buffer."""
 
     def __init__(self, arena, optimizer=None, bucket_elems=None, group=None, wire_dtype=None):
-        """bucket_elems: fp32 gradients per bucket (default 7 Mi = 28 MB, i.e. 4 buckets for R50 + projector);
-        ``PASSL_DP_BUCKETS=n`` asks for n equal buckets instead (bench.py --dp-buckets).
+        """bucket_elems: fp32 gradients per bucket; ``PASSL_DP_BUCKETS=n`` asks for n equal buckets (bench.py
+        --dp-buckets); default: two buckets, a big one and a small tail (see below).
         wire_dtype: torch.bfloat16 (or ``PASSL_DP_WIRE=bf16``) sends every bucket as bf16 — half the bytes per xGMI
         link (56 MB instead of 112 MB for R50; the last bucket, which backward cannot hide, shrinks with it): the
         bucket is cast into a resident bf16 twin of the gradient buffer right before its all-reduce and cast back
         after the final wait, so accumulation, the 1 / world scale and the optimizer stay fp32.  The SUM over ranks is
         then formed in bf16 by the collective: gradients agree with the fp32 wire to bf16 rounding (~3 significant
         digits), not bit for bit — opt-in; the default (fp32) is the reference's behaviour."""
+        tail_elems = None
+        n_train = getattr(arena, 'n_train', None) or sum(n for _o, n in arena.param_slices)
         if bucket_elems is None:
             n_b = int(os.environ.get('PASSL_DP_BUCKETS', '0') or 0)
-            bucket_elems = -(-arena.n_train // n_b) if n_b > 0 else 7 * 1024 * 1024
+            if n_b > 0:
+                bucket_elems = -(-n_train // n_b)
+            else:
+                # default (round 6): TWO buckets — everything but the head of the buffer in one, the head (the first
+                # layers' parameters, whose gradients arrive last: at most 1.5 M elements = 6 MB, and at most 1/8 of the
+                # buffer) in a second one.  Only the LAST bucket's all-reduce cannot hide under backward whatever the
+                # bucket count, so it should be small; every further bucket costs a live call on the host between two
+                # segments of the step (measured with a world-1 communicator, profiles/r06_dp_overhead.txt: +0.18 ms of
+                # step time per bucket — 4 x 28 MB: +0.70 ms, 1 bucket: +0.16 ms).  The big bucket (R50: layer3, layer4
+                # and the projector, 106 MB) is complete 60 % into the backward pass.
+                bucket_elems = 1 << 62
+                tail_elems = int(os.environ.get('PASSL_DP_TAIL_ELEMS', str(3 * 512 * 1024)))
+                tail_elems = min(tail_elems, n_train // 8)
         if wire_dtype is None and os.environ.get('PASSL_DP_WIRE', '').lower() in ('bf16', 'bfloat16'):
             wire_dtype = torch.bfloat16
         if wire_dtype not in (None, torch.float32, torch.bfloat16):
@@ -150,7 +164,8 @@ class GradReducer(object):
                 end = off + n
             cur.append(idx)
             cur_n += n
-            if cur_n >= bucket_elems or idx == 0:
+            # (tail scheme: the big bucket closes at the first parameter that starts inside the head of the buffer)
+            if cur_n >= bucket_elems or idx == 0 or (tail_elems and not self.buckets and off <= tail_elems):
                 self.buckets.append((off, end, cur))
                 cur, cur_n, end = [], 0, None
         self.bucket_of = {}

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(os.path.dirname(HERE), 'lib')
 LIB = os.path.join(OUT_DIR, 'libpassl_hip.so')
 SOURCES = ['runtime.hip', 'plan.hip', 'flat.hip', 'layout_pool.hip', 'stem_pool.hip', 'bn.hip', 'head.hip', 'ntxent.hip', 'vit.hip', 'attention.hip', 'attention_bf16.hip', 'clip.hip', 'clas.hip',
-           'conv_igemm.hip', 'conv_igemm_ring.hip', 'conv_igemm_8p.hip', 'conv_stem.hip', 'conv_wgrad.hip']
+           'conv_igemm.hip', 'conv3x3_wave.hip', 'conv_igemm_ring.hip', 'conv_igemm_8p.hip', 'conv_stem.hip', 'conv_wgrad.hip']
 HEADERS = ['common.h', 'plan.h', 'prof.h', 'igemm_epi.h', 'igemm_dma.h', 'halo_geom.h', 'wgrad_halo_geom.h', 'conv_wgrad_halo.inc', os.path.join('..', '..', 'include', 'passl_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
          '-Wno-unused-result']

@@ -1,0 +1,453 @@
+// 3x3 / stride-1 / pad-1 convolution with 64 input and 64 output channels, bf16 (the conv2 layers of ResNet-50's first
+// stage, forward and data gradient) — one WAVE per 8 x 8 output patch, no workgroup barrier in the loop (gfx950).
+//
+// Why another kernel (round 6).  The LDS-DMA ring kernel (conv_igemm_ring.hip) takes 95-120 us for this layer against a
+// traffic floor of 38 us (206 MB at the 5.4 TB/s a mixed read / write stream reaches on this chip,
+// profiles/r06_store_probe.txt) and an MFMA floor of 30 us: it fetches every input pixel nine times through L2 (216 KB
+// of LDS-DMA per 128-row tile), re-stages the weights for every tile, and a tile's life is setup + operand wait + nine
+// barrier-separated K-tiles + an LDS-staged epilogue that nothing overlaps (2.6 + 0.8 + 4.2 + 2.6 us).
+// Rounds 4-5 measured three spatially tiled forms of the same WORKGROUP-per-tile structure; none beat it.  Here the
+// structure itself goes:
+//
+//  * the nine weight taps (64 x 576 bf16 = 72 KB) are staged ONCE per workgroup and stay in LDS (rows of 128 B, the
+//    ring kernel's XOR swizzle); workgroups are persistent (one per CU);
+//  * each of a workgroup's four waves (one per SIMD, up to 512 registers) owns a private 16 KB halo buffer and walks
+//    its own list of 8 x 8 patches: [write the 10 x 10 x 64 halo of patch t from staging registers into LDS] ->
+//    [request the halo of patch t+1 into the staging registers: in flight under everything below] -> [9 taps x 2
+//    k-steps x 16 MFMAs straight out of LDS: a tap is an immediate offset, the zero padding is physically in the halo]
+//    -> [epilogue from the accumulators: affine / ReLU, bf16 pack, v_permlane32_swap to 16-byte pieces, stores,
+//    statistics in registers].  No s_barrier, no LDS-DMA wait, no LDS-staged output: the four waves drift apart and
+//    cover each other's epilogues and load waits;
+//  * halo pixel pitch 160 B (8 data + 2 pad 16-byte slots) and the lane -> pixel map {lanes 0-3, 12-15: first row of a
+//    fragment's 2 x 8 pixels, lanes 4-11: second row} put the 16 lanes of every ds_read_b128 service group on 16 different
+//    bank quads for every tap (10 c mod 16 runs through the even residues; the other k-group of the group sits one slot
+//    further: the odd ones);
+//  * arithmetic: taps in (r, s) order, channels ascending, fp32 accumulation in the MFMA — the ring kernel's order:
+//    the stored bf16 output is bit-identical to it.  The fused statistics (forward: shifted sums per 128 rows; data
+//    gradient: BatchNorm-backward sums of the producing layer, csrc/igemm_epi.h) are summed in a different, equally
+//    fixed order: deterministic, equal to the staged epilogue's to fp32 rounding.  A slab row is two consecutive patches
+//    (128 pixels) — bn_finalize only needs every row to hold 128 pixels, not which ones.
+//
+// Envelope (passl_conv3x3_wave_try returns PASSL_EUNSUPPORTED outside it and the ring kernel takes the launch):
+// R = S = 3, stride 1, pad 1, C = NCOLS = 64, bf16 in / out, dense NHWC operands, IH and IW multiples of 8, no residual;
+// epilogues: affine (+ReLU), forward statistics, BatchNorm-backward statistics with the ReLU mask recomputed from y
+// (bnb_relu 0 or 2).  Option conv3x3_wave = 0 / 1 (passl_hip_set_option, PASSL_CONV3X3_WAVE).
+#include <stdlib.h>
+#include <string.h>
+#include "igemm_dma.h"
+#include "igemm_epi.h"
+
+namespace w3 {
+
+using ring::bf16x8_t;
+using ring::u32x4;
+using ring::FastDiv;
+using ring::fdiv;
+using ring::make_fastdiv;
+using ring::kOOB;
+
+constexpr int kThreads = 256;
+constexpr int kC = 64;                     // input channels = output channels
+constexpr int kPix = 160;                  // bytes per halo pixel: 128 data + 32 pad
+constexpr int kHaloW = 10;                 // 8 + 2
+constexpr int kHaloBytes = kHaloW * kHaloW * kPix;          // 16 000
+constexpr int kHaloStride = 16128;         // per-wave halo buffer (256-byte multiple)
+constexpr int kTapBytes = kC * 128;        // one tap of the weights: 64 rows x 128 B
+constexpr int kWBytes = 9 * kTapBytes;     // 73 728
+constexpr int kLds = kWBytes + 4 * kHaloStride;             // 138 240
+constexpr int kLoads = 13;                 // 16-byte halo chunks per lane: 800 of 832
+
+struct Params {
+  const char* a;
+  const char* b;
+  char* y;
+  const float* scale;
+  const float* shift;
+  float* stats;
+  int stats_tiles;
+  const char* bnb_y;
+  const float* bnb_mean;
+  const float* bnb_invstd;
+  const float* bnb_scale;
+  const float* bnb_shift;
+  float* bnb_partial;
+  int bnb_relu, bnb_tile_off;
+  uint32_t a_bytes;
+  int N, IH, IW, PH, PW;                   // PH x PW patches per image
+  int npatches, nslabs;                    // slab row = two consecutive patches
+  int relu;
+  FastDiv d_pp, d_pw;                      // / (PH * PW), / PW
+};
+
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_rd(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+// MODE 0: affine (+ReLU); 1: + forward statistics; 2: BatchNorm-backward statistics of the producing layer
+template <int MODE>
+__global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+
+  // ---- the nine weight taps, once: global [col][tap][c] -> LDS [tap][col][128 B], slot ^= (col >> 1) & 7
+  for (int q = tid; q < 9 * kC * 8; q += kThreads) {
+    const int chunk = q & 7, row = (q >> 3) % kC, tap = (q >> 3) / kC;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.b + ((size_t)row * 9 + tap) * 128 + chunk * 16);
+    *reinterpret_cast<uint4*>(smem + tap * kTapBytes + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = v;
+  }
+  __syncthreads();                          // the only workgroup barrier of the kernel
+
+  // ---- per-lane geometry of the halo staging: chunk q = lane + 64 i -> halo pixel q >> 3, 16-byte piece q & 7
+  char* halo = smem + kWBytes + wave * kHaloStride;
+  const uint32_t halo0 = lds0 + kWBytes + wave * kHaloStride;
+  int rel[kLoads];                          // byte offset of the chunk relative to the patch's first pixel
+  int hyx[kLoads];                          // (hy << 8) | hx, or -1 for the 32 chunks past the halo
+  uint32_t hdst[kLoads];
+#pragma unroll
+  for (int i = 0; i < kLoads; ++i) {
+    const int q = lane + 64 * i;
+    const int hq = q >> 3;
+    const int hy = hq / kHaloW, hx = hq - hy * kHaloW;
+    rel[i] = ((hy - 1) * p.IW + (hx - 1)) * (kC * 2) + (q & 7) * 16;
+    hyx[i] = hq < kHaloW * kHaloW ? ((hy << 8) | hx) : -1;
+    hdst[i] = (uint32_t)(hq * kPix + (q & 7) * 16);
+  }
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
+
+  // ---- fragment read addresses.  Pixel of lane l15 inside a fragment's 2 x 8 block: lanes 0-3 / 12-15 -> first row,
+  // columns 0-3 / 4-7; lanes 4-11 -> second row, columns 0-7
+  const int fr = (l15 >= 4 && l15 < 12) ? 1 : 0;
+  const int fc = l15 < 4 ? l15 : (l15 < 12 ? l15 - 4 : l15 - 8);
+  const uint32_t a_rd = halo0 + (uint32_t)((fr * kHaloW + fc) * kPix + l4 * 16);
+  // weights: fragment row of lane l15 with bits 2 and 3 exchanged (the 8-phase kernel's direct epilogue): accumulator
+  // register r of lane (l15, l4) is output channel {0, 8, 4, 12}[l4] + r of its 16-channel fragment
+  const int pl = (l15 & 3) | ((l15 & 4) << 1) | ((l15 & 8) >> 1);
+  uint32_t b_rd[2], b_rd_hi[2];             // (the ds_read offset field holds 16 bits: taps 5-8 get a base of their own)
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    b_rd[ks] = lds0 + (uint32_t)(pl * 128 + (((ks * 4 + l4) ^ ((pl >> 1) & 7)) << 4));
+    b_rd_hi[ks] = b_rd[ks] + 5 * kTapBytes;
+  }
+
+  // ---- this wave's slab rows: workgroup iteration u = blockIdx.x + k * gridDim.x through the XCD-aware map, four
+  // consecutive slab rows (eight consecutive patches) per workgroup iteration
+  const int units = (p.nslabs + 3) >> 2;
+  auto unit_of = [&](int v) __attribute__((always_inline)) {
+    const int xcd = v & 7, local = v >> 3;
+    const int q = units >> 3, r = units & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + local;
+  };
+  int v = blockIdx.x;
+  auto slab_of = [&](int vv) __attribute__((always_inline)) { return vv < units ? unit_of(vv) * 4 + wave : p.nslabs; };
+  int slab = slab_of(v);
+  int patch = slab * 2;                     // the patch being MULTIPLIED
+  if (patch >= p.npatches) return;
+
+  // ---- request a patch's halo into the staging registers
+  u32x4 stage[kLoads];
+  auto request = [&](int pt) __attribute__((always_inline)) {
+    const int n = fdiv(pt, p.d_pp);
+    const int rem = pt - n * (p.PH * p.PW);
+    const int py = fdiv(rem, p.d_pw), px = rem - py * p.PW;
+    const uint32_t base = (uint32_t)(((n * p.IH + py * 8) * p.IW + px * 8) * (kC * 2));
+    const int y0 = py * 8 - 1, x0 = px * 8 - 1;
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {
+      const bool ok = hyx[i] >= 0 && (uint32_t)(y0 + (hyx[i] >> 8)) < (uint32_t)p.IH &&
+                      (uint32_t)(x0 + (hyx[i] & 255)) < (uint32_t)p.IW;
+      const uint32_t off = ok ? base + (uint32_t)rel[i] : kOOB;       // out of range -> the descriptor returns zeros
+      stage[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, off, 0, 0));
+    }
+  };
+  auto stage_to_lds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i)
+      if (hyx[i] >= 0) *reinterpret_cast<u32x4*>(halo + hdst[i]) = stage[i];
+  };
+
+  // per-lane statistics of the slab row in flight (MODE 1 / 2): 2 column halves x 8 columns
+  float s0[2][8], s1[2][8], sh[2][8];
+  // per-column constants of MODE 2 for this lane's 16 columns
+  const int colb = (lane >> 5) * 16 + (l4 & 1) * 8;     // + jh * 32: first of this lane's 8 consecutive output channels
+
+  request(patch);
+  for (;;) {
+    const bool first_of_slab = (patch & 1) == 0;
+    // ---- halo of this patch: staging registers -> LDS (the previous patch's fragment reads are retired: lgkmcnt(0) at
+    // the end of its last step; LDS operations of one wave execute in order)
+    stage_to_lds();
+    // ---- the patch after this one (same slab row, or the first of this wave's next slab row)
+    int npatch = patch + 1, nv = v;
+    if (!first_of_slab || npatch >= p.npatches) {
+      nv = v + gridDim.x;
+      npatch = slab_of(nv) * 2;
+    }
+    const bool has_next = npatch < p.npatches;
+    if (has_next) request(npatch);          // in flight until the top of the next iteration
+
+    // ---- output coordinates of this patch (and, MODE 2, the BatchNorm-input rows the epilogue needs: requested now)
+    const int n = fdiv(patch, p.d_pp);
+    const int rem = patch - n * (p.PH * p.PW);
+    const int py = fdiv(rem, p.d_pw), px = rem - py * p.PW;
+    uint32_t orow[4];                        // element offset of this lane's pixel in fragment i
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      orow[i] = (uint32_t)(((n * p.IH + py * 8 + 2 * i + fr) * p.IW + px * 8 + fc) * kC);
+    uint4 ybn[MODE == 2 ? 4 : 1][2];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh)
+          ybn[i][jh] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_y) + orow[i] + jh * 32 + colb);
+    }
+
+    // ---- 9 taps x 2 k-steps: 8 fragment reads + 16 MFMAs per step, the reads of step t+1 under the MFMAs of step t
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 af[2][4], bf[2][4];
+    auto read_step = [&](auto SET, auto STEP) __attribute__((always_inline)) {
+      constexpr int S_ = decltype(SET)::value, T_ = decltype(STEP)::value;
+      constexpr int tap = T_ >> 1, ks = T_ & 1;
+      constexpr int r = tap / 3, s = tap % 3;
+      constexpr int AOFF = (r * kHaloW + s) * kPix + ks * 64;
+      af[S_][0] = lds_rd<AOFF>(a_rd);
+      af[S_][1] = lds_rd<AOFF + 2 * kHaloW * kPix>(a_rd);
+      af[S_][2] = lds_rd<AOFF + 4 * kHaloW * kPix>(a_rd);
+      af[S_][3] = lds_rd<AOFF + 6 * kHaloW * kPix>(a_rd);
+      constexpr int BOFF = (tap < 5 ? tap : tap - 5) * kTapBytes;
+      const uint32_t bb = tap < 5 ? b_rd[ks] : b_rd_hi[ks];
+      bf[S_][0] = lds_rd<BOFF>(bb);
+      bf[S_][1] = lds_rd<BOFF + 16 * 128>(bb);
+      bf[S_][2] = lds_rd<BOFF + 32 * 128>(bb);
+      bf[S_][3] = lds_rd<BOFF + 48 * 128>(bb);
+    };
+    auto mma_step = [&](auto SET) __attribute__((always_inline)) {
+      constexpr int S_ = decltype(SET)::value;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[S_][j]),
+                                                              __builtin_bit_cast(bf16x8_t, af[S_][i]), acc[i][j], 0, 0, 0);
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the halo writes above are in LDS
+    read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    auto step = [&](auto STEP) __attribute__((always_inline)) {
+      constexpr int T_ = decltype(STEP)::value;
+      if constexpr (T_ + 1 < 18)
+        read_step(std::integral_constant<int, (T_ + 1) & 1>{}, std::integral_constant<int, T_ + 1>{});
+      mma_step(std::integral_constant<int, T_ & 1>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});  step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});  step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});  step(std::integral_constant<int, 9>{});
+    step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+    step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+    step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
+
+    // ---- epilogue from the accumulators.  Fragment pair jh = (j 2jh, 2jh + 1): after the affine and the bf16 pack,
+    // v_permlane32_swap leaves lanes 0-31 with 8 consecutive channels of fragment 2jh and lanes 32-63 with 8 of 2jh + 1
+    bf16_t* yb = reinterpret_cast<bf16_t*>(p.y);
+    if (first_of_slab) {
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[jh][e] = 0.f; s1[jh][e] = 0.f; sh[jh][e] = 0.f; }
+    }
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+      const int pcol = ((l4 & 1) << 3) | ((l4 & 2) << 1);              // {0, 8, 4, 12}[l4]: this lane's own columns
+      float4 sc[2], shf[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        sc[f] = make_float4(1.f, 1.f, 1.f, 1.f);
+        shf[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.scale) sc[f] = *reinterpret_cast<const float4*>(p.scale + (jh * 2 + f) * 16 + pcol);
+        if (p.shift) shf[f] = *reinterpret_cast<const float4*>(p.shift + (jh * 2 + f) * 16 + pcol);
+      }
+      float c0[8], c1[8], c2[8], c3[8];
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int col = jh * 32 + colb + e;
+          c0[e] = p.bnb_mean[col]; c1[e] = p.bnb_invstd[col];
+          c2[e] = p.bnb_relu == 2 ? p.bnb_scale[col] : 0.f;
+          c3[e] = p.bnb_relu == 2 ? p.bnb_shift[col] : 1.f;          // relu 0: y * 0 + 1 > 0 always
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t w[2][2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          f32x4 a = acc[i][jh * 2 + f];
+          a[0] = a[0] * sc[f].x + shf[f].x; a[1] = a[1] * sc[f].y + shf[f].y;
+          a[2] = a[2] * sc[f].z + shf[f].z; a[3] = a[3] * sc[f].w + shf[f].w;
+          if (p.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
+          }
+          w[f][0] = pack2bf(a[0], a[1]);
+          w[f][1] = pack2bf(a[2], a[3]);
+        }
+        const auto x0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+        const auto x1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+        uint4 vv = make_uint4(x0[0], x1[0], x0[1], x1[1]);
+        if constexpr (MODE == 1) {
+          float x[8];
+          epi::unpack8(vv, x);
+          if (first_of_slab && i == 0) {
+            // shift of the slab row = the value lane l15 = 0 of this 16-lane row stores for fragment 0 (any stored
+            // value of the row serves: bn_finalize re-centres on it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh[jh][e] = __shfl(x[e], lane & 48, 64);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = x[e] - sh[jh][e];
+            s0[jh][e] += d;
+            s1[jh][e] += d * d;
+          }
+        }
+        if constexpr (MODE == 2) {
+          float g[8], yv[8];
+          epi::unpack8(vv, g);
+          epi::unpack8(ybn[i][jh], yv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            g[e] = (yv[e] * c2[e] + c3[e]) > 0.f ? g[e] : 0.f;
+            s0[jh][e] += g[e];
+            s1[jh][e] += g[e] * (yv[e] - c0[e]) * c1[e];
+          }
+          vv = epi::pack8(g);
+        }
+        *reinterpret_cast<uint4*>(yb + orow[i] + jh * 32 + colb) = vv;
+      }
+    }
+    if constexpr (MODE != 0) {
+      if (!first_of_slab || patch + 1 >= p.npatches) {
+        // ---- the slab row is complete: fold the 16 lanes that share this lane's columns (one DPP row), fixed order
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+              s0[jh][e] += __shfl_xor(s0[jh][e], o, 64);
+              s1[jh][e] += __shfl_xor(s1[jh][e], o, 64);
+            }
+          }
+        if (l15 == 0) {
+          const int t = patch >> 1;
+#pragma unroll
+          for (int jh = 0; jh < 2; ++jh) {
+            const int col = jh * 32 + colb;
+            float* slab_row = MODE == 1 ? p.stats + ((size_t)t * kC + col) * 2
+                                        : p.bnb_partial + ((size_t)(p.bnb_tile_off + t) * kC + col) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2)
+              *reinterpret_cast<float4*>(slab_row + e * 2) = make_float4(s0[jh][e], s1[jh][e], s0[jh][e + 1], s1[jh][e + 1]);
+            if constexpr (MODE == 1) {
+              float* sp = p.stats + (size_t)p.stats_tiles * kC * 2 + (size_t)t * kC + col;
+              *reinterpret_cast<float4*>(sp) = make_float4(sh[jh][0], sh[jh][1], sh[jh][2], sh[jh][3]);
+              *reinterpret_cast<float4*>(sp + 4) = make_float4(sh[jh][4], sh[jh][5], sh[jh][6], sh[jh][7]);
+            }
+          }
+        }
+      }
+    }
+    if (!has_next) return;
+    patch = npatch;
+    v = nv;
+  }
+}
+
+template <int MODE>
+static int launch(const Params& p, hipStream_t st) {
+  static bool attr_set = false;
+  static int cus = 0;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wave_kernel<MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+      cus = 256;
+    cus &= ~7;                              // a multiple of 8: a workgroup's iterations stay on its XCD's range
+    attr_set = true;
+  }
+  const int units = (p.nslabs + 3) >> 2;
+  const int grid = units < cus ? units : cus;
+  hipLaunchKernelGGL((conv3x3_wave_kernel<MODE>), dim3(grid), dim3(kThreads), kLds, st, p);
+  return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+}  // namespace w3
+
+static int g_w3 = -1;
+int passl_conv3x3_wave_option(const char* name, int value) {
+  if (strcmp(name, "conv3x3_wave")) return PASSL_EINVAL;
+  g_w3 = value != 0;
+  return PASSL_OK;
+}
+
+int passl_conv3x3_wave_try(const passl_conv_desc* d, hipStream_t st) {
+  if (g_w3 < 0) {
+    const char* e = getenv("PASSL_CONV3X3_WAVE");
+    g_w3 = e ? (atoi(e) != 0) : 1;
+  }
+  if (!g_w3) return PASSL_EUNSUPPORTED;
+  if (d->dtype != PASSL_BF16 || d->out_f32 || d->residual) return PASSL_EUNSUPPORTED;
+  if (d->R != 3 || d->S != 3 || d->sh != 1 || d->sw != 1 || d->ph != 1 || d->pw != 1) return PASSL_EUNSUPPORTED;
+  if (d->C != w3::kC || d->NCOLS != w3::kC || d->IH != d->OP || d->IW != d->OQ) return PASSL_EUNSUPPORTED;
+  if ((d->IH & 7) || (d->IW & 7) || d->IH > 248 || d->IW > 248) return PASSL_EUNSUPPORTED;
+  if (d->a_sw != d->C || d->a_sh != (int64_t)d->IW * d->C || d->a_sn != (int64_t)d->IH * d->IW * d->C ||
+      d->y_sw != d->NCOLS || d->y_sh != (int64_t)d->OQ * d->NCOLS || d->y_sn != (int64_t)d->OP * d->OQ * d->NCOLS)
+    return PASSL_EUNSUPPORTED;
+  const int64_t a_bytes = (int64_t)d->N * d->IH * d->IW * d->C * 2;
+  if (a_bytes >= 0x7ffffff0ll) return PASSL_EUNSUPPORTED;           // 32-bit buffer offsets, also for the output
+  if (d->stats && d->bnb_partial) return PASSL_EUNSUPPORTED;
+  if (d->bnb_partial && (d->relu || d->scale || d->shift || (d->bnb_relu != 0 && d->bnb_relu != 2) || d->bnb2_partial))
+    return PASSL_EUNSUPPORTED;
+  if (d->stats && (d->relu || d->scale || d->shift)) return PASSL_EUNSUPPORTED;
+  w3::Params p;
+  p.a = reinterpret_cast<const char*>(d->a);
+  p.b = reinterpret_cast<const char*>(d->b);
+  p.y = reinterpret_cast<char*>(d->y);
+  p.scale = d->scale; p.shift = d->shift;
+  p.stats = d->stats;
+  p.bnb_y = reinterpret_cast<const char*>(d->bnb_y);
+  p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
+  p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
+  p.a_bytes = (uint32_t)a_bytes;
+  p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.PH = d->IH / 8; p.PW = d->IW / 8;
+  p.npatches = d->N * p.PH * p.PW;
+  p.nslabs = (p.npatches + 1) / 2;
+  p.stats_tiles = p.nslabs;                 // = ceil(M / 128): what the caller sized the slab for
+  if (d->stats && d->stats_tiles != p.nslabs) return PASSL_EINVAL;
+  p.relu = d->relu;
+  p.d_pp = w3::make_fastdiv((uint32_t)(p.PH * p.PW));
+  p.d_pw = w3::make_fastdiv((uint32_t)p.PW);
+  if (d->stats) return w3::launch<1>(p, st);
+  if (d->bnb_partial) return w3::launch<2>(p, st);
+  return w3::launch<0>(p, st);
+}

@@ -521,6 +521,7 @@ int passl_igemm_ring_try(const passl_conv_desc* d, hipStream_t st);   // conv_ig
 int passl_igemm_ring_bnb2(const passl_conv_desc* d, hipStream_t st);  // ... its two-BatchNorm instantiation
 int passl_igemm_8p_try(const passl_conv_desc* d, hipStream_t st);     // conv_igemm_8p.hip
 int passl_stem_try(const passl_conv_desc* d, hipStream_t st);         // conv_stem.hip
+int passl_conv3x3_wave_try(const passl_conv_desc* d, hipStream_t st); // conv3x3_wave.hip
 
 static int g_last_kernel = -1;
 extern "C" int passl_hip_last_igemm_kernel(void) { return g_last_kernel; }
@@ -630,7 +631,14 @@ extern "C" int passl_hip_conv_igemm(const passl_conv_desc* d, passl_stream_t str
     return rc2;
   }
   passl_prof_begin(0, st);
-  int rc = passl_igemm_8p_try(d, st);              // 256 x 256 tiles, 8-phase schedule: wide, deep GEMMs
+  int rc = passl_conv3x3_wave_try(d, st);          // 64 -> 64 3x3 / stride 1: one wave per 8 x 8 patch, weights resident
+  if (rc != PASSL_EUNSUPPORTED) {
+    passl_prof_work(0, w_flops, w_bytes);
+    passl_prof_end(0, st);
+    g_last_kernel = 4;
+    return rc;
+  }
+  rc = passl_igemm_8p_try(d, st);                  // 256 x 256 tiles, 8-phase schedule: wide, deep GEMMs
   if (rc != PASSL_EUNSUPPORTED) {
     passl_prof_retag(0, 3);
     passl_prof_work(3, w_flops, w_bytes);

@@ -123,12 +123,14 @@ int passl_bn_option(const char* name, int value);            // bn.hip
 int passl_stem_option(const char* name, int value);          // conv_stem.hip
 int passl_pool_option(const char* name, int value);          // stem_pool.hip
 int passl_igemm_persist_option(int value);                   // conv_igemm.hip
+int passl_conv3x3_wave_option(const char* name, int value);  // conv3x3_wave.hip
 int passl_igemm_persist_grid_option(int value);
 
 extern "C" int passl_hip_set_option(const char* name, int value) {
   if (!name) return PASSL_EINVAL;
   if (!strcmp(name, "igemm_persist")) return passl_igemm_persist_option(value);
   if (!strcmp(name, "igemm_persist_grid")) return passl_igemm_persist_grid_option(value);
+  if (passl_conv3x3_wave_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_wgrad_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_bn_option(name, value) == PASSL_OK) return PASSL_OK;
   if (passl_stem_option(name, value) == PASSL_OK) return PASSL_OK;

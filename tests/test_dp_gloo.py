@@ -479,3 +479,26 @@ def test_grad_reducer_bf16_wire_matches_fp32_to_bf16_rounding():
     # ... each rank's contribution is rounded to bf16 (2^-9 relative to ITS magnitude) and so is their sum
     bound = 2.0 ** -8 * (out[0]['own'].abs() + out[1]['own'].abs() + ref.abs()) + 1e-30
     assert bool(((got - ref).abs() <= bound).all()), float(((got - ref).abs() / bound).max())
+
+
+def test_default_buckets_are_one_big_bucket_and_a_small_tail(monkeypatch):
+    """Round 6: by default the gradient buffer is all-reduced as TWO buckets — the head of the buffer (the first layers,
+    whose gradients arrive last: <= 1.5 M elements and <= 1/8 of the buffer) and everything else — instead of 4 x 28 MB:
+    only the last bucket's collective is exposed, and every bucket is a live host call between two plan segments."""
+    from passl_amd.core.sync_utils import GradReducer
+    monkeypatch.delenv('PASSL_DP_BUCKETS', raising=False)
+    # R50-like: stem + 4 stages + projector (elements per parameter tensor, flat-buffer order)
+    sizes = [9408, 64, 64] + [70000] * 3 + [400000] * 3 + [2300000] * 3 + [5000000] * 3 + [4194304, 2048, 262144, 128]
+    arena = _fake_arena(sizes)
+    red = GradReducer(arena, SimpleNamespace(grad_scale=1.0))
+    assert len(red.buckets) == 2
+    (s0, e0, i0), (s1, e1, i1) = red.buckets              # launch order: the big one first
+    assert e0 == arena.param_slices[-1][0] + sizes[-1] and s1 == 0 and e1 == s0
+    assert sorted(i0 + i1) == list(range(len(sizes)))
+    assert e1 - s1 <= 3 * 512 * 1024 + max(sizes[:9]) and (e1 - s1) * 8 <= sum(sizes) + 8 * len(sizes) + max(sizes[:9]) * 8
+    assert len(i1) >= 6                                    # stem + the first stages: what backward finishes with
+    # tiny buffers: one bucket would do, two are still valid
+    small = GradReducer(_fake_arena([40, 8, 8, 100]), SimpleNamespace(grad_scale=1.0))
+    assert sorted(i for b in small.buckets for i in b[2]) == [0, 1, 2, 3] and 1 <= len(small.buckets) <= 2
+    monkeypatch.setenv('PASSL_DP_BUCKETS', '4')
+    assert len(GradReducer(_fake_arena(sizes), SimpleNamespace(grad_scale=1.0)).buckets) >= 3
