@@ -76,6 +76,7 @@ struct Params {
   int N, IH, IW, PH, PW;                   // PH x PW patches per image
   int npatches, nslabs;                    // slab row = two consecutive patches
   int relu;
+  int dbg;                                 // ablation (conv3x3_wave_dbg): 1 no statistics, 2 no epilogue, 4 no MFMA loop, 8 no halo loads
   FastDiv d_pp, d_pw;                      // / (PH * PW), / PW
 };
 
@@ -86,9 +87,12 @@ __device__ __forceinline__ u32x4 lds_rd(uint32_t addr) {
   return v;
 }
 
-// MODE 0: affine (+ReLU); 1: + forward statistics; 2: BatchNorm-backward statistics of the producing layer
-template <int MODE>
-__global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params p) {
+// MODE 0: affine (+ReLU); 1: + forward statistics; 2: BatchNorm-backward statistics of the producing layer.
+// AFFINE / RELU are compile-time: as run-time branches they cost the epilogue 512 accumulator-register moves and 32
+// loads per patch (the compiler keeps every branch's result in the accumulator file)
+template <int MODE, bool AFFINE, bool RELU>
+__global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
+    conv3x3_wave_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -174,9 +178,9 @@ __global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params 
   };
 
   // per-lane statistics of the slab row in flight (MODE 1 / 2): 2 column halves x 8 columns
-  float s0[2][8], s1[2][8], sh[2][8];
-  // per-column constants of MODE 2 for this lane's 16 columns
-  const int colb = (lane >> 5) * 16 + (l4 & 1) * 8;     // + jh * 32: first of this lane's 8 consecutive output channels
+  float s0[8], s1[8], sh[8];
+  // the 8 consecutive output channels this lane stores (after the epilogue's trade: see there)
+  const int mycol = fr * 32 + l4 * 8;
 
   request(patch);
   for (;;) {
@@ -191,23 +195,25 @@ __global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params 
       npatch = slab_of(nv) * 2;
     }
     const bool has_next = npatch < p.npatches;
-    if (has_next) request(npatch);          // in flight until the top of the next iteration
+    if (has_next && !(p.dbg & 8)) request(npatch);          // in flight until the top of the next iteration
 
     // ---- output coordinates of this patch (and, MODE 2, the BatchNorm-input rows the epilogue needs: requested now)
     const int n = fdiv(patch, p.d_pp);
     const int rem = patch - n * (p.PH * p.PW);
     const int py = fdiv(rem, p.d_pw), px = rem - py * p.PW;
-    uint32_t orow[4];                        // element offset of this lane's pixel in fragment i
+    uint32_t orow[4][2];                     // element offset of the pixel (row rr of fragment i, this lane's column)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      orow[i] = (uint32_t)(((n * p.IH + py * 8 + 2 * i + fr) * p.IW + px * 8 + fc) * kC);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+        orow[i][rr] = (uint32_t)(((n * p.IH + py * 8 + 2 * i + rr) * p.IW + px * 8 + fc) * kC);
     uint4 ybn[MODE == 2 ? 4 : 1][2];
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jh = 0; jh < 2; ++jh)
-          ybn[i][jh] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_y) + orow[i] + jh * 32 + colb);
+        for (int rr = 0; rr < 2; ++rr)
+          ybn[i][rr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_y) + orow[i][rr] + mycol);
     }
 
     // ---- 9 taps x 2 k-steps: 8 fragment reads + 16 MFMAs per step, the reads of step t+1 under the MFMAs of step t
@@ -250,10 +256,14 @@ __global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params 
       constexpr int T_ = decltype(STEP)::value;
       if constexpr (T_ + 1 < 18)
         read_step(std::integral_constant<int, (T_ + 1) & 1>{}, std::integral_constant<int, T_ + 1>{});
+      __builtin_amdgcn_sched_barrier(0);      // all eight reads of step t+1 go out BEFORE the MFMAs of step t (hipcc
+                                              // otherwise reuses the operand registers and issues them behind the MFMAs)
       mma_step(std::integral_constant<int, T_ & 1>{});
+      __builtin_amdgcn_sched_barrier(0);      // ... and the wait for them comes BEHIND the sixteen MFMAs, not among them
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     };
+    if (!(p.dbg & 4)) {
     step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});
     step(std::integral_constant<int, 2>{});  step(std::integral_constant<int, 3>{});
     step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
@@ -263,46 +273,55 @@ __global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params 
     step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
     step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
     step(std::integral_constant<int, 16>{}); step(std::integral_constant<int, 17>{});
+    }
 
     // ---- epilogue from the accumulators.  Fragment pair jh = (j 2jh, 2jh + 1): after the affine and the bf16 pack,
-    // v_permlane32_swap leaves lanes 0-31 with 8 consecutive channels of fragment 2jh and lanes 32-63 with 8 of 2jh + 1
+    // v_permlane32_swap leaves lane (l15, l4) with the 16-byte piece l4 of its pixel's 64-byte half jh.  A store
+    // instruction made of those would write 64 B of sixteen different pixels (half lines: measured 36 of the kernel's
+    // 95 us).  So the two rows of a fragment trade halves first: lane l15 and lane l15 ^ 4 hold the same column of the
+    // fragment's first / second row (lanes 0-3, 12-15 / 4-11); the first-row lanes give away their half 1 and keep
+    // half 0 of BOTH rows, the second-row lanes keep half 1 of both — and each of the two store instructions per
+    // fragment writes one complete patch row: 8 pixels x 128 B = 1 KB of consecutive memory.  A lane then only ever
+    // sees ONE set of 8 output channels: first-row lanes channels l4*8 .., second-row lanes 32 + l4*8 ...
     bf16_t* yb = reinterpret_cast<bf16_t*>(p.y);
+    if (!(p.dbg & 2)) {
     if (first_of_slab) {
 #pragma unroll
-      for (int jh = 0; jh < 2; ++jh)
+      for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; sh[e] = 0.f; }
+    }
+    const int pcol = ((l4 & 1) << 3) | ((l4 & 2) << 1);              // {0, 8, 4, 12}[l4]: this lane's own columns, pre-swap
+    float4 asc[4], ash[4];                   // per fragment j: scale / shift of this lane's 4 channels
+    if constexpr (AFFINE) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s0[jh][e] = 0.f; s1[jh][e] = 0.f; sh[jh][e] = 0.f; }
+      for (int j = 0; j < 4; ++j) {
+        asc[j] = p.scale ? *reinterpret_cast<const float4*>(p.scale + j * 16 + pcol) : make_float4(1.f, 1.f, 1.f, 1.f);
+        ash[j] = p.shift ? *reinterpret_cast<const float4*>(p.shift + j * 16 + pcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float c0[8], c1[8], c2[8], c3[8];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        c0[e] = p.bnb_mean[mycol + e]; c1[e] = p.bnb_invstd[mycol + e];
+        c2[e] = p.bnb_relu == 2 ? p.bnb_scale[mycol + e] : 0.f;
+        c3[e] = p.bnb_relu == 2 ? p.bnb_shift[mycol + e] : 1.f;          // relu 0: y * 0 + 1 > 0 always
+      }
     }
 #pragma unroll
-    for (int jh = 0; jh < 2; ++jh) {
-      const int pcol = ((l4 & 1) << 3) | ((l4 & 2) << 1);              // {0, 8, 4, 12}[l4]: this lane's own columns
-      float4 sc[2], shf[2];
+    for (int i = 0; i < 4; ++i) {
+      uint4 half[2];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        sc[f] = make_float4(1.f, 1.f, 1.f, 1.f);
-        shf[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.scale) sc[f] = *reinterpret_cast<const float4*>(p.scale + (jh * 2 + f) * 16 + pcol);
-        if (p.shift) shf[f] = *reinterpret_cast<const float4*>(p.shift + (jh * 2 + f) * 16 + pcol);
-      }
-      float c0[8], c1[8], c2[8], c3[8];
-      if constexpr (MODE == 2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int col = jh * 32 + colb + e;
-          c0[e] = p.bnb_mean[col]; c1[e] = p.bnb_invstd[col];
-          c2[e] = p.bnb_relu == 2 ? p.bnb_scale[col] : 0.f;
-          c3[e] = p.bnb_relu == 2 ? p.bnb_shift[col] : 1.f;          // relu 0: y * 0 + 1 > 0 always
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int jh = 0; jh < 2; ++jh) {
         uint32_t w[2][2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
           f32x4 a = acc[i][jh * 2 + f];
-          a[0] = a[0] * sc[f].x + shf[f].x; a[1] = a[1] * sc[f].y + shf[f].y;
-          a[2] = a[2] * sc[f].z + shf[f].z; a[3] = a[3] * sc[f].w + shf[f].w;
-          if (p.relu) {
+          if constexpr (AFFINE) {
+            const float4 sc = asc[jh * 2 + f], sf = ash[jh * 2 + f];
+            a[0] = a[0] * sc.x + sf.x; a[1] = a[1] * sc.y + sf.y;
+            a[2] = a[2] * sc.z + sf.z; a[3] = a[3] * sc.w + sf.w;
+          }
+          if constexpr (RELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[r] = fmaxf(a[r], 0.f);
           }
@@ -311,69 +330,80 @@ __global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params 
         }
         const auto x0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
         const auto x1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-        uint4 vv = make_uint4(x0[0], x1[0], x0[1], x1[1]);
-        if constexpr (MODE == 1) {
+        half[jh] = make_uint4(x0[0], x1[0], x0[1], x1[1]);
+      }
+      // trade: first-row lanes send half 1, second-row lanes send half 0, to lane ^ 4
+      const uint4 snd = fr ? half[0] : half[1];
+      uint4 rcv;
+      // lane ^ 4: ds_swizzle in bit mode (and 0x1f, or 0, xor 4) — no address register, no LDS memory
+      rcv.x = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.x, 0x101F); rcv.y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.y, 0x101F);
+      rcv.z = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.z, 0x101F); rcv.w = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.w, 0x101F);
+      uint4 out[2];                              // [row of the fragment]: this lane's 16 bytes of that row's pixel
+      out[0] = fr ? rcv : half[0];
+      out[1] = fr ? half[1] : rcv;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        uint4 vv = out[rr];
+        if (MODE == 1 && !(p.dbg & 1)) {
           float x[8];
           epi::unpack8(vv, x);
-          if (first_of_slab && i == 0) {
-            // shift of the slab row = the value lane l15 = 0 of this 16-lane row stores for fragment 0 (any stored
-            // value of the row serves: bn_finalize re-centres on it)
+          if (first_of_slab && i == 0 && rr == 0) {
+            // shift of the slab row = what the first lane of this lane's channel set stores here (any stored value of
+            // the row serves: bn_finalize re-centres on it)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sh[jh][e] = __shfl(x[e], lane & 48, 64);
+            for (int e = 0; e < 8; ++e) sh[e] = __shfl(x[e], (lane & 48) | (fr << 2), 64);
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float d = x[e] - sh[jh][e];
-            s0[jh][e] += d;
-            s1[jh][e] += d * d;
+            const float d = x[e] - sh[e];
+            s0[e] += d;
+            s1[e] += d * d;
           }
         }
         if constexpr (MODE == 2) {
           float g[8], yv[8];
           epi::unpack8(vv, g);
-          epi::unpack8(ybn[i][jh], yv);
+          epi::unpack8(ybn[i][rr], yv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             g[e] = (yv[e] * c2[e] + c3[e]) > 0.f ? g[e] : 0.f;
-            s0[jh][e] += g[e];
-            s1[jh][e] += g[e] * (yv[e] - c0[e]) * c1[e];
+            s0[e] += g[e];
+            s1[e] += g[e] * (yv[e] - c0[e]) * c1[e];
           }
           vv = epi::pack8(g);
         }
-        *reinterpret_cast<uint4*>(yb + orow[i] + jh * 32 + colb) = vv;
+        *reinterpret_cast<uint4*>(yb + orow[i][rr] + mycol) = vv;
       }
     }
     if constexpr (MODE != 0) {
       if (!first_of_slab || patch + 1 >= p.npatches) {
-        // ---- the slab row is complete: fold the 16 lanes that share this lane's columns (one DPP row), fixed order
+        // ---- the slab row is complete: fold the 8 lanes that share this lane's channels (same l4, same row class:
+        // quad swaps and the row mirror stay inside {0-3, 12-15} and inside {4-11}), fixed order
 #pragma unroll
-        for (int jh = 0; jh < 2; ++jh)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-              s0[jh][e] += __shfl_xor(s0[jh][e], o, 64);
-              s1[jh][e] += __shfl_xor(s1[jh][e], o, 64);
-            }
-          }
-        if (l15 == 0) {
+        for (int e = 0; e < 8; ++e) {
+          // DPP: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_mirror (lane i <-> 15 - i: {0-3} <-> {15-12}, {4-7} <-> {11-8})
+          s0[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0[e]), 0xB1, 0xf, 0xf, true));
+          s1[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[e]), 0xB1, 0xf, 0xf, true));
+          s0[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0[e]), 0x4E, 0xf, 0xf, true));
+          s1[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[e]), 0x4E, 0xf, 0xf, true));
+          s0[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0[e]), 0x140, 0xf, 0xf, true));
+          s1[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[e]), 0x140, 0xf, 0xf, true));
+        }
+        if (l15 == (fr << 2)) {                  // lanes 0 / 4 of every 16-lane row: one writer per channel set
           const int t = patch >> 1;
+          float* slab_row = MODE == 1 ? p.stats + ((size_t)t * kC + mycol) * 2
+                                      : p.bnb_partial + ((size_t)(p.bnb_tile_off + t) * kC + mycol) * 2;
 #pragma unroll
-          for (int jh = 0; jh < 2; ++jh) {
-            const int col = jh * 32 + colb;
-            float* slab_row = MODE == 1 ? p.stats + ((size_t)t * kC + col) * 2
-                                        : p.bnb_partial + ((size_t)(p.bnb_tile_off + t) * kC + col) * 2;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2)
-              *reinterpret_cast<float4*>(slab_row + e * 2) = make_float4(s0[jh][e], s1[jh][e], s0[jh][e + 1], s1[jh][e + 1]);
-            if constexpr (MODE == 1) {
-              float* sp = p.stats + (size_t)p.stats_tiles * kC * 2 + (size_t)t * kC + col;
-              *reinterpret_cast<float4*>(sp) = make_float4(sh[jh][0], sh[jh][1], sh[jh][2], sh[jh][3]);
-              *reinterpret_cast<float4*>(sp + 4) = make_float4(sh[jh][4], sh[jh][5], sh[jh][6], sh[jh][7]);
-            }
+          for (int e = 0; e < 8; e += 2)
+            *reinterpret_cast<float4*>(slab_row + e * 2) = make_float4(s0[e], s1[e], s0[e + 1], s1[e + 1]);
+          if constexpr (MODE == 1) {
+            float* sp = p.stats + (size_t)p.stats_tiles * kC * 2 + (size_t)t * kC + mycol;
+            *reinterpret_cast<float4*>(sp) = make_float4(sh[0], sh[1], sh[2], sh[3]);
+            *reinterpret_cast<float4*>(sp + 4) = make_float4(sh[4], sh[5], sh[6], sh[7]);
           }
         }
       }
+    }
     }
     if (!has_next) return;
     patch = npatch;
@@ -381,12 +411,12 @@ __global__ void __launch_bounds__(kThreads, 1) conv3x3_wave_kernel(const Params 
   }
 }
 
-template <int MODE>
+template <int MODE, bool AFFINE = false, bool RELU = false>
 static int launch(const Params& p, hipStream_t st) {
   static bool attr_set = false;
   static int cus = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wave_kernel<MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wave_kernel<MODE, AFFINE, RELU>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -397,14 +427,15 @@ static int launch(const Params& p, hipStream_t st) {
   }
   const int units = (p.nslabs + 3) >> 2;
   const int grid = units < cus ? units : cus;
-  hipLaunchKernelGGL((conv3x3_wave_kernel<MODE>), dim3(grid), dim3(kThreads), kLds, st, p);
+  hipLaunchKernelGGL((conv3x3_wave_kernel<MODE, AFFINE, RELU>), dim3(grid), dim3(kThreads), kLds, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
 }
 
 }  // namespace w3
 
-static int g_w3 = -1;
+static int g_w3 = -1, g_w3_dbg = 0;
 int passl_conv3x3_wave_option(const char* name, int value) {
+  if (!strcmp(name, "conv3x3_wave_dbg")) { g_w3_dbg = value; return PASSL_OK; }
   if (strcmp(name, "conv3x3_wave")) return PASSL_EINVAL;
   g_w3 = value != 0;
   return PASSL_OK;
@@ -445,9 +476,12 @@ int passl_conv3x3_wave_try(const passl_conv_desc* d, hipStream_t st) {
   p.stats_tiles = p.nslabs;                 // = ceil(M / 128): what the caller sized the slab for
   if (d->stats && d->stats_tiles != p.nslabs) return PASSL_EINVAL;
   p.relu = d->relu;
+  p.dbg = g_w3_dbg;
   p.d_pp = w3::make_fastdiv((uint32_t)(p.PH * p.PW));
   p.d_pw = w3::make_fastdiv((uint32_t)p.PW);
   if (d->stats) return w3::launch<1>(p, st);
   if (d->bnb_partial) return w3::launch<2>(p, st);
-  return w3::launch<0>(p, st);
+  const bool affine = d->scale || d->shift;
+  if (affine) return d->relu ? w3::launch<0, true, true>(p, st) : w3::launch<0, true, false>(p, st);
+  return d->relu ? w3::launch<0, false, true>(p, st) : w3::launch<0, false, false>(p, st);
 }

@@ -238,7 +238,7 @@ static int64_t check_case(const Shape& s, int variant, Buffers& B, int* kernel_u
 }
 
 static const char* kname(int k) {
-  switch (k) { case 0: return "igemm"; case 1: return "ring"; case 2: return "stem"; case 3: return "8p"; default: return "?"; }
+  switch (k) { case 0: return "igemm"; case 1: return "ring"; case 2: return "stem"; case 3: return "8p"; case 4: return "wave"; default: return "?"; }
 }
 
 static int run_check() {
