@@ -54,6 +54,13 @@ int passl_hip_abi_version(void);
  *   "igemm_8p_min_nk" n         ... (mode 1) only for reductions of at least n 64-element K-tiles (8)
  *   "igemm_8p_tk" / "_te" / "_ring_tk" / "_ring_te" / "_margin"   the cost model's constants (0.01 us per K-tile and
  *                               per tile of either kernel, margin in %: conv_igemm_8p.hip)
+ *   "conv3x3_wave" 0/1          the wave-per-patch kernel (conv3x3_wave.hip) for 3x3 / stride 1 / pad 1 launches with 64 input
+ *                               and 64 output channels whose image sides are multiples of 8 (ResNet-50 stage 1, forward and
+ *                               data gradient; affine / ReLU, fused statistics or BatchNorm-backward epilogue): the nine weight
+ *                               taps stay in LDS, every wave walks its own patches, no workgroup barrier (1);
+ *                               "conv3x3_wave_rows" 4|8: 4 x 8 patches on eight waves (default) / 8 x 8 patches on four
+ *   "igemm_persist" 0/1         persistent form of the register-staged kernel for dense 1x1 launches: bit-identical, measured
+ *                               slower (profiles/r06_negative_results.txt): off;  "igemm_persist_grid" n: its grid (tests)
  *   "wgrad_halo" 0|1|2          spatially tiled 3x3 / stride 1 weight-gradient kernel (conv_wgrad_halo.inc): off / images
  *                               whose sides are multiples of 8 / every such layer (default: the 8 x 8 patches overhang,
  *                               out-of-image pixels are fetched as zeros);  "wgrad_halo_stages" 2|3.
@@ -65,8 +72,8 @@ int passl_hip_abi_version(void);
  * Returns PASSL_EINVAL for an unknown name. */
 int passl_hip_set_option(const char* name, int value);
 /* Which kernel the most recent passl_hip_conv_igemm call of this process launched: 0 = igemm_kernel
- * (register-staged), 1 = igemm_ring_kernel, 2 = stem_kernel, 3 = igemm_8p_kernel; -1 before the
- * first call.
+ * (register-staged), 1 = igemm_ring_kernel, 2 = stem_kernel, 3 = igemm_8p_kernel, 4 = conv3x3_wave_kernel; -1
+ * before the first call.
  * Diagnostics for tests and benchmarks (not thread-safe). */
 int passl_hip_last_igemm_kernel(void);
 /* Human readable text for a passl_status. */

@@ -46,16 +46,22 @@ using ring::fdiv;
 using ring::make_fastdiv;
 using ring::kOOB;
 
-constexpr int kThreads = 256;
 constexpr int kC = 64;                     // input channels = output channels
 constexpr int kPix = 160;                  // bytes per halo pixel: 128 data + 32 pad
-constexpr int kHaloW = 10;                 // 8 + 2
-constexpr int kHaloBytes = kHaloW * kHaloW * kPix;          // 16 000
-constexpr int kHaloStride = 16128;         // per-wave halo buffer (256-byte multiple)
+constexpr int kHaloW = 10;                 // 8 + 2 pixels per halo row
+// ROWS = output rows of a wave's patch (8 columns wide): 8 -> four waves per workgroup (one per SIMD), 4 -> eight waves
+// (two per SIMD: one wave's epilogue / halo staging under the other's MFMAs; the 32-pixel patches re-read more halo)
+template <int ROWS> struct Geo {
+  static constexpr int kWaves = ROWS == 8 ? 4 : 8;
+  static constexpr int kThreads = kWaves * 64;
+  static constexpr int kHaloPx = (ROWS + 2) * kHaloW;
+  static constexpr int kHaloStride = (kHaloPx * kPix + 255) / 256 * 256;      // per-wave halo buffer
+  static constexpr int kLoads = (kHaloPx * 8 + 63) / 64;                        // 16-byte halo chunks per lane
+  static constexpr int kFrags = ROWS / 2;                                       // 2 x 8-pixel fragments per patch
+  static constexpr int kPerSlab = 128 / (ROWS * 8);                             // patches per 128-pixel slab row
+};
 constexpr int kTapBytes = kC * 128;        // one tap of the weights: 64 rows x 128 B
 constexpr int kWBytes = 9 * kTapBytes;     // 73 728
-constexpr int kLds = kWBytes + 4 * kHaloStride;             // 138 240
-constexpr int kLoads = 13;                 // 16-byte halo chunks per lane: 800 of 832
 
 struct Params {
   const char* a;
@@ -74,7 +80,7 @@ struct Params {
   int bnb_relu, bnb_tile_off;
   uint32_t a_bytes;
   int N, IH, IW, PH, PW;                   // PH x PW patches per image
-  int npatches, nslabs;                    // slab row = two consecutive patches
+  int npatches, nslabs;                    // slab row = 128 pixels = 2 (ROWS 8) / 4 (ROWS 4) consecutive patches
   int relu;
   int dbg;                                 // ablation (conv3x3_wave_dbg): 1 no statistics, 2 no epilogue, 4 no MFMA loop, 8 no halo loads
   FastDiv d_pp, d_pw;                      // / (PH * PW), / PW
@@ -90,9 +96,10 @@ __device__ __forceinline__ u32x4 lds_rd(uint32_t addr) {
 // MODE 0: affine (+ReLU); 1: + forward statistics; 2: BatchNorm-backward statistics of the producing layer.
 // AFFINE / RELU are compile-time: as run-time branches they cost the epilogue 512 accumulator-register moves and 32
 // loads per patch (the compiler keeps every branch's result in the accumulator file)
-template <int MODE, bool AFFINE, bool RELU>
-__global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_eu(1, 1)))
-    conv3x3_wave_kernel(const Params p) {
+template <int MODE, bool AFFINE, bool RELU, int ROWS>
+__global__ void __launch_bounds__(Geo<ROWS>::kThreads, ROWS == 8 ? 1 : 2) conv3x3_wave_kernel(const Params p) {
+  typedef Geo<ROWS> G;
+  constexpr int kThreads = G::kThreads, kLoads = G::kLoads, kHaloStride = G::kHaloStride, FI = G::kFrags;
   extern __shared__ __attribute__((aligned(256))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -120,7 +127,7 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
     const int hq = q >> 3;
     const int hy = hq / kHaloW, hx = hq - hy * kHaloW;
     rel[i] = ((hy - 1) * p.IW + (hx - 1)) * (kC * 2) + (q & 7) * 16;
-    hyx[i] = hq < kHaloW * kHaloW ? ((hy << 8) | hx) : -1;
+    hyx[i] = hq < G::kHaloPx ? ((hy << 8) | hx) : -1;
     hdst[i] = (uint32_t)(hq * kPix + (q & 7) * 16);
   }
   __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
@@ -142,7 +149,7 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
 
   // ---- this wave's slab rows: workgroup iteration u = blockIdx.x + k * gridDim.x through the XCD-aware map, four
   // consecutive slab rows (eight consecutive patches) per workgroup iteration
-  const int units = (p.nslabs + 3) >> 2;
+  const int units = (p.nslabs + G::kWaves - 1) / G::kWaves;
   auto unit_of = [&](int v) __attribute__((always_inline)) {
     const int xcd = v & 7, local = v >> 3;
     const int q = units >> 3, r = units & 7;
@@ -150,9 +157,9 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
     return start + local;
   };
   int v = blockIdx.x;
-  auto slab_of = [&](int vv) __attribute__((always_inline)) { return vv < units ? unit_of(vv) * 4 + wave : p.nslabs; };
+  auto slab_of = [&](int vv) __attribute__((always_inline)) { return vv < units ? unit_of(vv) * G::kWaves + wave : p.nslabs; };
   int slab = slab_of(v);
-  int patch = slab * 2;                     // the patch being MULTIPLIED
+  int patch = slab * G::kPerSlab;           // the patch being MULTIPLIED
   if (patch >= p.npatches) return;
 
   // ---- request a patch's halo into the staging registers
@@ -161,8 +168,8 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
     const int n = fdiv(pt, p.d_pp);
     const int rem = pt - n * (p.PH * p.PW);
     const int py = fdiv(rem, p.d_pw), px = rem - py * p.PW;
-    const uint32_t base = (uint32_t)(((n * p.IH + py * 8) * p.IW + px * 8) * (kC * 2));
-    const int y0 = py * 8 - 1, x0 = px * 8 - 1;
+    const uint32_t base = (uint32_t)(((n * p.IH + py * ROWS) * p.IW + px * 8) * (kC * 2));
+    const int y0 = py * ROWS - 1, x0 = px * 8 - 1;
 #pragma unroll
     for (int i = 0; i < kLoads; ++i) {
       const bool ok = hyx[i] >= 0 && (uint32_t)(y0 + (hyx[i] >> 8)) < (uint32_t)p.IH &&
@@ -184,15 +191,16 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
 
   request(patch);
   for (;;) {
-    const bool first_of_slab = (patch & 1) == 0;
+    const bool first_of_slab = (patch % G::kPerSlab) == 0;
+    const bool last_of_slab = (patch % G::kPerSlab) == G::kPerSlab - 1 || patch + 1 >= p.npatches;
     // ---- halo of this patch: staging registers -> LDS (the previous patch's fragment reads are retired: lgkmcnt(0) at
     // the end of its last step; LDS operations of one wave execute in order)
     stage_to_lds();
     // ---- the patch after this one (same slab row, or the first of this wave's next slab row)
     int npatch = patch + 1, nv = v;
-    if (!first_of_slab || npatch >= p.npatches) {
+    if (last_of_slab) {
       nv = v + gridDim.x;
-      npatch = slab_of(nv) * 2;
+      npatch = slab_of(nv) * G::kPerSlab;
     }
     const bool has_next = npatch < p.npatches;
     if (has_next && !(p.dbg & 8)) request(npatch);          // in flight until the top of the next iteration
@@ -201,28 +209,28 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
     const int n = fdiv(patch, p.d_pp);
     const int rem = patch - n * (p.PH * p.PW);
     const int py = fdiv(rem, p.d_pw), px = rem - py * p.PW;
-    uint32_t orow[4][2];                     // element offset of the pixel (row rr of fragment i, this lane's column)
+    uint32_t orow[FI][2];                     // element offset of the pixel (row rr of fragment i, this lane's column)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr)
-        orow[i][rr] = (uint32_t)(((n * p.IH + py * 8 + 2 * i + rr) * p.IW + px * 8 + fc) * kC);
-    uint4 ybn[MODE == 2 ? 4 : 1][2];
+        orow[i][rr] = (uint32_t)(((n * p.IH + py * ROWS + 2 * i + rr) * p.IW + px * 8 + fc) * kC);
+    uint4 ybn[MODE == 2 ? FI : 1][2];
     if constexpr (MODE == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
           ybn[i][rr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.bnb_y) + orow[i][rr] + mycol);
     }
 
     // ---- 9 taps x 2 k-steps: 8 fragment reads + 16 MFMAs per step, the reads of step t+1 under the MFMAs of step t
-    f32x4 acc[4][4];
+    f32x4 acc[FI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 af[2][4], bf[2][4];
+    u32x4 af[3][FI], bf[3][4];            // three fragment sets: the reads run TWO steps ahead of the MFMAs
     auto read_step = [&](auto SET, auto STEP) __attribute__((always_inline)) {
       constexpr int S_ = decltype(SET)::value, T_ = decltype(STEP)::value;
       constexpr int tap = T_ >> 1, ks = T_ & 1;
@@ -230,8 +238,10 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
       constexpr int AOFF = (r * kHaloW + s) * kPix + ks * 64;
       af[S_][0] = lds_rd<AOFF>(a_rd);
       af[S_][1] = lds_rd<AOFF + 2 * kHaloW * kPix>(a_rd);
-      af[S_][2] = lds_rd<AOFF + 4 * kHaloW * kPix>(a_rd);
-      af[S_][3] = lds_rd<AOFF + 6 * kHaloW * kPix>(a_rd);
+      if constexpr (FI == 4) {
+        af[S_][2] = lds_rd<AOFF + 4 * kHaloW * kPix>(a_rd);
+        af[S_][3] = lds_rd<AOFF + 6 * kHaloW * kPix>(a_rd);
+      }
       constexpr int BOFF = (tap < 5 ? tap : tap - 5) * kTapBytes;
       const uint32_t bb = tap < 5 ? b_rd[ks] : b_rd_hi[ks];
       bf[S_][0] = lds_rd<BOFF>(bb);
@@ -242,25 +252,31 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
     auto mma_step = [&](auto SET) __attribute__((always_inline)) {
       constexpr int S_ = decltype(SET)::value;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf[S_][j]),
                                                               __builtin_bit_cast(bf16x8_t, af[S_][i]), acc[i][j], 0, 0, 0);
     };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the halo writes above are in LDS
+    // Reads two steps ahead: with one step of lead the wait at the end of a step still saw part of the LDS latency (8
+    // MFMAs = 136 clocks of cover at ROWS 4).  LDS operations of a wave return in order, so `lgkmcnt(NRD)` — NRD = reads
+    // per step — means "everything but the newest step's reads has arrived".
+    constexpr int NRD = FI + 4;
     read_step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    read_step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");
     __builtin_amdgcn_sched_barrier(0);
     auto step = [&](auto STEP) __attribute__((always_inline)) {
       constexpr int T_ = decltype(STEP)::value;
-      if constexpr (T_ + 1 < 18)
-        read_step(std::integral_constant<int, (T_ + 1) & 1>{}, std::integral_constant<int, T_ + 1>{});
-      __builtin_amdgcn_sched_barrier(0);      // all eight reads of step t+1 go out BEFORE the MFMAs of step t (hipcc
-                                              // otherwise reuses the operand registers and issues them behind the MFMAs)
-      mma_step(std::integral_constant<int, T_ & 1>{});
-      __builtin_amdgcn_sched_barrier(0);      // ... and the wait for them comes BEHIND the sixteen MFMAs, not among them
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (T_ + 2 < 18)
+        read_step(std::integral_constant<int, (T_ + 2) % 3>{}, std::integral_constant<int, T_ + 2>{});
+      __builtin_amdgcn_sched_barrier(0);      // the reads of step t+2 go out BEFORE the MFMAs of step t (hipcc otherwise
+                                              // reuses the operand registers and issues them behind the MFMAs)
+      mma_step(std::integral_constant<int, T_ % 3>{});
+      __builtin_amdgcn_sched_barrier(0);      // ... and the wait comes BEHIND the MFMAs, not among them
+      if constexpr (T_ + 2 < 18) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NRD) : "memory");    // step t+1 has landed
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     };
     if (!(p.dbg & 4)) {
@@ -308,7 +324,7 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < FI; ++i) {
       uint4 half[2];
 #pragma unroll
       for (int jh = 0; jh < 2; ++jh) {
@@ -333,17 +349,19 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
         half[jh] = make_uint4(x0[0], x1[0], x0[1], x1[1]);
       }
       // trade: first-row lanes send half 1, second-row lanes send half 0, to lane ^ 4
-      const uint4 snd = fr ? half[0] : half[1];
+      uint4 snd;                                 // (component-wise selects: a select of whole arrays went through scratch)
+      snd.x = fr ? half[0].x : half[1].x; snd.y = fr ? half[0].y : half[1].y;
+      snd.z = fr ? half[0].z : half[1].z; snd.w = fr ? half[0].w : half[1].w;
       uint4 rcv;
       // lane ^ 4: ds_swizzle in bit mode (and 0x1f, or 0, xor 4) — no address register, no LDS memory
       rcv.x = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.x, 0x101F); rcv.y = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.y, 0x101F);
       rcv.z = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.z, 0x101F); rcv.w = (uint32_t)__builtin_amdgcn_ds_swizzle((int)snd.w, 0x101F);
-      uint4 out[2];                              // [row of the fragment]: this lane's 16 bytes of that row's pixel
-      out[0] = fr ? rcv : half[0];
-      out[1] = fr ? half[1] : rcv;
+      uint4 out0, out1;                          // this lane's 16 bytes of the fragment's first / second row pixel
+      out0.x = fr ? rcv.x : half[0].x; out0.y = fr ? rcv.y : half[0].y; out0.z = fr ? rcv.z : half[0].z; out0.w = fr ? rcv.w : half[0].w;
+      out1.x = fr ? half[1].x : rcv.x; out1.y = fr ? half[1].y : rcv.y; out1.z = fr ? half[1].z : rcv.z; out1.w = fr ? half[1].w : rcv.w;
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        uint4 vv = out[rr];
+        uint4 vv = rr == 0 ? out0 : out1;
         if (MODE == 1 && !(p.dbg & 1)) {
           float x[8];
           epi::unpack8(vv, x);
@@ -376,7 +394,7 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
       }
     }
     if constexpr (MODE != 0) {
-      if (!first_of_slab || patch + 1 >= p.npatches) {
+      if (last_of_slab) {
         // ---- the slab row is complete: fold the 8 lanes that share this lane's channels (same l4, same row class:
         // quad swaps and the row mirror stay inside {0-3, 12-15} and inside {4-11}), fixed order
 #pragma unroll
@@ -390,7 +408,7 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
           s1[e] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1[e]), 0x140, 0xf, 0xf, true));
         }
         if (l15 == (fr << 2)) {                  // lanes 0 / 4 of every 16-lane row: one writer per channel set
-          const int t = patch >> 1;
+          const int t = patch / G::kPerSlab;
           float* slab_row = MODE == 1 ? p.stats + ((size_t)t * kC + mycol) * 2
                                       : p.bnb_partial + ((size_t)(p.bnb_tile_off + t) * kC + mycol) * 2;
 #pragma unroll
@@ -411,12 +429,14 @@ __global__ void __launch_bounds__(kThreads, 1) __attribute__((amdgpu_waves_per_e
   }
 }
 
-template <int MODE, bool AFFINE = false, bool RELU = false>
+template <int ROWS, int MODE, bool AFFINE = false, bool RELU = false>
 static int launch(const Params& p, hipStream_t st) {
+  typedef Geo<ROWS> G;
+  constexpr int kLds = kWBytes + G::kWaves * G::kHaloStride;      // 138 240 (ROWS 8) / 151 552 (ROWS 4)
   static bool attr_set = false;
   static int cus = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wave_kernel<MODE, AFFINE, RELU>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wave_kernel<MODE, AFFINE, RELU, ROWS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -425,17 +445,38 @@ static int launch(const Params& p, hipStream_t st) {
     cus &= ~7;                              // a multiple of 8: a workgroup's iterations stay on its XCD's range
     attr_set = true;
   }
-  const int units = (p.nslabs + 3) >> 2;
+  const int units = (p.nslabs + G::kWaves - 1) / G::kWaves;
   const int grid = units < cus ? units : cus;
-  hipLaunchKernelGGL((conv3x3_wave_kernel<MODE, AFFINE, RELU>), dim3(grid), dim3(kThreads), kLds, st, p);
+  hipLaunchKernelGGL((conv3x3_wave_kernel<MODE, AFFINE, RELU, ROWS>), dim3(grid), dim3(G::kThreads), kLds, st, p);
   return hipGetLastError() == hipSuccess ? PASSL_OK : PASSL_ELAUNCH;
+}
+
+template <int ROWS>
+static int dispatch(const passl_conv_desc* d, Params& p, hipStream_t st) {
+  p.PH = d->IH / ROWS; p.PW = d->IW / 8;
+  p.npatches = d->N * p.PH * p.PW;
+  p.nslabs = (p.npatches + Geo<ROWS>::kPerSlab - 1) / Geo<ROWS>::kPerSlab;
+  p.stats_tiles = p.nslabs;                 // = ceil(M / 128): what the caller sized the slab for
+  if (d->stats && d->stats_tiles != p.nslabs) return PASSL_EINVAL;
+  p.d_pp = make_fastdiv((uint32_t)(p.PH * p.PW));
+  p.d_pw = make_fastdiv((uint32_t)p.PW);
+  if (d->stats) return launch<ROWS, 1>(p, st);
+  if (d->bnb_partial) return launch<ROWS, 2>(p, st);
+  const bool affine = d->scale || d->shift;
+  if (affine) return d->relu ? launch<ROWS, 0, true, true>(p, st) : launch<ROWS, 0, true, false>(p, st);
+  return d->relu ? launch<ROWS, 0, false, true>(p, st) : launch<ROWS, 0, false, false>(p, st);
 }
 
 }  // namespace w3
 
-static int g_w3 = -1, g_w3_dbg = 0;
+static int g_w3 = -1, g_w3_dbg = 0, g_w3_rows = 4;
 int passl_conv3x3_wave_option(const char* name, int value) {
   if (!strcmp(name, "conv3x3_wave_dbg")) { g_w3_dbg = value; return PASSL_OK; }
+  if (!strcmp(name, "conv3x3_wave_rows")) {          // 8: four waves x (8 x 8 patches); 4: eight waves x (4 x 8 patches)
+    if (value != 4 && value != 8) return PASSL_EINVAL;
+    g_w3_rows = value;
+    return PASSL_OK;
+  }
   if (strcmp(name, "conv3x3_wave")) return PASSL_EINVAL;
   g_w3 = value != 0;
   return PASSL_OK;
@@ -470,18 +511,8 @@ int passl_conv3x3_wave_try(const passl_conv_desc* d, hipStream_t st) {
   p.bnb_mean = d->bnb_mean; p.bnb_invstd = d->bnb_invstd; p.bnb_scale = d->bnb_scale; p.bnb_shift = d->bnb_shift;
   p.bnb_partial = d->bnb_partial; p.bnb_relu = d->bnb_relu; p.bnb_tile_off = d->bnb_tile_off;
   p.a_bytes = (uint32_t)a_bytes;
-  p.N = d->N; p.IH = d->IH; p.IW = d->IW; p.PH = d->IH / 8; p.PW = d->IW / 8;
-  p.npatches = d->N * p.PH * p.PW;
-  p.nslabs = (p.npatches + 1) / 2;
-  p.stats_tiles = p.nslabs;                 // = ceil(M / 128): what the caller sized the slab for
-  if (d->stats && d->stats_tiles != p.nslabs) return PASSL_EINVAL;
+  p.N = d->N; p.IH = d->IH; p.IW = d->IW;
   p.relu = d->relu;
   p.dbg = g_w3_dbg;
-  p.d_pp = w3::make_fastdiv((uint32_t)(p.PH * p.PW));
-  p.d_pw = w3::make_fastdiv((uint32_t)p.PW);
-  if (d->stats) return w3::launch<1>(p, st);
-  if (d->bnb_partial) return w3::launch<2>(p, st);
-  const bool affine = d->scale || d->shift;
-  if (affine) return d->relu ? w3::launch<0, true, true>(p, st) : w3::launch<0, true, false>(p, st);
-  return d->relu ? w3::launch<0, false, true>(p, st) : w3::launch<0, false, false>(p, st);
+  return g_w3_rows == 8 ? w3::dispatch<8>(d, p, st) : w3::dispatch<4>(d, p, st);
 }

@@ -26,10 +26,20 @@ def _kbench():
 
 
 @pytest.mark.gpu
-def test_conv_igemm_is_bit_exact_through_the_c_abi():
-    r = subprocess.run([_kbench(), 'check'], capture_output=True, text=True, timeout=600)
+@pytest.mark.parametrize('options', [(), ('conv3x3_wave_rows=8',), ('conv3x3_wave=0',),
+                                     ('igemm_persist=1', 'igemm_persist_grid=8')],
+                         ids=['default', 'wave-8x8', 'no-wave', 'persistent-1x1'])
+def test_conv_igemm_is_bit_exact_through_the_c_abi(options):
+    """The default kernel selection (round 6: the wave-per-patch kernel on the 64 -> 64 3x3 cases), its 8 x 8-patch form,
+    the selection without it, and the opt-in persistent form of the register-staged kernel with a grid of 8 workgroups
+    (every workgroup walks many tiles): every output bit, every slab entry."""
+    r = subprocess.run([_kbench(), 'check', *options], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert 'CHECK OK' in r.stdout
+    if not options:
+        assert 'kernel wave' in r.stdout
+    if options == ('conv3x3_wave=0',):
+        assert 'kernel wave' not in r.stdout
 
 
 @pytest.mark.gpu

@@ -943,3 +943,78 @@ def test_fill_copy_cast_unpad_kernels():
     assert torch.equal(dst, dst0 + src[:, :, :7, :3])
     one = torch.zeros(1, device=DEV)
     assert ops.ones_like_cached(one) is ops.ones_like_cached(one) and float(ops.ones_like_cached(one)) == 1.0
+
+
+@pytest.mark.parametrize('rows', [4, 8])
+def test_conv3x3_wave_kernel_against_ring_kernel(rows):
+    """csrc/conv3x3_wave.hip (round 6: one wave per patch, weights resident in LDS, register epilogue) on the 64 -> 64
+    3x3 layers of the first stage: the stored bf16 output — forward with fused statistics, the key encoder's affine +
+    ReLU form, the data gradient with the BatchNorm-backward epilogue — equals the ring kernel's BIT FOR BIT (same taps,
+    same channel order, fp32 accumulation in the MFMA); the statistics slabs are summed in another fixed order: equal
+    column totals to fp32 rounding, identical from run to run."""
+    from passl_amd.hip import lib as L
+    lib = L.load()
+    gen = torch.Generator().manual_seed(64)
+    cin = cout = 64
+    try:
+        for H, N in ((56, 3), (8, 5), (24, 2)):
+            g = P.ConvGeom(cin, cout, 3, 1, 1)
+            fd = P.fwd_desc(g, N, H, H)
+            dds, skipped = P.dgrad_plan(g, N, H, H)
+            assert len(dds) == 1 and not skipped
+            packer = WeightPacker()
+            for d in [fd] + dds:
+                packer.add(0, cout, 3, 3, cin, d.pack)
+            packer.build(DEV, torch.bfloat16).run((torch.randn(cout * 9 * cin, generator=gen) * 0.05).to(DEV))
+            x = torch.randn(N, H, H, cin, generator=gen).to(DEV).to(torch.bfloat16)
+            dy = torch.randn(N, H, H, cout, generator=gen).to(DEV).to(torch.bfloat16)
+            yb = torch.randn(N, H, H, cin, generator=gen).to(DEV).to(torch.bfloat16)
+            sc, sf = torch.rand(cout, generator=gen).to(DEV) + 0.5, torch.randn(cout, generator=gen).to(DEV) * 0.3
+            slab, tiles = ops.conv_stats_buffer(fd, DEV)
+            d = dds[0]
+            td = ops.conv_tiles(d)
+            part = torch.zeros(ops.bn_partial_floats(td, cin, False), device=DEV)
+            bnb = dict(y=yb, mask=None, mean=torch.randn(cin, generator=gen).to(DEV) * 0.1,
+                       invstd=torch.rand(cin, generator=gen).to(DEV) + 0.5, scale=sc, shift=sf, relu=2, partial=part,
+                       tile_off=0)
+            got = {}
+            for wave in (0, 1, 1):
+                assert lib.passl_hip_set_option(b'conv3x3_wave', wave) == 0
+                assert lib.passl_hip_set_option(b'conv3x3_wave_rows', rows) == 0
+                y = torch.zeros(N, H, H, cout, device=DEV, dtype=torch.bfloat16)
+                yk = torch.zeros_like(y)
+                dx = torch.zeros(N, H, H, cin, device=DEV, dtype=torch.bfloat16)
+                slab.fill_(float('nan')); part.fill_(float('nan'))
+                ops.conv_igemm(fd, x, packer.view(fd.pack, cout), y, stats=slab)
+                k1 = lib.passl_hip_last_igemm_kernel()
+                ops.conv_igemm(fd, x, packer.view(fd.pack, cout), yk, scale=sc, shift=sf, relu=True)
+                k2 = lib.passl_hip_last_igemm_kernel()
+                ops.conv_igemm(d, dy, packer.view(d.pack, cin), dx, bnb=bnb)
+                k3 = lib.passl_hip_last_igemm_kernel()
+                assert (k1, k2, k3) == ((4, 4, 4) if wave else (1, 1, 1)), (k1, k2, k3)
+                # column totals of the slabs in fp64: sum (v - s) + n s, sum g, sum g xhat
+                sl = slab[:tiles * cout * 3].double()
+                sums = sl[:tiles * cout * 2].view(tiles, cout, 2)
+                shifts = sl[tiles * cout * 2:].view(tiles, cout)
+                nrow = torch.full((tiles, 1), 128.0, device=DEV, dtype=torch.float64)
+                nrow[-1] = N * H * H - 128 * (tiles - 1)
+                tot1 = (sums[:, :, 0] + nrow * shifts).sum(0)
+                tot2 = (sums[:, :, 1] + 2 * shifts * sums[:, :, 0] + nrow * shifts * shifts).sum(0)
+                pt = part[:td * cin * 2].double().view(td, cin, 2).sum(0)
+                got.setdefault(wave, []).append([t.clone() for t in (y, yk, dx, tot1, tot2, pt[:, 0], pt[:, 1],
+                                                                     slab[:tiles * cout * 3], part[:td * cin * 2])])
+            ring, w1, w2 = got[0][0], got[1][0], got[1][1]
+            for i in range(3):                                   # the three stored tensors: bit for bit
+                assert torch.equal(_bits(ring[i]), _bits(w1[i])), (H, N, i)
+            yd = ring[0].double().reshape(-1, cout)
+            assert float((w1[3] - yd.sum(0)).abs().max()) < 1e-3 * float(yd.abs().sum(0).max())     # sums of the STORED values
+            assert float((w1[4] - (yd * yd).sum(0)).abs().max()) < 1e-3 * float((yd * yd).sum(0).max())
+            for i in (3, 4, 5, 6):                               # ... and the ring kernel's slabs say the same
+                scale = float(ring[i].abs().max()) + 1e-6
+                assert float((ring[i] - w1[i]).abs().max()) < 2e-5 * scale + 1e-4, (H, N, i)
+            for i in range(9):                                   # second run of the wave kernel: identical bits everywhere
+                assert not torch.isnan(w1[i].float()).any()
+                assert torch.equal(_bits(w1[i]), _bits(w2[i])), (H, N, i)
+    finally:
+        assert lib.passl_hip_set_option(b'conv3x3_wave', 1) == 0
+        assert lib.passl_hip_set_option(b'conv3x3_wave_rows', 4) == 0
