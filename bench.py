@@ -93,7 +93,7 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='skip the instrumented loop (use under rocprofv3)')
     ap.add_argument('--dp-buckets', type=int, default=0,
-                    help='number of gradient all-reduce buckets (default: 28 MB buckets = 4 for MoCo)')
+                    help='number of EQUAL gradient all-reduce buckets (default: two buckets, a big one and a <= 6 MB tail: core/sync_utils.py)')
     ap.add_argument('--dp-wire', default='', choices=['', 'fp32', 'bf16'],
                     help='dtype of the gradient buckets on the wire (default fp32 = the reference; bf16 halves the bytes per '
                          'xGMI link, sums agree to bf16 rounding: core/sync_utils.py)')
@@ -294,7 +294,11 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            # (the communicator is created lazily — engine/trainer.py — so the barrier names its device itself)
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # PASSL_MAIN_PRIORITY: the whole iteration (hooks included: they read the step's outputs) under a stream of that
@@ -561,7 +565,8 @@ def main():
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()
     if world > 1:
-        dist.barrier()
+        barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

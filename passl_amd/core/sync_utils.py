@@ -10,12 +10,16 @@ What it replaces in the reference:
 MI355X design: gradients already live in ONE flat fp32 buffer (EncoderArena.grads), so a bucket is
 a contiguous slice — no flatten/unflatten copies.  The backward kernels' host code reports each
 layer's parameters as ready (arena.grad_ready); when every parameter of a bucket is ready the
-slice is all-reduced asynchronously (RCCL runs on its own stream and waits on an event of the
-compute stream, so it overlaps with the remaining backward kernels).  Buckets are walked from the
-END of the buffer (the last layers finish first in backward).  The 1/world_size scale is folded
-into the optimizer kernel (no extra pass).  xGMI is point-to-point (7 links/GPU): 112 MB of fp32
-gradients in 4 x 28 MB buckets keeps every collective large enough to be bandwidth- rather than
-latency-bound while leaving 3/4 of the traffic overlappable with backward.
+slice is all-reduced asynchronously: the collective is ISSUED from a stream of its own that waits for the
+bucket's producers (hip/streams.py:comm_stream), RCCL runs it on its stream, the main chain waits for
+nothing until the optimizer — it overlaps with the remaining backward kernels.  Buckets are walked from
+the END of the buffer (the last layers finish first in backward).  The 1/world_size scale is folded into
+the optimizer kernel (no extra pass).  Bucket layout (round 6): TWO buckets — everything but
+the head of the buffer (R50: 106 MB, complete 60 % into backward, fully hidden) and the <= 6 MB head, whose
+all-reduce is the only one backward cannot hide; every further bucket is a live host call inside the step
+(+0.18 ms each, measured).  xGMI is point-to-point (7 links/GPU): one 106 MB collective is as
+bandwidth-bound as a ring gets.  The communicator itself is created at the first collective, not at
+init_process_group (engine/trainer.py: its existence from init on costs the step 8 %).
 """
 import os
 import time
@@ -139,7 +143,7 @@ class GradReducer(object):
                 # bucket count, so it should be small; every further bucket costs a live call on the host between two
                 # segments of the step (measured with a world-1 communicator, profiles/r06_dp_overhead.txt: +0.18 ms of
                 # step time per bucket — 4 x 28 MB: +0.70 ms, 1 bucket: +0.16 ms).  The big bucket (R50: layer3, layer4
-                # and the projector, 106 MB) is complete 60 % into the backward pass.
+                # and the projector, 106 MB) is complete 60 % into the backward pass; the tail is stem + layer1 + layer2.
                 bucket_elems = 1 << 62
                 tail_elems = int(os.environ.get('PASSL_DP_TAIL_ELEMS', str(3 * 512 * 1024)))
                 tail_elems = min(tail_elems, n_train // 8)

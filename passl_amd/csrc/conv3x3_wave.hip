@@ -107,14 +107,6 @@ __global__ void __launch_bounds__(Geo<ROWS>::kThreads, ROWS == 8 ? 1 : 2) conv3x
   const int l15 = lane & 15, l4 = lane >> 4;
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
 
-  // ---- the nine weight taps, once: global [col][tap][c] -> LDS [tap][col][128 B], slot ^= (col >> 1) & 7
-  for (int q = tid; q < 9 * kC * 8; q += kThreads) {
-    const int chunk = q & 7, row = (q >> 3) % kC, tap = (q >> 3) / kC;
-    const uint4 v = *reinterpret_cast<const uint4*>(p.b + ((size_t)row * 9 + tap) * 128 + chunk * 16);
-    *reinterpret_cast<uint4*>(smem + tap * kTapBytes + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = v;
-  }
-  __syncthreads();                          // the only workgroup barrier of the kernel
-
   // ---- per-lane geometry of the halo staging: chunk q = lane + 64 i -> halo pixel q >> 3, 16-byte piece q & 7
   char* halo = smem + kWBytes + wave * kHaloStride;
   const uint32_t halo0 = lds0 + kWBytes + wave * kHaloStride;
@@ -160,7 +152,7 @@ __global__ void __launch_bounds__(Geo<ROWS>::kThreads, ROWS == 8 ? 1 : 2) conv3x
   auto slab_of = [&](int vv) __attribute__((always_inline)) { return vv < units ? unit_of(vv) * G::kWaves + wave : p.nslabs; };
   int slab = slab_of(v);
   int patch = slab * G::kPerSlab;           // the patch being MULTIPLIED
-  if (patch >= p.npatches) return;
+  const bool has_work = patch < p.npatches;
 
   // ---- request a patch's halo into the staging registers
   u32x4 stage[kLoads];
@@ -189,7 +181,17 @@ __global__ void __launch_bounds__(Geo<ROWS>::kThreads, ROWS == 8 ? 1 : 2) conv3x
   // the 8 consecutive output channels this lane stores (after the epilogue's trade: see there)
   const int mycol = fr * 32 + l4 * 8;
 
-  request(patch);
+  if (has_work) request(patch);             // the first halo travels while the weights are staged
+
+  // ---- the nine weight taps, once: global [col][tap][c] -> LDS [tap][col][128 B], slot ^= (col >> 1) & 7
+  for (int q = tid; q < 9 * kC * 8; q += kThreads) {
+    const int chunk = q & 7, row = (q >> 3) % kC, tap = (q >> 3) / kC;
+    const uint4 v = *reinterpret_cast<const uint4*>(p.b + ((size_t)row * 9 + tap) * 128 + chunk * 16);
+    *reinterpret_cast<uint4*>(smem + tap * kTapBytes + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = v;
+  }
+  __syncthreads();                          // the only workgroup barrier of the kernel
+  if (!has_work) return;
+
   for (;;) {
     const bool first_of_slab = (patch % G::kPerSlab) == 0;
     const bool last_of_slab = (patch % G::kPerSlab) == G::kPerSlab - 1 || patch + 1 >= p.npatches;

@@ -14,7 +14,8 @@ so that its workgroups fill the CUs next to the main chain's (different bottlene
 LDS-heavy GEMM workgroups + register-light streaming workgroups) instead of extending the chain.  Ordering: the side stream waits for an event recorded on
 the main stream at the hand-off point (its inputs are complete), and the main stream waits
 for the side stream before anything consumes the results (``join``): at the end of every backward
-pass (autograd engine callback), before a gradient bucket is all-reduced and before the optimizer's update kernel.  Every kernel stays
+pass (autograd engine callback) and before the optimizer's update kernel; a gradient bucket's all-reduce is ordered
+behind it through ``comm_stream`` / ``gather_into`` without making the main stream wait (round 6).  Every kernel stays
 deterministic; only the interleaving changes.
 
 Memory.  The tensors a hand-off reads (allocated on the main stream) must not be recycled while the
