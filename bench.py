@@ -35,7 +35,7 @@ FLOP_PER_SAMPLE = 32.77e9      # 2*[(3+1)*(4.0871+0.00446) + 2*0.00
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured streaming ceiling)
-PMC_TRAFFIC_FILE = os.path.join('profiles', 'r05_pmc_traffic.json')
+PMC_TRAFFIC_FILE = os.path.join('profiles', 'r06_pmc_traffic.json')
 STREAM_HBM_GBS = 6290.0        # measured float4-copy ceiling (MI355X_MICROARCH.md, chip-level parameters)
 
 # workload -> (config, default per-GPU batch, algorithmic FLOP per sample, metric text, workload text)

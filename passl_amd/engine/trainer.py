@@ -223,6 +223,7 @@ class Trainer:
         hook = opt_hooks[0]
 
         def full_step(*data):
+            self.outputs = None                 # see train_step
             self.outputs = self.model(*data, total_iters=self.total_iters, current_iter=self.current_iter,
                                       mixup_fn=self.mixup_fn)
             hook.optimize(self)
@@ -238,6 +239,10 @@ class Trainer:
         """The body of one iteration between the ``train_iter_begin`` and ``train_iter_end`` hook calls: the
         model call of trainer.py:318-321, plus — when the step runs as a HIP graph — OptimizerHook's work, which
         the hook then skips."""
+        # the previous step's outputs go first: the loss holds its autograd graph, and the nodes hold what the layers
+        # parked on them (not only saved tensors) — kept across the next forward that is up to a third of a step's
+        # activations twice (SimCLR R50 at 512 / GPU: 71 GB)
+        self.outputs = None
         if self.step_graph is not None and self.mode == 'train':
             self.outputs = self.step_graph.run(*data)
             self._step_done = True
