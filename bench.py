@@ -334,6 +334,7 @@ def main():
     elapsed = time.perf_counter() - t0
     loss = float(trainer.outputs['loss'].detach())
     mem = torch.cuda.memory_stats()
+    launch_desc = step_launch(trainer)      # how the TIMED steps were issued (the instrumentation below may drop the plan)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     if world > 1:
@@ -383,6 +384,13 @@ def main():
         graph_was = trainer.step_graph.enabled if trainer.step_graph is not None else None
         if trainer.step_graph is not None:
             trainer.step_graph.enabled = False          # per-launch HIP events need the eager step
+            # a recorded plan keeps its whole step's memory reserved; the eager step beside it needs the same again
+            # (SimCLR R50 at 512 / GPU: 184 GB + 167 GB).  The timed loop is over: give the plan's pool back first.
+            free_b, total_b = torch.cuda.mem_get_info()
+            if torch.cuda.memory_reserved() > free_b and hasattr(trainer.step_graph, 'reset'):
+                trainer.outputs = None
+                trainer.step_graph.reset()
+                torch.cuda.empty_cache()
         step()
         barrier()
         lib.passl_hip_prof_enable(1)
@@ -459,7 +467,7 @@ def main():
                        'timed_region': 'product path only (full hook bus); kernel instrumentation runs '
                                        'in a separate loop afterwards',
                        'host_enqueue_ms_per_step': round(1000 * host_elapsed / args.steps, 3),
-                       'step_launch': step_launch(trainer), 'extra_untimed_steps': extra_warm,
+                       'step_launch': launch_desc, 'extra_untimed_steps': extra_warm,
                        'main_stream_priority': main_stream.priority if main_stream is not None else None},
             'step_flop_roofline': {
                 'algorithmic_gflop_per_sample': flop_per_sample / 1e9,

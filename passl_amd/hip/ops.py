@@ -37,6 +37,14 @@ class _Workspace:
             self._bufs[key] = buf
         return buf
 
+    def pin(self):
+        """References to every scratch buffer that exists right now, for somebody whose recorded launches carry raw
+        pointers into them (hip/replay.py): ``get`` REPLACES a buffer when a later call asks for more, and the old one
+        must then outlive its last recorded user.  Dropping the returned list is the unpin.  (The library's own
+        finalize-counter slices, csrc/bn.hip, live as long as the library: recorded launches hold those too, and a
+        plan and an eager step must not run concurrently on one device for that reason.)"""
+        return list(self._bufs.values())
+
 
 workspace = _Workspace()
 

@@ -291,7 +291,7 @@ class StepPlan(object):
         # a tail batch through the eager fallback): without these references the old buffer would be freed and every
         # replay would write its slabs into memory that belongs to somebody else.
         from . import ops
-        self._scratch_pins = list(ops.workspace._bufs.values())
+        self._scratch_pins = ops.workspace.pin()
         return None
 
     def run(self, *data):

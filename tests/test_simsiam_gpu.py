@@ -141,8 +141,15 @@ def _run_against_golden(name, dtype):
             if ref < 1e-12:
                 rep.check(pre + 'gradnorm/' + n + ' (zero)', g, 1e-9)
                 continue
+            # bf16 floor: 0.25 of the norm — except the predictor's last bias, whose gradient is the batch SUM of
+            # per-sample cosine gradients that all but cancel: two equally valid fp32 summation orders of the SAME
+            # first-stage BatchNorm statistics (128 consecutive rows per partial in the ring kernel, four 4 x 8 patches
+            # in csrc/conv3x3_wave.hip; the convolution outputs are bit-identical) move it from 0.217 to 0.272 at
+            # step 0 and from 0.279 to 0.157 at step 2 (profiles/r06_simsiam_bf16_statistics_order.txt); every other
+            # watched tensor stays below 0.11 under either order
+            floor = (0.4 if n == 'predictor.3.bias' else 0.25) if bf else 4e-3
             rep.check(pre + 'gradnorm/' + n, abs(g - ref) / ref,
-                      bound(pre + 'gradnorm/' + n, p64 + 'gradnorm/' + n, 0.0) / ref + (0.25 if bf else 4e-3) * 2 ** s)
+                      bound(pre + 'gradnorm/' + n, p64 + 'gradnorm/' + n, 0.0) / ref + floor * 2 ** s)
             rep.check(pre + 'pnorm/' + n, abs(sd[n].double().norm().item() - float(z[p64 + 'pnorm/' + n])),
                       bound(pre + 'pnorm/' + n, p64 + 'pnorm/' + n, (2e-4 if bf else 2e-6) * 4 ** s))
         for n in stats:
