@@ -255,6 +255,11 @@ class StepPlan(object):
                 if began:
                     rc = lib.passl_hip_plan_record_end(handle)
                 torch._C._cuda_endAllocateToPool(idx, pool.id)
+                # begin took a reference of its own (torch.cuda.use_mem_pool pairs end with release): without this the
+                # pool outlives its MemPool object and reset() gives nothing back — a second plan, or an eager step of a
+                # large batch after a reset, then finds the whole recorded step still reserved
+                if hasattr(torch._C, '_cuda_releasePool'):
+                    torch._C._cuda_releasePool(idx, pool.id)
             L.check(rc, 'plan_record_end')
         except Exception:
             lib.passl_hip_plan_destroy(handle)
@@ -345,6 +350,8 @@ class StepPlan(object):
             torch.cuda.synchronize()
             L.load().passl_hip_plan_destroy(self.handle)
         self.handle = self.static_in = self.static_out = self._src = self._pool = self._scratch_pins = None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()            # the plan's pool: its blocks are ordinary cached blocks now
         self._host_calls = []
         self.failed = None
         self.calls = 0

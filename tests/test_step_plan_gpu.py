@@ -90,6 +90,60 @@ def test_stem_tail_scheduling_changes_nothing_but_the_stem_filter_rounding():
             assert int(diff.max() - diff.min()) < 64 * 3 * 7 * 7 + 64          # one contiguous slot of the arena
 
 
+def test_reset_gives_the_plan_memory_back_and_the_next_plan_continues_the_run():
+    """StepPlan.reset() (another batch shape, bench.py's eager instrumentation after the timed loop): the recorded step's
+    private allocator pool goes back to the allocator — the recording has to pair `_cuda_endAllocateToPool` with
+    `_cuda_releasePool`, otherwise the pool outlives its MemPool object (SimCLR R50 at 512 / GPU: 184 GB that the next
+    eager step could not have) — and the plan recorded afterwards continues the run bit for bit."""
+    from passl_amd.engine.trainer import Trainer
+    from passl_amd.utils.config import get_config
+
+    def run(plan, reset_after=None, steps=12):
+        cfg = get_config(os.path.join(ROOT, CASES[0][0]),
+                         ['dataloader.train.sampler.batch_size=32', 'compute_dtype=bf16', 'seed=3'])
+        cfg.timestamp = ''
+        cfg.step_plan = plan
+        tr = Trainer(cfg)
+        tr.mode = 'train'
+        tr.model.train()
+        data = next(iter(tr.train_dataloader))
+        tr.call_hook('run_begin')
+        tr.call_hook('train_epoch_begin')
+        losses, mem = [], None
+        for it in range(steps):
+            tr.inner_iter = tr.current_iter % tr.iters_per_epoch
+            tr.current_iter += 1
+            tr.call_hook('train_iter_begin')
+            tr.train_step(data)
+            tr.call_hook('train_iter_end')
+            losses.append(tr.outputs['loss'].detach().reshape(()).float().clone())
+            if reset_after is not None and it == reset_after:
+                assert tr.step_graph.captured
+                torch.cuda.synchronize()
+                tr.outputs = None
+                before = torch.cuda.memory_reserved()
+                tr.step_graph.reset()
+                torch.cuda.empty_cache()
+                mem = (before, torch.cuda.memory_reserved())
+                assert not tr.step_graph.captured
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), tr.model.arena_q.flat.clone().cpu(), tr.step_graph, mem
+
+    torch.cuda.empty_cache()
+    le, fe, _, _ = run(False)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    lp, fp, sg, (before, after) = run(True, reset_after=6)
+    step_bytes = torch.cuda.max_memory_allocated() - base
+    print('reserved before / after reset: %.2f / %.2f GB; one step allocates %.2f GB at its peak'
+          % (before / 2 ** 30, after / 2 ** 30, step_bytes / 2 ** 30))
+    assert before - after > 0.5 * step_bytes, (before, after, step_bytes)
+    assert sg.captured and sg.replays == 4, sg.replays          # 4-6 replay; 7-9 warm up again, 10 records, 11 replays
+    assert torch.equal(le.view(torch.int32), lp.view(torch.int32)), (le, lp)
+    assert torch.equal(fe.view(torch.int32), fp.view(torch.int32))
+
+
 def test_plan_kill_switch(monkeypatch):
     from passl_amd.engine.trainer import Trainer
     from passl_amd.utils.config import get_config
