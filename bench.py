@@ -37,6 +37,9 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s is the measured streaming ceiling)
 PMC_TRAFFIC_FILE = os.path.join('profiles', 'r06_pmc_traffic.json')
 STREAM_HBM_GBS = 6290.0        # measured float4-copy ceiling (MI355X_MICROARCH.md, chip-level parameters)
+MIXED_HBM_GBS = 5500.0         # what a dependent read + 16-byte-store stream of the 1x1 layers' shape reaches on this pool:
+                               # 5.2 - 5.9 TB/s for every occupancy / persistence tried (scratch/probe/store_probe.cpp,
+                               # profiles/r06_store_probe.txt)
 
 # workload -> (config, default per-GPU batch, algorithmic FLOP per sample, metric text, workload text)
 WORKLOADS = {
@@ -510,6 +513,7 @@ def main():
                      'frac': round(max(frac_mfma, frac_hbm), 5),
                      'frac_mfma': round(frac_mfma, 5), 'frac_hbm': round(frac_hbm, 5),
                      'frac_hbm_of_measured_copy_ceiling': round(gbs / STREAM_HBM_GBS, 5),
+                     'frac_hbm_of_measured_mixed_rw_ceiling_5.5TBs': round(gbs / MIXED_HBM_GBS, 5),
                      'floor_us_mfma': round(d['flops'] / d['n'] / (peak * 1e12) * 1e6, 2),
                      'floor_us_hbm': round(d['bytes'] / d['n'] / (PEAK_HBM_GBS * 1e9) * 1e6, 2),
                      'launches': int(d['n']), 'avg_launch_us': round(1000 * d['ms'] / d['n'], 2),
