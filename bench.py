@@ -489,8 +489,10 @@ def main():
                           'write_gb': step_traffic['write_gb'],
                           'floor_ms_at_measured_copy_ceiling_6.29TBs': round(gb / STREAM_HBM_GBS * 1e3, 3),
                           'floor_ms_at_spec_8TBs': round(gb / PEAK_HBM_GBS * 1e3, 3),
+                          'floor_ms_at_measured_mixed_rw_ceiling_5.5TBs': round(gb / MIXED_HBM_GBS * 1e3, 3),
                           'step_over_floor': round(1000 * elapsed / args.steps / (gb / STREAM_HBM_GBS * 1e3), 3),
                           'average_tb_per_s': round(gb / (1000 * elapsed / args.steps), 3),
+                          'average_over_mixed_rw_ceiling': round(gb / (1000 * elapsed / args.steps) / (MIXED_HBM_GBS / 1e3), 3),
                           'source': step_traffic['source']}
         if kern and kern['ring']['n'] + kern['igemm']['n'] + kern['g8p']['n'] > 0:
             traffic = pmc_traffic(args)
