@@ -225,7 +225,8 @@ def wgrad_slices(d: P.Desc, dtype):
     M = d.N * d.OP * d.OQ
     bkm = 64 if dtype == torch.bfloat16 else 32
     esz = 2 if dtype == torch.bfloat16 else 4
-    return P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm, row_bytes=max(d.NCOLS, d.C * d.sh * d.sw) * esz)
+    return P.wgrad_splits(M, d.NCOLS, d.R * d.S * d.C, bkm, target_blocks=P.wgrad_target_blocks(d.IH * d.IW > 1),
+                          row_bytes=max(d.NCOLS, d.C * d.sh * d.sw) * esz)
 
 
 def conv_wgrad(d: P.Desc, a, dy, dw, splits=None):

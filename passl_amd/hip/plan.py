@@ -8,6 +8,7 @@ Reference call sites being planned: nn.Conv2D uses at
 passl_v110/modeling/backbones/resnetimagenet.py:114-131 (bottleneck), :190-195 (stem),
 :216-224 (downsample); nn.Linear at passl_v110/modeling/necks/base_neck.py:80-85.
 """
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -182,20 +183,45 @@ def stem_desc(cout, N, H, W) -> Desc:
                           c_pad=STEM_CP, size=cout * STEM_K * 8 * STEM_CP))
 
 
-def wgrad_halo_splits(N, IH, IW, ncols, C, target_blocks=512):
+# Grid targets of the weight-gradient launches (workgroups per launch).  Inside a training step these kernels run on the
+# side stream NEXT TO the main chain's kernels; every reduction slice writes a full fp32 tile of dW to a slab that
+# slab_reduce reads again (with 512 workgroups per launch: 3.4 GB of the R50 step's 100 GB).  Round 6, same-box A/Bs inside
+# the steps (profiles/r06_wgrad_grid_ab.txt):
+#   * convolutional networks — the launch shares the memory system with bandwidth-bound BatchNorm / 1x1 kernels: ONE
+#     workgroup per CU instead of two takes the MoCo step from 23.13 / 22.96 / 23.06 to 22.82 / 22.63 / 22.85 ms on three boxes
+#     (spatially tiled 3x3 kernel -0.2 ms, LDS-DMA kernel -0.1), SimCLR 35.37 -> 35.16; 192 is level, 128 too few
+#     (+0.2 ... +1.2 ms); the last stage's layers, although MFMA-bound by their shapes, prefer it too;
+#   * transformer Linears (M = tokens, no spatial extent) — the launch runs beside MFMA-bound GEMMs and needs two workgroups
+#     per CU: with 256 MAE loses 9 %, CLIP 10 %.
+# So: layers with a spatial extent 256, Linears 512.  PASSL_WGRAD_TARGET_BLOCKS / PASSL_WGRAD_HALO_TARGET_BLOCKS override
+# (experiments).
+_WGRAD_HALO_TARGET = int(os.environ.get('PASSL_WGRAD_HALO_TARGET_BLOCKS', '0') or 0)
+_WGRAD_TARGET = int(os.environ.get('PASSL_WGRAD_TARGET_BLOCKS', '0') or 0)
+
+
+def wgrad_halo_splits(N, IH, IW, ncols, C, target_blocks=256):
     """Slices for the spatially tiled 3x3 weight-gradient kernel (csrc/conv_wgrad_halo.inc): its grid is one
-    workgroup per 64 x 64 block of dW and slice (all nine taps), a k-tile is one 8 x 8 patch.  Measured at 64 -> 64 @56
-    (profiles/r04_kbench_halo_experiment.txt): 256 slices 83 us, 512 slices 77 us, 1024 slices 104 us."""
+    workgroup per 64 x 64 block of dW and slice (all nine taps), a k-tile is one 8 x 8 patch.  Stand-alone at 64 -> 64 @56
+    (profiles/r04_kbench_halo_experiment.txt): 256 slices 83 us, 512 slices 77 us, 1024 slices 104 us; inside the step
+    256 wins (see above)."""
     blocks = ((ncols + 63) // 64) * ((C + 63) // 64)
     patches = N * ((IH + 7) // 8) * ((IW + 7) // 8)
+    if _WGRAD_HALO_TARGET:
+        target_blocks = _WGRAD_HALO_TARGET
     return max(1, min(patches, target_blocks // max(blocks, 1)))
 
 
+def wgrad_target_blocks(spatial):
+    """Workgroups per weight-gradient launch of the LDS-DMA kernel (see the note above): ``spatial`` = the layer is a
+    convolution over an image (IH * IW > 1), not a Linear over rows."""
+    if _WGRAD_TARGET:
+        return _WGRAD_TARGET
+    return 256 if spatial else 512
+
+
 def wgrad_splits(M, ncols, kdim, bkm, target_blocks=512, row_bytes=0):
-    """Number of reduction slices so that the grid has ~target_blocks workgroups (2 per CU on
-    256 CUs = one resident wave of workgroups).  Every slice adds a full fp32 tile of global
-    atomics — measured on MI355X: 1024 blocks cost ~35 us of atomics per launch, 512 blocks ~18 us
-    while still filling the chip; 256 blocks leave the DMA pipeline latency-bound."""
+    """Number of reduction slices so that the grid has ~target_blocks workgroups (``wgrad_target_blocks``: one or two
+    per CU).  Every slice adds a full fp32 tile of slab traffic; too few leave the DMA pipeline latency-bound."""
     tiles = ((ncols + 127) // 128) * ((kdim + 127) // 128)
     nk = (M + bkm - 1) // bkm
     s = max(1, min(nk, target_blocks // max(tiles, 1)))

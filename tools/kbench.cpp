@@ -292,7 +292,8 @@ static passl_wgrad_desc make_wdesc(const Shape& s, const void* a, const void* dy
 }
 static int wgrad_splits(int64_t M, int ncols, int64_t kdim) {        // passl_amd/hip/plan.py: wgrad_splits
   const int64_t tiles = ((ncols + 127) / 128) * ((kdim + 127) / 128), nk = (M + 63) / 64;
-  int64_t sp = 512 / (tiles > 0 ? tiles : 1);
+  const int64_t target = 256;            // plan.py: wgrad_target_blocks(spatial = true): every shape here is a convolution
+  int64_t sp = target / (tiles > 0 ? tiles : 1);
   if (sp > nk) sp = nk;
   return (int)(sp < 1 ? 1 : sp);
 }
