@@ -10,9 +10,9 @@ What it replaces in the reference:
 MI355X design: gradients already live in ONE flat fp32 buffer (EncoderArena.grads), so a bucket is
 a contiguous slice — no flatten/unflatten copies.  The backward kernels' host code reports each
 layer's parameters as ready (arena.grad_ready); when every parameter of a bucket is ready the
-slice is all-reduced asynchronously: the collective is ISSUED from a stream of its own that waits for the
-bucket's producers (hip/streams.py:comm_stream), RCCL runs it on its stream, the main chain waits for
-nothing until the optimizer — it overlaps with the remaining backward kernels.  Buckets are walked from
+slice is all-reduced asynchronously: the collective is ISSUED from the weight-gradient (side) stream after it has been
+made to wait for the bucket's other producers (hip/streams.py:comm_stream), RCCL runs it on its stream, the main chain
+waits for nothing until the optimizer — it overlaps with the remaining backward kernels.  Buckets are walked from
 the END of the buffer (the last layers finish first in backward).  The 1/world_size scale is folded into
 the optimizer kernel (no extra pass).  Bucket layout (round 6): TWO buckets — everything but
 the head of the buffer (R50: 106 MB, complete 60 % into backward, fully hidden) and the <= 6 MB head, whose
@@ -210,8 +210,8 @@ class GradReducer(object):
             # The bucket's producers sit on up to three streams: weight gradients on the side stream
             # (hip/streams.py), BatchNorm / bias gradients on the stream backward() was called on, and this very
             # call may come from a node autograd runs on the side stream (a forked downsample branch).  The
-            # collective is ordered behind the CURRENT stream only, so it is issued from a stream of its own that
-            # waits for all of them (streams.comm_stream) — the main chain itself waits for nothing here (until
+            # collective is ordered behind the CURRENT stream only, so it is issued from a stream that waits for all of
+            # them (streams.comm_stream: the side stream itself) — the main chain itself waits for nothing here (until
             # round 5 it joined the side stream in front of every bucket: four waits per backward pass on the
             # critical chain).  The waits go through hip/streams.py: a recorded step replays them.
             from ..hip import streams

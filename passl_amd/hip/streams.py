@@ -151,15 +151,25 @@ _comm_streams = {}
 def comm_stream(device):
     """Stream a gradient bucket's collective is ISSUED from (core/sync_utils.py:GradReducer).  torch.distributed
     orders its communication stream behind the CURRENT stream, and a bucket has producers on two streams (weight
-    gradients on the side stream, BatchNorm / bias gradients on the stream backward() runs on).  Making the main
+    gradients on the side stream, BatchNorm / bias gradients on the stream backward() runs on).  Making the MAIN
     stream wait for the side stream in front of every bucket (rounds 1-5) put a cross-stream wait — and whatever the
-    side stream was behind by — on the step's critical chain four times per backward pass.  Instead THIS stream waits
-    for both and the collective is issued with it current: RCCL waits for the two producers, the main chain waits
-    for nobody until the optimizer."""
+    side stream was behind by — on the step's critical chain four times per backward pass.  Instead the issuing stream
+    waits for the producers (``gather_into``) and the main chain waits for nobody until the optimizer.
+
+    The issuing stream is the SIDE stream itself (the weight gradients' own stream: it is behind the main chain anyway,
+    so its wait for the main stream's BatchNorm / bias gradients costs nothing).  A dedicated fifth stream — the first
+    form of this round — measured +0.47 ms per forced data-parallel step against +0.09 ms this way
+    (profiles/r06_dp_overhead.txt, call 32; 4 hardware queues by default: main, side, key and torch.distributed's own
+    stream fill them, a fifth stream shares a queue with one of the product streams and its waits hold that queue).
+    PASSL_DP_COMM_STREAM=own restores the dedicated stream."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     s = _comm_streams.get(key)
     if s is None:
-        s = _comm_streams[key] = torch.cuda.Stream(device=device, priority=_aux_priority())
+        if os.environ.get('PASSL_DP_COMM_STREAM', 'side') != 'own':
+            s = side_stream(device)
+        else:
+            s = torch.cuda.Stream(device=device, priority=_aux_priority())
+        _comm_streams[key] = s
     return s
 
 
