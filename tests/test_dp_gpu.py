@@ -110,6 +110,28 @@ def test_rccl_world1(workload):
     assert gloo.split('digest=')[1] == plain.split('digest=')[1], (gloo, plain)
 
 
+def test_rccl_world1_dedicated_collective_stream_gives_the_same_bits():
+    """The gradient collectives are issued from the weight-gradient stream by default (hip/streams.py:comm_stream, round 6:
+    a fifth stream shares a hardware queue with a product stream); the dedicated stream stays selectable and must end in
+    the same state."""
+    own = _run_worker('moco', 1, dict(PASSL_DP_FORCE='1', PASSL_EXPECT_BACKEND='nccl', PASSL_DP_COMM_STREAM='own'))
+    side = _run_worker('moco', 1, dict(PASSL_DP_FORCE='1', PASSL_EXPECT_BACKEND='nccl'))
+    assert own.split('digest=')[1] == side.split('digest=')[1], (own, side)
+
+
+def test_collectives_are_issued_from_the_side_stream_by_default(monkeypatch):
+    import torch
+    from passl_amd.hip import streams
+    dev = torch.device('cuda', 0)
+    monkeypatch.delenv('PASSL_DP_COMM_STREAM', raising=False)
+    streams._comm_streams.clear()
+    assert streams.comm_stream(dev) is streams.side_stream(dev)
+    monkeypatch.setenv('PASSL_DP_COMM_STREAM', 'own')
+    streams._comm_streams.clear()
+    assert streams.comm_stream(dev) != streams.side_stream(dev)
+    streams._comm_streams.clear()
+
+
 def test_bench_self_launch_gpus1_and_world1_launcher():
     """bench.py under the driver's launcher form with one rank (RCCL world 1 is NOT forced here:
     the production gate is world > 1) and the plain form; both print exactly one JSON line."""

@@ -92,3 +92,18 @@ def test_stem_plan(hw):
 def test_wgrad_splits_bounds():
     assert P.wgrad_splits(802816, 64, 64, 64) >= 256
     assert P.wgrad_splits(64, 2048, 4608, 64) == 1
+
+
+def test_wgrad_grid_targets_one_workgroup_per_cu_for_convolutions_two_for_linears():
+    """Round 6 (profiles/r06_wgrad_grid_ab.txt): inside the step a convolutional layer's weight-gradient
+    launch gets ~256 workgroups, a Linear's ~512; the slice count follows."""
+    import torch
+    from passl_amd.hip import ops
+    assert P.wgrad_target_blocks(True) == 256 and P.wgrad_target_blocks(False) == 512
+    g1 = P.ConvGeom(cin=64, cout=256, k=1, stride=1, pad=0)
+    conv = P.wgrad_desc(g1, 256, 56, 56)                    # 64 -> 256 1x1 at 56 x 56: 2 tiles of dW
+    lin = P.wgrad_desc(g1, 256 * 56 * 56, 1, 1)             # the same matrix product as a Linear over rows
+    assert ops.wgrad_slices(conv, torch.bfloat16) == 128 and ops.wgrad_slices(lin, torch.bfloat16) == 256
+    g3 = P.ConvGeom(cin=64, cout=64, k=3, stride=1, pad=1)
+    assert ops.wgrad_slices(P.wgrad_desc(g3, 256, 56, 56), torch.bfloat16) == 256      # spatially tiled 3x3 kernel
+    assert P.wgrad_halo_splits(256, 14, 14, 256, 256) == 16
