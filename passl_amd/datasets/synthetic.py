@@ -154,6 +154,9 @@ class SyntheticLoader(object):
             yield b
 
 
+_RING_DIAG = os.environ.get('PASSL_RING_DIAG', '')
+
+
 class HostRingLoader(object):
     """A loader whose batches MOVE: a ring of ``ring`` (>= 3) distinct pinned host batches; batch i's host -> device
     copy is issued one step ahead on a copy stream of its own into one of three device slots, so that the step that
@@ -205,8 +208,9 @@ class HostRingLoader(object):
         if self._freed[slot] is not None:
             self._copy.wait_event(self._freed[slot])
         with torch.cuda.stream(self._copy):
-            for d, h in zip(self._slots[slot], self._host[i % len(self._host)]):
-                d.copy_(h, non_blocking=True)
+            if not (_RING_DIAG == 'noh2d' and i >= self.SLOTS):       # (diagnostic: every slot filled once, then no transfers)
+                for d, h in zip(self._slots[slot], self._host[i % len(self._host)]):
+                    d.copy_(h, non_blocking=True)
             self._ready[slot] = self._copy.record_event()
         self._issued += 1
 
