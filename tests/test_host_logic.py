@@ -1295,3 +1295,19 @@ def test_reference_mae_finetune_config_loads_and_builds_unchanged():
     assert sched.warmup_steps == 50 and sched.learning_rate.T_max == 1000 and abs(sched() - 1e-6) < 1e-12
     opt = build_optimizer(cfg.optimizer, sched, [model])
     assert opt.type == 'adamw' and (opt._b1, opt._b2, opt._wd) == (0.9, 0.999, 0.05)
+
+
+def test_step_ab_variant_grammar():
+    """tools/step_ab.py (same-box A/B of whole steps): `label:` opens a variant, NAME=value goes to its environment,
+    everything else to bench.py's command line."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('step_ab', os.path.join(ROOT, 'tools', 'step_ab.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    v = m.parse_variants(['base:', 'grid512:', 'PASSL_WGRAD_TARGET_BLOCKS=512', 'X=a=b', 'dp:', '--dp-force', '--batch', '128'])
+    assert [x['label'] for x in v] == ['base', 'grid512', 'dp']
+    assert v[0] == {'label': 'base', 'env': {}, 'flags': []}
+    assert v[1]['env'] == {'PASSL_WGRAD_TARGET_BLOCKS': '512', 'X': 'a=b'} and v[1]['flags'] == []
+    assert v[2]['flags'] == ['--dp-force', '--batch', '128'] and v[2]['env'] == {}
+    with pytest.raises(SystemExit):
+        m.parse_variants(['A=1'])
