@@ -58,7 +58,9 @@ int passl_hip_abi_version(void);
  *                               and 64 output channels whose image sides are multiples of 8 (ResNet-50 stage 1, forward and
  *                               data gradient; affine / ReLU, fused statistics or BatchNorm-backward epilogue): the nine weight
  *                               taps stay in LDS, every wave walks its own patches, no workgroup barrier (1);
- *                               "conv3x3_wave_rows" 4|8: 4 x 8 patches on eight waves (default) / 8 x 8 patches on four
+ *                               "conv3x3_wave_rows" 4|8: 4 x 8 patches on eight waves (default) / 8 x 8 patches on four;
+ *                               "conv3x3_wave_modes" bit mask of the launches that take it (1 plain / affine / ReLU, 2 fused
+ *                               statistics, 4 BatchNorm-backward sums; default 7 — in-step experiments)
  *   "igemm_persist" 0/1         persistent form of the register-staged kernel for dense 1x1 launches: bit-identical, measured
  *                               slower (profiles/r06_negative_results.txt): off;  "igemm_persist_grid" n: its grid (tests)
  *   "wgrad_halo" 0|1|2          spatially tiled 3x3 / stride 1 weight-gradient kernel (conv_wgrad_halo.inc): off / images

@@ -471,9 +471,12 @@ static int dispatch(const passl_conv_desc* d, Params& p, hipStream_t st) {
 
 }  // namespace w3
 
-static int g_w3 = -1, g_w3_dbg = 0, g_w3_rows = 4;
+static int g_w3 = -1, g_w3_dbg = 0, g_w3_rows = 4, g_w3_modes = 7;
 int passl_conv3x3_wave_option(const char* name, int value) {
   if (!strcmp(name, "conv3x3_wave_dbg")) { g_w3_dbg = value; return PASSL_OK; }
+  // which launches take the kernel (in-step experiments): bit 0 = plain / affine / ReLU epilogues (the key encoder's
+  // folded BatchNorm, evaluation), bit 1 = forward with fused statistics, bit 2 = data gradient with the BatchNorm-backward sums
+  if (!strcmp(name, "conv3x3_wave_modes")) { g_w3_modes = value & 7; return PASSL_OK; }
   if (!strcmp(name, "conv3x3_wave_rows")) {          // 8: four waves x (8 x 8 patches); 4: eight waves x (4 x 8 patches)
     if (value != 4 && value != 8) return PASSL_EINVAL;
     g_w3_rows = value;
@@ -500,6 +503,7 @@ int passl_conv3x3_wave_try(const passl_conv_desc* d, hipStream_t st) {
   const int64_t a_bytes = (int64_t)d->N * d->IH * d->IW * d->C * 2;
   if (a_bytes >= 0x7ffffff0ll) return PASSL_EUNSUPPORTED;           // 32-bit buffer offsets, also for the output
   if (d->stats && d->bnb_partial) return PASSL_EUNSUPPORTED;
+  if (!((g_w3_modes >> (d->stats ? 1 : d->bnb_partial ? 2 : 0)) & 1)) return PASSL_EUNSUPPORTED;
   if (d->bnb_partial && (d->relu || d->scale || d->shift || (d->bnb_relu != 0 && d->bnb_relu != 2) || d->bnb2_partial))
     return PASSL_EUNSUPPORTED;
   if (d->stats && (d->relu || d->scale || d->shift)) return PASSL_EUNSUPPORTED;
